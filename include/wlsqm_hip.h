@@ -1,0 +1,129 @@
+/* wlsqm_hip.h — C ABI of libwlsqm_hip.so, the MI355X (gfx950) batched WLSQM fitter.
+ *
+ * This is the drop-in boundary for ONE hot path of Technologicat/python-wlsqm:
+ * the per-case "assemble weighted normal equations -> factor -> solve" loop behind
+ * wlsqm.fitter.simple.fit_*D_many[_parallel] / fit_*D_iterative_many[_parallel]
+ * and wlsqm.fitter.expert.ExpertSolver.prepare()/solve().  The reference has no
+ * FFI layer of its own (it is Cython); each entry point below names the reference
+ * interface it replaces (file:line relative to the reference repo).  Plain pointers
+ * and sizes only; no torch / numpy types.  All functions return 0 on success or a
+ * negative WLSQM_E* code; wlsqm_hip_last_error() gives a thread-local message.
+ *
+ * Strides are in ELEMENTS of the array's dtype (not bytes).  Arrays follow the
+ * reference's layout contract (simple.pyx:131-159): the innermost axis of xk, xi,
+ * fi and sens must be contiguous, every other axis may have any stride.
+ */
+#ifndef WLSQM_HIP_H
+#define WLSQM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- constants: wlsqm/fitter/defs.pyx:69-75 ---- */
+#define WLSQM_ALGO_BASIC      1
+#define WLSQM_ALGO_ITERATIVE  2
+#define WLSQM_WEIGHT_UNIFORM  1
+#define WLSQM_WEIGHT_CENTER   2
+
+/* ---- error codes (mapped by the Python shim to the reference's exception classes) ---- */
+#define WLSQM_OK            0
+#define WLSQM_EVALUE       -1   /* -> ValueError   (bad dimension/order/length; expert.pyx:131-159, infra.pyx:311-313) */
+#define WLSQM_ERUNTIME     -2   /* -> RuntimeError (solve before prepare, expert.pyx:493-494; HIP failure) */
+#define WLSQM_EMEMORY      -3   /* -> MemoryError  (infra.pyx:237,243,363,819) */
+#define WLSQM_ENODEVICE    -4   /* -> RuntimeError: no HIP device; there is NO CPU fallback in this library */
+
+const char* wlsqm_hip_last_error(void);
+
+/* Number of usable HIP devices (0 if none).  Never initialises a context on failure. */
+int wlsqm_hip_device_count(void);
+
+/* ---- host-side index contract (pure integer work, bit-exact with the reference) ---- */
+
+/* infra.pyx:67-112  number_of_dofs: returns no, or -1 (bad dimension) / -2 (bad order). */
+int wlsqm_hip_number_of_dofs(int dimension, int order);
+/* infra.pyx:119-121 number_of_reduced_dofs = n - popcountll(mask) (bits >= n are NOT masked off). */
+int wlsqm_hip_number_of_reduced_dofs(int n, int64_t mask);
+/* infra.pyx:145-200 remap: fills o2r[n], r2o[n] with -1 sentinels, returns nr. */
+int wlsqm_hip_remap(int32_t* o2r, int32_t* r2o, int n, int64_t mask);
+
+/* ---- batch description shared by the fit entry points ----
+ * Mirrors the argument list of simple.pyx:953-957 generic_fit_basic_many_parallel
+ * (and :1065-1069 for the iterative variant).  dimension==1: xk is [ncases,max_nk]
+ * (xk_stride_k is the neighbour stride), xi is [ncases].
+ */
+typedef struct wlsqm_batch {
+    int32_t dimension;            /* 1, 2 or 3 */
+    int32_t do_sens;              /* simple.pyx: do_sens */
+    int64_t ncases;
+    const double*  xk;   int64_t xk_stride_case, xk_stride_k;   /* [j,k,m], m contiguous */
+    const double*  fk;   int64_t fk_stride_case, fk_stride_k;   /* [j,k] */
+    const int32_t* nk;   int64_t nk_stride;                     /* [j] */
+    const double*  xi;   int64_t xi_stride_case;                /* [j,m], m contiguous */
+    double*        fi;   int64_t fi_stride_case;                /* [j,n] in/out: knowns read, unknowns written */
+    double*        sens; int64_t sens_stride_case, sens_stride_k; /* [j,k,n] or NULL */
+    const int32_t* order;            int64_t order_stride;      /* [j] */
+    const int64_t* knowns;           int64_t knowns_stride;     /* [j] */
+    const int32_t* weighting_method; int64_t wm_stride;         /* [j] */
+    int32_t iterative;            /* 0: ALGO_BASIC body (impl.pyx:731 solve); 1: impl.pyx:986 solve_iterative */
+    int32_t max_iter;             /* simple.pyx:112 default 10 */
+    int64_t max_nk;               /* extent of the k axis of xk/fk/sens (upper bound on nk[j]) */
+} wlsqm_batch;
+
+/* fit_{1,2,3}D_many_parallel / _iterative_many_parallel on HOST arrays
+ * (simple.pyx:192-234, 379-421, 562-604; drivers :953-1058, :1065-1170).
+ * Copies the batch to the device, runs the HIP kernels, commits fi (and sens) back.
+ * Aliasing guarantee of simple.pyx:1010-1019 holds: all inputs are read before any
+ * output is committed.  *iterations_out (nullable) receives the return value of the
+ * reference function: 0 for basic, max refinement iterations otherwise.
+ * device: HIP device ordinal. */
+int wlsqm_hip_fit_many_host(const wlsqm_batch* b, int device, int32_t* iterations_out);
+
+/* Same computation on DEVICE-RESIDENT arrays (all pointers in `b` are device pointers of
+ * `device`), enqueued on `stream` (a hipStream_t, NULL = default stream), no host sync
+ * unless iterations_out != NULL (a host pointer; needs one D2H of 4 bytes) .
+ * `order_uniform` >= 0 states that every case has this order (required: the kernels are
+ * specialised per (dimension, order); heterogeneous batches are bucketed by the caller,
+ * one call per order with `case_index`).  `case_index` (device, nullable): the ncases_sel
+ * case numbers to process; NULL = all b->ncases cases in order.
+ * fi is updated in place (knowns untouched); the caller guarantees fk/xk do not alias fi. */
+int wlsqm_hip_fit_many_device(const wlsqm_batch* b, int device, void* stream, int order_uniform,
+                              const int64_t* case_index, int64_t ncases_sel, int32_t* iterations_out);
+
+/* ---- ExpertSolver (expert.pyx:66-781): handle-based prepare-once / solve-many ---- */
+typedef struct wlsqm_expert wlsqm_expert;
+
+/* expert.pyx:92-264 __init__: host arrays nk/order/knowns/weighting_method of length ncases. */
+int wlsqm_hip_expert_create(wlsqm_expert** out, int device, int dimension, int64_t ncases,
+                            const int32_t* nk, const int32_t* order, const int64_t* knowns,
+                            const int32_t* weighting_method, int algorithm, int do_sens, int max_iter);
+/* expert.pyx:309-426 prepare(xi, xk): host arrays; geometry is uploaded and kept device-resident. */
+int wlsqm_hip_expert_prepare(wlsqm_expert* h, const double* xi, int64_t xi_stride_case,
+                             const double* xk, int64_t xk_stride_case, int64_t xk_stride_k, int64_t max_nk);
+/* expert.pyx:467-655 solve(fk, fi, sens): host arrays; returns max iterations via *iterations_out. */
+int wlsqm_hip_expert_solve(wlsqm_expert* h, const double* fk, int64_t fk_stride_case, int64_t fk_stride_k,
+                           double* fi, int64_t fi_stride_case,
+                           double* sens, int64_t sens_stride_case, int64_t sens_stride_k,
+                           int32_t* iterations_out);
+/* Device-resident variant of solve(): fk [ncases,max_nk] and fi [ncases,fi_stride_case] are device
+ * pointers (contiguous k axis); enqueued on `stream`; no host synchronisation. */
+int wlsqm_hip_expert_solve_device(wlsqm_expert* h, void* stream, const double* fk, int64_t fk_stride_case,
+                                  double* fi, int64_t fi_stride_case);
+/* expert.pyx:289-306 memory_used(): (bytes in use, bytes reserved) of the device-side state. */
+int wlsqm_hip_expert_memory_used(const wlsqm_expert* h, int64_t* used, int64_t* total);
+/* expert.pyx:267-286 __del__ */
+int wlsqm_hip_expert_destroy(wlsqm_expert* h);
+
+/* ---- measurement hooks used by bench.py (not part of the reference surface) ---- */
+/* Runs `reps` back-to-back launches of the fit kernel for batch `b` (device-resident, uniform
+ * order) on `stream`, bracketed by HIP events on that stream; returns the mean kernel time in
+ * milliseconds in *ms_out. */
+int wlsqm_hip_time_fit_device(const wlsqm_batch* b, int device, void* stream, int order_uniform,
+                              int reps, float* ms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WLSQM_HIP_H */

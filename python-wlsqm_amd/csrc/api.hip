@@ -1,0 +1,292 @@
+// api.hip — C ABI of libwlsqm_hip.so (see include/wlsqm_hip.h for the contract and the
+// reference file:line each entry point replaces).  Host logic only; kernels live in
+// fit_lane.hip / fit_tile.hip / fit_wave.hip.
+#include <algorithm>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "wlsqm_internal.hpp"
+
+namespace wlsqm {
+
+static thread_local std::string g_err;
+static thread_local const char* g_kernel = "";
+void set_error(const std::string& msg) { g_err = msg; }
+int hip_fail(hipError_t e, const char* what) {
+    g_err = std::string("HIP error: ") + hipGetErrorString(e) + " in " + what;
+    if (e == hipErrorOutOfMemory) return WLSQM_EMEMORY;
+    if (e == hipErrorNoDevice || e == hipErrorInvalidDevice) return WLSQM_ENODEVICE;
+    return WLSQM_ERUNTIME;
+}
+const char* last_kernel_name() { return g_kernel; }
+void note_kernel(const char* name) { g_kernel = name; }
+
+int launch_fit_lane(int dimension, int order, const KParams& p, hipStream_t stream);
+int launch_fit_tile(int dimension, int order, const KParams& p, long long max_nk, hipStream_t stream, bool* handled);
+int launch_fit_wave(int dimension, int order, const KParams& p, hipStream_t stream);
+
+int launch_fit(int dimension, int order, const KParams& p, long long max_nk, hipStream_t stream) {
+    const int no = wlsqm_hip_number_of_dofs(dimension, order);
+    if (no < 0) { set_error("bad dimension/order"); return WLSQM_EVALUE; }
+    if (p.ncases <= 0) return WLSQM_OK;
+    bool handled = false;
+    int rc = launch_fit_tile(dimension, order, p, max_nk, stream, &handled);
+    if (rc != WLSQM_OK || handled) return rc;
+    if (no <= 15) return launch_fit_lane(dimension, order, p, stream);
+    return launch_fit_wave(dimension, order, p, stream);
+}
+
+int check_device(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        set_error("no HIP device available: libwlsqm_hip has no CPU fallback");
+        return WLSQM_ENODEVICE;
+    }
+    if (device < 0 || device >= n) { set_error("invalid device ordinal"); return WLSQM_ENODEVICE; }
+    WLSQM_HIP_CHECK(hipSetDevice(device));
+    return WLSQM_OK;
+}
+
+static int validate_batch(const wlsqm_batch* b) {
+    if (!b) { set_error("null batch"); return WLSQM_EVALUE; }
+    if (b->dimension < 1 || b->dimension > 3) { set_error("dimension must be 1, 2 or 3"); return WLSQM_EVALUE; }
+    if (b->ncases < 1) { set_error("max_cases must be >= 1"); return WLSQM_EVALUE; }   // infra.pyx:311-313
+    if (!b->xk || !b->fk || !b->nk || !b->xi || !b->fi || !b->order || !b->knowns || !b->weighting_method) {
+        set_error("null array in batch"); return WLSQM_EVALUE;
+    }
+    if (b->max_nk < 0) { set_error("max_nk must be >= 0"); return WLSQM_EVALUE; }
+    return WLSQM_OK;
+}
+
+static KParams params_from(const wlsqm_batch* b) {
+    KParams p{};
+    p.xk = b->xk; p.sxk_j = b->xk_stride_case; p.sxk_k = b->xk_stride_k;
+    p.fk = b->fk; p.sfk_j = b->fk_stride_case; p.sfk_k = b->fk_stride_k;
+    p.nk = b->nk; p.snk = b->nk_stride;
+    p.xi = b->xi; p.sxi_j = b->xi_stride_case;
+    p.fi = b->fi; p.sfi_j = b->fi_stride_case;
+    p.sens = (b->do_sens ? b->sens : nullptr); p.ss_j = b->sens_stride_case; p.ss_k = b->sens_stride_k;
+    p.knowns = (const long long*)b->knowns; p.sknowns = b->knowns_stride;
+    p.wm = b->weighting_method; p.swm = b->wm_stride;
+    p.case_index = nullptr; p.ncases = b->ncases;
+    p.do_sens = (b->do_sens && b->sens) ? 1 : 0;
+    p.iterative = b->iterative ? 1 : 0;
+    p.max_iter = b->max_iter;
+    p.iters_out = nullptr;
+    return p;
+}
+
+}  // namespace wlsqm
+
+using namespace wlsqm;
+
+extern "C" {
+
+const char* wlsqm_hip_last_error(void) { return g_err.c_str(); }
+
+int wlsqm_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+int wlsqm_hip_number_of_dofs(int dimension, int order) {
+    if (dimension < 1 || dimension > 3) return -1;
+    if (order < 0 || order > 4) return -2;
+    static const int tab[3][5] = {{1, 2, 3, 4, 5}, {1, 3, 6, 10, 15}, {1, 4, 10, 20, 35}};
+    return tab[dimension - 1][order];
+}
+
+int wlsqm_hip_number_of_reduced_dofs(int n, int64_t mask) {
+    return n - __builtin_popcountll((unsigned long long)mask);
+}
+
+int wlsqm_hip_remap(int32_t* o2r, int32_t* r2o, int n, int64_t mask) {
+    int k = 0;
+    for (int j = 0; j < n; ++j) {
+        if (mask & (1LL << j)) o2r[j] = -1;
+        else o2r[j] = k++;
+    }
+    for (int j = 0; j < n; ++j)
+        if (o2r[j] != -1) r2o[o2r[j]] = j;
+    for (int j = k; j < n; ++j) r2o[j] = -1;
+    return k;
+}
+
+int wlsqm_hip_fit_many_device(const wlsqm_batch* b, int device, void* stream, int order_uniform,
+                              const int64_t* case_index, int64_t ncases_sel, int32_t* iterations_out) {
+    int rc = validate_batch(b);
+    if (rc != WLSQM_OK) return rc;
+    rc = check_device(device);
+    if (rc != WLSQM_OK) return rc;
+    if (order_uniform < 0 || order_uniform > 4) { set_error("order_uniform must be 0..4"); return WLSQM_EVALUE; }
+    hipStream_t s = (hipStream_t)stream;
+    KParams p = params_from(b);
+    if (case_index) { p.case_index = (const long long*)case_index; p.ncases = ncases_sel; }
+    DevBuf it;
+    if (b->iterative) {
+        rc = it.alloc(sizeof(int)); if (rc != WLSQM_OK) return rc;
+        WLSQM_HIP_CHECK(hipMemsetAsync(it.p, 0, sizeof(int), s));
+        p.iters_out = it.as<int>();
+    }
+    rc = launch_fit(b->dimension, order_uniform, p, b->max_nk, s);
+    if (rc != WLSQM_OK) return rc;
+    if (iterations_out) {
+        *iterations_out = 0;
+        if (b->iterative) {
+            WLSQM_HIP_CHECK(hipMemcpyAsync(iterations_out, it.p, sizeof(int), hipMemcpyDeviceToHost, s));
+            WLSQM_HIP_CHECK(hipStreamSynchronize(s));
+        }
+    } else if (b->iterative) {
+        WLSQM_HIP_CHECK(hipStreamSynchronize(s));   // `it` is freed on return
+    }
+    return WLSQM_OK;
+}
+
+// Host-array entry point: stage -> device -> kernels -> commit.
+int wlsqm_hip_fit_many_host(const wlsqm_batch* b, int device, int32_t* iterations_out) {
+    int rc = validate_batch(b);
+    if (rc != WLSQM_OK) return rc;
+    const int dim = b->dimension;
+    const int64_t n = b->ncases;
+    // metadata (also validates order)
+    std::vector<int32_t> h_nk(n), h_order(n), h_wm(n), h_no(n);
+    std::vector<int64_t> h_kn(n);
+    int64_t max_nk = 0; int max_no = 0;
+    for (int64_t j = 0; j < n; ++j) {
+        h_nk[j] = b->nk[j * b->nk_stride];
+        h_order[j] = b->order[j * b->order_stride];
+        h_wm[j] = b->weighting_method[j * b->wm_stride];
+        h_kn[j] = b->knowns[j * b->knowns_stride];
+        const int no = wlsqm_hip_number_of_dofs(dim, h_order[j]);
+        if (no < 0) { set_error("order must be 0, 1, 2, 3 or 4"); return WLSQM_EVALUE; }
+        if (h_nk[j] < 0) { set_error("nk must be >= 0"); return WLSQM_EVALUE; }
+        h_no[j] = no;
+        max_nk = std::max<int64_t>(max_nk, h_nk[j]);
+        max_no = std::max(max_no, no);
+    }
+    rc = check_device(device);
+    if (rc != WLSQM_OK) return rc;
+
+    // contiguous host staging (only entries the reference would read: k < nk[j], n < no_j)
+    const int64_t K = std::max<int64_t>(max_nk, 1);
+    std::vector<double> s_xk((size_t)n * K * dim, 0.0), s_fk((size_t)n * K, 0.0), s_xi((size_t)n * dim), s_fi((size_t)n * max_no, 0.0);
+#pragma omp parallel for schedule(static)
+    for (int64_t j = 0; j < n; ++j) {
+        const double* xr = b->xk + j * b->xk_stride_case;
+        const double* fr = b->fk + j * b->fk_stride_case;
+        for (int64_t k = 0; k < h_nk[j]; ++k) {
+            for (int m = 0; m < dim; ++m) s_xk[((size_t)j * K + k) * dim + m] = xr[k * b->xk_stride_k + m];
+            s_fk[(size_t)j * K + k] = fr[k * b->fk_stride_k];
+        }
+        for (int m = 0; m < dim; ++m) s_xi[(size_t)j * dim + m] = b->xi[j * b->xi_stride_case + m];
+        for (int a = 0; a < h_no[j]; ++a) s_fi[(size_t)j * max_no + a] = b->fi[j * b->fi_stride_case + a];
+    }
+    const bool want_sens = b->do_sens && b->sens;
+    DevBuf d_xk, d_fk, d_xi, d_fi, d_nk, d_wm, d_kn, d_sens, d_it, d_idx;
+    if ((rc = d_xk.alloc(s_xk.size() * 8)) || (rc = d_fk.alloc(s_fk.size() * 8)) || (rc = d_xi.alloc(s_xi.size() * 8)) ||
+        (rc = d_fi.alloc(s_fi.size() * 8)) || (rc = d_nk.alloc(n * 4)) || (rc = d_wm.alloc(n * 4)) ||
+        (rc = d_kn.alloc(n * 8)) || (rc = d_it.alloc(4)))
+        return rc;
+    if (want_sens && (rc = d_sens.alloc((size_t)n * K * max_no * 8))) return rc;
+    hipStream_t s = nullptr;
+    WLSQM_HIP_CHECK(hipMemcpyAsync(d_xk.p, s_xk.data(), d_xk.n, hipMemcpyHostToDevice, s));
+    WLSQM_HIP_CHECK(hipMemcpyAsync(d_fk.p, s_fk.data(), d_fk.n, hipMemcpyHostToDevice, s));
+    WLSQM_HIP_CHECK(hipMemcpyAsync(d_xi.p, s_xi.data(), d_xi.n, hipMemcpyHostToDevice, s));
+    WLSQM_HIP_CHECK(hipMemcpyAsync(d_fi.p, s_fi.data(), d_fi.n, hipMemcpyHostToDevice, s));
+    WLSQM_HIP_CHECK(hipMemcpyAsync(d_nk.p, h_nk.data(), d_nk.n, hipMemcpyHostToDevice, s));
+    WLSQM_HIP_CHECK(hipMemcpyAsync(d_wm.p, h_wm.data(), d_wm.n, hipMemcpyHostToDevice, s));
+    WLSQM_HIP_CHECK(hipMemcpyAsync(d_kn.p, h_kn.data(), d_kn.n, hipMemcpyHostToDevice, s));
+    WLSQM_HIP_CHECK(hipMemsetAsync(d_it.p, 0, 4, s));
+    if (want_sens) WLSQM_HIP_CHECK(hipMemsetAsync(d_sens.p, 0, d_sens.n, s));
+
+    KParams p{};
+    p.xk = d_xk.as<double>(); p.sxk_j = K * dim; p.sxk_k = dim;
+    p.fk = d_fk.as<double>(); p.sfk_j = K; p.sfk_k = 1;
+    p.nk = d_nk.as<int>(); p.snk = 1;
+    p.xi = d_xi.as<double>(); p.sxi_j = dim;
+    p.fi = d_fi.as<double>(); p.sfi_j = max_no;
+    p.sens = want_sens ? d_sens.as<double>() : nullptr; p.ss_j = K * max_no; p.ss_k = max_no;
+    p.knowns = d_kn.as<long long>(); p.sknowns = 1;
+    p.wm = d_wm.as<int>(); p.swm = 1;
+    p.do_sens = want_sens ? 1 : 0; p.iterative = b->iterative ? 1 : 0; p.max_iter = b->max_iter;
+    p.iters_out = d_it.as<int>();
+
+    // bucket by order (the kernels are specialised per (dimension, order))
+    const bool uniform_order = std::all_of(h_order.begin(), h_order.end(), [&](int o) { return o == h_order[0]; });
+    if (uniform_order) {
+        p.case_index = nullptr; p.ncases = n;
+        rc = launch_fit(dim, h_order[0], p, K, s);
+        if (rc != WLSQM_OK) return rc;
+    } else {
+        std::vector<long long> idx; idx.reserve(n);
+        int64_t off[6] = {0};
+        for (int o = 0; o <= 4; ++o) {
+            off[o] = (int64_t)idx.size();
+            for (int64_t j = 0; j < n; ++j) if (h_order[j] == o) idx.push_back(j);
+        }
+        off[5] = (int64_t)idx.size();
+        if ((rc = d_idx.alloc(idx.size() * 8))) return rc;
+        WLSQM_HIP_CHECK(hipMemcpyAsync(d_idx.p, idx.data(), d_idx.n, hipMemcpyHostToDevice, s));
+        for (int o = 0; o <= 4; ++o) {
+            if (off[o + 1] == off[o]) continue;
+            p.case_index = d_idx.as<long long>() + off[o]; p.ncases = off[o + 1] - off[o];
+            rc = launch_fit(dim, o, p, K, s);
+            if (rc != WLSQM_OK) return rc;
+        }
+    }
+    // commit: everything was read before anything is written back (simple.pyx:1010-1019)
+    std::vector<double> s_sens;
+    int h_it = 0;
+    WLSQM_HIP_CHECK(hipMemcpyAsync(s_fi.data(), d_fi.p, d_fi.n, hipMemcpyDeviceToHost, s));
+    if (want_sens) { s_sens.resize((size_t)n * K * max_no); WLSQM_HIP_CHECK(hipMemcpyAsync(s_sens.data(), d_sens.p, d_sens.n, hipMemcpyDeviceToHost, s)); }
+    WLSQM_HIP_CHECK(hipMemcpyAsync(&h_it, d_it.p, 4, hipMemcpyDeviceToHost, s));
+    WLSQM_HIP_CHECK(hipStreamSynchronize(s));
+#pragma omp parallel for schedule(static)
+    for (int64_t j = 0; j < n; ++j) {
+        if (wlsqm_hip_number_of_reduced_dofs(h_no[j], h_kn[j]) < 1) continue;   // nr < 1: reference leaves the case untouched
+        unsigned long long known, dropped;
+        effective_mask_host(h_no[j], h_kn[j], known, dropped);
+        for (int a = 0; a < h_no[j]; ++a) b->fi[j * b->fi_stride_case + a] = s_fi[(size_t)j * max_no + a];
+        if (want_sens) {
+            double* sr = b->sens + j * b->sens_stride_case;
+            for (int64_t k = 0; k < h_nk[j]; ++k)
+                for (int a = 0; a < h_no[j]; ++a) {
+                    if ((dropped >> a) & 1ull) continue;   // never written by the reference
+                    sr[k * b->sens_stride_k + a] = s_sens[((size_t)j * K + k) * max_no + a];
+                }
+        }
+    }
+    if (iterations_out) *iterations_out = b->iterative ? h_it : 0;
+    return WLSQM_OK;
+}
+
+int wlsqm_hip_time_fit_device(const wlsqm_batch* b, int device, void* stream, int order_uniform, int reps, float* ms_out) {
+    int rc = validate_batch(b);
+    if (rc != WLSQM_OK) return rc;
+    rc = check_device(device);
+    if (rc != WLSQM_OK) return rc;
+    if (reps < 1 || !ms_out) { set_error("reps must be >= 1"); return WLSQM_EVALUE; }
+    hipStream_t s = (hipStream_t)stream;
+    KParams p = params_from(b);
+    hipEvent_t e0, e1;
+    WLSQM_HIP_CHECK(hipEventCreate(&e0));
+    WLSQM_HIP_CHECK(hipEventCreate(&e1));
+    rc = launch_fit(b->dimension, order_uniform, p, b->max_nk, s);   // warm-up / code object load
+    if (rc == WLSQM_OK) {
+        (void)hipEventRecord(e0, s);
+        for (int r = 0; r < reps && rc == WLSQM_OK; ++r) rc = launch_fit(b->dimension, order_uniform, p, b->max_nk, s);
+        (void)hipEventRecord(e1, s);
+        hipError_t e = hipEventSynchronize(e1);
+        if (e != hipSuccess) rc = hip_fail(e, "hipEventSynchronize");
+        else { float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1); *ms_out = ms / reps; }
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,209 @@
+// expert.hip — handle-based ExpertSolver state (expert.pyx:66-655): configuration is fixed at
+// create (expert.pyx:92-264), geometry is uploaded once by prepare (expert.pyx:309-426) and stays
+// resident in HBM, solve (expert.pyx:467-655) streams fk in and fi in/out.
+//
+// On MI355X the "prepared" state is the device-resident, packed geometry (xi, xk, nk, knowns,
+// weighting, order buckets): refitting a case from its 8*nk*dim bytes of coordinates moves fewer
+// HBM bytes than reading back a stored factorisation (no x nk operator or c/w/LU arrays, what the
+// reference's Case holds, infra.pxd:124-182) and the fit kernels are HBM-bound, so solve() re-runs
+// the fused assemble+factor+solve kernel on the resident geometry.
+#include <algorithm>
+#include <new>
+#include <vector>
+
+#include "wlsqm_internal.hpp"
+
+struct wlsqm_expert {
+    int device = 0, dimension = 0, algorithm = 1, do_sens = 0, max_iter = 10;
+    int64_t ncases = 0, max_nk = 1;
+    int max_no = 0;
+    bool ready = false, uniform_order = true;
+    std::vector<int32_t> nk, order, wm, no;
+    std::vector<int64_t> kn;
+    std::vector<long long> idx; int64_t off[6] = {0, 0, 0, 0, 0, 0};
+    wlsqm::DevBuf d_nk, d_wm, d_kn, d_idx, d_xk, d_xi, d_fk, d_fi, d_sens, d_it;
+    int64_t bytes() const {
+        return (int64_t)(d_nk.n + d_wm.n + d_kn.n + d_idx.n + d_xk.n + d_xi.n + d_fk.n + d_fi.n + d_sens.n + d_it.n);
+    }
+};
+
+using namespace wlsqm;
+
+static KParams expert_params(const wlsqm_expert* h, const double* d_fk, int64_t sfk_j, double* d_fi, int64_t sfi_j) {
+    KParams p{};
+    const int dim = h->dimension;
+    p.xk = h->d_xk.as<double>(); p.sxk_j = h->max_nk * dim; p.sxk_k = dim;
+    p.fk = d_fk; p.sfk_j = sfk_j; p.sfk_k = 1;
+    p.nk = h->d_nk.as<int>(); p.snk = 1;
+    p.xi = h->d_xi.as<double>(); p.sxi_j = dim;
+    p.fi = d_fi; p.sfi_j = sfi_j;
+    p.sens = nullptr; p.ss_j = 0; p.ss_k = 0;
+    p.knowns = h->d_kn.as<long long>(); p.sknowns = 1;
+    p.wm = h->d_wm.as<int>(); p.swm = 1;
+    p.case_index = nullptr; p.ncases = h->ncases;
+    p.do_sens = 0; p.iterative = (h->algorithm == WLSQM_ALGO_ITERATIVE) ? 1 : 0; p.max_iter = h->max_iter;
+    p.iters_out = h->d_it.as<int>();
+    return p;
+}
+
+static int expert_launch(const wlsqm_expert* h, KParams p, hipStream_t s) {
+    if (h->uniform_order) return launch_fit(h->dimension, h->order[0], p, h->max_nk, s);
+    for (int o = 0; o <= 4; ++o) {
+        if (h->off[o + 1] == h->off[o]) continue;
+        p.case_index = h->d_idx.as<long long>() + h->off[o];
+        p.ncases = h->off[o + 1] - h->off[o];
+        int rc = launch_fit(h->dimension, o, p, h->max_nk, s);
+        if (rc != WLSQM_OK) return rc;
+    }
+    return WLSQM_OK;
+}
+
+extern "C" {
+
+int wlsqm_hip_expert_create(wlsqm_expert** out, int device, int dimension, int64_t ncases,
+                            const int32_t* nk, const int32_t* order, const int64_t* knowns,
+                            const int32_t* weighting_method, int algorithm, int do_sens, int max_iter) {
+    if (!out) { set_error("null out"); return WLSQM_EVALUE; }
+    *out = nullptr;
+    if (dimension < 1 || dimension > 3) { set_error("Dimension must be 1, 2 or 3"); return WLSQM_EVALUE; }   // expert.pyx:134-135
+    if (algorithm != WLSQM_ALGO_BASIC && algorithm != WLSQM_ALGO_ITERATIVE) { set_error("Unknown algorithm specifier"); return WLSQM_EVALUE; }   // :151-156
+    if (ncases < 1) { set_error("max_cases must be >= 1"); return WLSQM_EVALUE; }                              // infra.pyx:311-313
+    if (!nk || !order || !knowns || !weighting_method) { set_error("null array"); return WLSQM_EVALUE; }
+    wlsqm_expert* h = new (std::nothrow) wlsqm_expert();
+    if (!h) { set_error("out of memory"); return WLSQM_EMEMORY; }
+    h->device = device; h->dimension = dimension; h->algorithm = algorithm; h->do_sens = do_sens ? 1 : 0;
+    h->max_iter = max_iter; h->ncases = ncases;
+    h->nk.assign(nk, nk + ncases); h->order.assign(order, order + ncases);
+    h->wm.assign(weighting_method, weighting_method + ncases); h->kn.assign(knowns, knowns + ncases);
+    h->no.resize(ncases);
+    int64_t mk = 0;
+    for (int64_t j = 0; j < ncases; ++j) {
+        const int no = wlsqm_hip_number_of_dofs(dimension, order[j]);
+        if (no < 0 || nk[j] < 0) { delete h; set_error("order must be 0..4 and nk >= 0"); return WLSQM_EVALUE; }
+        h->no[j] = no; h->max_no = std::max(h->max_no, no); mk = std::max<int64_t>(mk, nk[j]);
+    }
+    h->max_nk = std::max<int64_t>(mk, 1);
+    h->uniform_order = std::all_of(h->order.begin(), h->order.end(), [&](int o) { return o == h->order[0]; });
+    int rc = check_device(device);
+    if (rc != WLSQM_OK) { delete h; return rc; }
+    if ((rc = h->d_nk.alloc(ncases * 4)) || (rc = h->d_wm.alloc(ncases * 4)) || (rc = h->d_kn.alloc(ncases * 8)) ||
+        (rc = h->d_it.alloc(4)) || (rc = h->d_xk.alloc((size_t)ncases * h->max_nk * dimension * 8)) ||
+        (rc = h->d_xi.alloc((size_t)ncases * dimension * 8)) || (rc = h->d_fk.alloc((size_t)ncases * h->max_nk * 8)) ||
+        (rc = h->d_fi.alloc((size_t)ncases * h->max_no * 8))) { delete h; return rc; }
+    if (h->do_sens && (rc = h->d_sens.alloc((size_t)ncases * h->max_nk * h->max_no * 8))) { delete h; return rc; }
+    hipError_t e;
+    if ((e = hipMemcpy(h->d_nk.p, h->nk.data(), h->d_nk.n, hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(h->d_wm.p, h->wm.data(), h->d_wm.n, hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(h->d_kn.p, h->kn.data(), h->d_kn.n, hipMemcpyHostToDevice)) != hipSuccess) {
+        delete h; return hip_fail(e, "hipMemcpy(expert metadata)");
+    }
+    if (!h->uniform_order) {
+        for (int o = 0; o <= 4; ++o) {
+            h->off[o] = (int64_t)h->idx.size();
+            for (int64_t j = 0; j < ncases; ++j) if (h->order[j] == o) h->idx.push_back(j);
+        }
+        h->off[5] = (int64_t)h->idx.size();
+        if ((rc = h->d_idx.alloc(h->idx.size() * 8))) { delete h; return rc; }
+        if ((e = hipMemcpy(h->d_idx.p, h->idx.data(), h->d_idx.n, hipMemcpyHostToDevice)) != hipSuccess) {
+            delete h; return hip_fail(e, "hipMemcpy(expert idx)");
+        }
+    }
+    *out = h;
+    return WLSQM_OK;
+}
+
+int wlsqm_hip_expert_prepare(wlsqm_expert* h, const double* xi, int64_t xi_stride_case,
+                             const double* xk, int64_t xk_stride_case, int64_t xk_stride_k, int64_t max_nk) {
+    if (!h || !xi || !xk) { set_error("null argument"); return WLSQM_EVALUE; }
+    h->ready = false;
+    if (max_nk < h->max_nk && h->max_nk > 1) { set_error("xk has fewer neighbour slots than max(nk)"); return WLSQM_EVALUE; }
+    int rc = check_device(h->device);
+    if (rc != WLSQM_OK) return rc;
+    const int dim = h->dimension; const int64_t n = h->ncases, K = h->max_nk;
+    std::vector<double> s_xk((size_t)n * K * dim, 0.0), s_xi((size_t)n * dim);
+#pragma omp parallel for schedule(static)
+    for (int64_t j = 0; j < n; ++j) {
+        const double* xr = xk + j * xk_stride_case;
+        for (int64_t k = 0; k < h->nk[j]; ++k)
+            for (int m = 0; m < dim; ++m) s_xk[((size_t)j * K + k) * dim + m] = xr[k * xk_stride_k + m];
+        for (int m = 0; m < dim; ++m) s_xi[(size_t)j * dim + m] = xi[j * xi_stride_case + m];
+    }
+    WLSQM_HIP_CHECK(hipMemcpy(h->d_xk.p, s_xk.data(), h->d_xk.n, hipMemcpyHostToDevice));
+    WLSQM_HIP_CHECK(hipMemcpy(h->d_xi.p, s_xi.data(), h->d_xi.n, hipMemcpyHostToDevice));
+    h->ready = true;
+    return WLSQM_OK;
+}
+
+int wlsqm_hip_expert_solve(wlsqm_expert* h, const double* fk, int64_t fk_stride_case, int64_t fk_stride_k,
+                           double* fi, int64_t fi_stride_case,
+                           double* sens, int64_t sens_stride_case, int64_t sens_stride_k, int32_t* iterations_out) {
+    if (!h || !fk || !fi) { set_error("null argument"); return WLSQM_EVALUE; }
+    if (!h->ready) { set_error("Solver is not in the ready state; prepare() must be called before solve()"); return WLSQM_ERUNTIME; }   // expert.pyx:493-494
+    int rc = check_device(h->device);
+    if (rc != WLSQM_OK) return rc;
+    const int64_t n = h->ncases, K = h->max_nk; const int NO = h->max_no;
+    std::vector<double> s_fk((size_t)n * K, 0.0), s_fi((size_t)n * NO, 0.0);
+#pragma omp parallel for schedule(static)
+    for (int64_t j = 0; j < n; ++j) {
+        for (int64_t k = 0; k < h->nk[j]; ++k) s_fk[(size_t)j * K + k] = fk[j * fk_stride_case + k * fk_stride_k];
+        for (int a = 0; a < h->no[j]; ++a) s_fi[(size_t)j * NO + a] = fi[j * fi_stride_case + a];
+    }
+    hipStream_t s = nullptr;
+    const bool want_sens = h->do_sens && sens;
+    WLSQM_HIP_CHECK(hipMemcpyAsync(h->d_fk.p, s_fk.data(), h->d_fk.n, hipMemcpyHostToDevice, s));
+    WLSQM_HIP_CHECK(hipMemcpyAsync(h->d_fi.p, s_fi.data(), h->d_fi.n, hipMemcpyHostToDevice, s));
+    WLSQM_HIP_CHECK(hipMemsetAsync(h->d_it.p, 0, 4, s));
+    KParams p = expert_params(h, h->d_fk.as<double>(), K, h->d_fi.as<double>(), NO);
+    if (want_sens) { p.sens = h->d_sens.as<double>(); p.ss_j = K * NO; p.ss_k = NO; p.do_sens = 1; }
+    rc = expert_launch(h, p, s);
+    if (rc != WLSQM_OK) return rc;
+    std::vector<double> s_sens;
+    int h_it = 0;
+    WLSQM_HIP_CHECK(hipMemcpyAsync(s_fi.data(), h->d_fi.p, h->d_fi.n, hipMemcpyDeviceToHost, s));
+    if (want_sens) { s_sens.resize((size_t)n * K * NO); WLSQM_HIP_CHECK(hipMemcpyAsync(s_sens.data(), h->d_sens.p, h->d_sens.n, hipMemcpyDeviceToHost, s)); }
+    WLSQM_HIP_CHECK(hipMemcpyAsync(&h_it, h->d_it.p, 4, hipMemcpyDeviceToHost, s));
+    WLSQM_HIP_CHECK(hipStreamSynchronize(s));
+#pragma omp parallel for schedule(static)
+    for (int64_t j = 0; j < n; ++j) {
+        if (wlsqm_hip_number_of_reduced_dofs(h->no[j], h->kn[j]) < 1) continue;
+        unsigned long long known, dropped;
+        effective_mask_host(h->no[j], h->kn[j], known, dropped);
+        for (int a = 0; a < h->no[j]; ++a) fi[j * fi_stride_case + a] = s_fi[(size_t)j * NO + a];
+        if (want_sens)
+            for (int64_t k = 0; k < h->nk[j]; ++k)
+                for (int a = 0; a < h->no[j]; ++a) {
+                    if ((dropped >> a) & 1ull) continue;
+                    sens[j * sens_stride_case + k * sens_stride_k + a] = s_sens[((size_t)j * K + k) * NO + a];
+                }
+    }
+    if (iterations_out) *iterations_out = (h->algorithm == WLSQM_ALGO_ITERATIVE) ? h_it : 0;
+    return WLSQM_OK;
+}
+
+int wlsqm_hip_expert_solve_device(wlsqm_expert* h, void* stream, const double* fk, int64_t fk_stride_case,
+                                  double* fi, int64_t fi_stride_case) {
+    if (!h || !fk || !fi) { set_error("null argument"); return WLSQM_EVALUE; }
+    if (!h->ready) { set_error("Solver is not in the ready state; prepare() must be called before solve()"); return WLSQM_ERUNTIME; }
+    int rc = check_device(h->device);
+    if (rc != WLSQM_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    KParams p = expert_params(h, fk, fk_stride_case, fi, fi_stride_case);
+    p.iters_out = nullptr;
+    return expert_launch(h, p, s);
+}
+
+int wlsqm_hip_expert_memory_used(const wlsqm_expert* h, int64_t* used, int64_t* total) {
+    if (!h) { set_error("null handle"); return WLSQM_EVALUE; }
+    if (used) *used = h->bytes();
+    if (total) *total = h->bytes();      // expert.pyx:296-297: the buffer is exactly as large as needed
+    return WLSQM_OK;
+}
+
+int wlsqm_hip_expert_destroy(wlsqm_expert* h) {
+    if (!h) return WLSQM_OK;
+    (void)hipSetDevice(h->device);
+    delete h;
+    return WLSQM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,74 @@
+// wlsqm_internal.hpp — host-side declarations shared by the translation units of libwlsqm_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "wlsqm_hip.h"
+
+namespace wlsqm {
+
+// Kernel parameter block (by value).  Strides in elements.
+struct KParams {
+    const double* xk;  long long sxk_j, sxk_k;
+    const double* fk;  long long sfk_j, sfk_k;
+    const int* nk;     long long snk;
+    const double* xi;  long long sxi_j;
+    double* fi;        long long sfi_j;
+    double* sens;      long long ss_j, ss_k;
+    const long long* knowns; long long sknowns;
+    const int* wm;     long long swm;
+    const long long* case_index;   // nullable
+    long long ncases;              // cases this launch processes
+    int do_sens, iterative, max_iter;
+    int* iters_out;                // device int (atomicMax), nullable
+};
+
+void set_error(const std::string& msg);
+int hip_fail(hipError_t e, const char* what);
+
+// Launch the fit kernels for one (dimension, order) bucket.  Returns WLSQM_* code.
+// max_nk: extent of the neighbour axis (upper bound of nk[j]).
+int launch_fit(int dimension, int order, const KParams& p, long long max_nk, hipStream_t stream);
+
+// name of the kernel family the last launch_fit on this thread dispatched to ("lane", "tile", "wave")
+const char* last_kernel_name();
+void note_kernel(const char* name);
+
+// RAII device buffer
+struct DevBuf {
+    void* p = nullptr; size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) {
+        if (p) { (void)hipFree(p); p = nullptr; }
+        n = bytes;
+        if (bytes == 0) return WLSQM_OK;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) { p = nullptr; n = 0; return hip_fail(e, "hipMalloc"); }
+        return WLSQM_OK;
+    }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+int check_device(int device);
+
+// Host mirror of effective_mask() in wlsqm_kernels.hpp (infra.pyx:119-121 quirk): returns the
+// mask of DOFs the reference never writes (true knowns | dropped) and the dropped subset.
+inline void effective_mask_host(int no, long long raw, unsigned long long& known, unsigned long long& dropped) {
+    const unsigned long long full = (no >= 64) ? ~0ull : ((1ull << no) - 1ull);
+    known = (unsigned long long)raw & full; dropped = 0;
+    int extra = __builtin_popcountll((unsigned long long)raw & ~full);
+    for (int t = no - 1; t >= 0 && extra > 0; --t)
+        if (!((known >> t) & 1ull)) { known |= 1ull << t; dropped |= 1ull << t; --extra; }
+}
+
+}  // namespace wlsqm
+
+#define WLSQM_HIP_CHECK(expr)                                                   \
+    do {                                                                        \
+        hipError_t _e = (expr);                                                 \
+        if (_e != hipSuccess) return ::wlsqm::hip_fail(_e, #expr);              \
+    } while (0)

@@ -1,0 +1,114 @@
+"""ctypes binding of libwlsqm_hip.so (C ABI declared in include/wlsqm_hip.h).
+
+There is no CPU fallback: if the shared library is missing the import of any fitting
+entry point fails loudly, and if no HIP device is present the library itself returns
+WLSQM_ENODEVICE (raised here as RuntimeError).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "libwlsqm_hip.so")
+
+WLSQM_OK, WLSQM_EVALUE, WLSQM_ERUNTIME, WLSQM_EMEMORY, WLSQM_ENODEVICE = 0, -1, -2, -3, -4
+
+
+class Batch(C.Structure):
+    """struct wlsqm_batch (include/wlsqm_hip.h)."""
+    _fields_ = [
+        ("dimension", C.c_int32), ("do_sens", C.c_int32), ("ncases", C.c_int64),
+        ("xk", C.c_void_p), ("xk_stride_case", C.c_int64), ("xk_stride_k", C.c_int64),
+        ("fk", C.c_void_p), ("fk_stride_case", C.c_int64), ("fk_stride_k", C.c_int64),
+        ("nk", C.c_void_p), ("nk_stride", C.c_int64),
+        ("xi", C.c_void_p), ("xi_stride_case", C.c_int64),
+        ("fi", C.c_void_p), ("fi_stride_case", C.c_int64),
+        ("sens", C.c_void_p), ("sens_stride_case", C.c_int64), ("sens_stride_k", C.c_int64),
+        ("order", C.c_void_p), ("order_stride", C.c_int64),
+        ("knowns", C.c_void_p), ("knowns_stride", C.c_int64),
+        ("weighting_method", C.c_void_p), ("wm_stride", C.c_int64),
+        ("iterative", C.c_int32), ("max_iter", C.c_int32), ("max_nk", C.c_int64),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    """Load libwlsqm_hip.so; raises ImportError with build instructions if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "wlsqm: the HIP library %s is missing. Build it with python-wlsqm_amd/build.sh "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    L.wlsqm_hip_last_error.restype = C.c_char_p
+    L.wlsqm_hip_device_count.restype = C.c_int
+    L.wlsqm_hip_number_of_dofs.argtypes = [C.c_int, C.c_int]
+    L.wlsqm_hip_number_of_reduced_dofs.argtypes = [C.c_int, C.c_int64]
+    L.wlsqm_hip_remap.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int64]
+    L.wlsqm_hip_fit_many_host.argtypes = [C.POINTER(Batch), C.c_int, C.POINTER(C.c_int32)]
+    L.wlsqm_hip_fit_many_device.argtypes = [C.POINTER(Batch), C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                            C.c_int64, C.POINTER(C.c_int32)]
+    L.wlsqm_hip_time_fit_device.argtypes = [C.POINTER(Batch), C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                            C.POINTER(C.c_float)]
+    L.wlsqm_hip_expert_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.wlsqm_hip_expert_prepare.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64]
+    L.wlsqm_hip_expert_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,
+                                         C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_int32)]
+    L.wlsqm_hip_expert_solve_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
+    L.wlsqm_hip_expert_memory_used.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.wlsqm_hip_expert_destroy.argtypes = [C.c_void_p]
+    for name in ("wlsqm_hip_fit_many_host", "wlsqm_hip_fit_many_device", "wlsqm_hip_time_fit_device",
+                 "wlsqm_hip_expert_create", "wlsqm_hip_expert_prepare", "wlsqm_hip_expert_solve",
+                 "wlsqm_hip_expert_solve_device", "wlsqm_hip_expert_memory_used", "wlsqm_hip_expert_destroy",
+                 "wlsqm_hip_number_of_dofs", "wlsqm_hip_number_of_reduced_dofs", "wlsqm_hip_remap"):
+        getattr(L, name).restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(rc):
+    """Map a WLSQM_E* code to the exception class the reference raises (SURVEY §8b 'Errors')."""
+    if rc == WLSQM_OK:
+        return
+    msg = lib().wlsqm_hip_last_error().decode("utf-8", "replace")
+    if rc == WLSQM_EVALUE:
+        raise ValueError(msg)
+    if rc == WLSQM_EMEMORY:
+        raise MemoryError(msg)
+    raise RuntimeError(msg)
+
+
+def default_device():
+    return int(os.environ.get("WLSQM_HIP_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+
+
+# ---- argument coercion with the reference's typed-memoryview rules (SURVEY §8b 'Array typing') ----
+
+def view(a, dtype, ndim, name, contiguous_last=False, writable=False):
+    """np.ndarray view of `a` with Cython-memoryview-like checks: exact dtype, exact ndim, and
+    (when the reference declares ::view.contiguous) unit stride on the last axis."""
+    arr = np.asarray(a)
+    if arr.dtype != np.dtype(dtype):
+        raise ValueError("Buffer dtype mismatch, expected '%s' but got '%s' (argument %s)"
+                         % (np.dtype(dtype).name, arr.dtype.name, name))
+    if arr.ndim != ndim:
+        raise ValueError("Buffer has wrong number of dimensions (expected %d, got %d) (argument %s)"
+                         % (ndim, arr.ndim, name))
+    if contiguous_last and arr.shape[-1] > 1 and arr.strides[-1] != arr.itemsize:
+        raise ValueError("Buffer and memoryview are not contiguous in the same dimension. (argument %s)" % name)
+    if any(s % arr.itemsize for s in arr.strides):
+        raise ValueError("argument %s: strides must be multiples of the item size" % name)
+    if writable and not arr.flags.writeable:
+        raise ValueError("buffer source array is read-only (argument %s)" % name)
+    return arr
+
+
+def es(arr, axis):
+    """element stride"""
+    return arr.strides[axis] // arr.itemsize

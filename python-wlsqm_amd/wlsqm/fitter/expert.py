@@ -1,0 +1,159 @@
+"""Advanced API ("expert mode" in the LAPACK sense): separate prepare and solve stages.
+
+Drop-in mirror of the reference's wlsqm/fitter/expert.pyx (ExpertSolver, expert.pyx:66-655,
+and number_of_dofs, expert.pyx:57-63), backed by the MI355X HIP kernels.  The prepared
+geometry lives in HBM for the lifetime of the solver; ``solve()`` streams ``fk`` in and the
+coefficient array ``fi`` in/out.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import defs
+from .. import _binding as B
+
+__all__ = ["number_of_dofs", "ExpertSolver"]
+
+
+def number_of_dofs(dimension, order):
+    """Number of DOFs of the full polynomial for dimension (1,2,3) and order (0..4) (expert.pyx:57-63)."""
+    return B.lib().wlsqm_hip_number_of_dofs(int(dimension), int(order))
+
+
+class ExpertSolver:
+    """Prepare once (geometry), solve many times (data).  See the reference's expert.pyx:66-90.
+
+    s = ExpertSolver(...); s.prepare(xi, xk); s.solve(fk, fi[, sens])
+    """
+
+    def __init__(self, dimension, nk, order, knowns, weighting_method, algorithm=defs.ALGO_BASIC, do_sens=False,
+                 max_iter=10, ntasks=1, debug=False, host=None):
+        self._handle = None
+        nk = B.view(nk, np.int32, 1, "nk")
+        order = B.view(order, np.int32, 1, "order")
+        knowns = B.view(knowns, np.int64, 1, "knowns")
+        weighting_method = B.view(weighting_method, np.int32, 1, "weighting_method")
+        ncases = nk.shape[0]
+        if order.shape[0] != ncases or knowns.shape[0] != ncases or weighting_method.shape[0] != ncases:   # expert.pyx:131-132
+            raise ValueError("nk, order, knowns and weighting method must have the same length; currently, "
+                             "len(nk)=%d, len(order)=%d, len(knowns)=%d, len(weighting_method)=%d"
+                             % (nk.shape[0], order.shape[0], knowns.shape[0], weighting_method.shape[0]))
+        if dimension not in (1, 2, 3):                                                                    # :134-135
+            raise ValueError("Dimension must be 1, 2 or 3, got %d" % dimension)
+        for name, v in (("algorithm", algorithm), ("do_sens", do_sens), ("max_iter", max_iter),
+                        ("ntasks", ntasks), ("debug", debug)):                                             # :139-148
+            if v is None:
+                raise ValueError("%s cannot be None" % name)
+        if algorithm not in (defs.ALGO_BASIC, defs.ALGO_ITERATIVE):                                      # :151-156
+            raise ValueError("Unknown algorithm specifier %d; see wlsqm.fitter.defs for valid specifiers ALGO_*" % algorithm)
+        if ntasks < 1:                                                                                    # :158-159
+            raise ValueError("ntasks must be >= 1, got %d" % ntasks)
+        if host is not None:                                                                              # :163-189
+            if not host.ready:
+                raise RuntimeError("In guest mode, host must be in the ready state (host.prepare() must have been "
+                                   "called before creating another ExpertSolver instance in guest mode).")
+            if host.ncases != ncases:
+                raise RuntimeError("In guest mode, number of cases (number of elements in nk) must match; got %d, host has %d" % (ncases, host.ncases))
+            if host.dimension != dimension:
+                raise ValueError("In guest mode, dimension must match; got %d, host has %d" % (dimension, host.dimension))
+            if bool(host.debug) != bool(debug):
+                raise ValueError("In guest mode, debug flag must match; got %s, host has %s" % (bool(debug), bool(host.debug)))
+            for name, mine, theirs in (("nk", nk, host.nk), ("order", order, host.order), ("knowns", knowns, host.knowns),
+                                       ("weighting_method", weighting_method, host.weighting_method)):
+                if (np.asanyarray(theirs) != np.asanyarray(mine)).any():
+                    raise ValueError("In guest mode, '%s' must match element-by-element." % name)
+        self.host = host
+        self.ready = False
+        self.dimension, self.algorithm, self.max_iter = int(dimension), int(algorithm), int(max_iter)
+        self.ncases, self.do_sens, self.ntasks, self.debug = ncases, bool(do_sens), int(ntasks), bool(debug)
+        self.xk = self.xi = self.tree = None
+        self.nk, self.order, self.knowns, self.weighting_method = nk, order, knowns, weighting_method
+        self._max_nk = int(nk.max()) if ncases else 0
+        h = C.c_void_p()
+        B.check(B.lib().wlsqm_hip_expert_create(
+            C.byref(h), B.default_device(), self.dimension, ncases,
+            np.ascontiguousarray(nk).ctypes.data, np.ascontiguousarray(order).ctypes.data,
+            np.ascontiguousarray(knowns).ctypes.data, np.ascontiguousarray(weighting_method).ctypes.data,
+            self.algorithm, int(self.do_sens), self.max_iter))
+        self._handle = h
+        if host is not None:
+            self.tree = host.tree
+
+    def close(self):
+        """Release the device-side state now (also done by __del__; expert.pyx:267-286)."""
+        if getattr(self, "_handle", None):
+            B.lib().wlsqm_hip_expert_destroy(self._handle)
+            self._handle = None
+            self.ready = False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def memory_used(self):
+        """(bytes in use, bytes reserved) of the device-side state (expert.pyx:289-306)."""
+        used, total = C.c_int64(0), C.c_int64(0)
+        B.check(B.lib().wlsqm_hip_expert_memory_used(self._handle, C.byref(used), C.byref(total)))
+        return (int(used.value), int(total.value))
+
+    def prepare(self, xi, xk):
+        """Upload the geometry (expert.pyx:309-426).  In guest mode the host's xi/xk are used (:350-352)."""
+        self.ready = False
+        if self.host is not None:
+            xi, xk = self.host.xi, self.host.xk
+        if self.dimension == 1:
+            xiv = B.view(xi, np.float64, 1, "xi")
+            xkv = B.view(xk, np.float64, 2, "xk")
+        else:
+            xiv = B.view(xi, np.float64, 2, "xi", contiguous_last=True)
+            xkv = B.view(xk, np.float64, 3, "xk", contiguous_last=True)
+            if xiv.shape[1] < self.dimension or xkv.shape[2] < self.dimension:
+                raise ValueError("xi/xk must have %d coordinates on the last axis" % self.dimension)
+        if xiv.shape[0] < self.ncases or xkv.shape[0] < self.ncases:
+            raise ValueError("xi/xk have fewer rows than ncases")
+        if xkv.shape[1] < self._max_nk:
+            raise ValueError("max(nk) = %d exceeds the neighbour axis of xk (%d)" % (self._max_nk, xkv.shape[1]))
+        B.check(B.lib().wlsqm_hip_expert_prepare(self._handle, xiv.ctypes.data, B.es(xiv, 0), xkv.ctypes.data,
+                                                 B.es(xkv, 0), B.es(xkv, 1), xkv.shape[1]))
+        self.xk, self.xi = xk, xi                                                                      # :387-388
+        if self.host is None:
+            self.tree = None
+        self.ready = True
+
+    def conds(self):
+        """2-norm condition numbers of the scaled problem matrices (expert.pyx:429-464).  Debug-only in the
+        reference (two dgesvd per case, impl.pyx:662-682); not provided by the HIP backend yet."""
+        if not self.ready:
+            raise RuntimeError("Solver is not in the ready state; prepare() must be called before conds()")
+        if not self.debug:
+            raise RuntimeError("Not in debug mode; condition number data has not been computed")
+        raise NotImplementedError("conds() (debug-mode SVD condition numbers) is not implemented in the HIP backend")
+
+    def solve(self, fk, fi, sens=None):
+        """Fit all cases to the data fk on the prepared geometry (expert.pyx:467-655).  Returns the maximum
+        number of refinement iterations taken (0 for ALGO_BASIC)."""
+        if not self.ready:
+            raise RuntimeError("Solver is not in the ready state; prepare() must be called before solve()")
+        fkv = B.view(fk, np.float64, 2, "fk")
+        fiv = B.view(fi, np.float64, 2, "fi", contiguous_last=True, writable=True)
+        if fkv.shape[0] < self.ncases or fiv.shape[0] < self.ncases:
+            raise ValueError("fk/fi have fewer rows than ncases")
+        if fkv.shape[1] < self._max_nk:
+            raise ValueError("max(nk) = %d exceeds the neighbour axis of fk" % self._max_nk)
+        max_no = max(number_of_dofs(self.dimension, int(o)) for o in np.unique(self.order))
+        if fiv.shape[1] < max_no:
+            raise ValueError("fi has %d columns, need at least %d" % (fiv.shape[1], max_no))
+        sp, ssj, ssk = None, 0, 0
+        if self.do_sens:
+            if sens is None:
+                raise ValueError("do_sens is set but sens is None")
+            sv = B.view(sens, np.float64, 3, "sens", contiguous_last=True, writable=True)
+            if sv.shape[0] < self.ncases or sv.shape[1] < self._max_nk or sv.shape[2] < max_no:
+                raise ValueError("sens is too small")
+            sp, ssj, ssk = sv.ctypes.data, B.es(sv, 0), B.es(sv, 1)
+        its = C.c_int32(0)
+        B.check(B.lib().wlsqm_hip_expert_solve(self._handle, fkv.ctypes.data, B.es(fkv, 0), B.es(fkv, 1),
+                                               fiv.ctypes.data, B.es(fiv, 0), sp, ssj, ssk, C.byref(its)))
+        return int(its.value)

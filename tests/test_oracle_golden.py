@@ -1,0 +1,154 @@
+"""Pins the CPU oracle (oracle/wlsqm_oracle.c) against golden vectors captured from the real
+reference (tests/golden/make_golden.py).  CPU only.  If these pass, oracle == reference up to the
+LAPACK rounding order, and the GPU parity tests may use the oracle as the checker at any size."""
+import numpy as np
+import pytest
+
+import _cases as K
+import _parity as P
+from oracle import oracle
+
+EPS = np.finfo(np.float64).eps
+
+
+def test_number_of_dofs_table():
+    # reference tests/test_package.py:47-53
+    for dim in (1, 2, 3):
+        assert [oracle.number_of_dofs(dim, k) for k in range(5)] == K.NDOF[dim]
+    assert oracle.number_of_dofs(4, 2) == -1 and oracle.number_of_dofs(2, 5) == -2   # infra.pyx:68-73
+
+
+def test_remap_bit_exact():
+    tab = K.golden("remap.npz")["table"]
+    for row in tab:
+        n, mask, nr = int(row[0]), int(row[1]), int(row[2])
+        k, o2r, r2o = oracle.remap(n, mask)
+        assert k == nr
+        assert np.array_equal(o2r, row[3:3 + n]) and np.array_equal(r2o, row[38:38 + n])
+
+
+@pytest.mark.parametrize("dim", [1, 2, 3])
+def test_sweep_intermediates_and_fi(dim):
+    d = K.sweep(dim)
+    fi = d["fi_in"].copy()
+    rc, cap = oracle.fit_many(dim, d["xk"], d["fk"], d["nk"], d["xi"], fi, None, 0, d["order"], d["knowns"], d["wm"],
+                              debug_capture=True)
+    assert rc == 0
+    # index work: bit-exact
+    for k in ("o2r", "r2o", "ipiv"):
+        assert np.array_equal(cap[k], d[k]), k
+    # arithmetic before the LAPACK call: bit-exact with the reference build
+    for k in ("c", "w", "A", "row_scale", "col_scale"):
+        assert np.array_equal(cap[k], d[k]), k
+    # (fi itself is judged in test_sweep_noise_floor_parity: LU/solution differ by LAPACK's rounding order)
+    n = len(d["nk"])
+    # knowns untouched (bit-identical), columns beyond `no` untouched
+    for j in range(n):
+        no = K.NDOF[dim][int(d["order"][j])]
+        for a in range(no):
+            if (int(d["knowns"][j]) >> a) & 1:
+                assert fi[j, a] == d["fi_in"][j, a]
+        assert np.array_equal(fi[j, no:], d["fi_in"][j, no:])
+
+
+@pytest.mark.parametrize("dim", [1, 2, 3])
+def test_sweep_noise_floor_parity(dim):
+    """Same sweep, judged with the extended-precision noise floor, grouped by order."""
+    d = K.sweep(dim)
+    fi = d["fi_in"].copy()
+    oracle.fit_many(dim, d["xk"], d["fk"], d["nk"], d["xi"], fi, None, 0, d["order"], d["knowns"], d["wm"])
+    truth = P.truth_fit(dim, d["xk"], d["fk"], d["nk"], d["xi"], d["fi_in"], d["order"], d["knowns"], d["wm"])
+    for o in range(5):
+        sel = d["order"] == o
+        no = K.NDOF[dim][o]
+        P.assert_parity(fi[sel, :no], d["fi"][sel, :no], truth[sel, :no], "sweep dim %d order %d" % (dim, o))
+
+
+@pytest.mark.parametrize("dim", [1, 2, 3])
+def test_sweep_sens(dim):
+    d = K.sweep(dim)
+    fi = d["fi_in"].copy()
+    sens = np.full(d["sens"].shape, 777.0)
+    oracle.fit_many(dim, d["xk"], d["fk"], d["nk"], d["xi"], fi, sens, 1, d["order"], d["knowns"], d["wm"])
+    assert np.array_equal(np.isnan(sens), np.isnan(d["sens"]))
+    assert np.array_equal(sens == 777.0, d["sens"] == 777.0)          # never-written entries stay untouched
+    for j in range(len(d["nk"])):
+        no = K.NDOF[dim][int(d["order"][j])]
+        kappa = K.scaled_cond(d, j, no, d["knowns"][j])
+        a, b = sens[j], d["sens"][j]
+        m = ~np.isnan(b) & (b != 777.0)
+        if m.any():
+            assert np.abs(a[m] - b[m]).max() <= (1e-10 + 1e3 * kappa * EPS) * np.abs(b[m]).max(), (j, kappa)
+
+
+@pytest.mark.parametrize("dim", [1, 2, 3])
+def test_sweep_iterative(dim):
+    d = K.sweep(dim)
+    fi = d["fi_in"].copy()
+    it = oracle.fit_many(dim, d["xk"], d["fk"], d["nk"], d["xi"], fi, None, 0, d["order"], d["knowns"], d["wm"],
+                         iterative=True, max_iter=10)
+    assert it == int(d["iters"])
+    truth = P.truth_fit(dim, d["xk"], d["fk"], d["nk"], d["xi"], d["fi_in"], d["order"], d["knowns"], d["wm"])
+    for o in range(5):
+        sel = d["order"] == o
+        no = K.NDOF[dim][o]
+        P.assert_parity(fi[sel, :no], d["fi_iter"][sel, :no], truth[sel, :no], "iter sweep dim %d order %d" % (dim, o))
+
+
+@pytest.mark.parametrize("name", K.CONFIGS)
+def test_config_parity(name):
+    c = K.config(name)
+    g = c["g"]
+    truth = P.truth_fit(c["dim"], c["xk"], c["fk"], c["nk_a"], c["xi"], c["fi0"], c["order_a"], c["knowns_a"], c["wm_a"])
+    fi = c["fi0"].copy()
+    oracle.fit_many(c["dim"], c["xk"], c["fk"], c["nk_a"], c["xi"], fi, None, 0, c["order_a"], c["knowns_a"], c["wm_a"],
+                    ntasks=4)
+    P.assert_parity(fi, g["fi"], truth, name)
+    fi2 = c["fi0"].copy()
+    it = oracle.fit_many(c["dim"], c["xk"], c["fk"], c["nk_a"], c["xi"], fi2, None, 0, c["order_a"], c["knowns_a"],
+                         c["wm_a"], iterative=True, max_iter=10, ntasks=4)
+    assert it == int(g["iters"])
+    P.assert_parity(fi2, g["fi_iter"], truth, name + " iterative")
+    ns = g["sens"].shape[0]
+    fi3 = c["fi0"][:ns].copy()
+    sens = np.zeros(g["sens"].shape)
+    oracle.fit_many(c["dim"], c["xk"][:ns], c["fk"][:ns], c["nk_a"][:ns], c["xi"][:ns], fi3, sens, 1,
+                    c["order_a"][:ns], c["knowns_a"][:ns], c["wm_a"][:ns])
+    m = ~np.isnan(g["sens"])
+    assert np.array_equal(np.isnan(sens), ~m)
+    assert np.abs(sens[m] - g["sens"][m]).max() <= 1e-10 * np.abs(g["sens"][m]).max()
+
+
+def test_edge_iter_quirk_and_stencil():
+    e = K.golden("edge.npz")
+    xk, fk = e["iter_xk"], e["iter_fk"]
+    for mi in (0, 1, 2, 10):
+        fi = np.zeros((1, 6))
+        it = oracle.fit_many(2, xk[None], fk[None], np.array([20], np.int32), np.zeros((1, 2)), fi, None, 0,
+                             np.array([2], np.int32), np.array([0], np.int64), np.array([2], np.int32),
+                             iterative=True, max_iter=mi)
+        ref_it = int(e["iter_mi%d_it" % mi])
+        if mi <= 1:
+            assert it == ref_it == 1                            # for/else quirk (impl.pyx:1080-1081): max_iter=0 returns 1
+        else:
+            # the stop test is exact fp equality of two residual norms (impl.pyx:1057): the count depends on the
+            # last bits of LAPACK's rounding order, so only its range is implementation-independent
+            assert 1 <= it <= mi and 1 <= ref_it <= mi
+        assert np.allclose(fi[0], e["iter_mi%d_fi" % mi], rtol=1e-12, atol=1e-13)
+    fi = np.zeros((1, 6))
+    oracle.fit_many(2, e["stencil_xk"][None], e["stencil_fk"][None], np.array([5], np.int32), np.zeros((1, 2)), fi,
+                    None, 0, np.array([2], np.int32), np.array([1 << 4], np.int64), np.array([1], np.int32))
+    assert fi[0, 4] == 0.0                                      # known b2_XY stays bit-identical (test_stencil.py:145)
+    assert np.allclose(fi[0], e["stencil_fi"], rtol=1e-11, atol=1e-12)
+
+
+def test_edge_strided_views():
+    e = K.golden("edge.npz")
+    n, nk = 12, 14
+    xkv = e["strided_big_xk"][::2, ::2, :]; fkv = e["strided_big_fk"][::2, ::2]
+    big_fi = np.zeros((2 * n, 8)); fiv = big_fi[::2, :6]
+    o = np.full(2 * n, 2, np.int32)[::2]; kn = np.zeros(2 * n, np.int64)[::2]
+    w = np.full(2 * n, 2, np.int32)[::2]; nka = np.full(2 * n, nk, np.int32)[::2]
+    oracle.fit_many(2, xkv, fkv, nka, e["strided_xi"], fiv, None, 0, o, kn, w)
+    assert np.allclose(big_fi, e["strided_big_fi_after"], rtol=1e-11, atol=1e-13)
+    assert np.all(big_fi[1::2] == 0) and np.all(big_fi[:, 6:] == 0)   # nothing outside the view is touched
