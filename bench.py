@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""bench.py — whole-job throughput of the WLSQM hot path on N MI355X of one node.
+
+A "step" is one pass of the fused assemble+factor+solve kernel over one batch of synthetic local
+fits (inputs resident in HBM before the timed region starts).  Default workload = BASELINE.json
+configs[1] ("C2"): 2D order-2, 1M Halton points, 32 nearest neighbours, WEIGHT_CENTER, all DOFs
+unknown.  One process per GPU; for N > 1 the driver launches this file under torch.distributed.run
+and every rank fits its own 1M-case shard (independent local problems: no data-path collective,
+"weak" scaling).
+
+Prints ONE JSON line on rank 0 (see DESIGN.md §Measurement for every field).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "python-wlsqm_amd"))
+
+import synth  # noqa: E402
+
+# BASELINE.json configs -> (dim, order, nk, weighting, knowns); B_fit from SURVEY.md §8d
+CONFIGS = {
+    "C1": dict(dim=1, order=2, nk=8, wm=1, knowns=0, desc="1D order-2, 8 neighbours, WEIGHT_UNIFORM"),
+    "C2": dict(dim=2, order=2, nk=32, wm=2, knowns=0, desc="2D order-2, Halton, 32 neighbours, WEIGHT_CENTER, all DOFs unknown"),
+    "C3": dict(dim=2, order=4, nk=64, wm=2, knowns=1, desc="2D order-4, Halton, 64 neighbours, WEIGHT_CENTER, F known"),
+    "C5": dict(dim=3, order=2, nk=40, wm=2, knowns=0, desc="3D order-2, Halton, 40 neighbours, WEIGHT_CENTER, all DOFs unknown"),
+}
+NDOF = {1: [1, 2, 3, 4, 5], 2: [1, 3, 6, 10, 15], 3: [1, 4, 10, 20, 35]}
+HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def bytes_per_fit(dim, order, nk, knowns):
+    """Algorithmic HBM bytes per fit, dense reference layout:
+    8 nk (dim+1) [xk+fk] + 8 dim [xi] + 8 no [fi out] + 8 popcount(knowns) [fi in] + 20 [nk, order, knowns, wm]."""
+    no = NDOF[dim][order]
+    return 8 * nk * (dim + 1) + 8 * dim + 8 * no + 8 * bin(knowns).count("1") + 20
+
+
+def build_problem(cfg, ncases, rank):
+    dim, nk = cfg["dim"], cfg["nk"]
+    if dim == 1:
+        p = synth.line_problem_1d(ncases, nk // 2, seed=rank)
+        return p["S"], p["F"], p["hoods"]
+    S = synth.halton(ncases, dim, skip=1 + rank * ncases)       # each rank owns a different stretch of the sequence
+    F = synth.field(S)
+    hoods = synth.knn(S, nk)
+    return S, F, hoods
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
+    ap.add_argument("--ncases", type=int, default=1_000_000, help="local fits per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    import wlsqm.hip as whip
+    cfg = CONFIGS[a.config]
+    dim, order, nk, n = cfg["dim"], cfg["order"], cfg["nk"], a.ncases
+    no = NDOF[dim][order]
+    S, F, hoods = build_problem(cfg, n, rank)
+
+    # device-resident inputs in the reference's dense layout: xk = S[hoods], fk = F[hoods]  (gathered on the GPU)
+    S_d = torch.from_numpy(np.ascontiguousarray(S)).to(dev)
+    F_d = torch.from_numpy(F).to(dev)
+    h_d = torch.from_numpy(hoods.astype(np.int64)).to(dev)
+    xk_d = S_d[h_d].contiguous()
+    fk_d = F_d[h_d].contiguous()
+    xi_d = S_d.clone()
+    fi_d = torch.zeros((n, no), dtype=torch.float64, device=dev)
+    fi_d[:, 0] = F_d
+    nk_d = torch.full((n,), nk, dtype=torch.int32, device=dev)
+    kn_d = torch.full((n,), cfg["knowns"], dtype=torch.int64, device=dev)
+    wm_d = torch.full((n,), cfg["wm"], dtype=torch.int32, device=dev)
+    del h_d
+    args = (dim, order, xk_d, fk_d, nk_d, xi_d, fi_d, kn_d, wm_d)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        whip.fit_many_device(*args)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        whip.fit_many_device(*args)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # dominant kernel, timed live with HIP events on the stream it is launched on
+    ms_kernel = whip.time_fit_device(*args, reps=max(a.steps, 5))
+    B_fit = bytes_per_fit(dim, order, nk, cfg["knowns"])
+    achieved = B_fit * n / (ms_kernel * 1e-3) / 1e9
+
+    out = None
+    if rank == 0:
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic_%s.json" % a.config)
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "local fits/s (whole node)", "value": world * n * a.steps / dt, "unit": "fits/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s: %s; %d local fits per GPU per step, device-resident dense xk/fk"
+                       % (a.config, cfg["desc"], n), "fits_per_gpu": n, "bytes_per_fit": B_fit},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "kernel_ms": ms_kernel},
+        }
+        # spot parity check of this very run against the CPU oracle (checker only)
+        from oracle import oracle
+        ns = min(n, 4096)
+        fi_g = fi_d[:ns].cpu().numpy()
+        xk_h = xk_d[:ns].cpu().numpy(); fk_h = fk_d[:ns].cpu().numpy(); xi_h = xi_d[:ns].cpu().numpy()
+        fi_o = np.zeros((ns, no)); fi_o[:, 0] = F[:ns]
+        meta = (np.full(ns, nk, np.int32), np.full(ns, order, np.int32), np.full(ns, cfg["knowns"], np.int64),
+                np.full(ns, cfg["wm"], np.int32))
+        oracle.fit_many(dim, xk_h, fk_h, meta[0], xi_h, fi_o, None, 0, meta[1], meta[2], meta[3], ntasks=8)
+        scale = np.abs(fi_o).max(axis=0); scale[scale == 0] = 1.0
+        out["parity_vs_oracle_colmax"] = float((np.abs(fi_g - fi_o).max(axis=0) / scale).max())
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(oracle, cfg, xk_d, fk_d, xi_d, F, n, no)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(oracle, cfg, xk_d, fk_d, xi_d, F, n, no):
+    """The CPU oracle (a restatement of the reference's Cython/OpenMP/LAPACK path, kind "port") timed on this
+    box's host cores on a bounded sample of the same workload."""
+    dim, order, nk = cfg["dim"], cfg["order"], cfg["nk"]
+    cores = len(os.sched_getaffinity(0))
+    ns = min(n, 400_000)
+    xk_h = xk_d[:ns].cpu().numpy(); fk_h = fk_d[:ns].cpu().numpy(); xi_h = xi_d[:ns].cpu().numpy()
+    meta = (np.full(ns, nk, np.int32), np.full(ns, order, np.int32), np.full(ns, cfg["knowns"], np.int64),
+            np.full(ns, cfg["wm"], np.int32))
+    best, reps, t_all = 0.0, 0, time.perf_counter()
+    while True:
+        fi = np.zeros((ns, no)); fi[:, 0] = F[:ns]
+        t0 = time.perf_counter()
+        oracle.fit_many(dim, xk_h, fk_h, meta[0], xi_h, fi, None, 0, meta[1], meta[2], meta[3], ntasks=cores)
+        dt = time.perf_counter() - t0
+        best = max(best, ns / dt); reps += 1
+        if reps >= 3 and time.perf_counter() - t_all > 5.0 or reps >= 20:
+            break
+    return {"value": best, "unit": "fits/s", "cores": cores, "kind": "port",
+            "sample": "%d cases of the same workload, best of %d passes, OpenMP static schedule over %d threads"
+                      % (ns, reps, cores)}
+
+
+if __name__ == "__main__":
+    main()

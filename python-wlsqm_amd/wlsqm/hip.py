@@ -1,0 +1,100 @@
+"""Device-resident entry points of the HIP backend (extension to the reference surface).
+
+The reference API (wlsqm.fitter.simple / expert) takes host arrays, so every call pays PCIe for
+8*nk*(dim+1) bytes per case.  These functions take arrays that already live in HBM — torch CUDA
+tensors, or anything exposing ``data_ptr()``/``stride()``/``shape``/``dtype`` the same way — and
+enqueue the same kernels on the caller's HIP stream with no host synchronisation.  torch is used
+only as the owner of device memory and streams.
+"""
+import ctypes as C
+
+from . import _binding as B
+
+__all__ = ["fit_many_device", "time_fit_device", "device_count"]
+
+
+def device_count():
+    return B.lib().wlsqm_hip_device_count()
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _check(t, name, dtype_name, ndim):
+    if str(t.dtype).split(".")[-1] != dtype_name:
+        raise ValueError("Buffer dtype mismatch, expected '%s' but got '%s' (argument %s)" % (dtype_name, t.dtype, name))
+    if t.dim() != ndim:
+        raise ValueError("Buffer has wrong number of dimensions (expected %d, got %d) (argument %s)" % (ndim, t.dim(), name))
+    if not t.is_cuda:
+        raise ValueError("argument %s must be a device (HIP) tensor" % name)
+
+
+def _batch(dimension, xk, fk, nk, xi, fi, knowns, weighting_method, sens, iterative, max_iter, order_dummy):
+    ncases = nk.shape[0]
+    _check(nk, "nk", "int32", 1); _check(knowns, "knowns", "int64", 1); _check(weighting_method, "weighting_method", "int32", 1)
+    _check(fk, "fk", "float64", 2); _check(fi, "fi", "float64", 2)
+    if dimension == 1:
+        _check(xk, "xk", "float64", 2); _check(xi, "xi", "float64", 1)
+    else:
+        _check(xk, "xk", "float64", 3); _check(xi, "xi", "float64", 2)
+        if xk.stride(2) != 1 or xi.stride(1) != 1:
+            raise ValueError("Buffer and memoryview are not contiguous in the same dimension.")
+    if fi.stride(1) != 1:
+        raise ValueError("Buffer and memoryview are not contiguous in the same dimension. (argument fi)")
+    b = B.Batch()
+    b.dimension, b.ncases = dimension, ncases
+    b.xk, b.xk_stride_case, b.xk_stride_k = xk.data_ptr(), xk.stride(0), xk.stride(1)
+    b.fk, b.fk_stride_case, b.fk_stride_k = fk.data_ptr(), fk.stride(0), fk.stride(1)
+    b.nk, b.nk_stride = nk.data_ptr(), nk.stride(0)
+    b.xi, b.xi_stride_case = xi.data_ptr(), xi.stride(0)
+    b.fi, b.fi_stride_case = fi.data_ptr(), fi.stride(0)
+    if sens is not None:
+        _check(sens, "sens", "float64", 3)
+        b.do_sens = 1
+        b.sens, b.sens_stride_case, b.sens_stride_k = sens.data_ptr(), sens.stride(0), sens.stride(1)
+    # the per-case order array is not read on this path (order_uniform is); point it somewhere valid
+    b.order, b.order_stride = order_dummy.data_ptr(), 0
+    b.knowns, b.knowns_stride = knowns.data_ptr(), knowns.stride(0)
+    b.weighting_method, b.wm_stride = weighting_method.data_ptr(), weighting_method.stride(0)
+    b.iterative, b.max_iter, b.max_nk = (1 if iterative else 0), int(max_iter), int(fk.shape[1])
+    return b
+
+
+def _stream_and_device(t, stream):
+    import torch
+    dev = t.device.index if t.device.index is not None else torch.cuda.current_device()
+    if stream is None:
+        stream = torch.cuda.current_stream(dev).cuda_stream
+    return C.c_void_p(int(stream) if stream else 0), dev
+
+
+def fit_many_device(dimension, order, xk, fk, nk, xi, fi, knowns, weighting_method, sens=None, iterative=False,
+                    max_iter=10, case_index=None, stream=None, want_iterations=False):
+    """fit_{1,2,3}D[_iterative]_many on device-resident tensors, all cases of polynomial order `order`.
+
+    xk (n, K, dim) [1D: (n, K)], fk (n, K), nk (n,) int32, xi (n, dim) [1D: (n,)], fi (n, >=no) in/out,
+    knowns (n,) int64, weighting_method (n,) int32, sens (n, K, >=no) or None.  `case_index` (int64 device
+    tensor) restricts the launch to those cases (used to bucket heterogeneous orders).  Asynchronous on
+    `stream` (default: torch's current stream) unless want_iterations=True.  The caller guarantees that
+    fk/xk do not alias fi (outputs are written in place)."""
+    b = _batch(dimension, xk, fk, nk, xi, fi, knowns, weighting_method, sens, iterative, max_iter, nk)
+    s, dev = _stream_and_device(fi, stream)
+    its = C.c_int32(0)
+    nsel = 0
+    ci = None
+    if case_index is not None:
+        _check(case_index, "case_index", "int64", 1)
+        ci, nsel = C.c_void_p(case_index.data_ptr()), int(case_index.shape[0])
+    B.check(B.lib().wlsqm_hip_fit_many_device(C.byref(b), dev, s, int(order), ci, nsel,
+                                              C.byref(its) if want_iterations else None))
+    return int(its.value)
+
+
+def time_fit_device(dimension, order, xk, fk, nk, xi, fi, knowns, weighting_method, reps=10, stream=None):
+    """Mean duration in milliseconds of one fit launch (HIP events on `stream`, `reps` back-to-back launches)."""
+    b = _batch(dimension, xk, fk, nk, xi, fi, knowns, weighting_method, None, False, 0, nk)
+    s, dev = _stream_and_device(fi, stream)
+    ms = C.c_float(0.0)
+    B.check(B.lib().wlsqm_hip_time_fit_device(C.byref(b), dev, s, int(order), int(reps), C.byref(ms)))
+    return float(ms.value)

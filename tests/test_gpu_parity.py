@@ -1,0 +1,251 @@
+"""GPU parity tests: the HIP path (through the C ABI, via the reference-mirror Python API) against
+ (1) the golden vectors captured from the real reference, (2) the CPU oracle on the same seeded
+inputs, (3) the extended-precision noise floor.  Tolerance: 1e-10 relative per DOF column
+(BASELINE.json north_star), widened only by the reference's own fp64 noise — see tests/_parity.py.
+Known DOFs must come back bit-identical."""
+import numpy as np
+import pytest
+
+import _cases as K
+import _parity as P
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def wlsqm():
+    import wlsqm as W
+    from wlsqm import _binding
+    assert _binding.lib().wlsqm_hip_device_count() >= 1, "no HIP device: the GPU tests need a real MI355X"
+    return W
+
+
+def _many(W, dim, variant="_many_parallel"):
+    return getattr(W, "fit_%dD%s" % (dim, variant))
+
+
+def _check_untouched(fi, fi_in, order, knowns, dim):
+    for j in range(len(order)):
+        no = K.NDOF[dim][int(order[j])]
+        kn = int(knowns[j])
+        for a in range(no):
+            if (kn >> a) & 1:
+                assert fi[j, a] == fi_in[j, a], "known DOF modified"
+        assert np.array_equal(fi[j, no:], fi_in[j, no:]), "columns beyond `no` modified"
+
+
+@pytest.mark.parametrize("dim", [1, 2, 3])
+def test_sweep_basic(wlsqm, dim):
+    """Heterogeneous batch: all orders x both weightings x knowns-mask sweep x ragged nk."""
+    d = K.sweep(dim)
+    fi = d["fi_in"].copy()
+    rc = _many(wlsqm, dim)(xk=d["xk"], fk=d["fk"], nk=d["nk"], xi=d["xi"], fi=fi, sens=None, do_sens=0,
+                           order=d["order"], knowns=d["knowns"], weighting_method=d["wm"], ntasks=8)
+    assert rc == 0
+    _check_untouched(fi, d["fi_in"], d["order"], d["knowns"], dim)
+    truth = P.truth_fit(dim, d["xk"], d["fk"], d["nk"], d["xi"], d["fi_in"], d["order"], d["knowns"], d["wm"])
+    for o in range(5):
+        sel = d["order"] == o
+        no = K.NDOF[dim][o]
+        P.assert_parity(fi[sel, :no], d["fi"][sel, :no], truth[sel, :no], "sweep dim %d order %d" % (dim, o))
+
+
+@pytest.mark.parametrize("dim", [1, 2, 3])
+def test_sweep_sens(wlsqm, dim):
+    d = K.sweep(dim)
+    fi = d["fi_in"].copy()
+    sens = np.full(d["sens"].shape, 777.0)
+    _many(wlsqm, dim, "_many")(xk=d["xk"], fk=d["fk"], nk=d["nk"], xi=d["xi"], fi=fi, sens=sens, do_sens=1,
+                               order=d["order"], knowns=d["knowns"], weighting_method=d["wm"])
+    assert np.array_equal(np.isnan(sens), np.isnan(d["sens"]))           # NaN for knowns (impl.pyx:821-823)
+    assert np.array_equal(sens == 777.0, d["sens"] == 777.0)              # padding (k >= nk, n >= no) untouched
+    eps = np.finfo(float).eps
+    for j in range(len(d["nk"])):
+        no = K.NDOF[dim][int(d["order"][j])]
+        kappa = K.scaled_cond(d, j, no, d["knowns"][j])
+        a, b = sens[j], d["sens"][j]
+        m = ~np.isnan(b) & (b != 777.0)
+        if m.any():
+            assert np.abs(a[m] - b[m]).max() <= (1e-10 + 1e3 * kappa * eps) * np.abs(b[m]).max(), (j, kappa)
+
+
+@pytest.mark.parametrize("dim", [1, 2, 3])
+def test_sweep_iterative(wlsqm, dim):
+    d = K.sweep(dim)
+    fi = d["fi_in"].copy()
+    it = _many(wlsqm, dim, "_iterative_many_parallel")(
+        xk=d["xk"], fk=d["fk"], nk=d["nk"], xi=d["xi"], fi=fi, sens=None, do_sens=0, order=d["order"],
+        knowns=d["knowns"], weighting_method=d["wm"], max_iter=10, ntasks=8)
+    assert 1 <= it <= 10
+    _check_untouched(fi, d["fi_in"], d["order"], d["knowns"], dim)
+    truth = P.truth_fit(dim, d["xk"], d["fk"], d["nk"], d["xi"], d["fi_in"], d["order"], d["knowns"], d["wm"])
+    for o in range(5):
+        sel = d["order"] == o
+        no = K.NDOF[dim][o]
+        P.assert_parity(fi[sel, :no], d["fi_iter"][sel, :no], truth[sel, :no], "iter sweep dim %d order %d" % (dim, o))
+
+
+@pytest.mark.parametrize("name", K.CONFIGS)
+def test_config_vs_reference_golden(wlsqm, name):
+    """BASELINE.json configs (reduced case count): golden fi from the reference's fit_*_many_parallel."""
+    c = K.config(name)
+    g = c["g"]
+    dim = c["dim"]
+    truth = P.truth_fit(dim, c["xk"], c["fk"], c["nk_a"], c["xi"], c["fi0"], c["order_a"], c["knowns_a"], c["wm_a"])
+    fi = c["fi0"].copy()
+    _many(wlsqm, dim)(xk=c["xk"], fk=c["fk"], nk=c["nk_a"], xi=c["xi"], fi=fi, sens=None, do_sens=0,
+                      order=c["order_a"], knowns=c["knowns_a"], weighting_method=c["wm_a"])
+    E = P.assert_parity(fi, g["fi"], truth, name)
+    N = P.column_metric(g["fi"], truth)
+    print("%s: column metric max %.2e (reference fp64 noise floor %.2e)" % (name, E.max(), N.max()))
+    # iterative variant
+    fi2 = c["fi0"].copy()
+    it = _many(wlsqm, dim, "_iterative_many_parallel")(
+        xk=c["xk"], fk=c["fk"], nk=c["nk_a"], xi=c["xi"], fi=fi2, sens=None, do_sens=0, order=c["order_a"],
+        knowns=c["knowns_a"], weighting_method=c["wm_a"], max_iter=10)
+    assert 1 <= it <= 10
+    P.assert_parity(fi2, g["fi_iter"], truth, name + " iterative")
+    # sensitivities (first cases)
+    ns = g["sens"].shape[0]
+    fi3 = c["fi0"][:ns].copy()
+    sens = np.zeros(g["sens"].shape)
+    _many(wlsqm, dim, "_many")(xk=c["xk"][:ns], fk=c["fk"][:ns], nk=c["nk_a"][:ns], xi=c["xi"][:ns], fi=fi3, sens=sens,
+                               do_sens=1, order=c["order_a"][:ns], knowns=c["knowns_a"][:ns],
+                               weighting_method=c["wm_a"][:ns])
+    m = ~np.isnan(g["sens"])
+    assert np.array_equal(np.isnan(sens), ~m)
+    kap = float(np.max(g["conds"][:ns]))
+    assert np.abs(sens[m] - g["sens"][m]).max() <= (1e-10 + 1e3 * kap * np.finfo(float).eps) * np.abs(g["sens"][m]).max()
+
+
+@pytest.mark.parametrize("name", ["C2", "C3", "C5"])
+def test_expert_solver_time_levels(wlsqm, name):
+    """ExpertSolver: prepare once, solve several right-hand sides (C4 pattern; reference tests/test_expert.py:92-117)."""
+    import synth
+    c = K.config(name)
+    g = c["g"]
+    dim, n = c["dim"], c["n"]
+    s = wlsqm.ExpertSolver(dimension=dim, nk=c["nk_a"], order=c["order_a"], knowns=c["knowns_a"],
+                           weighting_method=c["wm_a"], algorithm=wlsqm.ALGO_BASIC, do_sens=False, ntasks=8)
+    with pytest.raises(RuntimeError):
+        s.solve(fk=c["fk"], fi=c["fi0"].copy())                            # expert.pyx:493-494
+    s.prepare(xi=c["xi"], xk=c["xk"])
+    used, total = s.memory_used()
+    assert used == total and used > 0
+    for t in range(3):
+        Ft = synth.field(c["S"], t=float(t))
+        fi = np.zeros((n, c["no"])); fi[:, 0] = Ft[:n]
+        fi_in = fi.copy()
+        fk = Ft[c["hoods"]]
+        rc = s.solve(fk=fk, fi=fi)
+        assert rc == 0
+        truth = P.truth_fit(dim, c["xk"], fk, c["nk_a"], c["xi"], fi_in, c["order_a"], c["knowns_a"], c["wm_a"])
+        P.assert_parity(fi, g["fi_t"][t], truth, "%s t=%d" % (name, t))
+    s.close()
+
+
+def test_edge_cases(wlsqm):
+    e = K.golden("edge.npz")
+    # iterative return value quirk: max_iter = 0 -> 1 (impl.pyx:1016, 1080-1081)
+    for mi in (0, 1, 2, 10):
+        fi = np.zeros(6)
+        it = wlsqm.fit_2D_iterative(xk=e["iter_xk"], fk=e["iter_fk"], xi=np.zeros(2), fi=fi, sens=None, do_sens=0,
+                                    order=2, knowns=0, weighting_method=wlsqm.WEIGHT_CENTER, max_iter=mi)
+        if mi <= 1:
+            assert it == 1
+        else:
+            assert 1 <= it <= mi
+        assert np.allclose(fi, e["iter_mi%d_fi" % mi], rtol=1e-11, atol=1e-13)
+    # 5-point stencil with knowns = b2_XY: known stays bit-identical (reference tests/test_stencil.py:134-145)
+    fi = np.zeros(6)
+    wlsqm.fit_2D(xk=e["stencil_xk"], fk=e["stencil_fk"], xi=np.zeros(2), fi=fi, sens=None, do_sens=0, order=2,
+                 knowns=wlsqm.b2_XY, weighting_method=wlsqm.WEIGHT_UNIFORM)
+    assert fi[4] == 0.0
+    assert np.allclose(fi, e["stencil_fi"], rtol=1e-10, atol=1e-12)
+    # strided views through the _many API; nothing outside the views is touched
+    n, nk = 12, 14
+    xkv = e["strided_big_xk"][::2, ::2, :]; fkv = e["strided_big_fk"][::2, ::2]
+    big_fi = np.zeros((2 * n, 8)); fiv = big_fi[::2, :6]
+    o = np.full(2 * n, 2, np.int32)[::2]; kn = np.zeros(2 * n, np.int64)[::2]
+    w = np.full(2 * n, 2, np.int32)[::2]; nka = np.full(2 * n, nk, np.int32)[::2]
+    wlsqm.fit_2D_many(xk=xkv, fk=fkv, nk=nka, xi=e["strided_xi"], fi=fiv, sens=None, do_sens=0, order=o, knowns=kn,
+                      weighting_method=w)
+    assert np.allclose(big_fi, e["strided_big_fi_after"], rtol=1e-10, atol=1e-13)
+    assert np.all(big_fi[1::2] == 0) and np.all(big_fi[:, 6:] == 0)
+
+
+def test_stray_high_mask_bits_match_oracle(wlsqm):
+    """infra.pyx:119-121 does not mask bits >= no; the kernels reproduce the resulting dropped DOFs."""
+    from oracle import oracle
+    rng = np.random.default_rng(5)
+    n, nk = 16, 12
+    xi = rng.uniform(-1, 1, (n, 2)); xk = xi[:, None, :] + 0.2 * rng.uniform(-1, 1, (n, nk, 2))
+    fk = np.sin(xk[..., 0]) * np.cos(xk[..., 1])
+    kn = np.array([(1 << 6) | (j % 3) for j in range(n)], np.int64)        # bit 6 is outside the 6 DOFs
+    args = dict(nk=np.full(n, nk, np.int32), order=np.full(n, 2, np.int32), knowns=kn)
+    fi0 = rng.uniform(-1, 1, (n, 6))
+    fi_o = fi0.copy()
+    oracle.fit_many(2, xk, fk, args["nk"], xi, fi_o, None, 0, args["order"], kn, np.full(n, 2, np.int32))
+    fi_g = fi0.copy()
+    wlsqm.fit_2D_many(xk=xk, fk=fk, nk=args["nk"], xi=xi, fi=fi_g, sens=None, do_sens=0, order=args["order"],
+                      knowns=kn, weighting_method=np.full(n, 2, np.int32))
+    assert np.array_equal(fi_g == fi0, fi_o == fi0)                       # same set of entries left untouched
+    assert np.allclose(fi_g, fi_o, rtol=1e-9, atol=1e-11)
+
+
+def test_many_equals_loop_of_single(wlsqm):
+    """fit_2D_many == loop of fit_2D (reference tests/test_simple.py:132-168), and parallel == serial
+    (tests/test_parallel.py:35-66); on the GPU these are the same kernels, so equality is exact."""
+    rng = np.random.default_rng(42)
+    n, nk = 8, 25
+    xi = rng.uniform(-1, 1, (n, 2)); xk = xi[:, None, :] + 0.3 * rng.uniform(-1, 1, (n, nk, 2))
+    fk = 1 + 2 * xk[..., 0] + 3 * xk[..., 1] + 0.5 * xk[..., 0] ** 2
+    nka = np.full(n, nk, np.int32); o = np.full(n, 2, np.int32); kn = np.zeros(n, np.int64); w = np.full(n, 2, np.int32)
+    fi_many = np.zeros((n, 6)); fi_par = np.zeros((n, 6)); fi_loop = np.zeros((n, 6))
+    wlsqm.fit_2D_many(xk, fk, nka, xi, fi_many, None, 0, o, kn, w)
+    wlsqm.fit_2D_many_parallel(xk, fk, nka, xi, fi_par, None, 0, o, kn, w, ntasks=4)
+    for j in range(n):
+        wlsqm.fit_2D(xk[j], fk[j], xi[j], fi_loop[j], None, do_sens=0, order=2, knowns=0,
+                     weighting_method=wlsqm.WEIGHT_CENTER)
+    assert np.array_equal(fi_many, fi_par) and np.array_equal(fi_many, fi_loop)
+    # exact quadratic is recovered (reference tests/test_simple.py:57, atol 1e-10)
+    x, y = xi[:, 0], xi[:, 1]
+    expect = np.stack([1 + 2 * x + 3 * y + 0.5 * x * x, 2 + x, np.full(n, 3.0), np.ones(n), np.zeros(n), np.zeros(n)], 1)
+    assert np.allclose(fi_many, expect, atol=1e-10)
+
+
+@pytest.mark.parametrize("dim,order", [(1, 2), (2, 2), (3, 2), (2, 3), (2, 4), (3, 3), (3, 4), (1, 0), (2, 0), (3, 0)])
+def test_exact_polynomial_recovery(wlsqm, dim, order):
+    """A polynomial of the fitted order is reproduced with all its derivatives
+    (reference tests/test_simple.py:39-110, tests/test_edge_cases.py:14-59)."""
+    rng = np.random.default_rng(100 * dim + order)
+    ex = P.exponents(dim, order)
+    no = len(ex)
+    coef = rng.uniform(-1, 1, no)                       # fi at the origin IS the coefficient vector (baked factorials)
+    nk = 3 * no + 5
+    xk = rng.uniform(-1, 1, (nk, dim))
+    fk = np.zeros(nk)
+    fact = [1, 1, 2, 6, 24]
+    for a, e in enumerate(ex):
+        term = np.full(nk, coef[a])
+        for m, p in enumerate(e):
+            term = term * xk[:, m] ** p / fact[p]
+        fk += term
+    fi = np.zeros(no)
+    if dim == 1:
+        wlsqm.fit_1D(xk[:, 0].copy(), fk, 0.0, fi, None, do_sens=0, order=order, knowns=0,
+                     weighting_method=wlsqm.WEIGHT_UNIFORM)
+    else:
+        getattr(wlsqm, "fit_%dD" % dim)(xk, fk, np.zeros(dim), fi, None, do_sens=0, order=order, knowns=0,
+                                        weighting_method=wlsqm.WEIGHT_CENTER)
+    assert np.allclose(fi, coef, atol=1e-8 if order == 4 else 1e-10)
+
+
+def test_sens_reconstructs_solution(wlsqm):
+    """fi == sens^T fk for unknown DOFs when nothing is known."""
+    rng = np.random.default_rng(3)
+    nk = 30
+    xk = rng.uniform(-1, 1, (nk, 2)); fk = np.exp(xk[:, 0]) * np.sin(xk[:, 1])
+    fi = np.zeros(6); sens = np.zeros((nk, 6))
+    wlsqm.fit_2D(xk, fk, np.zeros(2), fi, sens, do_sens=1, order=2, knowns=0, weighting_method=wlsqm.WEIGHT_CENTER)
+    assert np.allclose(sens.T @ fk, fi, rtol=1e-11, atol=1e-12)
