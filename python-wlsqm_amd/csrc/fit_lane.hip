@@ -169,6 +169,7 @@ static int launch_lane(const KParams& p, hipStream_t stream) {
     else
         hipLaunchKernelGGL((fit_lane_kernel<DIM, ORDER, false>), dim3((unsigned)blocks), dim3(LANE_BLOCK), 0, stream, p);
     WLSQM_HIP_CHECK(hipGetLastError());
+    note_kernel("lane");
     return WLSQM_OK;
 }
 

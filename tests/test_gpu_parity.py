@@ -249,3 +249,29 @@ def test_sens_reconstructs_solution(wlsqm):
     fi = np.zeros(6); sens = np.zeros((nk, 6))
     wlsqm.fit_2D(xk, fk, np.zeros(2), fi, sens, do_sens=1, order=2, knowns=0, weighting_method=wlsqm.WEIGHT_CENTER)
     assert np.allclose(sens.T @ fk, fi, rtol=1e-11, atol=1e-12)
+
+
+@pytest.mark.parametrize("ncases", [64, 1000, 4097])
+def test_tile_path_equals_lane_path(wlsqm, ncases, monkeypatch):
+    """The LDS-tiled fast path (contiguous, K = 32) against the generic lane kernel on the same inputs:
+    ragged nk <= K, mixed weightings and knowns, tail tiles.  Same arithmetic except for the split of the
+    neighbour sum over 4 waves, so agreement is to rounding."""
+    rng = np.random.default_rng(ncases)
+    K = 32
+    xi = rng.uniform(0, 1, (ncases, 2))
+    xk = xi[:, None, :] + 0.05 * rng.uniform(-1, 1, (ncases, K, 2))
+    fk = np.sin(3 * xk[..., 0]) * np.cos(2 * xk[..., 1])
+    nk = rng.integers(10, K + 1, ncases).astype(np.int32); nk[0] = K
+    order = np.full(ncases, 2, np.int32)
+    knowns = rng.choice(np.array([0, 0, 1, 1 << 4, 1 | (1 << 3), 63], np.int64), ncases)
+    wm = rng.choice(np.array([1, 2], np.int32), ncases)
+    fi0 = rng.uniform(-1, 1, (ncases, 6)); fi0[:, 0] = np.sin(3 * xi[:, 0]) * np.cos(2 * xi[:, 1])
+    fi_t = fi0.copy(); fi_l = fi0.copy()
+    wlsqm.fit_2D_many_parallel(xk, fk, nk, xi, fi_t, None, 0, order, knowns, wm)
+    monkeypatch.setenv("WLSQM_HIP_DISABLE_TILE", "1")
+    wlsqm.fit_2D_many_parallel(xk, fk, nk, xi, fi_l, None, 0, order, knowns, wm)
+    monkeypatch.delenv("WLSQM_HIP_DISABLE_TILE")
+    _check_untouched(fi_t, fi0, order, knowns, 2)
+    assert np.array_equal(fi_t == fi0, fi_l == fi0)
+    truth = P.truth_fit(2, xk, fk, nk, xi, fi0, order, knowns, wm)
+    P.assert_parity(fi_t, fi_l, truth, "tile vs lane")
