@@ -1,0 +1,153 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library loads and exports every symbol that
+include/wlsqm_hip.h declares, the pure-integer host functions are bit-exact with the reference's
+golden table, the Python mirror validates arguments like the reference's typed memoryviews, and the
+product fails loudly (no CPU fallback) when there is no HIP device."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import _cases as K
+
+ROOT = K.ROOT
+
+
+@pytest.fixture(scope="module")
+def binding():
+    from wlsqm import _binding
+    if not os.path.exists(_binding.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return _binding
+
+
+def test_library_exports_every_declared_symbol(binding):
+    hdr = open(os.path.join(ROOT, "include", "wlsqm_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(wlsqm_hip_\w+)\s*\(", hdr)))
+    assert len(declared) >= 14
+    lib = C.CDLL(binding.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), "libwlsqm_hip.so does not export %s" % name
+
+
+def test_number_of_dofs_and_remap_bit_exact(binding):
+    L = binding.lib()
+    for dim in (1, 2, 3):
+        assert [L.wlsqm_hip_number_of_dofs(dim, k) for k in range(5)] == K.NDOF[dim]
+    assert L.wlsqm_hip_number_of_dofs(0, 2) == -1 and L.wlsqm_hip_number_of_dofs(2, 7) == -2
+    tab = K.golden("remap.npz")["table"]
+    for row in tab:
+        n, mask, nr = int(row[0]), int(row[1]), int(row[2])
+        o2r = np.full(n, -7, np.int32); r2o = np.full(n, -7, np.int32)
+        k = L.wlsqm_hip_remap(o2r.ctypes.data, r2o.ctypes.data, n, mask)
+        assert k == nr
+        assert np.array_equal(o2r, row[3:3 + n]) and np.array_equal(r2o, row[38:38 + n])
+        assert L.wlsqm_hip_number_of_reduced_dofs(n, mask) == n - bin(mask).count("1")
+
+
+def test_public_api_surface():
+    """Names the reference re-exports flat (wlsqm/__init__.py:25-28; tests/test_package.py:24-32)."""
+    import wlsqm
+    for dim in (1, 2, 3):
+        for suffix in ("", "_iterative", "_many", "_iterative_many", "_many_parallel", "_iterative_many_parallel"):
+            assert callable(getattr(wlsqm, "fit_%dD%s" % (dim, suffix)))
+    for name in ("ExpertSolver", "number_of_dofs", "WEIGHT_UNIFORM", "WEIGHT_CENTER", "ALGO_BASIC", "ALGO_ITERATIVE",
+                 "b1_F", "b2_F", "b3_F", "i2_X2", "i3_XYZ2", "b3_XYZ2", "i3_0th_end", "SIZE3"):
+        assert hasattr(wlsqm, name), name
+    assert not hasattr(wlsqm, "i1_0th_end") and not hasattr(wlsqm, "i2_0th_end")      # defs.pyx:316, 346
+    assert wlsqm.b2_XY == 1 << 4 and wlsqm.b3_XZ == 1 << 9 and wlsqm.i3_X2YZ == 32
+    assert re.match(r"^\d+\.\d+\.\d+(\.(dev|a|b|rc|post)\d+)?$", wlsqm.__version__)
+    import inspect
+    sig = inspect.signature(wlsqm.fit_2D_many_parallel)
+    assert list(sig.parameters) == ["xk", "fk", "nk", "xi", "fi", "sens", "do_sens", "order", "knowns",
+                                    "weighting_method", "ntasks", "debug"]
+    assert sig.parameters["ntasks"].default == 8                                       # simple.pyx:192-194
+    sig = inspect.signature(wlsqm.fit_3D_iterative)
+    assert sig.parameters["knowns"].default == wlsqm.b3_F and sig.parameters["max_iter"].default == 10
+    assert sig.parameters["weighting_method"].default == wlsqm.WEIGHT_CENTER and sig.parameters["order"].default == 2
+
+
+def _batch(n=4, nk=7):
+    rng = np.random.default_rng(0)
+    return dict(xk=rng.uniform(-1, 1, (n, nk, 2)), fk=rng.uniform(-1, 1, (n, nk)), nk=np.full(n, nk, np.int32),
+                xi=np.zeros((n, 2)), fi=np.zeros((n, 6)), sens=None, do_sens=0, order=np.full(n, 2, np.int32),
+                knowns=np.zeros(n, np.int64), weighting_method=np.full(n, 2, np.int32))
+
+
+def test_argument_validation_like_typed_memoryviews():
+    import wlsqm
+    b = _batch()
+    bad = dict(b, nk=b["nk"].astype(np.int64))
+    with pytest.raises(ValueError, match="dtype mismatch"):
+        wlsqm.fit_2D_many(**bad)
+    bad = dict(b, knowns=b["knowns"].astype(np.int32))
+    with pytest.raises(ValueError, match="dtype mismatch"):
+        wlsqm.fit_2D_many(**bad)
+    bad = dict(b, xk=b["xk"].astype(np.float32))
+    with pytest.raises(ValueError, match="dtype mismatch"):
+        wlsqm.fit_2D_many(**bad)
+    bad = dict(b, xk=np.asfortranarray(b["xk"]))                                        # TODO_DEFERRED.md "Issue #5"
+    with pytest.raises(ValueError, match="not contiguous in the same dimension"):
+        wlsqm.fit_2D_many(**bad)
+    bad = dict(b, fi=np.zeros((4, 12))[:, ::2])
+    with pytest.raises(ValueError, match="not contiguous in the same dimension"):
+        wlsqm.fit_2D_many(**bad)
+    bad = dict(b, fk=b["fk"][:, 0])
+    with pytest.raises(ValueError, match="wrong number of dimensions"):
+        wlsqm.fit_2D_many(**bad)
+    bad = dict(b, order=np.full(4, 5, np.int32))
+    with pytest.raises(ValueError):
+        wlsqm.fit_2D_many(**bad)
+    bad = dict(b, fi=np.zeros((4, 3)))
+    with pytest.raises(ValueError, match="columns"):
+        wlsqm.fit_2D_many(**bad)
+    bad = dict(b, nk=np.full(4, 9, np.int32))
+    with pytest.raises(ValueError, match="neighbour axis"):
+        wlsqm.fit_2D_many(**bad)
+    with pytest.raises(ValueError, match="ntasks"):
+        wlsqm.fit_2D_many_parallel(ntasks=0, **b)
+    with pytest.raises(ValueError, match="sens is None"):
+        wlsqm.fit_2D_many(**dict(b, do_sens=1))
+
+
+def test_expert_solver_argument_checks():
+    import wlsqm
+    n = 3
+    nk = np.full(n, 5, np.int32); o = np.full(n, 1, np.int32); kn = np.zeros(n, np.int64); w = np.full(n, 2, np.int32)
+    with pytest.raises(ValueError, match="same length"):                                 # expert.pyx:131-132
+        wlsqm.ExpertSolver(2, nk, o[:2], kn, w)
+    with pytest.raises(ValueError, match="Dimension must be 1, 2 or 3"):                 # :134-135
+        wlsqm.ExpertSolver(4, nk, o, kn, w)
+    with pytest.raises(ValueError, match="Unknown algorithm"):                           # :151-156
+        wlsqm.ExpertSolver(2, nk, o, kn, w, algorithm=7)
+    with pytest.raises(ValueError, match="ntasks must be >= 1"):                         # :158-159
+        wlsqm.ExpertSolver(2, nk, o, kn, w, ntasks=0)
+    with pytest.raises(ValueError, match="cannot be None"):                              # :139-148
+        wlsqm.ExpertSolver(2, nk, o, kn, w, max_iter=None)
+
+
+def test_fails_loudly_without_a_gpu(binding):
+    """No HIP device -> RuntimeError from the library itself; nothing silently falls back to a CPU path."""
+    import wlsqm
+    if binding.lib().wlsqm_hip_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        wlsqm.fit_2D_many(**_batch())
+    nk = np.full(3, 5, np.int32)
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        wlsqm.ExpertSolver(2, nk, np.full(3, 1, np.int32), np.zeros(3, np.int64), np.full(3, 2, np.int32))
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under python-wlsqm_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "python-wlsqm_amd")
+    for dirpath, _, files in os.walk(pkg):
+        if "build" in dirpath.split(os.sep):
+            continue
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".sh", ".cpp")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "oracle" not in text.lower() or f == "nothing", "%s mentions the oracle" % os.path.join(dirpath, f)

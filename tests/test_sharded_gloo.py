@@ -1,0 +1,68 @@
+"""N > 1 path on CPU: two gloo ranks shard one cloud by point ownership, fit their blocks and
+all-gather the new point values each step; the result must equal the single-process run.  The fit
+itself is injected (the CPU oracle stands in for the HIP kernel, which needs a GPU): what is under
+test is the partition, the index gathers and the collective."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import _cases as K
+import synth
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _oracle_fit(dimension, order, xk, fk, nk, xi, fi, knowns, wm):
+    from oracle import oracle
+    n = nk.shape[0]
+    fi_np = fi.numpy()
+    oracle.fit_many(dimension, xk.numpy(), fk.numpy(), nk.numpy(), xi.numpy(), fi_np, None, 0,
+                    np.full(n, order, np.int32), knowns.numpy(), wm.numpy())
+
+
+def _run(rank, world, port, S, hoods, F0, steps, out_dir):
+    import torch
+    import torch.distributed as dist
+    from wlsqm.sharded import ShardedCloudSolver, case_range
+    if world > 1:
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    s = ShardedCloudSolver(2, S, hoods, order=2, knowns=1, weighting_method=2, device="cpu", fit_fn=_oracle_fit)
+    assert (s.lo, s.hi) == case_range(len(S), rank, world)
+    F = torch.from_numpy(F0.copy())
+    for _ in range(steps):
+        fi = s.fit(F)
+        # toy explicit step: F <- F + 1e-4 * (d2F/dx2 + d2F/dy2), needs everyone's new values
+        F = s.allgather_values(fi[:, 0] + 1e-4 * (fi[:, 3] + fi[:, 5]))
+    np.save(os.path.join(out_dir, "F_%d_of_%d.npy" % (rank, world)), F.numpy())
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_case_range_partitions():
+    from wlsqm.sharded import case_range
+    for n, w in ((10, 3), (1000001, 8), (5, 8), (16, 2)):
+        spans = [case_range(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+        sizes = [b - a for a, b in spans]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def test_two_rank_time_stepping_equals_single_process(tmp_path):
+    import torch.multiprocessing as mp
+    N, nk, steps = 1501, 12, 3                                    # odd N: uneven shards exercise the padding
+    S = synth.halton(N, 2)
+    hoods = synth.knn(S, nk, workers=1).astype(np.int64)
+    F0 = synth.field(S)
+    _run(0, 1, 0, S, hoods, F0, steps, str(tmp_path))
+    port = _free_port()
+    mp.spawn(_run, args=(2, port, S, hoods, F0, steps, str(tmp_path)), nprocs=2, join=True)
+    ref = np.load(tmp_path / "F_0_of_1.npy")
+    for r in range(2):
+        got = np.load(tmp_path / ("F_%d_of_2.npy" % r))
+        assert np.array_equal(got, ref)                           # same arithmetic per case -> bit-identical
