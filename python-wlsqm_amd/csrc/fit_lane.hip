@@ -59,6 +59,7 @@ __global__ __launch_bounds__(LANE_BLOCK) void fit_lane_kernel(const KParams p) {
             if (d2 > max_d2) max_d2 = d2;
         }
     }
+    const double inv_max = inverse_max(max_d2);
 
     // pass 2: M = C^T W C (upper triangle), g = C^T W f
     double M[NE], g[NO];
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(LANE_BLOCK) void fit_lane_kernel(const KParams p) {
         double d[DIM], c[NO];
         load_offset<DIM>(xr, k, p.sxk_k, xi, d);
         const double d2 = monomials<DIM, ORDER>(d, c);
-        const double w = weight(d2, max_d2, uniform);
+        const double w = weight(d2, inv_max, uniform);
         accumulate<NO>(M, g, c, w, fr[k * p.sfk_k]);
     }
 
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(LANE_BLOCK) void fit_lane_kernel(const KParams p) {
                 double d[DIM], c[NO], s[NO];
                 load_offset<DIM>(xr, k, p.sxk_k, xi, d);
                 const double d2 = monomials<DIM, ORDER>(d, c);
-                const double w = weight(d2, max_d2, uniform);
+                const double w = weight(d2, inv_max, uniform);
 #pragma unroll
                 for (int a = 0; a < NO; ++a) s[a] = ((known >> a) & 1ull) ? 0.0 : ((a == 0) ? w : w * c[a]);
                 ldlt_solve<NO>(M, s);
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(LANE_BLOCK) void fit_lane_kernel(const KParams p) {
                     double d[DIM], c[NO];
                     load_offset<DIM>(xr, k, p.sxk_k, xi, d);
                     const double d2 = monomials<DIM, ORDER>(d, c);
-                    const double w = weight(d2, max_d2, uniform);
+                    const double w = weight(d2, inv_max, uniform);
                     double model = fi[0];                       // taylor_*D (polyeval.pyx): sum_a c[a] fi[a]
 #pragma unroll
                     for (int a = 1; a < NO; ++a) model += c[a] * fi[a];

@@ -41,8 +41,10 @@ template <int DIM> __host__ __device__ constexpr int row_stride_x(int K) {
 }
 __host__ __device__ constexpr int row_stride_f(int K) { return round_up_mod(K, 2, 1); }
 
-template <int DIM, int ORDER, int K, int KSPLIT>
-__global__ __launch_bounds__(TILE * KSPLIT) void fit_tile_kernel(const KParams p, const long long ntiles) {
+// UNR: unroll factor of the neighbour loops (KPW = fully unrolled); MINW: min waves per SIMD for the
+// register allocator (__launch_bounds__ 2nd argument).
+template <int DIM, int ORDER, int K, int KSPLIT, int UNR, int MINW, bool PREFETCH>
+__global__ __launch_bounds__(TILE * KSPLIT, MINW) void fit_tile_kernel(const KParams p, const long long ntiles) {
     constexpr int NO = ndofs(DIM, ORDER);
     constexpr int NE = NO * (NO + 1) / 2;
     constexpr int NT = TILE * KSPLIT;                      // threads per workgroup
@@ -69,30 +71,35 @@ __global__ __launch_bounds__(TILE * KSPLIT) void fit_tile_kernel(const KParams p
     const int lane = tid & (TILE - 1);
     const int wave = tid / TILE;                           // wave-uniform
 
+    // Issue every global load of one tile (coalesced 16 B per lane); nothing waits on them here.
+    double2_ bx[NX], bf[NF];
+    auto issue_loads = [&](long long t) {
+        const long long j0 = t * TILE;
+        const long long nvalid = (p.ncases - j0 < TILE) ? (p.ncases - j0) : TILE;
+        const double2_* gx = reinterpret_cast<const double2_*>(p.xk + j0 * (long long)(K * DIM));
+        const double2_* gf = reinterpret_cast<const double2_*>(p.fk + j0 * (long long)K);
+        const long long xlim = nvalid * CPRX, flim = nvalid * CPRF;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const long long q = tid + (long long)i * NT;
+            bx[i] = gx[q < xlim ? q : xlim - 1];
+        }
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            const long long q = tid + (long long)i * NT;
+            bf[i] = gf[q < flim ? q : flim - 1];
+        }
+    };
+    if constexpr (PREFETCH) { if ((long long)blockIdx.x < ntiles) issue_loads(blockIdx.x); }
+
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long long j0 = tile * TILE;
         const long long j = j0 + lane;
         const bool valid = j < p.ncases;
         const long long jc = valid ? j : p.ncases - 1;     // clamp: tail lanes replay the last case, never store
-        const long long nvalid = (p.ncases - j0 < TILE) ? (p.ncases - j0) : TILE;
 
-        // ---- stage 1: issue every load of the tile (coalesced 16 B per lane)
-        double2_ bx[NX], bf[NF];
-        {
-            const double2_* gx = reinterpret_cast<const double2_*>(p.xk + j0 * (long long)(K * DIM));
-            const double2_* gf = reinterpret_cast<const double2_*>(p.fk + j0 * (long long)K);
-            const long long xlim = nvalid * CPRX, flim = nvalid * CPRF;
-#pragma unroll
-            for (int i = 0; i < NX; ++i) {
-                const long long q = tid + (long long)i * NT;
-                bx[i] = gx[q < xlim ? q : xlim - 1];
-            }
-#pragma unroll
-            for (int i = 0; i < NF; ++i) {
-                const long long q = tid + (long long)i * NT;
-                bf[i] = gf[q < flim ? q : flim - 1];
-            }
-        }
+        // ---- stage 1: the tile's loads (already in flight from the previous iteration when PREFETCH)
+        if constexpr (!PREFETCH) issue_loads(tile);
         // per-case scalars (small, straight to registers)
         const int nkc = min(p.nk[jc * p.snk], K);
         const bool uniform = (p.wm[jc * p.swm] == WLSQM_WEIGHT_UNIFORM);
@@ -119,19 +126,26 @@ __global__ __launch_bounds__(TILE * KSPLIT) void fit_tile_kernel(const KParams p
             d[0] = bf[i].x; d[1] = bf[i].y;
         }
         __syncthreads();
+        // software prefetch: the next tile's loads fly while this one is computed (costs NX+NF staging registers)
+        if constexpr (PREFETCH) { if (tile + gridDim.x < ntiles) issue_loads(tile + gridDim.x); }
 
         const double* xr = sX + lane * RS;
         const double* fr = sF + lane * FS;
         const int k0 = wave * KPW;
-        const int k1 = min(k0 + KPW, nkc);
+
+        // Both passes run a fixed KPW iterations (fully unrolled, all ds_reads hoistable); neighbours
+        // k >= nk[j] of a ragged case are neutralised by zero offset + zero weight instead of a branch.
 
         // ---- pass 1: largest squared distance of the case (impl.pyx:389-391): each wave scans its share,
         // the KSPLIT partial maxima meet in LDS
         double max_d2 = 0.0;
-        for (int k = k0; k < k1; ++k) {
+#pragma unroll UNR
+        for (int kk = 0; kk < KPW; ++kk) {
+            const int k = k0 + kk;
             double d2 = 0.0;
 #pragma unroll
             for (int m = 0; m < DIM; ++m) { const double dd = xr[k * DIM + m] - xi[m]; d2 += dd * dd; }
+            d2 = (k < nkc) ? d2 : 0.0;
             max_d2 = d2 > max_d2 ? d2 : max_d2;
         }
         if constexpr (KSPLIT > 1) {
@@ -140,14 +154,16 @@ __global__ __launch_bounds__(TILE * KSPLIT) void fit_tile_kernel(const KParams p
 #pragma unroll
             for (int w = 0; w < KSPLIT; ++w) { const double o = sMax[w * TILE + lane]; max_d2 = o > max_d2 ? o : max_d2; }
         }
+        const double inv_max = inverse_max(max_d2);
 
-        // ---- pass 2: this wave's share of the neighbours
+        // ---- pass 2: this wave's share of the neighbours.  A wave whose 64 cases all use the full K
+        // neighbours (the common case) runs the loop without the per-neighbour `live` selects.
         double M[NE], g[NO];
 #pragma unroll
         for (int e = 0; e < NE; ++e) M[e] = 0.0;
 #pragma unroll
         for (int a = 0; a < NO; ++a) g[a] = 0.0;
-        for (int k = k0; k < k1; ++k) {
+        auto neighbour = [&](int k, bool live) {
             double d[DIM], c[NO];
             if constexpr (DIM == 2) {
                 const double2_ xy = *reinterpret_cast<const double2_*>(xr + 2 * k);   // ds_read_b128
@@ -156,9 +172,19 @@ __global__ __launch_bounds__(TILE * KSPLIT) void fit_tile_kernel(const KParams p
 #pragma unroll
                 for (int m = 0; m < DIM; ++m) d[m] = xr[k * DIM + m] - xi[m];
             }
+#pragma unroll
+            for (int m = 0; m < DIM; ++m) d[m] = live ? d[m] : 0.0;
             const double d2 = monomials<DIM, ORDER>(d, c);
-            const double w = weight(d2, max_d2, uniform);
-            accumulate<NO>(M, g, c, w, fr[k]);
+            const double w = live ? weight(d2, inv_max, uniform) : 0.0;
+            const double f = live ? fr[k] : 0.0;
+            accumulate<NO>(M, g, c, w, f);
+        };
+        if (__all(nkc >= K)) {
+#pragma unroll UNR
+            for (int kk = 0; kk < KPW; ++kk) neighbour(k0 + kk, true);
+        } else {
+#pragma unroll 1
+            for (int kk = 0; kk < KPW; ++kk) neighbour(k0 + kk, k0 + kk < nkc);
         }
 
         // ---- combine the KSPLIT partial sums through LDS (the tile's storage is dead now)
@@ -207,7 +233,7 @@ __global__ __launch_bounds__(TILE * KSPLIT) void fit_tile_kernel(const KParams p
     }
 }
 
-template <int DIM, int ORDER, int K, int KSPLIT>
+template <int DIM, int ORDER, int K, int KSPLIT, int UNR = 2, int MINW = 3, bool PREFETCH = false>
 static int launch_tile(const KParams& p, hipStream_t stream) {
     constexpr int NO = ndofs(DIM, ORDER);
     constexpr int NE = NO * (NO + 1) / 2;
@@ -218,7 +244,7 @@ static int launch_tile(const KParams& p, hipStream_t stream) {
     static_assert(lds_bytes <= 160 * 1024, "tile does not fit LDS");
     const long long ntiles = (p.ncases + TILE - 1) / TILE;
     static int per_cu = 0, cus = 0;
-    auto kern = fit_tile_kernel<DIM, ORDER, K, KSPLIT>;
+    auto kern = fit_tile_kernel<DIM, ORDER, K, KSPLIT, UNR, MINW, PREFETCH>;
     if (!cus) {
         int dev = 0;
         WLSQM_HIP_CHECK(hipGetDevice(&dev));
@@ -255,7 +281,24 @@ int launch_fit_tile(int dimension, int order, const KParams& p, long long max_nk
     if (!tile_eligible(dimension, p, max_nk)) return WLSQM_OK;
 #define TILE_CASE(D, O, KK, S)                                                   \
     if (dimension == D && order == O && max_nk == KK) { *handled = true; return launch_tile<D, O, KK, S>(p, stream); }
-    TILE_CASE(2, 2, 32, 4)
+    if (dimension == 2 && order == 2 && max_nk == 32) {      // tuning variants, selected by WLSQM_TILE_VARIANT (default 0)
+        const char* v = getenv("WLSQM_TILE_VARIANT");
+        const int var = v ? atoi(v) : 0;
+        *handled = true;
+        switch (var) {
+            case 1: return launch_tile<2, 2, 32, 4, 1, 3>(p, stream);
+            case 2: return launch_tile<2, 2, 32, 4, 8, 2>(p, stream);
+            case 4: return launch_tile<2, 2, 32, 4, 4, 3>(p, stream);
+            case 5: return launch_tile<2, 2, 32, 2, 2, 2>(p, stream);
+            case 6: return launch_tile<2, 2, 32, 2, 4, 2>(p, stream);
+            case 7: return launch_tile<2, 2, 32, 4, 2, 2, true>(p, stream);
+            case 8: return launch_tile<2, 2, 32, 4, 4, 2, true>(p, stream);
+            case 9: return launch_tile<2, 2, 32, 4, 1, 2, true>(p, stream);
+            case 10: return launch_tile<2, 2, 32, 4, 2, 3, true>(p, stream);
+            case 11: return launch_tile<2, 2, 32, 4, 2, 3>(p, stream);
+            default: return launch_tile<2, 2, 32, 4, 8, 2>(p, stream);   // best of the round-1 A/B (tools/tune.py)
+        }
+    }
     TILE_CASE(2, 2, 16, 4)
     TILE_CASE(2, 2, 24, 4)
     TILE_CASE(2, 2, 48, 4)

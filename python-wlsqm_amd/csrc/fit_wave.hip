@@ -112,6 +112,7 @@ __global__ __launch_bounds__(WAVE) void fit_wave_kernel(const KParams p) {
         }
         max_d2 = wave_max(max_d2);
     }
+    const double inv_max = inverse_max(max_d2);
 
     // this lane's entries of the packed upper triangle
     int ea[EPL], eb[EPL];
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(WAVE) void fit_wave_kernel(const KParams p) {
 #pragma unroll
             for (int m = 0; m < DIM; ++m) d[m] = xr[(kb + lane) * p.sxk_k + m] - xi[m];
             const double d2 = monomials<DIM, ORDER>(d, c);
-            const double w = weight(d2, max_d2, uniform);
+            const double w = weight(d2, inv_max, uniform);
 #pragma unroll
             for (int a = 0; a < NO; ++a) sC[lane * LC + a] = c[a];
             sW[lane] = w;
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(WAVE) void fit_wave_kernel(const KParams p) {
 #pragma unroll
                 for (int m = 0; m < DIM; ++m) d[m] = xr[k * p.sxk_k + m] - xi[m];
                 const double d2 = monomials<DIM, ORDER>(d, c);
-                const double w = weight(d2, max_d2, uniform);
+                const double w = weight(d2, inv_max, uniform);
 #pragma unroll
                 for (int a = 0; a < NO; ++a) X[a * WAVE + lane] = ((known >> a) & 1ull) ? 0.0 : w * c[a];
                 column_ldlt_solve<NO, LD>(sM, X, lane);
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(WAVE) void fit_wave_kernel(const KParams p) {
 #pragma unroll
                     for (int m = 0; m < DIM; ++m) d[m] = xr[(kb + lane) * p.sxk_k + m] - xi[m];
                     const double d2 = monomials<DIM, ORDER>(d, c);
-                    const double w = weight(d2, max_d2, uniform);
+                    const double w = weight(d2, inv_max, uniform);
                     double model = sVal[0];                                 // taylor_*D (polyeval.pyx): sum_a c[a] fi[a]
 #pragma unroll
                     for (int a = 1; a < NO; ++a) model += c[a] * sVal[a];

@@ -78,13 +78,40 @@ __device__ __forceinline__ double monomials(const double (&d)[DIM], double (&c)[
     return d2;
 }
 
-// infra.pyx:668-702.  UNIFORM: 1; otherwise (CENTER and any other value, :691):
-// alpha + beta*(1 - sqrt(d2/max_d2))^2, alpha = 1e-4.
-__device__ __forceinline__ double weight(double d2, double max_d2, bool uniform) {
-    if (uniform) return 1.0;
-    const double t = 1.0 - sqrt(d2 / max_d2);
-    return 1e-4 + (1.0 - 1e-4) * t * t;
+// sqrt(q) for q in [0, 1]: v_rsq_f64 seed + two Goldschmidt/Newton steps (<= 1 ulp).  hipcc's generic
+// sqrt() spends another ~10 instructions on range scaling for denormal/huge arguments that cannot occur for
+// a ratio of squared distances; q == 0 (a neighbour coincident with xi) is handled explicitly.
+__device__ __forceinline__ double sqrt_unit(double q) {
+    const double y = __builtin_amdgcn_rsq(q);
+    double g = q * y, h = 0.5 * y;
+    double r = fma(-h, g, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    r = fma(-g, g, q);
+    g = fma(r, h, g);
+    r = fma(-g, g, q);
+    g = fma(r, h, g);
+    return q > 0.0 ? g : q;          // q == 0 -> 0; NaN (max_d2 == 0, infra.pyx:701) propagates
 }
+
+// infra.pyx:668-702.  UNIFORM: 1; otherwise (CENTER and any other value, :691):
+// alpha + beta*(1 - sqrt(d2/max_d2))^2, alpha = 1e-4.  `inv_max` = 1/max_d2 is formed once per case
+// (one IEEE divide) and multiplied in: the quotient differs from d2/max_d2 by at most 1 ulp.
+__device__ __forceinline__ double weight(double d2, double inv_max, bool uniform) {
+    const double t = 1.0 - sqrt_unit(d2 * inv_max);
+    const double w = 1e-4 + (1.0 - 1e-4) * t * t;
+    return uniform ? 1.0 : w;        // select, not a branch: keeps the neighbour loop straight-line
+}
+// 1/x for the pivots and 1/max_d2: v_rcp_f64 seed + two Newton steps (full double accuracy for normal
+// x; 0 -> inf and NaN propagate like IEEE division).  hipcc's IEEE a/b is a 12-instruction sequence.
+__device__ __forceinline__ double recip(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-x, y, 1.0);
+    const double z = fma(y, e, y);
+    return (z == z) ? z : y;         // x = 0 or inf: the Newton step makes inf*0 = NaN, keep the raw seed (inf / 0)
+}
+__device__ __forceinline__ double inverse_max(double max_d2) { return recip(max_d2); }
 
 // Effective knowns mask over the `NO` DOFs.  The reference sizes the reduced system as
 // nr = no - popcountll(mask) WITHOUT masking bits >= no (infra.pyx:119-121) but builds
@@ -109,7 +136,7 @@ __device__ __forceinline__ void effective_mask(long long raw, unsigned long long
 template <int N> __device__ __forceinline__ void ldlt_factor(double (&M)[N * (N + 1) / 2]) {
 #pragma unroll
     for (int j = 0; j < N; ++j) {
-        const double inv = 1.0 / M[tri<N>(j, j)];
+        const double inv = recip(M[tri<N>(j, j)]);
 #pragma unroll
         for (int i = j + 1; i < N; ++i) {
             const double t = M[tri<N>(j, i)] * inv;
