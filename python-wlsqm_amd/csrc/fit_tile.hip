@@ -1,24 +1,25 @@
 // fit_tile.hip — contiguous fast path of the WLSQM fit for gfx950: LDS-staged tiles.
 //
-// Same arithmetic as fit_lane.hip (one lane owns one local fit, normal matrix in VGPRs; see
+// Same arithmetic as fit_lane.hip (the normal matrix of a case lives in VGPRs; see
 // wlsqm_kernels.hpp for the reference citations), but the dense reference layout
 // xk[ncases, K, dim], fk[ncases, K] is "array of structures" for a lane-per-case mapping, so
 // the tile kernel moves it through LDS:
 //
-//   * a workgroup of 64*KSPLIT threads owns a tile of 64 consecutive cases; the tile's xk and
-//     fk blocks are single contiguous byte ranges in HBM and are read with fully coalesced
-//     16-byte-per-lane loads, ALL issued before the first is consumed (K*(dim+1)/(2*KSPLIT)
-//     loads in flight per lane), then parked in LDS with a padded row per case;
-//   * lane c of every wave reads row c back with conflict-free ds_read_b128/b64 (row stride
-//     chosen so that 16/32 consecutive lanes cover all 64 banks);
-//   * the K neighbours are split over the KSPLIT waves (k ascending inside each share); the
-//     partial normal matrices are combined through LDS (reusing the tile's storage) and wave 0
-//     does knowns elimination + LDL^T + substitution and writes the `no` results.
+//   * a workgroup of KSPLIT waves owns a tile of TC = 64/LPC consecutive cases; the tile's xk
+//     and fk blocks are single contiguous byte ranges in HBM and are read with fully coalesced
+//     16-byte-per-lane loads, ALL issued before the first is consumed, then parked in LDS with
+//     a padded row per case;
+//   * lane (h, c) of every wave reads row c back with conflict-free ds_read_b128/b64 (row
+//     stride chosen so that 16/32 consecutive lanes cover all 64 banks) and accumulates the
+//     neighbours of share s = wave*LPC + h (k ascending inside a share);
+//   * the LPC lanes of a case are summed with wave shuffles, the KSPLIT waves through LDS
+//     (reusing the tile's storage); wave 0 does knowns elimination + LDL^T + substitution and
+//     writes the `no` results.
 //
-// LDS per workgroup is 64 * K * (dim+1) * 8 B plus padding (49.9 KB for 2D/32 neighbours), so
-// three workgroups share a CU's 160 KB and 12 waves are resident with KSPLIT = 4; while one
-// workgroup computes, the others have their ~48 KB of loads in flight, which is what keeps
-// HBM busy (no intra-workgroup double buffering: LDS is the scarce resource here).
+// LDS per workgroup is TC * K * (dim+1) * 8 B plus padding (50.7 KB for 2D/32 neighbours with
+// TC = 64), so three workgroups share a CU's 160 KB; while one workgroup computes, the others
+// have their ~48 KB of loads in flight, which is what keeps HBM busy.  Intra-workgroup software
+// prefetch through registers was measured and lost 15 % (it costs the third resident workgroup).
 #include <cstdlib>
 
 #include "wlsqm_internal.hpp"
@@ -26,7 +27,7 @@
 
 namespace wlsqm {
 
-constexpr int TILE = 64;          // cases per tile = lanes per wave
+constexpr int WV = 64;            // lanes per wave
 
 typedef double double2_ __attribute__((ext_vector_type(2)));   // 16-byte aligned pair -> dwordx4 / ds_*_b128
 
@@ -41,65 +42,73 @@ template <int DIM> __host__ __device__ constexpr int row_stride_x(int K) {
 }
 __host__ __device__ constexpr int row_stride_f(int K) { return round_up_mod(K, 2, 1); }
 
-// UNR: unroll factor of the neighbour loops (KPW = fully unrolled); MINW: min waves per SIMD for the
-// register allocator (__launch_bounds__ 2nd argument).
-template <int DIM, int ORDER, int K, int KSPLIT, int UNR, int MINW, bool PREFETCH>
-__global__ __launch_bounds__(TILE * KSPLIT, MINW) void fit_tile_kernel(const KParams p, const long long ntiles) {
-    constexpr int NO = ndofs(DIM, ORDER);
-    constexpr int NE = NO * (NO + 1) / 2;
-    constexpr int NT = TILE * KSPLIT;                      // threads per workgroup
-    constexpr int RS = row_stride_x<DIM>(K);
-    constexpr int FS = row_stride_f(K);
-    constexpr int XCH = TILE * K * DIM / 2;                // 16-byte chunks in the tile's xk block
-    constexpr int FCH = TILE * K / 2;                      // ... and in its fk block
+template <int DIM, int ORDER, int K, int KSPLIT, int LPC>
+struct TileGeom {
+    static constexpr int NO = ndofs(DIM, ORDER);
+    static constexpr int NE = NO * (NO + 1) / 2;
+    static constexpr int TC = WV / LPC;                      // cases per tile
+    static constexpr int NT = WV * KSPLIT;                   // threads per workgroup
+    static constexpr int SHARES = KSPLIT * LPC;              // neighbour shares per case
+    static constexpr int KPL = K / SHARES;                   // neighbours per lane
+    static constexpr int RS = row_stride_x<DIM>(K), FS = row_stride_f(K);
+    static constexpr int XCH = TC * K * DIM / 2, FCH = TC * K / 2;      // 16-byte chunks per tile
+    static constexpr int NX = (XCH + NT - 1) / NT, NF = (FCH + NT - 1) / NT;
+    static constexpr int CPRX = K * DIM / 2, CPRF = K / 2;  // chunks per row
+    static constexpr int NRED = NE + NO;                     // partial sums per case
+    static constexpr int LDS_TILE = TC * (RS + FS);
+    static constexpr int LDS_RED = (KSPLIT - 1) * NRED * TC;
+    static constexpr int LDS_MAIN = LDS_TILE > LDS_RED ? LDS_TILE : LDS_RED;
+    static constexpr size_t LDS_BYTES = sizeof(double) * (LDS_MAIN + SHARES * TC);
     static_assert((K * DIM) % 2 == 0 && K % 2 == 0, "rows must be multiples of 16 bytes");
-    static_assert(XCH % NT == 0 && FCH % NT == 0, "chunks must divide evenly over the workgroup");
-    constexpr int NX = XCH / NT, NF = FCH / NT;            // chunks per thread
-    constexpr int CPRX = K * DIM / 2, CPRF = K / 2;        // chunks per row
-    constexpr int KPW = K / KSPLIT;                        // neighbours per wave
-    static_assert(K % KSPLIT == 0, "K must split evenly over the waves");
-    constexpr int NRED = NE + NO + 1;                      // partials per lane: M, g, max_d2
-    constexpr int LDS_TILE = TILE * (RS + FS);
-    constexpr int LDS_RED = (KSPLIT - 1) * NRED * TILE;
-    constexpr int LDS_DOUBLES = LDS_TILE > LDS_RED ? LDS_TILE : LDS_RED;
+    static_assert(K % SHARES == 0, "K must split evenly over the shares");
+    static_assert(LPC == 1 || LPC == 2 || LPC == 4, "1, 2 or 4 lanes per case");
+    static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit LDS");
+};
+
+// UNR: unroll factor of the neighbour loops; MINW: min waves per SIMD for the register allocator
+// (__launch_bounds__ 2nd argument).
+template <int DIM, int ORDER, int K, int KSPLIT, int LPC, int UNR, int MINW>
+__global__ __launch_bounds__(WV * KSPLIT, MINW) void fit_tile_kernel(const KParams p, const long long ntiles) {
+    using G = TileGeom<DIM, ORDER, K, KSPLIT, LPC>;
+    constexpr int NO = G::NO, NE = G::NE, TC = G::TC, NT = G::NT, RS = G::RS, FS = G::FS;
+    constexpr int NX = G::NX, NF = G::NF, CPRX = G::CPRX, CPRF = G::CPRF, KPL = G::KPL, NRED = G::NRED;
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    double* sX = lds;                                      // [TILE][RS]
-    double* sF = lds + TILE * RS;                          // [TILE][FS]
-    double* sMax = lds + LDS_DOUBLES;                      // [KSPLIT][TILE] partial max_d2 (outside the reused region)
+    double* sX = lds;                                      // [TC][RS]
+    double* sF = lds + TC * RS;                            // [TC][FS]
+    double* sMax = lds + G::LDS_MAIN;                      // [SHARES][TC] partial max_d2 (outside the reused region)
 
     const int tid = threadIdx.x;
-    const int lane = tid & (TILE - 1);
-    const int wave = tid / TILE;                           // wave-uniform
-
-    // Issue every global load of one tile (coalesced 16 B per lane); nothing waits on them here.
-    double2_ bx[NX], bf[NF];
-    auto issue_loads = [&](long long t) {
-        const long long j0 = t * TILE;
-        const long long nvalid = (p.ncases - j0 < TILE) ? (p.ncases - j0) : TILE;
-        const double2_* gx = reinterpret_cast<const double2_*>(p.xk + j0 * (long long)(K * DIM));
-        const double2_* gf = reinterpret_cast<const double2_*>(p.fk + j0 * (long long)K);
-        const long long xlim = nvalid * CPRX, flim = nvalid * CPRF;
-#pragma unroll
-        for (int i = 0; i < NX; ++i) {
-            const long long q = tid + (long long)i * NT;
-            bx[i] = gx[q < xlim ? q : xlim - 1];
-        }
-#pragma unroll
-        for (int i = 0; i < NF; ++i) {
-            const long long q = tid + (long long)i * NT;
-            bf[i] = gf[q < flim ? q : flim - 1];
-        }
-    };
-    if constexpr (PREFETCH) { if ((long long)blockIdx.x < ntiles) issue_loads(blockIdx.x); }
+    const int lane = tid & (WV - 1);
+    const int wave = tid / WV;                             // wave-uniform
+    const int c = lane % TC;                               // case within the tile
+    const int h = lane / TC;                               // which of the LPC lanes of that case
+    const int share = wave * LPC + h;
+    const int k0 = share * KPL;
 
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const long long j0 = tile * TILE;
-        const long long j = j0 + lane;
+        const long long j0 = tile * TC;
+        const long long j = j0 + c;
         const bool valid = j < p.ncases;
         const long long jc = valid ? j : p.ncases - 1;     // clamp: tail lanes replay the last case, never store
+        const long long nvalid = (p.ncases - j0 < TC) ? (p.ncases - j0) : TC;
 
-        // ---- stage 1: the tile's loads (already in flight from the previous iteration when PREFETCH)
-        if constexpr (!PREFETCH) issue_loads(tile);
+        // ---- stage 1: issue every global load of the tile (coalesced 16 B per lane)
+        double2_ bx[NX], bf[NF];
+        {
+            const double2_* gx = reinterpret_cast<const double2_*>(p.xk + j0 * (long long)(K * DIM));
+            const double2_* gf = reinterpret_cast<const double2_*>(p.fk + j0 * (long long)K);
+            const long long xlim = nvalid * CPRX, flim = nvalid * CPRF;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                const long long q = tid + (long long)i * NT;
+                bx[i] = gx[q < xlim ? q : xlim - 1];
+            }
+#pragma unroll
+            for (int i = 0; i < NF; ++i) {
+                const long long q = tid + (long long)i * NT;
+                bf[i] = gf[q < flim ? q : flim - 1];
+            }
+        }
         // per-case scalars (small, straight to registers)
         const int nkc = min(p.nk[jc * p.snk], K);
         const bool uniform = (p.wm[jc * p.swm] == WLSQM_WEIGHT_UNIFORM);
@@ -113,34 +122,32 @@ __global__ __launch_bounds__(TILE * KSPLIT, MINW) void fit_tile_kernel(const KPa
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const int q = tid + i * NT;
-            const int r = q / CPRX, c2 = q - r * CPRX;     // compile-time divisors
-            double* d = sX + r * RS + 2 * c2;
-            if constexpr (RS % 2 == 0) *reinterpret_cast<double2_*>(d) = bx[i];
-            else { d[0] = bx[i].x; d[1] = bx[i].y; }
+            if (G::XCH % NT == 0 || q < G::XCH) {
+                const int r = q / CPRX, c2 = q - r * CPRX;     // compile-time divisors
+                double* d = sX + r * RS + 2 * c2;
+                if constexpr (RS % 2 == 0) *reinterpret_cast<double2_*>(d) = bx[i];
+                else { d[0] = bx[i].x; d[1] = bx[i].y; }
+            }
         }
 #pragma unroll
         for (int i = 0; i < NF; ++i) {
             const int q = tid + i * NT;
-            const int r = q / CPRF, c2 = q - r * CPRF;
-            double* d = sF + r * FS + 2 * c2;
-            d[0] = bf[i].x; d[1] = bf[i].y;
+            if (G::FCH % NT == 0 || q < G::FCH) {
+                const int r = q / CPRF, c2 = q - r * CPRF;
+                double* d = sF + r * FS + 2 * c2;
+                d[0] = bf[i].x; d[1] = bf[i].y;
+            }
         }
         __syncthreads();
-        // software prefetch: the next tile's loads fly while this one is computed (costs NX+NF staging registers)
-        if constexpr (PREFETCH) { if (tile + gridDim.x < ntiles) issue_loads(tile + gridDim.x); }
 
-        const double* xr = sX + lane * RS;
-        const double* fr = sF + lane * FS;
-        const int k0 = wave * KPW;
+        const double* xr = sX + c * RS;
+        const double* fr = sF + c * FS;
 
-        // Both passes run a fixed KPW iterations (fully unrolled, all ds_reads hoistable); neighbours
-        // k >= nk[j] of a ragged case are neutralised by zero offset + zero weight instead of a branch.
-
-        // ---- pass 1: largest squared distance of the case (impl.pyx:389-391): each wave scans its share,
-        // the KSPLIT partial maxima meet in LDS
+        // ---- pass 1: largest squared distance of the case (impl.pyx:389-391): every share scans its
+        // neighbours, the partial maxima meet in LDS.  Neighbours k >= nk[j] of a ragged case count as 0.
         double max_d2 = 0.0;
 #pragma unroll UNR
-        for (int kk = 0; kk < KPW; ++kk) {
+        for (int kk = 0; kk < KPL; ++kk) {
             const int k = k0 + kk;
             double d2 = 0.0;
 #pragma unroll
@@ -148,15 +155,15 @@ __global__ __launch_bounds__(TILE * KSPLIT, MINW) void fit_tile_kernel(const KPa
             d2 = (k < nkc) ? d2 : 0.0;
             max_d2 = d2 > max_d2 ? d2 : max_d2;
         }
-        if constexpr (KSPLIT > 1) {
-            sMax[wave * TILE + lane] = max_d2;
+        if constexpr (G::SHARES > 1) {
+            sMax[share * TC + c] = max_d2;
             __syncthreads();
 #pragma unroll
-            for (int w = 0; w < KSPLIT; ++w) { const double o = sMax[w * TILE + lane]; max_d2 = o > max_d2 ? o : max_d2; }
+            for (int s = 0; s < G::SHARES; ++s) { const double o = sMax[s * TC + c]; max_d2 = o > max_d2 ? o : max_d2; }
         }
         const double inv_max = inverse_max(max_d2);
 
-        // ---- pass 2: this wave's share of the neighbours.  A wave whose 64 cases all use the full K
+        // ---- pass 2: this lane's share of the neighbours.  A wave whose cases all use the full K
         // neighbours (the common case) runs the loop without the per-neighbour `live` selects.
         double M[NE], g[NO];
 #pragma unroll
@@ -164,7 +171,7 @@ __global__ __launch_bounds__(TILE * KSPLIT, MINW) void fit_tile_kernel(const KPa
 #pragma unroll
         for (int a = 0; a < NO; ++a) g[a] = 0.0;
         auto neighbour = [&](int k, bool live) {
-            double d[DIM], c[NO];
+            double d[DIM], cc[NO];
             if constexpr (DIM == 2) {
                 const double2_ xy = *reinterpret_cast<const double2_*>(xr + 2 * k);   // ds_read_b128
                 d[0] = xy.x - xi[0]; d[1] = xy.y - xi[1];
@@ -174,39 +181,49 @@ __global__ __launch_bounds__(TILE * KSPLIT, MINW) void fit_tile_kernel(const KPa
             }
 #pragma unroll
             for (int m = 0; m < DIM; ++m) d[m] = live ? d[m] : 0.0;
-            const double d2 = monomials<DIM, ORDER>(d, c);
+            const double d2 = monomials<DIM, ORDER>(d, cc);
             const double w = live ? weight(d2, inv_max, uniform) : 0.0;
             const double f = live ? fr[k] : 0.0;
-            accumulate<NO>(M, g, c, w, f);
+            accumulate<NO>(M, g, cc, w, f);
         };
         if (__all(nkc >= K)) {
 #pragma unroll UNR
-            for (int kk = 0; kk < KPW; ++kk) neighbour(k0 + kk, true);
+            for (int kk = 0; kk < KPL; ++kk) neighbour(k0 + kk, true);
         } else {
 #pragma unroll 1
-            for (int kk = 0; kk < KPW; ++kk) neighbour(k0 + kk, k0 + kk < nkc);
+            for (int kk = 0; kk < KPL; ++kk) neighbour(k0 + kk, k0 + kk < nkc);
         }
 
-        // ---- combine the KSPLIT partial sums through LDS (the tile's storage is dead now)
+        // ---- sum the LPC lanes of a case (lanes c, c+TC, ...) with wave shuffles
+        if constexpr (LPC > 1) {
+#pragma unroll
+            for (int off = TC; off < WV; off <<= 1) {
+#pragma unroll
+                for (int e = 0; e < NE; ++e) M[e] += __shfl_xor(M[e], off, WV);
+#pragma unroll
+                for (int a = 0; a < NO; ++a) g[a] += __shfl_xor(g[a], off, WV);
+            }
+        }
+        // ---- sum the KSPLIT waves through LDS (the tile's storage is dead now)
         if constexpr (KSPLIT > 1) {
             __syncthreads();
             double* red = lds;
-            if (wave > 0) {
-                double* mine = red + (wave - 1) * (NRED * TILE) + lane;
+            if (wave > 0 && h == 0) {
+                double* mine = red + (wave - 1) * (NRED * TC) + c;
 #pragma unroll
-                for (int e = 0; e < NE; ++e) mine[e * TILE] = M[e];
+                for (int e = 0; e < NE; ++e) mine[e * TC] = M[e];
 #pragma unroll
-                for (int a = 0; a < NO; ++a) mine[(NE + a) * TILE] = g[a];
+                for (int a = 0; a < NO; ++a) mine[(NE + a) * TC] = g[a];
             }
             __syncthreads();
             if (wave == 0) {
 #pragma unroll
                 for (int w = 1; w < KSPLIT; ++w) {
-                    const double* other = red + (w - 1) * (NRED * TILE) + lane;
+                    const double* other = red + (w - 1) * (NRED * TC) + c;
 #pragma unroll
-                    for (int e = 0; e < NE; ++e) M[e] += other[e * TILE];
+                    for (int e = 0; e < NE; ++e) M[e] += other[e * TC];
 #pragma unroll
-                    for (int a = 0; a < NO; ++a) g[a] += other[(NE + a) * TILE];
+                    for (int a = 0; a < NO; ++a) g[a] += other[(NE + a) * TC];
                 }
             }
         }
@@ -214,7 +231,7 @@ __global__ __launch_bounds__(TILE * KSPLIT, MINW) void fit_tile_kernel(const KPa
         // ---- wave 0: knowns elimination, LDL^T, substitution, store
         if (wave == 0) {
             constexpr unsigned long long FULL = (1ull << NO) - 1ull;
-            if (valid && known != FULL) {
+            if (valid && h == 0 && known != FULL) {
                 double* fio = p.fi + j * p.sfi_j;
                 if (known) {
                     double val[NO];
@@ -233,18 +250,13 @@ __global__ __launch_bounds__(TILE * KSPLIT, MINW) void fit_tile_kernel(const KPa
     }
 }
 
-template <int DIM, int ORDER, int K, int KSPLIT, int UNR = 2, int MINW = 3, bool PREFETCH = false>
+template <int DIM, int ORDER, int K, int KSPLIT, int LPC = 1, int UNR = 2, int MINW = 2>
 static int launch_tile(const KParams& p, hipStream_t stream) {
-    constexpr int NO = ndofs(DIM, ORDER);
-    constexpr int NE = NO * (NO + 1) / 2;
-    constexpr int NRED = NE + NO + 1;
-    constexpr int RS = row_stride_x<DIM>(K), FS = row_stride_f(K);
-    constexpr int LDS_TILE = TILE * (RS + FS), LDS_RED = (KSPLIT - 1) * NRED * TILE;
-    constexpr size_t lds_bytes = sizeof(double) * ((LDS_TILE > LDS_RED ? LDS_TILE : LDS_RED) + TILE * KSPLIT);
-    static_assert(lds_bytes <= 160 * 1024, "tile does not fit LDS");
-    const long long ntiles = (p.ncases + TILE - 1) / TILE;
+    using G = TileGeom<DIM, ORDER, K, KSPLIT, LPC>;
+    constexpr size_t lds_bytes = G::LDS_BYTES;
+    const long long ntiles = (p.ncases + G::TC - 1) / G::TC;
     static int per_cu = 0, cus = 0;
-    auto kern = fit_tile_kernel<DIM, ORDER, K, KSPLIT, UNR, MINW, PREFETCH>;
+    auto kern = fit_tile_kernel<DIM, ORDER, K, KSPLIT, LPC, UNR, MINW>;
     if (!cus) {
         int dev = 0;
         WLSQM_HIP_CHECK(hipGetDevice(&dev));
@@ -253,13 +265,13 @@ static int launch_tile(const KParams& p, hipStream_t stream) {
         if (lds_bytes > 64 * 1024)
             WLSQM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         int occ = 0;
-        WLSQM_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, TILE * KSPLIT, lds_bytes));
+        WLSQM_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, G::NT, lds_bytes));
         per_cu = occ > 0 ? occ : 1;
         cus = prop.multiProcessorCount;
     }
     long long grid = (long long)per_cu * cus;
     if (grid > ntiles) grid = ntiles;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(TILE * KSPLIT), lds_bytes, stream, p, ntiles);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G::NT), lds_bytes, stream, p, ntiles);
     WLSQM_HIP_CHECK(hipGetLastError());
     note_kernel("tile");
     return WLSQM_OK;
@@ -279,35 +291,45 @@ int launch_fit_tile(int dimension, int order, const KParams& p, long long max_nk
     const char* off = getenv("WLSQM_HIP_DISABLE_TILE");
     if (off && off[0] == '1') return WLSQM_OK;
     if (!tile_eligible(dimension, p, max_nk)) return WLSQM_OK;
-#define TILE_CASE(D, O, KK, S)                                                   \
-    if (dimension == D && order == O && max_nk == KK) { *handled = true; return launch_tile<D, O, KK, S>(p, stream); }
-    if (dimension == 2 && order == 2 && max_nk == 32) {      // tuning variants, selected by WLSQM_TILE_VARIANT (default 0)
-        const char* v = getenv("WLSQM_TILE_VARIANT");
-        const int var = v ? atoi(v) : 0;
+    // WLSQM_TILE_VARIANT selects a tuning variant of the BASELINE configs (tools/tune.py); default = best measured
+    const char* v = getenv("WLSQM_TILE_VARIANT");
+    const int var = v ? atoi(v) : 0;
+#define TILE_CASE(D, O, KK, ...)                                                 \
+    if (dimension == D && order == O && max_nk == KK) { *handled = true; return launch_tile<D, O, KK, __VA_ARGS__>(p, stream); }
+    if (dimension == 2 && order == 2 && max_nk == 32) {      // C2
         *handled = true;
         switch (var) {
-            case 1: return launch_tile<2, 2, 32, 4, 1, 3>(p, stream);
-            case 2: return launch_tile<2, 2, 32, 4, 8, 2>(p, stream);
-            case 4: return launch_tile<2, 2, 32, 4, 4, 3>(p, stream);
-            case 5: return launch_tile<2, 2, 32, 2, 2, 2>(p, stream);
-            case 6: return launch_tile<2, 2, 32, 2, 4, 2>(p, stream);
-            case 7: return launch_tile<2, 2, 32, 4, 2, 2, true>(p, stream);
-            case 8: return launch_tile<2, 2, 32, 4, 4, 2, true>(p, stream);
-            case 9: return launch_tile<2, 2, 32, 4, 1, 2, true>(p, stream);
-            case 10: return launch_tile<2, 2, 32, 4, 2, 3, true>(p, stream);
-            case 11: return launch_tile<2, 2, 32, 4, 2, 3>(p, stream);
-            default: return launch_tile<2, 2, 32, 4, 8, 2>(p, stream);   // best of the round-1 A/B (tools/tune.py)
+            case 1: return launch_tile<2, 2, 32, 4, 1, 1, 3>(p, stream);
+            case 2: return launch_tile<2, 2, 32, 4, 1, 4, 3>(p, stream);
+            case 3: return launch_tile<2, 2, 32, 2, 1, 4, 2>(p, stream);
+            case 4: return launch_tile<2, 2, 32, 2, 2, 8, 2>(p, stream);
+            case 5: return launch_tile<2, 2, 32, 4, 2, 4, 2>(p, stream);
+            case 6: return launch_tile<2, 2, 32, 1, 2, 4, 2>(p, stream);
+            default: return launch_tile<2, 2, 32, 4, 1, 8, 2>(p, stream);   // best of the round-1 A/B
         }
     }
-    TILE_CASE(2, 2, 16, 4)
-    TILE_CASE(2, 2, 24, 4)
-    TILE_CASE(2, 2, 48, 4)
-    TILE_CASE(2, 2, 64, 4)
-    TILE_CASE(2, 1, 16, 4)
-    TILE_CASE(2, 1, 32, 4)
-    TILE_CASE(1, 2, 8, 2)
-    TILE_CASE(1, 2, 16, 4)
-    TILE_CASE(3, 1, 32, 4)
+    if (dimension == 3 && order == 2 && max_nk == 40) {      // C5
+        *handled = true;
+        switch (var) {
+            case 1: return launch_tile<3, 2, 40, 4, 2, 1, 2>(p, stream);
+            case 2: return launch_tile<3, 2, 40, 4, 2, 5, 2>(p, stream);
+            default: return launch_tile<3, 2, 40, 2, 2, 2, 2>(p, stream);   // best of the round-1 A/B
+        }
+    }
+    // C3 (2D order 4, 64 neighbours): every tile variant tried (KSPLIT x LPC in {1x4, 2x4, 4x2, 2x2}) lost to the
+    // generic lane kernel (2.1-3.5 ms vs 1.27 ms per 1M cases): 136 accumulators per lane leave no registers for
+    // the staging/shuffle traffic.  It stays on fit_lane until the moment-based assembly lands.
+    TILE_CASE(2, 2, 16, 4, 1, 4, 2)
+    TILE_CASE(2, 2, 24, 2, 1, 4, 2)
+    TILE_CASE(2, 2, 48, 4, 1, 4, 2)
+    TILE_CASE(2, 2, 64, 4, 1, 4, 2)
+    TILE_CASE(2, 1, 16, 4, 1, 4, 2)
+    TILE_CASE(2, 1, 32, 4, 1, 4, 2)
+    TILE_CASE(1, 2, 8, 2, 1, 4, 2)
+    TILE_CASE(1, 2, 16, 4, 1, 4, 2)
+    TILE_CASE(3, 1, 32, 4, 1, 4, 2)
+    TILE_CASE(3, 2, 32, 4, 2, 4, 2)
+    TILE_CASE(2, 3, 40, 4, 2, 5, 2)
 #undef TILE_CASE
     return WLSQM_OK;
 }

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 import _cases as K
+import _cases as K_
 import _parity as P
 
 pytestmark = pytest.mark.gpu
@@ -251,27 +252,34 @@ def test_sens_reconstructs_solution(wlsqm):
     assert np.allclose(sens.T @ fk, fi, rtol=1e-11, atol=1e-12)
 
 
-@pytest.mark.parametrize("ncases", [64, 1000, 4097])
-def test_tile_path_equals_lane_path(wlsqm, ncases, monkeypatch):
-    """The LDS-tiled fast path (contiguous, K = 32) against the generic lane kernel on the same inputs:
+@pytest.mark.parametrize("dim,order,K,ncases", [(2, 2, 32, 64), (2, 2, 32, 1000), (2, 2, 32, 4097), (1, 2, 8, 777),
+                                                 (3, 2, 40, 1500), (2, 3, 40, 515), (2, 1, 16, 300), (3, 2, 32, 130)])
+def test_tile_path_equals_lane_path(wlsqm, dim, order, K, ncases, monkeypatch):
+    """The LDS-tiled fast path (contiguous, curated K) against the generic lane kernel on the same inputs:
     ragged nk <= K, mixed weightings and knowns, tail tiles.  Same arithmetic except for the split of the
-    neighbour sum over 4 waves, so agreement is to rounding."""
+    neighbour sum over lanes/waves, so agreement is to rounding."""
+    from wlsqm import _binding
     rng = np.random.default_rng(ncases)
-    K = 32
-    xi = rng.uniform(0, 1, (ncases, 2))
-    xk = xi[:, None, :] + 0.05 * rng.uniform(-1, 1, (ncases, K, 2))
-    fk = np.sin(3 * xk[..., 0]) * np.cos(2 * xk[..., 1])
-    nk = rng.integers(10, K + 1, ncases).astype(np.int32); nk[0] = K
-    order = np.full(ncases, 2, np.int32)
-    knowns = rng.choice(np.array([0, 0, 1, 1 << 4, 1 | (1 << 3), 63], np.int64), ncases)
+    no = K_.NDOF[dim][order]
+    xi = rng.uniform(0, 1, (ncases, dim))
+    xk = xi[:, None, :] + 0.05 * rng.uniform(-1, 1, (ncases, K, dim))
+    fk = np.sin(3 * xk[..., 0]) * np.cos(2 * xk[..., -1])
+    nk = rng.integers(max(no + 2, K // 3), K + 1, ncases).astype(np.int32); nk[0] = K
+    nk[ncases // 2:] = K                                         # whole tiles at full K take the unpredicated loop
+    orders = np.full(ncases, order, np.int32)
+    masks = [0, 0, 1, (1 << no) - 1] + ([1 << (no - 1), 1 | (1 << (no // 2))] if no >= 3 else [])
+    knowns = rng.choice(np.array(masks, np.int64), ncases)
     wm = rng.choice(np.array([1, 2], np.int32), ncases)
-    fi0 = rng.uniform(-1, 1, (ncases, 6)); fi0[:, 0] = np.sin(3 * xi[:, 0]) * np.cos(2 * xi[:, 1])
+    fi0 = rng.uniform(-1, 1, (ncases, no)); fi0[:, 0] = np.sin(3 * xi[:, 0]) * np.cos(2 * xi[:, -1])
+    if dim == 1:
+        xi, xk = np.ascontiguousarray(xi[:, 0]), np.ascontiguousarray(xk[..., 0])
+    f = _many(wlsqm, dim)
     fi_t = fi0.copy(); fi_l = fi0.copy()
-    wlsqm.fit_2D_many_parallel(xk, fk, nk, xi, fi_t, None, 0, order, knowns, wm)
+    f(xk, fk, nk, xi, fi_t, None, 0, orders, knowns, wm)
     monkeypatch.setenv("WLSQM_HIP_DISABLE_TILE", "1")
-    wlsqm.fit_2D_many_parallel(xk, fk, nk, xi, fi_l, None, 0, order, knowns, wm)
+    f(xk, fk, nk, xi, fi_l, None, 0, orders, knowns, wm)
     monkeypatch.delenv("WLSQM_HIP_DISABLE_TILE")
-    _check_untouched(fi_t, fi0, order, knowns, 2)
+    _check_untouched(fi_t, fi0, orders, knowns, dim)
     assert np.array_equal(fi_t == fi0, fi_l == fi0)
-    truth = P.truth_fit(2, xk, fk, nk, xi, fi0, order, knowns, wm)
+    truth = P.truth_fit(dim, xk, fk, nk, xi, fi0, orders, knowns, wm)
     P.assert_parity(fi_t, fi_l, truth, "tile vs lane")
