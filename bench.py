@@ -49,7 +49,8 @@ def build_problem(cfg, ncases, rank):
         return p["S"], p["F"], p["hoods"]
     S = synth.halton(ncases, dim, skip=1 + rank * ncases)       # each rank owns a different stretch of the sequence
     F = synth.field(S)
-    hoods = synth.knn(S, nk)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    hoods = synth.knn(S, nk, workers=max(1, len(os.sched_getaffinity(0)) // world))
     return S, F, hoods
 
 
@@ -72,7 +73,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if "RANK" in os.environ:        # launched by torch.distributed.run: one rank per GPU, RCCL ("nccl") process group
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 

@@ -111,6 +111,9 @@ int wlsqm_hip_expert_solve(wlsqm_expert* h, const double* fk, int64_t fk_stride_
  * pointers (contiguous k axis); enqueued on `stream`; no host synchronisation. */
 int wlsqm_hip_expert_solve_device(wlsqm_expert* h, void* stream, const double* fk, int64_t fk_stride_case,
                                   double* fi, int64_t fi_stride_case);
+/* expert.pyx:429-464 conds(): 2-norm condition number of the Ruiz-scaled reduced matrix of every case
+ * (impl.pyx:662-682), out[ncases] on the host.  Diagnostics path (one-sided Jacobi SVD per case). */
+int wlsqm_hip_expert_conds(wlsqm_expert* h, double* out);
 /* expert.pyx:289-306 memory_used(): (bytes in use, bytes reserved) of the device-side state. */
 int wlsqm_hip_expert_memory_used(const wlsqm_expert* h, int64_t* used, int64_t* total);
 /* expert.pyx:267-286 __del__ */

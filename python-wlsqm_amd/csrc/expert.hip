@@ -21,13 +21,19 @@ struct wlsqm_expert {
     std::vector<int32_t> nk, order, wm, no;
     std::vector<int64_t> kn;
     std::vector<long long> idx; int64_t off[6] = {0, 0, 0, 0, 0, 0};
-    wlsqm::DevBuf d_nk, d_wm, d_kn, d_idx, d_xk, d_xi, d_fk, d_fi, d_sens, d_it;
+    wlsqm::DevBuf d_nk, d_wm, d_kn, d_order, d_idx, d_xk, d_xi, d_fk, d_fi, d_sens, d_it;
     int64_t bytes() const {
-        return (int64_t)(d_nk.n + d_wm.n + d_kn.n + d_idx.n + d_xk.n + d_xi.n + d_fk.n + d_fi.n + d_sens.n + d_it.n);
+        return (int64_t)(d_nk.n + d_wm.n + d_kn.n + d_order.n + d_idx.n + d_xk.n + d_xi.n + d_fk.n + d_fi.n + d_sens.n + d_it.n);
     }
 };
 
 using namespace wlsqm;
+
+namespace wlsqm {
+long long cond_workspace_doubles(int no);
+int launch_conds(int dimension, int order, const KParams& p, const int* order_arr, double* ws, long long CH,
+                 long long case0, double* out, hipStream_t stream);
+}
 
 static KParams expert_params(const wlsqm_expert* h, const double* d_fk, int64_t sfk_j, double* d_fi, int64_t sfi_j) {
     KParams p{};
@@ -87,6 +93,7 @@ int wlsqm_hip_expert_create(wlsqm_expert** out, int device, int dimension, int64
     int rc = check_device(device);
     if (rc != WLSQM_OK) { delete h; return rc; }
     if ((rc = h->d_nk.alloc(ncases * 4)) || (rc = h->d_wm.alloc(ncases * 4)) || (rc = h->d_kn.alloc(ncases * 8)) ||
+        (rc = h->d_order.alloc(ncases * 4)) ||
         (rc = h->d_it.alloc(4)) || (rc = h->d_xk.alloc((size_t)ncases * h->max_nk * dimension * 8)) ||
         (rc = h->d_xi.alloc((size_t)ncases * dimension * 8)) || (rc = h->d_fk.alloc((size_t)ncases * h->max_nk * 8)) ||
         (rc = h->d_fi.alloc((size_t)ncases * h->max_no * 8))) { delete h; return rc; }
@@ -94,7 +101,8 @@ int wlsqm_hip_expert_create(wlsqm_expert** out, int device, int dimension, int64
     hipError_t e;
     if ((e = hipMemcpy(h->d_nk.p, h->nk.data(), h->d_nk.n, hipMemcpyHostToDevice)) != hipSuccess ||
         (e = hipMemcpy(h->d_wm.p, h->wm.data(), h->d_wm.n, hipMemcpyHostToDevice)) != hipSuccess ||
-        (e = hipMemcpy(h->d_kn.p, h->kn.data(), h->d_kn.n, hipMemcpyHostToDevice)) != hipSuccess) {
+        (e = hipMemcpy(h->d_kn.p, h->kn.data(), h->d_kn.n, hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(h->d_order.p, h->order.data(), h->d_order.n, hipMemcpyHostToDevice)) != hipSuccess) {
         delete h; return hip_fail(e, "hipMemcpy(expert metadata)");
     }
     if (!h->uniform_order) {
@@ -190,6 +198,31 @@ int wlsqm_hip_expert_solve_device(wlsqm_expert* h, void* stream, const double* f
     KParams p = expert_params(h, fk, fk_stride_case, fi, fi_stride_case);
     p.iters_out = nullptr;
     return expert_launch(h, p, s);
+}
+
+int wlsqm_hip_expert_conds(wlsqm_expert* h, double* out) {
+    if (!h || !out) { set_error("null argument"); return WLSQM_EVALUE; }
+    if (!h->ready) { set_error("Solver is not in the ready state; prepare() must be called before conds()"); return WLSQM_ERUNTIME; }   // expert.pyx:438-439
+    int rc = check_device(h->device);
+    if (rc != WLSQM_OK) return rc;
+    const int64_t n = h->ncases;
+    const long long CH = std::min<int64_t>(n, 32768);
+    DevBuf ws, d_out;
+    if ((rc = ws.alloc((size_t)CH * cond_workspace_doubles(h->max_no) * 8)) || (rc = d_out.alloc((size_t)n * 8))) return rc;
+    KParams p = expert_params(h, nullptr, 0, nullptr, 0);
+    hipStream_t s = nullptr;
+    bool present[5] = {false, false, false, false, false};
+    for (int64_t j = 0; j < n; ++j) present[h->order[j]] = true;
+    for (long long c0 = 0; c0 < n; c0 += CH)
+        for (int o = 0; o <= 4; ++o) {
+            if (!present[o]) continue;
+            rc = launch_conds(h->dimension, o, p, h->uniform_order ? nullptr : h->d_order.as<int>(), ws.as<double>(), CH, c0,
+                              d_out.as<double>(), s);
+            if (rc != WLSQM_OK) return rc;
+        }
+    WLSQM_HIP_CHECK(hipMemcpyAsync(out, d_out.p, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+    WLSQM_HIP_CHECK(hipStreamSynchronize(s));
+    return WLSQM_OK;
 }
 
 int wlsqm_hip_expert_memory_used(const wlsqm_expert* h, int64_t* used, int64_t* total) {

@@ -123,13 +123,16 @@ class ExpertSolver:
         self.ready = True
 
     def conds(self):
-        """2-norm condition numbers of the scaled problem matrices (expert.pyx:429-464).  Debug-only in the
-        reference (two dgesvd per case, impl.pyx:662-682); not provided by the HIP backend yet."""
+        """2-norm condition numbers of the (Ruiz-scaled) problem matrices, shape (ncases,) (expert.pyx:429-464).
+        Only available in debug mode, like the reference (which fills them during prepare(), impl.pyx:662-682);
+        here they are computed on the device from the resident geometry when asked for."""
         if not self.ready:
             raise RuntimeError("Solver is not in the ready state; prepare() must be called before conds()")
         if not self.debug:
             raise RuntimeError("Not in debug mode; condition number data has not been computed")
-        raise NotImplementedError("conds() (debug-mode SVD condition numbers) is not implemented in the HIP backend")
+        out = np.empty((self.ncases,), dtype=np.float64)
+        B.check(B.lib().wlsqm_hip_expert_conds(self._handle, out.ctypes.data))
+        return out
 
     def solve(self, fk, fi, sens=None):
         """Fit all cases to the data fk on the prepared geometry (expert.pyx:467-655).  Returns the maximum

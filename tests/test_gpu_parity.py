@@ -283,3 +283,26 @@ def test_tile_path_equals_lane_path(wlsqm, dim, order, K, ncases, monkeypatch):
     assert np.array_equal(fi_t == fi0, fi_l == fi0)
     truth = P.truth_fit(dim, xk, fk, nk, xi, fi0, orders, knowns, wm)
     P.assert_parity(fi_t, fi_l, truth, "tile vs lane")
+
+
+@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C5", "X2", "X3"])
+def test_expert_conds_vs_reference(wlsqm, name):
+    """ExpertSolver(debug=True).conds(): 2-norm condition numbers of the Ruiz-scaled reduced matrices
+    (expert.pyx:429-464) against the values the reference's dgesvd path produced (golden `conds`)."""
+    c = K.config(name)
+    g = c["g"]
+    s = wlsqm.ExpertSolver(dimension=c["dim"], nk=c["nk_a"], order=c["order_a"], knowns=c["knowns_a"],
+                           weighting_method=c["wm_a"], debug=True)
+    with pytest.raises(RuntimeError):
+        s.conds()                                                  # not prepared yet (expert.pyx:438-439)
+    s.prepare(xi=c["xi"], xk=c["xk"])
+    got = s.conds()
+    assert got.shape == (c["n"],)
+    ref = g["conds"]
+    rel = np.abs(got - ref) / ref
+    assert rel.max() <= 1e-8 * max(1.0, ref.max() / 1e3), (rel.max(), ref.max())
+    s2 = wlsqm.ExpertSolver(dimension=c["dim"], nk=c["nk_a"], order=c["order_a"], knowns=c["knowns_a"],
+                            weighting_method=c["wm_a"], debug=False)
+    s2.prepare(xi=c["xi"], xk=c["xk"])
+    with pytest.raises(RuntimeError):
+        s2.conds()                                                 # not in debug mode (expert.pyx:440-441)
