@@ -92,6 +92,20 @@ int wlsqm_hip_fit_many_host(const wlsqm_batch* b, int device, int32_t* iteration
 int wlsqm_hip_fit_many_device(const wlsqm_batch* b, int device, void* stream, int order_uniform,
                               const int64_t* case_index, int64_t ncases_sel, int32_t* iterations_out);
 
+/* Index-based ("cloud") variant of wlsqm_hip_fit_many_device — an EXTENSION of the reference surface (the step
+ * before the path: examples/expertsolver_example.py:91-92 builds xk = S[hoods], fk = F[hoods] on the host).
+ * The kernels gather the neighbour rows themselves from the device-resident point tables S[npoints, dim] and
+ * F[npoints] through hoods[ncases, max_nk] (int32), which cuts the algorithmic HBM bytes per fit from
+ * 8 nk (dim+1) to 4 nk.  xi of case j is S[point_index ? point_index[j] : j].  All cases have polynomial order
+ * `order`; nk / knowns / weighting_method are per-case device arrays (unit stride); fi is in/out as usual.
+ * Supported for systems with no <= 15 DOFs (everything except 3D order 3/4). */
+int wlsqm_hip_fit_cloud_device(int dimension, int order, int64_t ncases, int64_t max_nk,
+                               const double* S, const double* F, const int32_t* hoods, int64_t hoods_stride_case,
+                               const int32_t* point_index, const int32_t* nk, const int64_t* knowns,
+                               const int32_t* weighting_method, double* fi, int64_t fi_stride_case,
+                               double* sens, int64_t sens_stride_case, int64_t sens_stride_k, int do_sens,
+                               int iterative, int max_iter, int device, void* stream, int32_t* iterations_out);
+
 /* ---- ExpertSolver (expert.pyx:66-781): handle-based prepare-once / solve-many ---- */
 typedef struct wlsqm_expert wlsqm_expert;
 
@@ -125,6 +139,12 @@ int wlsqm_hip_expert_destroy(wlsqm_expert* h);
  * milliseconds in *ms_out. */
 int wlsqm_hip_time_fit_device(const wlsqm_batch* b, int device, void* stream, int order_uniform,
                               int reps, float* ms_out);
+/* Same for the index-based path (basic algorithm, no sensitivities). */
+int wlsqm_hip_time_fit_cloud_device(int dimension, int order, int64_t ncases, int64_t max_nk,
+                                    const double* S, const double* F, const int32_t* hoods, int64_t hoods_stride_case,
+                                    const int32_t* point_index, const int32_t* nk, const int64_t* knowns,
+                                    const int32_t* weighting_method, double* fi, int64_t fi_stride_case,
+                                    int device, void* stream, int reps, float* ms_out);
 
 #ifdef __cplusplus
 }

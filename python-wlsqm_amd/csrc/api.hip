@@ -31,6 +31,7 @@ int launch_fit(int dimension, int order, const KParams& p, long long max_nk, hip
     const int no = wlsqm_hip_number_of_dofs(dimension, order);
     if (no < 0) { set_error("bad dimension/order"); return WLSQM_EVALUE; }
     if (p.ncases <= 0) return WLSQM_OK;
+    if (p.hoods && no > 15) { set_error("the index-based path supports systems with at most 15 DOFs"); return WLSQM_EVALUE; }
     bool handled = false;
     int rc = launch_fit_tile(dimension, order, p, max_nk, stream, &handled);
     if (rc != WLSQM_OK || handled) return rc;
@@ -265,21 +266,62 @@ int wlsqm_hip_fit_many_host(const wlsqm_batch* b, int device, int32_t* iteration
     return WLSQM_OK;
 }
 
-int wlsqm_hip_time_fit_device(const wlsqm_batch* b, int device, void* stream, int order_uniform, int reps, float* ms_out) {
-    int rc = validate_batch(b);
+static int cloud_params(KParams& p, int dimension, int order, int64_t ncases, int64_t max_nk, const double* S, const double* F,
+                        const int32_t* hoods, int64_t hoods_stride_case, const int32_t* point_index, const int32_t* nk,
+                        const int64_t* knowns, const int32_t* wm, double* fi, int64_t fi_stride_case) {
+    if (dimension < 1 || dimension > 3) { set_error("dimension must be 1, 2 or 3"); return WLSQM_EVALUE; }
+    if (wlsqm_hip_number_of_dofs(dimension, order) < 0) { set_error("order must be 0..4"); return WLSQM_EVALUE; }
+    if (ncases < 1) { set_error("max_cases must be >= 1"); return WLSQM_EVALUE; }
+    if (!S || !F || !hoods || !nk || !knowns || !wm || !fi) { set_error("null array"); return WLSQM_EVALUE; }
+    p = KParams{};
+    p.hoods = hoods; p.shoods_j = hoods_stride_case; p.S = S; p.F = F; p.pidx = point_index;
+    p.nk = nk; p.snk = 1; p.knowns = (const long long*)knowns; p.sknowns = 1; p.wm = wm; p.swm = 1;
+    p.fi = fi; p.sfi_j = fi_stride_case; p.ncases = ncases;
+    (void)max_nk;
+    return WLSQM_OK;
+}
+
+int wlsqm_hip_fit_cloud_device(int dimension, int order, int64_t ncases, int64_t max_nk,
+                               const double* S, const double* F, const int32_t* hoods, int64_t hoods_stride_case,
+                               const int32_t* point_index, const int32_t* nk, const int64_t* knowns,
+                               const int32_t* weighting_method, double* fi, int64_t fi_stride_case,
+                               double* sens, int64_t sens_stride_case, int64_t sens_stride_k, int do_sens,
+                               int iterative, int max_iter, int device, void* stream, int32_t* iterations_out) {
+    KParams p;
+    int rc = cloud_params(p, dimension, order, ncases, max_nk, S, F, hoods, hoods_stride_case, point_index, nk, knowns,
+                          weighting_method, fi, fi_stride_case);
     if (rc != WLSQM_OK) return rc;
     rc = check_device(device);
     if (rc != WLSQM_OK) return rc;
-    if (reps < 1 || !ms_out) { set_error("reps must be >= 1"); return WLSQM_EVALUE; }
     hipStream_t s = (hipStream_t)stream;
-    KParams p = params_from(b);
+    p.sens = (do_sens ? sens : nullptr); p.ss_j = sens_stride_case; p.ss_k = sens_stride_k;
+    p.do_sens = (do_sens && sens) ? 1 : 0; p.iterative = iterative ? 1 : 0; p.max_iter = max_iter;
+    DevBuf it;
+    if (iterative) {
+        rc = it.alloc(sizeof(int)); if (rc != WLSQM_OK) return rc;
+        WLSQM_HIP_CHECK(hipMemsetAsync(it.p, 0, sizeof(int), s));
+        p.iters_out = it.as<int>();
+    }
+    rc = launch_fit(dimension, order, p, max_nk, s);
+    if (rc != WLSQM_OK) return rc;
+    if (iterations_out) *iterations_out = 0;
+    if (iterative) {
+        int h_it = 0;
+        WLSQM_HIP_CHECK(hipMemcpyAsync(&h_it, it.p, sizeof(int), hipMemcpyDeviceToHost, s));
+        WLSQM_HIP_CHECK(hipStreamSynchronize(s));
+        if (iterations_out) *iterations_out = h_it;
+    }
+    return WLSQM_OK;
+}
+
+static int time_launches(int dimension, int order, const KParams& p, long long max_nk, hipStream_t s, int reps, float* ms_out) {
     hipEvent_t e0, e1;
     WLSQM_HIP_CHECK(hipEventCreate(&e0));
     WLSQM_HIP_CHECK(hipEventCreate(&e1));
-    rc = launch_fit(b->dimension, order_uniform, p, b->max_nk, s);   // warm-up / code object load
+    int rc = launch_fit(dimension, order, p, max_nk, s);   // warm-up / code object load
     if (rc == WLSQM_OK) {
         (void)hipEventRecord(e0, s);
-        for (int r = 0; r < reps && rc == WLSQM_OK; ++r) rc = launch_fit(b->dimension, order_uniform, p, b->max_nk, s);
+        for (int r = 0; r < reps && rc == WLSQM_OK; ++r) rc = launch_fit(dimension, order, p, max_nk, s);
         (void)hipEventRecord(e1, s);
         hipError_t e = hipEventSynchronize(e1);
         if (e != hipSuccess) rc = hip_fail(e, "hipEventSynchronize");
@@ -287,6 +329,30 @@ int wlsqm_hip_time_fit_device(const wlsqm_batch* b, int device, void* stream, in
     }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return rc;
+}
+
+int wlsqm_hip_time_fit_cloud_device(int dimension, int order, int64_t ncases, int64_t max_nk,
+                                    const double* S, const double* F, const int32_t* hoods, int64_t hoods_stride_case,
+                                    const int32_t* point_index, const int32_t* nk, const int64_t* knowns,
+                                    const int32_t* weighting_method, double* fi, int64_t fi_stride_case,
+                                    int device, void* stream, int reps, float* ms_out) {
+    KParams p;
+    int rc = cloud_params(p, dimension, order, ncases, max_nk, S, F, hoods, hoods_stride_case, point_index, nk, knowns,
+                          weighting_method, fi, fi_stride_case);
+    if (rc != WLSQM_OK) return rc;
+    rc = check_device(device);
+    if (rc != WLSQM_OK) return rc;
+    if (reps < 1 || !ms_out) { set_error("reps must be >= 1"); return WLSQM_EVALUE; }
+    return time_launches(dimension, order, p, max_nk, (hipStream_t)stream, reps, ms_out);
+}
+
+int wlsqm_hip_time_fit_device(const wlsqm_batch* b, int device, void* stream, int order_uniform, int reps, float* ms_out) {
+    int rc = validate_batch(b);
+    if (rc != WLSQM_OK) return rc;
+    rc = check_device(device);
+    if (rc != WLSQM_OK) return rc;
+    if (reps < 1 || !ms_out) { set_error("reps must be >= 1"); return WLSQM_EVALUE; }
+    return time_launches(b->dimension, order_uniform, params_from(b), b->max_nk, (hipStream_t)stream, reps, ms_out);
 }
 
 }  // extern "C"

@@ -17,13 +17,19 @@ namespace wlsqm {
 
 constexpr int LANE_BLOCK = 64;   // one wave per workgroup: no cross-wave coupling, max scheduling freedom
 
+// Row access of one case: dense (xk/fk rows with strides) or index-based (hoods row into the S/F point tables).
 template <int DIM>
-__device__ __forceinline__ void load_offset(const double* xr, long long k, long long sxk_k,
-                                            const double (&xi)[DIM], double (&d)[DIM]) {
-    const double* q = xr + k * sxk_k;
+struct CaseRows {
+    const double* xr; long long sxk_k;
+    const double* fr; long long sfk_k;
+    const int* hr; const double* S; const double* F;      // hr != nullptr: index-based
+    __device__ __forceinline__ void offset(int k, const double (&xi)[DIM], double (&d)[DIM]) const {
+        const double* q = hr ? S + (long long)hr[k] * DIM : xr + k * sxk_k;
 #pragma unroll
-    for (int m = 0; m < DIM; ++m) d[m] = q[m] - xi[m];
-}
+        for (int m = 0; m < DIM; ++m) d[m] = q[m] - xi[m];
+    }
+    __device__ __forceinline__ double value(int k) const { return hr ? F[hr[k]] : fr[k * sfk_k]; }
+};
 
 template <int DIM, int ORDER, bool EXTRAS>
 __global__ __launch_bounds__(LANE_BLOCK) void fit_lane_kernel(const KParams p) {
@@ -41,10 +47,17 @@ __global__ __launch_bounds__(LANE_BLOCK) void fit_lane_kernel(const KParams p) {
     if (known == FULL) return;                      // nr < 1: no-op (impl.pyx:574, 636, 742)
 
     double xi[DIM];
+    CaseRows<DIM> rows;
+    if (p.hoods) {
+        const long long pj = p.pidx ? p.pidx[j] : j;
 #pragma unroll
-    for (int m = 0; m < DIM; ++m) xi[m] = p.xi[j * p.sxi_j + m];
-    const double* xr = p.xk + j * p.sxk_j;
-    const double* fr = p.fk + j * p.sfk_j;
+        for (int m = 0; m < DIM; ++m) xi[m] = p.S[pj * DIM + m];
+        rows = CaseRows<DIM>{nullptr, 0, nullptr, 0, p.hoods + j * p.shoods_j, p.S, p.F};
+    } else {
+#pragma unroll
+        for (int m = 0; m < DIM; ++m) xi[m] = p.xi[j * p.sxi_j + m];
+        rows = CaseRows<DIM>{p.xk + j * p.sxk_j, p.sxk_k, p.fk + j * p.sfk_j, p.sfk_k, nullptr, nullptr, nullptr};
+    }
     double* fio = p.fi + j * p.sfi_j;
 
     // pass 1: largest squared distance (impl.pyx:389-391 etc.); not needed for uniform weights
@@ -52,7 +65,7 @@ __global__ __launch_bounds__(LANE_BLOCK) void fit_lane_kernel(const KParams p) {
     if (!uniform) {
         for (int k = 0; k < nk; ++k) {
             double d[DIM];
-            load_offset<DIM>(xr, k, p.sxk_k, xi, d);
+            rows.offset(k, xi, d);
             double d2 = d[0] * d[0];
             if constexpr (DIM >= 2) d2 += d[1] * d[1];
             if constexpr (DIM == 3) d2 += d[2] * d[2];
@@ -69,10 +82,10 @@ __global__ __launch_bounds__(LANE_BLOCK) void fit_lane_kernel(const KParams p) {
     for (int a = 0; a < NO; ++a) g[a] = 0.0;
     for (int k = 0; k < nk; ++k) {
         double d[DIM], c[NO];
-        load_offset<DIM>(xr, k, p.sxk_k, xi, d);
+        rows.offset(k, xi, d);
         const double d2 = monomials<DIM, ORDER>(d, c);
         const double w = weight(d2, inv_max, uniform);
-        accumulate<NO>(M, g, c, w, fr[k * p.sfk_k]);
+        accumulate<NO>(M, g, c, w, rows.value(k));
     }
 
     // knowns: values come from the user's fi (Case_set_fi, infra.pyx:780-785)
@@ -95,7 +108,7 @@ __global__ __launch_bounds__(LANE_BLOCK) void fit_lane_kernel(const KParams p) {
             double* sr = p.sens + j * p.ss_j;
             for (int k = 0; k < nk; ++k) {
                 double d[DIM], c[NO], s[NO];
-                load_offset<DIM>(xr, k, p.sxk_k, xi, d);
+                rows.offset(k, xi, d);
                 const double d2 = monomials<DIM, ORDER>(d, c);
                 const double w = weight(d2, inv_max, uniform);
 #pragma unroll
@@ -127,13 +140,13 @@ __global__ __launch_bounds__(LANE_BLOCK) void fit_lane_kernel(const KParams p) {
                 for (int a = 0; a < NO; ++a) r[a] = 0.0;
                 for (int k = 0; k < nk; ++k) {
                     double d[DIM], c[NO];
-                    load_offset<DIM>(xr, k, p.sxk_k, xi, d);
+                    rows.offset(k, xi, d);
                     const double d2 = monomials<DIM, ORDER>(d, c);
                     const double w = weight(d2, inv_max, uniform);
                     double model = fi[0];                       // taylor_*D (polyeval.pyx): sum_a c[a] fi[a]
 #pragma unroll
                     for (int a = 1; a < NO; ++a) model += c[a] * fi[a];
-                    const double res = fr[k * p.sfk_k] - model;
+                    const double res = rows.value(k) - model;
                     const double ar = fabs(res);
                     if (k == 0) norm = ar; else if (ar > norm) norm = ar;   // impl.pyx:1037-1041
                     const double wr = w * res;

@@ -67,7 +67,9 @@ struct TileGeom {
 
 // UNR: unroll factor of the neighbour loops; MINW: min waves per SIMD for the register allocator
 // (__launch_bounds__ 2nd argument).
-template <int DIM, int ORDER, int K, int KSPLIT, int LPC, int UNR, int MINW>
+// GATHER: index-based ("cloud") input — the tile's rows are gathered from the point tables S/F through
+// hoods[ncases, K] instead of being read from dense xk/fk; everything after the LDS staging is identical.
+template <int DIM, int ORDER, int K, int KSPLIT, int LPC, int UNR, int MINW, bool GATHER>
 __global__ __launch_bounds__(WV * KSPLIT, MINW) void fit_tile_kernel(const KParams p, const long long ntiles) {
     using G = TileGeom<DIM, ORDER, K, KSPLIT, LPC>;
     constexpr int NO = G::NO, NE = G::NE, TC = G::TC, NT = G::NT, RS = G::RS, FS = G::FS;
@@ -92,50 +94,101 @@ __global__ __launch_bounds__(WV * KSPLIT, MINW) void fit_tile_kernel(const KPara
         const long long jc = valid ? j : p.ncases - 1;     // clamp: tail lanes replay the last case, never store
         const long long nvalid = (p.ncases - j0 < TC) ? (p.ncases - j0) : TC;
 
-        // ---- stage 1: issue every global load of the tile (coalesced 16 B per lane)
-        double2_ bx[NX], bf[NF];
-        {
-            const double2_* gx = reinterpret_cast<const double2_*>(p.xk + j0 * (long long)(K * DIM));
-            const double2_* gf = reinterpret_cast<const double2_*>(p.fk + j0 * (long long)K);
-            const long long xlim = nvalid * CPRX, flim = nvalid * CPRF;
-#pragma unroll
-            for (int i = 0; i < NX; ++i) {
-                const long long q = tid + (long long)i * NT;
-                bx[i] = gx[q < xlim ? q : xlim - 1];
-            }
-#pragma unroll
-            for (int i = 0; i < NF; ++i) {
-                const long long q = tid + (long long)i * NT;
-                bf[i] = gf[q < flim ? q : flim - 1];
-            }
-        }
         // per-case scalars (small, straight to registers)
         const int nkc = min(p.nk[jc * p.snk], K);
         const bool uniform = (p.wm[jc * p.swm] == WLSQM_WEIGHT_UNIFORM);
         unsigned long long known, dropped;
         effective_mask<NO>(p.knowns[jc * p.sknowns], known, dropped);
         double xi[DIM];
-#pragma unroll
-        for (int m = 0; m < DIM; ++m) xi[m] = p.xi[jc * p.sxi_j + m];
 
-        // ---- stage 2: park the tile in LDS (padded rows)
+        if constexpr (!GATHER) {
+            // ---- stage 1: issue every global load of the tile (coalesced 16 B per lane)
+            double2_ bx[NX], bf[NF];
+            {
+                const double2_* gx = reinterpret_cast<const double2_*>(p.xk + j0 * (long long)(K * DIM));
+                const double2_* gf = reinterpret_cast<const double2_*>(p.fk + j0 * (long long)K);
+                const long long xlim = nvalid * CPRX, flim = nvalid * CPRF;
 #pragma unroll
-        for (int i = 0; i < NX; ++i) {
-            const int q = tid + i * NT;
-            if (G::XCH % NT == 0 || q < G::XCH) {
-                const int r = q / CPRX, c2 = q - r * CPRX;     // compile-time divisors
-                double* d = sX + r * RS + 2 * c2;
-                if constexpr (RS % 2 == 0) *reinterpret_cast<double2_*>(d) = bx[i];
-                else { d[0] = bx[i].x; d[1] = bx[i].y; }
+                for (int i = 0; i < NX; ++i) {
+                    const long long q = tid + (long long)i * NT;
+                    bx[i] = gx[q < xlim ? q : xlim - 1];
+                }
+#pragma unroll
+                for (int i = 0; i < NF; ++i) {
+                    const long long q = tid + (long long)i * NT;
+                    bf[i] = gf[q < flim ? q : flim - 1];
+                }
             }
-        }
 #pragma unroll
-        for (int i = 0; i < NF; ++i) {
-            const int q = tid + i * NT;
-            if (G::FCH % NT == 0 || q < G::FCH) {
-                const int r = q / CPRF, c2 = q - r * CPRF;
-                double* d = sF + r * FS + 2 * c2;
-                d[0] = bf[i].x; d[1] = bf[i].y;
+            for (int m = 0; m < DIM; ++m) xi[m] = p.xi[jc * p.sxi_j + m];
+
+            // ---- stage 2: park the tile in LDS (padded rows)
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                const int q = tid + i * NT;
+                if (G::XCH % NT == 0 || q < G::XCH) {
+                    const int r = q / CPRX, c2 = q - r * CPRX;     // compile-time divisors
+                    double* d = sX + r * RS + 2 * c2;
+                    if constexpr (RS % 2 == 0) *reinterpret_cast<double2_*>(d) = bx[i];
+                    else { d[0] = bx[i].x; d[1] = bx[i].y; }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NF; ++i) {
+                const int q = tid + i * NT;
+                if (G::FCH % NT == 0 || q < G::FCH) {
+                    const int r = q / CPRF, c2 = q - r * CPRF;
+                    double* d = sF + r * FS + 2 * c2;
+                    d[0] = bf[i].x; d[1] = bf[i].y;
+                }
+            }
+        } else {
+            // ---- stage 1: the tile's neighbour lists, TC*K int32 contiguous (coalesced 16 B per lane) ...
+            static_assert(!GATHER || K % 4 == 0, "index rows must be multiples of 16 bytes");
+            constexpr int HCH = TC * K / 4, NH = (HCH + NT - 1) / NT, CPRH = K / 4;
+            typedef int int4_ __attribute__((ext_vector_type(4)));
+            int4_ hb[NH];
+            {
+                const int4_* gh = reinterpret_cast<const int4_*>(p.hoods + j0 * (long long)K);
+                const long long hlim = nvalid * CPRH;
+#pragma unroll
+                for (int i = 0; i < NH; ++i) {
+                    const long long q = tid + (long long)i * NT;
+                    hb[i] = gh[q < hlim ? q : hlim - 1];
+                }
+            }
+            const long long pj = p.pidx ? (long long)p.pidx[jc] : jc;
+#pragma unroll
+            for (int m = 0; m < DIM; ++m) xi[m] = p.S[pj * DIM + m];
+            // ... then the gathers of the point rows they name (4 per index chunk), all in flight together
+            double gx[NH * 4][DIM], gf[NH * 4];
+#pragma unroll
+            for (int i = 0; i < NH; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const long long idx = hb[i][e];
+                    if constexpr (DIM == 2) {
+                        const double2_ v = *reinterpret_cast<const double2_*>(p.S + idx * 2);
+                        gx[i * 4 + e][0] = v.x; gx[i * 4 + e][1] = v.y;
+                    } else {
+#pragma unroll
+                        for (int m = 0; m < DIM; ++m) gx[i * 4 + e][m] = p.S[idx * DIM + m];
+                    }
+                    gf[i * 4 + e] = p.F[idx];
+                }
+            // ---- stage 2: park them in the same padded LDS image the dense path builds
+#pragma unroll
+            for (int i = 0; i < NH; ++i) {
+                const int q = tid + i * NT;
+                if (HCH % NT == 0 || q < HCH) {
+                    const int r = q / CPRH, kq = 4 * (q - r * CPRH);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                        for (int m = 0; m < DIM; ++m) sX[r * RS + (kq + e) * DIM + m] = gx[i * 4 + e][m];
+                        sF[r * FS + kq + e] = gf[i * 4 + e];
+                    }
+                }
             }
         }
         __syncthreads();
@@ -251,12 +304,15 @@ __global__ __launch_bounds__(WV * KSPLIT, MINW) void fit_tile_kernel(const KPara
 }
 
 template <int DIM, int ORDER, int K, int KSPLIT, int LPC = 1, int UNR = 2, int MINW = 2>
-static int launch_tile(const KParams& p, hipStream_t stream) {
+static int launch_tile_any(const KParams& p, hipStream_t stream, bool gather);
+
+template <int DIM, int ORDER, int K, int KSPLIT, int LPC, int UNR, int MINW, bool GATHER>
+static int launch_tile_impl(const KParams& p, hipStream_t stream) {
     using G = TileGeom<DIM, ORDER, K, KSPLIT, LPC>;
     constexpr size_t lds_bytes = G::LDS_BYTES;
     const long long ntiles = (p.ncases + G::TC - 1) / G::TC;
     static int per_cu = 0, cus = 0;
-    auto kern = fit_tile_kernel<DIM, ORDER, K, KSPLIT, LPC, UNR, MINW>;
+    auto kern = fit_tile_kernel<DIM, ORDER, K, KSPLIT, LPC, UNR, MINW, GATHER>;
     if (!cus) {
         int dev = 0;
         WLSQM_HIP_CHECK(hipGetDevice(&dev));
@@ -273,13 +329,28 @@ static int launch_tile(const KParams& p, hipStream_t stream) {
     if (grid > ntiles) grid = ntiles;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G::NT), lds_bytes, stream, p, ntiles);
     WLSQM_HIP_CHECK(hipGetLastError());
-    note_kernel("tile");
+    note_kernel(GATHER ? "tile-gather" : "tile");
     return WLSQM_OK;
 }
 
-// The tile path needs: no extras, all cases in order, dense contiguous arrays, 16-byte aligned bases.
+template <int DIM, int ORDER, int K, int KSPLIT, int LPC, int UNR, int MINW>
+static int launch_tile_any(const KParams& p, hipStream_t stream, bool gather) {
+    if constexpr (K % 4 == 0) {
+        if (gather) return launch_tile_impl<DIM, ORDER, K, KSPLIT, LPC, UNR, MINW, true>(p, stream);
+    } else {
+        if (gather) { set_error("index-based tile path needs K % 4 == 0"); return WLSQM_EVALUE; }
+    }
+    return launch_tile_impl<DIM, ORDER, K, KSPLIT, LPC, UNR, MINW, false>(p, stream);
+}
+
+// The tile path needs: no extras, all cases in order, dense contiguous arrays, 16-byte aligned bases
+// (index-based mode: contiguous 16-byte aligned hoods rows, 16-byte aligned S).
 static bool tile_eligible(int dim, const KParams& p, long long K) {
     if (p.do_sens || p.iterative || p.case_index) return false;
+    if (p.hoods) {
+        if (p.shoods_j != K || (K % 4) != 0) return false;
+        return ((reinterpret_cast<uintptr_t>(p.hoods) | reinterpret_cast<uintptr_t>(p.S)) & 15u) == 0;
+    }
     if (p.sxk_k != dim || p.sxk_j != K * dim || p.sfk_k != 1 || p.sfk_j != K) return false;
     if ((reinterpret_cast<uintptr_t>(p.xk) | reinterpret_cast<uintptr_t>(p.fk)) & 15u) return false;
     return true;
@@ -294,26 +365,27 @@ int launch_fit_tile(int dimension, int order, const KParams& p, long long max_nk
     // WLSQM_TILE_VARIANT selects a tuning variant of the BASELINE configs (tools/tune.py); default = best measured
     const char* v = getenv("WLSQM_TILE_VARIANT");
     const int var = v ? atoi(v) : 0;
+    const bool gather = p.hoods != nullptr;
 #define TILE_CASE(D, O, KK, ...)                                                 \
-    if (dimension == D && order == O && max_nk == KK) { *handled = true; return launch_tile<D, O, KK, __VA_ARGS__>(p, stream); }
+    if (dimension == D && order == O && max_nk == KK) { *handled = true; return launch_tile_any<D, O, KK, __VA_ARGS__>(p, stream, gather); }
     if (dimension == 2 && order == 2 && max_nk == 32) {      // C2
         *handled = true;
         switch (var) {
-            case 1: return launch_tile<2, 2, 32, 4, 1, 1, 3>(p, stream);
-            case 2: return launch_tile<2, 2, 32, 4, 1, 4, 3>(p, stream);
-            case 3: return launch_tile<2, 2, 32, 2, 1, 4, 2>(p, stream);
-            case 4: return launch_tile<2, 2, 32, 2, 2, 8, 2>(p, stream);
-            case 5: return launch_tile<2, 2, 32, 4, 2, 4, 2>(p, stream);
-            case 6: return launch_tile<2, 2, 32, 1, 2, 4, 2>(p, stream);
-            default: return launch_tile<2, 2, 32, 4, 1, 8, 2>(p, stream);   // best of the round-1 A/B
+            case 1: return launch_tile_any<2, 2, 32, 4, 1, 1, 3>(p, stream, gather);
+            case 2: return launch_tile_any<2, 2, 32, 4, 1, 4, 3>(p, stream, gather);
+            case 3: return launch_tile_any<2, 2, 32, 2, 1, 4, 2>(p, stream, gather);
+            case 4: return launch_tile_any<2, 2, 32, 2, 2, 8, 2>(p, stream, gather);
+            case 5: return launch_tile_any<2, 2, 32, 4, 2, 4, 2>(p, stream, gather);
+            case 6: return launch_tile_any<2, 2, 32, 1, 2, 4, 2>(p, stream, gather);
+            default: return launch_tile_any<2, 2, 32, 4, 1, 8, 2>(p, stream, gather);   // best of the round-1 A/B
         }
     }
     if (dimension == 3 && order == 2 && max_nk == 40) {      // C5
         *handled = true;
         switch (var) {
-            case 1: return launch_tile<3, 2, 40, 4, 2, 1, 2>(p, stream);
-            case 2: return launch_tile<3, 2, 40, 4, 2, 5, 2>(p, stream);
-            default: return launch_tile<3, 2, 40, 2, 2, 2, 2>(p, stream);   // best of the round-1 A/B
+            case 1: return launch_tile_any<3, 2, 40, 4, 2, 1, 2>(p, stream, gather);
+            case 2: return launch_tile_any<3, 2, 40, 4, 2, 5, 2>(p, stream, gather);
+            default: return launch_tile_any<3, 2, 40, 2, 2, 2, 2>(p, stream, gather);   // best of the round-1 A/B
         }
     }
     // C3 (2D order 4, 64 neighbours): every tile variant tried (KSPLIT x LPC in {1x4, 2x4, 4x2, 2x2}) lost to the

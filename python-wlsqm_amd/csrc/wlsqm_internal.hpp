@@ -18,6 +18,11 @@ struct KParams {
     double* sens;      long long ss_j, ss_k;
     const long long* knowns; long long sknowns;
     const int* wm;     long long swm;
+    // Index-based ("cloud") mode, hoods != nullptr: the neighbours of case j are rows hoods[j, k] of the point
+    // table S[npoints, dim] with values F[npoints]; xi = S[pidx ? pidx[j] : j]; xk / fk / xi above are unused.
+    const int* hoods;  long long shoods_j;
+    const double* S;   const double* F;
+    const int* pidx;
     const long long* case_index;   // nullable
     long long ncases;              // cases this launch processes
     int do_sens, iterative, max_iter;

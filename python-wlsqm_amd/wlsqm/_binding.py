@@ -35,6 +35,25 @@ class Batch(C.Structure):
 _lib = None
 
 
+def _init_torch_hip_first():
+    """PyTorch-ROCm wheels bundle their own HIP runtime (torch/lib/libamdhip64.so, no SONAME) next to the
+    system one this library links (libamdhip64.so.7).  Both can live in one process, but only if torch's is
+    initialised FIRST (the other order makes torch report "No HIP GPUs are available").  torch is the designated
+    owner of device memory and streams for the device-resident API, so when it is installed we let it
+    initialise the GPU before libwlsqm_hip.so is loaded.  Set WLSQM_HIP_SKIP_TORCH_INIT=1 to skip."""
+    if os.environ.get("WLSQM_HIP_SKIP_TORCH_INIT") == "1":
+        return
+    try:
+        import torch
+    except Exception:
+        return
+    try:
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
+
+
 def lib():
     """Load libwlsqm_hip.so; raises ImportError with build instructions if it is missing."""
     global _lib
@@ -44,6 +63,7 @@ def lib():
         raise ImportError(
             "wlsqm: the HIP library %s is missing. Build it with python-wlsqm_amd/build.sh "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    _init_torch_hip_first()
     L = C.CDLL(LIB_PATH)
     L.wlsqm_hip_last_error.restype = C.c_char_p
     L.wlsqm_hip_device_count.restype = C.c_int
@@ -55,6 +75,11 @@ def lib():
                                             C.c_int64, C.POINTER(C.c_int32)]
     L.wlsqm_hip_time_fit_device.argtypes = [C.POINTER(Batch), C.c_int, C.c_void_p, C.c_int, C.c_int,
                                             C.POINTER(C.c_float)]
+    cloud = [C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+             C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+    L.wlsqm_hip_fit_cloud_device.argtypes = cloud + [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                     C.c_void_p, C.POINTER(C.c_int32)]
+    L.wlsqm_hip_time_fit_cloud_device.argtypes = cloud + [C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_float)]
     L.wlsqm_hip_expert_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
     L.wlsqm_hip_expert_prepare.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64]
@@ -67,7 +92,7 @@ def lib():
     for name in ("wlsqm_hip_fit_many_host", "wlsqm_hip_fit_many_device", "wlsqm_hip_time_fit_device",
                  "wlsqm_hip_expert_create", "wlsqm_hip_expert_prepare", "wlsqm_hip_expert_solve",
                  "wlsqm_hip_expert_solve_device", "wlsqm_hip_expert_memory_used", "wlsqm_hip_expert_destroy",
-                 "wlsqm_hip_expert_conds",
+                 "wlsqm_hip_expert_conds", "wlsqm_hip_fit_cloud_device", "wlsqm_hip_time_fit_cloud_device",
                  "wlsqm_hip_number_of_dofs", "wlsqm_hip_number_of_reduced_dofs", "wlsqm_hip_remap"):
         getattr(L, name).restype = C.c_int
     _lib = L

@@ -10,7 +10,7 @@ import ctypes as C
 
 from . import _binding as B
 
-__all__ = ["fit_many_device", "time_fit_device", "device_count"]
+__all__ = ["fit_many_device", "time_fit_device", "fit_cloud_device", "time_fit_cloud_device", "device_count"]
 
 
 def device_count():
@@ -97,4 +97,50 @@ def time_fit_device(dimension, order, xk, fk, nk, xi, fi, knowns, weighting_meth
     s, dev = _stream_and_device(fi, stream)
     ms = C.c_float(0.0)
     B.check(B.lib().wlsqm_hip_time_fit_device(C.byref(b), dev, s, int(order), int(reps), C.byref(ms)))
+    return float(ms.value)
+
+
+def _cloud_args(dimension, order, S, F, hoods, fi, nk, knowns, weighting_method, point_index):
+    _check(F, "F", "float64", 1); _check(hoods, "hoods", "int32", 2); _check(fi, "fi", "float64", 2)
+    _check(S, "S", "float64", 1 if dimension == 1 else 2)
+    _check(nk, "nk", "int32", 1); _check(knowns, "knowns", "int64", 1); _check(weighting_method, "weighting_method", "int32", 1)
+    if not S.is_contiguous() or not F.is_contiguous() or hoods.stride(1) != 1 or fi.stride(1) != 1:
+        raise ValueError("S, F must be contiguous; hoods and fi must have a contiguous last axis")
+    for t in (nk, knowns, weighting_method):
+        if t.stride(0) != 1:
+            raise ValueError("nk, knowns, weighting_method must have unit stride")
+    if point_index is not None:
+        _check(point_index, "point_index", "int32", 1)
+    ncases, K = int(hoods.shape[0]), int(hoods.shape[1])
+    return [int(dimension), int(order), ncases, K, _ptr(S), _ptr(F), _ptr(hoods), int(hoods.stride(0)), _ptr(point_index),
+            _ptr(nk), _ptr(knowns), _ptr(weighting_method), _ptr(fi), int(fi.stride(0))]
+
+
+def fit_cloud_device(dimension, order, S, F, hoods, fi, nk, knowns, weighting_method, point_index=None, sens=None,
+                     iterative=False, max_iter=10, stream=None, want_iterations=False):
+    """Index-based fit (extension): the kernels gather xk = S[hoods], fk = F[hoods] themselves.
+
+    S (npoints, dim) [1D: (npoints,)] and F (npoints,) are the device-resident point tables, hoods (ncases, K)
+    int32 the neighbour lists, xi of case j is S[point_index[j]] (default: S[j]); nk/knowns/weighting_method
+    per case; fi (ncases, >= no) in/out.  4 nk bytes of indices per fit instead of 8 nk (dim+1) bytes of gathered
+    coordinates; order the points along a space-filling curve (synth.morton_order) so that the gathers hit L2."""
+    a = _cloud_args(dimension, order, S, F, hoods, fi, nk, knowns, weighting_method, point_index)
+    s, dev = _stream_and_device(fi, stream)
+    ss = (int(sens.stride(0)), int(sens.stride(1))) if sens is not None else (0, 0)
+    if sens is not None:
+        _check(sens, "sens", "float64", 3)
+    its = C.c_int32(0)
+    B.check(B.lib().wlsqm_hip_fit_cloud_device(*a, _ptr(sens), ss[0], ss[1], 1 if sens is not None else 0,
+                                               1 if iterative else 0, int(max_iter), dev, s,
+                                               C.byref(its) if (want_iterations or iterative) else None))
+    return int(its.value)
+
+
+def time_fit_cloud_device(dimension, order, S, F, hoods, fi, nk, knowns, weighting_method, point_index=None, reps=10,
+                          stream=None):
+    """Mean duration in milliseconds of one index-based fit launch (HIP events on `stream`)."""
+    a = _cloud_args(dimension, order, S, F, hoods, fi, nk, knowns, weighting_method, point_index)
+    s, dev = _stream_and_device(fi, stream)
+    ms = C.c_float(0.0)
+    B.check(B.lib().wlsqm_hip_time_fit_cloud_device(*a, dev, s, int(reps), C.byref(ms)))
     return float(ms.value)

@@ -18,10 +18,6 @@ def case_range(ncases, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def _default_fit(dimension, order, xk, fk, nk, xi, fi, knowns, wm):
-    from . import hip
-    hip.fit_many_device(dimension, order, xk, fk, nk, xi, fi, knowns, wm)
-
 
 class ShardedCloudSolver:
     """Fits every point of ONE global cloud, sharded by point ownership.
@@ -39,18 +35,23 @@ class ShardedCloudSolver:
         self.dimension, self.order = int(dimension), int(order)
         self.N, self.nk = int(hoods.shape[0]), int(hoods.shape[1])
         self.lo, self.hi = case_range(self.N, self.rank, self.world)
-        self.fit_fn = fit_fn or _default_fit
+        self.fit_fn = fit_fn          # None: index-based HIP kernel (no dense xk/fk is ever materialised)
         n = self.hi - self.lo
         S = torch.as_tensor(S, dtype=torch.float64)
         if S.dim() == 1:
             S = S[:, None]
         self.S = S.to(device)
         self.hoods = torch.as_tensor(hoods[self.lo:self.hi], dtype=torch.int64).to(device)
-        # geometry of the owned cases is gathered once (the "prepare" of this solver)
-        xk = self.S[self.hoods]                                   # (n, nk, dim)
-        self.xk = (xk[..., 0] if self.dimension == 1 else xk).contiguous()
-        xi = self.S[self.lo:self.hi]
-        self.xi = (xi[:, 0] if self.dimension == 1 else xi).contiguous()
+        if fit_fn is None:
+            self.hoods32 = self.hoods.to(torch.int32).contiguous()
+            self.pidx = torch.arange(self.lo, self.hi, dtype=torch.int32, device=device)
+            self.S_tab = (self.S[:, 0] if self.dimension == 1 else self.S).contiguous()
+        else:
+            # injected (dense) fit: the geometry of the owned cases is gathered once
+            xk = self.S[self.hoods]                               # (n, nk, dim)
+            self.xk = (xk[..., 0] if self.dimension == 1 else xk).contiguous()
+            xi = self.S[self.lo:self.hi]
+            self.xi = (xi[:, 0] if self.dimension == 1 else xi).contiguous()
         self.nk_t = torch.full((n,), self.nk, dtype=torch.int32, device=device)
         self.kn_t = torch.full((n,), int(knowns), dtype=torch.int64, device=device)
         self.wm_t = torch.full((n,), int(weighting_method), dtype=torch.int32, device=device)
@@ -61,9 +62,14 @@ class ShardedCloudSolver:
 
     def fit(self, F_global):
         """One pass: fit all owned points to the global point values F_global (N,).  Returns fi (n_own, no)."""
-        fk = F_global[self.hoods].contiguous()
         self.fi[:, 0] = F_global[self.lo:self.hi]
-        self.fit_fn(self.dimension, self.order, self.xk, fk, self.nk_t, self.xi, self.fi, self.kn_t, self.wm_t)
+        if self.fit_fn is None:
+            from . import hip
+            hip.fit_cloud_device(self.dimension, self.order, self.S_tab, F_global.contiguous(), self.hoods32, self.fi,
+                                 self.nk_t, self.kn_t, self.wm_t, point_index=self.pidx)
+        else:
+            fk = F_global[self.hoods].contiguous()
+            self.fit_fn(self.dimension, self.order, self.xk, fk, self.nk_t, self.xi, self.fi, self.kn_t, self.wm_t)
         return self.fi
 
     def allgather_values(self, v_own):

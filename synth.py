@@ -84,3 +84,18 @@ def line_problem_1d(npoints=10000, half=4, seed=0):
     mask = win != i[:, None]
     hoods = win[mask].reshape(npoints, nk)
     return dict(S=x, F=F, hoods=hoods.astype(np.int32), xk=x[hoods], fk=F[hoods], xi=x.copy())
+
+
+def morton_order(S, bits=16):
+    """Permutation that sorts points of [0,1]^dim along a Z-order (Morton) curve, so that points close in
+    space are close in memory — what the index-based kernels want for L2 locality of the neighbour gathers."""
+    S = np.asarray(S)
+    if S.ndim == 1:
+        return np.argsort(S, kind="stable")
+    dim = S.shape[1]
+    q = np.clip((S * (1 << bits)).astype(np.uint64), 0, (1 << bits) - 1)
+    key = np.zeros(S.shape[0], dtype=np.uint64)
+    for b in range(bits):
+        for d in range(dim):
+            key |= ((q[:, d] >> np.uint64(b)) & np.uint64(1)) << np.uint64(b * dim + d)
+    return np.argsort(key, kind="stable")

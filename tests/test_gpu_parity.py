@@ -306,3 +306,60 @@ def test_expert_conds_vs_reference(wlsqm, name):
     s2.prepare(xi=c["xi"], xk=c["xk"])
     with pytest.raises(RuntimeError):
         s2.conds()                                                 # not in debug mode (expert.pyx:440-441)
+
+
+@pytest.mark.parametrize("dim,order,K,n", [(2, 2, 32, 3000), (3, 2, 40, 1500), (2, 4, 64, 700), (1, 2, 8, 999), (2, 3, 20, 500)])
+def test_index_based_path_equals_dense_path(wlsqm, dim, order, K, n):
+    """wlsqm.hip.fit_cloud_device (the kernels gather S[hoods], F[hoods] themselves) against the dense
+    device-resident path on the gathered arrays: same arithmetic, so bit-identical; plus knowns and sens."""
+    import torch
+    import synth
+    import wlsqm.hip as whip
+    dev = torch.device("cuda", 0)
+    npts = 4 * n
+    S = synth.halton(npts, dim) if dim > 1 else np.sort(np.random.default_rng(1).uniform(0, 1, npts))
+    if dim > 1:
+        S = np.ascontiguousarray(S[synth.morton_order(S)])
+    F = synth.field(S)
+    hoods = synth.knn(S if dim > 1 else S[:, None], K, workers=1)
+    pidx = np.random.default_rng(2).permutation(npts)[:n].astype(np.int32)      # cases are a subset of the points
+    hoods_c = np.ascontiguousarray(hoods[pidx])
+    no = K_.NDOF[dim][order]
+    rng = np.random.default_rng(3)
+    masks = np.array([0, 1] + ([1 << (no - 1)] if no > 1 else []), np.int64)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    S_d, F_d, h_d, p_d = t(S), t(F), t(hoods_c), t(pidx)
+    nk_d = t(rng.integers(max(no + 1, K // 2), K + 1, n).astype(np.int32))
+    kn_d = t(rng.choice(masks, n)); wm_d = t(rng.choice(np.array([1, 2], np.int32), n))
+    fi0 = rng.uniform(-1, 1, (n, no)); fi0[:, 0] = F[pidx]
+    hl = h_d.long()
+    xk_d = S_d[hl].contiguous(); fk_d = F_d[hl].contiguous(); xi_d = S_d[p_d.long()].contiguous()
+    fi_a = t(fi0); fi_b = t(fi0)
+    whip.fit_many_device(dim, order, xk_d, fk_d, nk_d, xi_d, fi_a, kn_d, wm_d)
+    whip.fit_cloud_device(dim, order, S_d, F_d, h_d, fi_b, nk_d, kn_d, wm_d, point_index=p_d)
+    torch.cuda.synchronize()
+    assert torch.equal(fi_a, fi_b)
+    # extras (sensitivities + iterative refinement) go through the generic kernel on both paths
+    sens_a = torch.zeros((n, K, no), dtype=torch.float64, device=dev); sens_b = torch.zeros_like(sens_a)
+    fi_a = t(fi0); fi_b = t(fi0)
+    whip.fit_many_device(dim, order, xk_d, fk_d, nk_d, xi_d, fi_a, kn_d, wm_d, sens=sens_a, iterative=True, want_iterations=True)
+    whip.fit_cloud_device(dim, order, S_d, F_d, h_d, fi_b, nk_d, kn_d, wm_d, point_index=p_d, sens=sens_b, iterative=True)
+    torch.cuda.synchronize()
+    assert torch.equal(fi_a, fi_b) and torch.equal(torch.nan_to_num(sens_a), torch.nan_to_num(sens_b))
+
+
+def test_sharded_cloud_solver_single_gpu(wlsqm):
+    """ShardedCloudSolver on one rank (index-based kernel underneath) reproduces the dense API."""
+    import torch
+    import synth
+    from wlsqm.sharded import ShardedCloudSolver
+    N, nk = 5000, 32
+    S = synth.halton(N, 2); F = synth.field(S); hoods = synth.knn(S, nk, workers=1).astype(np.int64)
+    s = ShardedCloudSolver(2, S, hoods, order=2, knowns=1, weighting_method=2, device=torch.device("cuda", 0))
+    fi = s.fit(torch.from_numpy(F).cuda()).cpu().numpy()
+    ref = np.zeros((N, 6)); ref[:, 0] = F
+    wlsqm.fit_2D_many_parallel(S[hoods], F[hoods], np.full(N, nk, np.int32), S, ref, None, 0, np.full(N, 2, np.int32),
+                               np.ones(N, np.int64), np.full(N, 2, np.int32))
+    assert np.array_equal(fi, ref)
+    vals = s.allgather_values(torch.from_numpy(fi[:, 1].copy()).cuda())
+    assert np.array_equal(vals.cpu().numpy(), fi[:, 1])
