@@ -18,8 +18,10 @@
 //
 // LDS per workgroup is TC * K * (dim+1) * 8 B plus padding (50.7 KB for 2D/32 neighbours with
 // TC = 64), so three workgroups share a CU's 160 KB; while one workgroup computes, the others
-// have their ~48 KB of loads in flight, which is what keeps HBM busy.  Intra-workgroup software
-// prefetch through registers was measured and lost 15 % (it costs the third resident workgroup).
+// have their ~48 KB of loads in flight, which is what keeps HBM busy.  Measured and rejected (C2, 1M cases,
+// tools/tune.py): software prefetch of the next tile through registers, early (-15 %) or late, during the solve
+// (-12 %): both cost the third resident workgroup; 4 lanes per case without barriers (-28 %: the shuffle
+// reduction and the redundant solves cost more VALU than the barriers they remove).
 #include <cstdlib>
 
 #include "wlsqm_internal.hpp"
