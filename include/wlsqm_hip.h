@@ -128,10 +128,21 @@ int wlsqm_hip_expert_solve_device(wlsqm_expert* h, void* stream, const double* f
 /* expert.pyx:429-464 conds(): 2-norm condition number of the Ruiz-scaled reduced matrix of every case
  * (impl.pyx:662-682), out[ncases] on the host.  Diagnostics path (one-sided Jacobi SVD per case). */
 int wlsqm_hip_expert_conds(wlsqm_expert* h, double* out);
+/* expert.pyx:687-781 interpolate(): evaluate the models of the last solve() (or their derivative `diff`, a DOF
+ * index) at nx host points x[nx, dim].  mode='nearest': I[nx] (host) names the model per point (expert.pyx:830-895;
+ * the nearest-origin search itself stays on the host, scipy cKDTree, as in the reference); mode='continuous':
+ * CSR lists list_off[nx+1], list_idx[] of the models within radius r of each point (expert.pyx:898-985). */
+int wlsqm_hip_expert_interpolate(wlsqm_expert* h, const double* x, int64_t x_stride, int64_t nx, const int64_t* I,
+                                 const int64_t* list_off, const int64_t* list_idx, double r, int diff, double* out);
 /* expert.pyx:289-306 memory_used(): (bytes in use, bytes reserved) of the device-side state. */
 int wlsqm_hip_expert_memory_used(const wlsqm_expert* h, int64_t* used, int64_t* total);
 /* expert.pyx:267-286 __del__ */
 int wlsqm_hip_expert_destroy(wlsqm_expert* h);
+
+/* ---- model evaluation (the step after the path) ---- */
+/* interp.pyx:34-143 interpolate_fit: one model (xi[dim], fi[no], order) or its derivative `diff` at nx host points. */
+int wlsqm_hip_interpolate_fit_host(int dimension, int order, const double* xi, const double* fi,
+                                   const double* x, int64_t x_stride, int64_t nx, int diff, double* out, int device);
 
 /* ---- measurement hooks used by bench.py (not part of the reference surface) ---- */
 /* Runs `reps` back-to-back launches of the fit kernel for batch `b` (device-resident, uniform

@@ -12,12 +12,13 @@
 #include <vector>
 
 #include "wlsqm_internal.hpp"
+#include "wlsqm_interp.hpp"
 
 struct wlsqm_expert {
     int device = 0, dimension = 0, algorithm = 1, do_sens = 0, max_iter = 10;
     int64_t ncases = 0, max_nk = 1;
     int max_no = 0;
-    bool ready = false, uniform_order = true;
+    bool ready = false, solved = false, uniform_order = true;
     std::vector<int32_t> nk, order, wm, no;
     std::vector<int64_t> kn;
     std::vector<long long> idx; int64_t off[6] = {0, 0, 0, 0, 0, 0};
@@ -185,6 +186,7 @@ int wlsqm_hip_expert_solve(wlsqm_expert* h, const double* fk, int64_t fk_stride_
                 }
     }
     if (iterations_out) *iterations_out = (h->algorithm == WLSQM_ALGO_ITERATIVE) ? h_it : 0;
+    h->solved = true;                  // d_fi now holds the coefficients interpolate() evaluates (case.fi in the reference)
     return WLSQM_OK;
 }
 
@@ -198,6 +200,47 @@ int wlsqm_hip_expert_solve_device(wlsqm_expert* h, void* stream, const double* f
     KParams p = expert_params(h, fk, fk_stride_case, fi, fi_stride_case);
     p.iters_out = nullptr;
     return expert_launch(h, p, s);
+}
+
+// ExpertSolver.interpolate (expert.pyx:687-781): evaluate the models of the last solve() at nx host points.
+// I (host, nullable) names the model per point (mode='nearest', expert.pyx:830-895); list_off/list_idx (host CSR,
+// nullable) give the models within radius r of each point (mode='continuous', expert.pyx:898-985).
+int wlsqm_hip_expert_interpolate(wlsqm_expert* h, const double* x, int64_t x_stride, int64_t nx, const int64_t* I,
+                                 const int64_t* list_off, const int64_t* list_idx, double r, int diff, double* out) {
+    if (!h || !x || !out) { set_error("null argument"); return WLSQM_EVALUE; }
+    if (!h->ready || !h->solved) { set_error("interpolate() needs prepare() and solve() first"); return WLSQM_ERUNTIME; }
+    if (!I && !list_off) { set_error("either I or the neighbour lists must be given"); return WLSQM_EVALUE; }
+    int rc = check_device(h->device);
+    if (rc != WLSQM_OK) return rc;
+    if (nx <= 0) return WLSQM_OK;
+    const int dim = h->dimension;
+    std::vector<double> sx((size_t)nx * dim);
+    for (int64_t m = 0; m < nx; ++m)
+        for (int c = 0; c < dim; ++c) sx[(size_t)m * dim + c] = x[m * x_stride + c];
+    DevBuf d_x, d_I, d_off, d_idx, d_out;
+    hipStream_t s = nullptr;
+    if ((rc = d_x.alloc(sx.size() * 8)) || (rc = d_out.alloc((size_t)nx * 8))) return rc;
+    WLSQM_HIP_CHECK(hipMemcpyAsync(d_x.p, sx.data(), d_x.n, hipMemcpyHostToDevice, s));
+    InterpParams q{};
+    q.xi = h->d_xi.as<double>(); q.sxi = dim; q.fi = h->d_fi.as<double>(); q.sfi = h->max_no;
+    q.order = h->d_order.as<int>(); q.sorder = 1; q.nmodels = h->ncases;
+    q.x = d_x.as<double>(); q.sx = dim; q.nx = nx; q.diff = diff; q.out = d_out.as<double>();
+    if (list_off) {
+        const int64_t nlist = list_off[nx];
+        if ((rc = d_off.alloc((size_t)(nx + 1) * 8)) || (rc = d_idx.alloc((size_t)std::max<int64_t>(nlist, 1) * 8))) return rc;
+        WLSQM_HIP_CHECK(hipMemcpyAsync(d_off.p, list_off, (size_t)(nx + 1) * 8, hipMemcpyHostToDevice, s));
+        if (nlist > 0) WLSQM_HIP_CHECK(hipMemcpyAsync(d_idx.p, list_idx, (size_t)nlist * 8, hipMemcpyHostToDevice, s));
+        q.list_off = d_off.as<long long>(); q.list_idx = d_idx.as<long long>(); q.r2 = r * r;
+    } else {
+        if ((rc = d_I.alloc((size_t)nx * 8))) return rc;
+        WLSQM_HIP_CHECK(hipMemcpyAsync(d_I.p, I, (size_t)nx * 8, hipMemcpyHostToDevice, s));
+        q.I = d_I.as<long long>();
+    }
+    rc = launch_interp(dim, q, s);
+    if (rc != WLSQM_OK) return rc;
+    WLSQM_HIP_CHECK(hipMemcpyAsync(out, d_out.p, (size_t)nx * 8, hipMemcpyDeviceToHost, s));
+    WLSQM_HIP_CHECK(hipStreamSynchronize(s));
+    return WLSQM_OK;
 }
 
 int wlsqm_hip_expert_conds(wlsqm_expert* h, double* out) {

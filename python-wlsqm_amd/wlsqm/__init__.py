@@ -6,7 +6,8 @@ so they are available as ``wlsqm.fit_2D_many_parallel(...)``, ``wlsqm.ExpertSolv
 
     wlsqm.fitter.defs    # named constants (algorithms, weightings, DOF indices, bitmasks)
     wlsqm.fitter.simple  # simple fit API
-    wlsqm.fitter.expert  # advanced API (prepare once / solve many)
+    wlsqm.fitter.interp  # evaluation of fitted models (interpolate_fit, lambdify_fit)
+    wlsqm.fitter.expert  # advanced API (prepare once / solve many, interpolate)
     wlsqm.hip            # device-resident entry points (torch tensors / raw pointers), bench hooks
 """
 from pathlib import Path as _Path
@@ -14,4 +15,5 @@ __version__ = (_Path(__file__).parent / "VERSION").read_text().strip()
 
 from .fitter.defs import *    # noqa: F401, F403
 from .fitter.simple import *  # noqa: F401, F403
+from .fitter.interp import *  # noqa: F401, F403
 from .fitter.expert import *  # noqa: F401, F403

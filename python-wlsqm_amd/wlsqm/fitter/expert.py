@@ -134,6 +134,65 @@ class ExpertSolver:
         B.check(B.lib().wlsqm_hip_expert_conds(self._handle, out.ctypes.data))
         return out
 
+    def prep_interpolate(self):
+        """Index the origins xi with a k-d tree so that interpolate() can find the nearest local model
+        (expert.pyx:658-681; the search runs on the host with scipy, as in the reference)."""
+        if not self.ready:
+            raise RuntimeError("Solver is not in the ready state; prepare() must be called before prep_interpolate()")
+        if self.host is not None:
+            self.tree = self.host.tree
+        else:
+            import scipy.spatial
+            xi = np.asarray(self.xi)
+            self.tree = scipy.spatial.cKDTree(data=xi if self.dimension >= 2 else np.atleast_2d(xi).T)
+
+    def interpolate(self, x, mode='nearest', r=None, diff=0, I=None):
+        """Interpolate the global (patched) model or its derivative `diff` to the points x (expert.pyx:687-781).
+
+        mode='nearest': use the local model whose origin is nearest (or the models named by I); returns
+        (out, I_out).  mode='continuous': weighted average of all local models within radius r; returns (out, None)."""
+        if mode not in ('nearest', 'continuous'):
+            raise ValueError("mode must be one of 'nearest', 'continuous'; got '%s'" % (mode,))
+        if mode == 'continuous' and r is None:
+            raise ValueError("r must be specified in mode='continuous'")
+        if diff is None:
+            raise ValueError("diff cannot be None")
+        if self.tree is None:
+            raise RuntimeError("Points xi have not been indexed; prep_interpolate() must be called before interpolate()")
+        if I is not None and len(I) != len(x):
+            raise ValueError("When 'I' is specified, 'I' must have the same length as x; got len(I) = %d, len(x) = %d." % (len(I), len(x)))
+        if self.dimension == 1:
+            xv = B.view(x, np.float64, 1, "x")
+            xq = np.atleast_2d(xv).T
+        else:
+            xv = B.view(x, np.float64, 2, "x", contiguous_last=True)
+            xq = xv
+        nx = xv.shape[0]
+        out = np.empty((nx,), dtype=np.float64)
+        lib = B.lib()
+        if mode == 'nearest':
+            if I is None:
+                _, I_out = self.tree.query(xq, k=1)
+            else:
+                I_out = I
+            Iv = np.ascontiguousarray(np.asarray(I_out, dtype=np.int64))
+            if (Iv == self.ncases).any():                                        # expert.pyx:861-864
+                out[:] = np.nan
+                return out, np.asanyarray(I_out)
+            B.check(lib.wlsqm_hip_expert_interpolate(self._handle, xv.ctypes.data, B.es(xv, 0), nx, Iv.ctypes.data,
+                                                     None, None, 0.0, int(diff), out.ctypes.data))
+            return out, np.asanyarray(I_out)
+        import scipy.spatial
+        lists = scipy.spatial.cKDTree(data=xq).query_ball_tree(other=self.tree, r=r)   # expert.pyx:901-903
+        off = np.zeros(nx + 1, dtype=np.int64)
+        off[1:] = np.cumsum([len(L) for L in lists])
+        idx = np.ascontiguousarray(np.fromiter((i for L in lists for i in L), dtype=np.int64, count=int(off[-1])))
+        if idx.size == 0:
+            idx = np.zeros(1, dtype=np.int64)
+        B.check(lib.wlsqm_hip_expert_interpolate(self._handle, xv.ctypes.data, B.es(xv, 0), nx, None, off.ctypes.data,
+                                                 idx.ctypes.data, float(r), int(diff), out.ctypes.data))
+        return out, np.asanyarray(None)
+
     def solve(self, fk, fi, sens=None):
         """Fit all cases to the data fk on the prepared geometry (expert.pyx:467-655).  Returns the maximum
         number of refinement iterations taken (0 for ALGO_BASIC)."""

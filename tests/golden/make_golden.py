@@ -329,8 +329,50 @@ def gen_edge(outdir):
     print("edge: %d arrays" % len(out))
 
 
+def gen_interp(outdir):
+    """interpolate_fit (interp.pyx:34-143) for every (dimension, order, diff), and ExpertSolver.interpolate
+    (expert.pyx:687-781) in both modes on a small 2D cloud."""
+    import wlsqm
+    rng = np.random.default_rng(11)
+    out = {}
+    for dim in (1, 2, 3):
+        for order in range(5):
+            no = wlsqm.number_of_dofs(dim, order)
+            fi = rng.uniform(-1, 1, no)
+            xi = rng.uniform(-0.5, 0.5, dim)
+            x = xi + rng.uniform(-0.3, 0.3, (17, dim))
+            vals = np.zeros((no + 2, 17))
+            for diff in range(no + 2):                      # two past-the-end values: must give zeros (interp.pyx:674-678)
+                if dim == 1:
+                    vals[diff] = wlsqm.interpolate_fit(float(xi[0]), fi, dim, order, np.ascontiguousarray(x[:, 0]), diff)
+                else:
+                    vals[diff] = wlsqm.interpolate_fit(xi, fi, dim, order, x, diff)
+            k = "d%do%d_" % (dim, order)
+            out[k + "fi"] = fi; out[k + "xi"] = xi; out[k + "x"] = x; out[k + "vals"] = vals
+    # ExpertSolver.interpolate on a 2D order-2 cloud
+    p = synth.cloud_problem(2, 2048, 16, 300)
+    n = 300
+    nk = np.full(n, 16, np.int32); o = np.full(n, 2, np.int32); o[::3] = 3
+    kn = np.zeros(n, np.int64); w = np.full(n, 2, np.int32)
+    solver = wlsqm.ExpertSolver(dimension=2, nk=nk, order=o, knowns=kn, weighting_method=w, algorithm=wlsqm.ALGO_BASIC)
+    solver.prepare(xi=p["xi"], xk=p["xk"])
+    fi = np.zeros((n, 10))
+    solver.solve(fk=p["fk"], fi=fi)
+    solver.prep_interpolate()
+    xq = p["xi"][rng.integers(0, n, 64)] + rng.uniform(-0.01, 0.01, (64, 2))
+    for diff in (0, 1, 4, 7):
+        v, I = solver.interpolate(xq, mode="nearest", diff=diff)
+        out["ex_nearest_%d" % diff] = v; out["ex_I"] = np.asarray(I, np.int64)
+        v2, _ = solver.interpolate(xq, mode="continuous", r=0.05, diff=diff)
+        out["ex_cont_%d" % diff] = v2
+    out["ex_xq"] = xq; out["ex_order"] = o; out["ex_fi"] = fi
+    np.savez_compressed(os.path.join(outdir, "interp.npz"), **out)
+    print("interp: %d arrays" % len(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None, help="generate just one fixture family (e.g. interp)")
     ap.add_argument("--scratch", default="/tmp/wlsqm_oracle")
     ap.add_argument("--out", default=HERE)
     a = ap.parse_args()
@@ -338,6 +380,9 @@ def main():
     build_reference(a.scratch)
     import wlsqm
     assert os.path.realpath(wlsqm.__file__).startswith(os.path.realpath(a.scratch)), wlsqm.__file__
+    if a.only == "interp":
+        gen_interp(a.out)
+        return
     gen_remap(a.out)
     for dim in (1, 2, 3):
         gen_sweep(dim, a.out)
@@ -348,6 +393,7 @@ def main():
     gen_config("C5", 3, 2, 40, wlsqm.WEIGHT_CENTER, 0, 32768, 512, a.out)
     gen_config("X3", 3, 4, 100, wlsqm.WEIGHT_CENTER, wlsqm.b3_F, 32768, 64, a.out, extra_sens=4)
     gen_config("X2", 2, 3, 40, wlsqm.WEIGHT_CENTER, wlsqm.b2_F, 16384, 256, a.out)
+    gen_interp(a.out)
 
 
 if __name__ == "__main__":

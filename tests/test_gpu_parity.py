@@ -363,3 +363,50 @@ def test_sharded_cloud_solver_single_gpu(wlsqm):
     assert np.array_equal(fi, ref)
     vals = s.allgather_values(torch.from_numpy(fi[:, 1].copy()).cuda())
     assert np.array_equal(vals.cpu().numpy(), fi[:, 1])
+
+
+def test_interpolate_fit_vs_reference(wlsqm):
+    """interpolate_fit for every (dimension, order, diff) against the reference's values (golden interp.npz),
+    incl. diff >= no -> 0 (interp.pyx:674-678); lambdify_fit wraps the same evaluation."""
+    g = K.golden("interp.npz")
+    for dim in (1, 2, 3):
+        for order in range(5):
+            k = "d%do%d_" % (dim, order)
+            fi, xi, x, vals = g[k + "fi"], g[k + "xi"], g[k + "x"], g[k + "vals"]
+            for diff in range(vals.shape[0]):
+                if dim == 1:
+                    got = wlsqm.interpolate_fit(float(xi[0]), fi, dim, order, np.ascontiguousarray(x[:, 0]), diff)
+                else:
+                    got = wlsqm.interpolate_fit(xi, fi, dim, order, x, diff)
+                assert np.allclose(got, vals[diff], rtol=1e-12, atol=1e-13), (dim, order, diff)
+    fi, xi, x, vals = g["d2o3_fi"], g["d2o3_xi"], g["d2o3_x"], g["d2o3_vals"]
+    f = wlsqm.lambdify_fit(xi, fi, 2, 3, diff=wlsqm.i2_XY)
+    assert np.allclose(f(x[:, 0], x[:, 1]), vals[wlsqm.i2_XY], rtol=1e-12, atol=1e-13)
+    assert np.allclose(f(x[0, 0], x[0, 1]), vals[wlsqm.i2_XY][0], rtol=1e-12, atol=1e-13)
+
+
+def test_expert_interpolate_vs_reference(wlsqm):
+    """ExpertSolver.prep_interpolate/interpolate, nearest and continuous modes (expert.pyx:658-781)."""
+    import synth
+    g = K.golden("interp.npz")
+    p = synth.cloud_problem(2, 2048, 16, 300)
+    n = 300
+    nk = np.full(n, 16, np.int32); o = g["ex_order"]; kn = np.zeros(n, np.int64); w = np.full(n, 2, np.int32)
+    s = wlsqm.ExpertSolver(dimension=2, nk=nk, order=o, knowns=kn, weighting_method=w)
+    s.prepare(xi=p["xi"], xk=p["xk"])
+    fi = np.zeros((n, 10))
+    s.solve(fk=p["fk"], fi=fi)
+    assert np.allclose(fi, g["ex_fi"], rtol=1e-9, atol=1e-9)
+    with pytest.raises(RuntimeError):
+        s.interpolate(g["ex_xq"])                                   # prep_interpolate() not called yet
+    s.prep_interpolate()
+    for diff in (0, 1, 4, 7):
+        v, I = s.interpolate(g["ex_xq"], mode="nearest", diff=diff)
+        assert np.array_equal(I, g["ex_I"])
+        ref = g["ex_nearest_%d" % diff]
+        assert np.allclose(v, ref, rtol=1e-8, atol=1e-8 * max(1.0, np.abs(ref).max()))
+        v2, none = s.interpolate(g["ex_xq"], mode="continuous", r=0.05, diff=diff)
+        ref2 = g["ex_cont_%d" % diff]
+        assert np.allclose(v2, ref2, rtol=1e-8, atol=1e-8 * max(1.0, np.abs(ref2).max()))
+        v3, _ = s.interpolate(g["ex_xq"], mode="nearest", diff=diff, I=I)  # re-use the model indices
+        assert np.array_equal(v3, v)
