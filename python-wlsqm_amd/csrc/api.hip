@@ -26,6 +26,7 @@ void note_kernel(const char* name) { g_kernel = name; }
 int launch_fit_lane(int dimension, int order, const KParams& p, hipStream_t stream);
 int launch_fit_tile(int dimension, int order, const KParams& p, long long max_nk, hipStream_t stream, bool* handled);
 int launch_fit_wave(int dimension, int order, const KParams& p, hipStream_t stream);
+int launch_fit_moment(int dimension, int order, const KParams& p, long long max_nk, hipStream_t stream, bool* handled);
 
 int launch_fit(int dimension, int order, const KParams& p, long long max_nk, hipStream_t stream) {
     const int no = wlsqm_hip_number_of_dofs(dimension, order);
@@ -33,7 +34,9 @@ int launch_fit(int dimension, int order, const KParams& p, long long max_nk, hip
     if (p.ncases <= 0) return WLSQM_OK;
     if (p.hoods && no > 15) { set_error("the index-based path supports systems with at most 15 DOFs"); return WLSQM_EVALUE; }
     bool handled = false;
-    int rc = launch_fit_tile(dimension, order, p, max_nk, stream, &handled);
+    int rc = launch_fit_moment(dimension, order, p, max_nk, stream, &handled);
+    if (rc != WLSQM_OK || handled) return rc;
+    rc = launch_fit_tile(dimension, order, p, max_nk, stream, &handled);
     if (rc != WLSQM_OK || handled) return rc;
     if (no <= 15) return launch_fit_lane(dimension, order, p, stream);
     return launch_fit_wave(dimension, order, p, stream);

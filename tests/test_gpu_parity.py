@@ -253,7 +253,8 @@ def test_sens_reconstructs_solution(wlsqm):
 
 
 @pytest.mark.parametrize("dim,order,K,ncases", [(2, 2, 32, 64), (2, 2, 32, 1000), (2, 2, 32, 4097), (1, 2, 8, 777),
-                                                 (3, 2, 40, 1500), (2, 3, 40, 515), (2, 1, 16, 300), (3, 2, 32, 130)])
+                                                 (3, 2, 40, 1500), (2, 3, 40, 515), (2, 1, 16, 300), (3, 2, 32, 130),
+                                                 (2, 4, 64, 700)])
 def test_tile_path_equals_lane_path(wlsqm, dim, order, K, ncases, monkeypatch):
     """The LDS-tiled fast path (contiguous, curated K) against the generic lane kernel on the same inputs:
     ragged nk <= K, mixed weightings and knowns, tail tiles.  Same arithmetic except for the split of the
@@ -338,7 +339,14 @@ def test_index_based_path_equals_dense_path(wlsqm, dim, order, K, n):
     whip.fit_many_device(dim, order, xk_d, fk_d, nk_d, xi_d, fi_a, kn_d, wm_d)
     whip.fit_cloud_device(dim, order, S_d, F_d, h_d, fi_b, nk_d, kn_d, wm_d, point_index=p_d)
     torch.cuda.synchronize()
-    assert torch.equal(fi_a, fi_b)
+    if (dim, order, K) == (2, 4, 64):
+        # the dense path takes the moment kernels here, the index-based one the generic kernel: equal to rounding
+        xk_h, fk_h, xi_h = xk_d.cpu().numpy(), fk_d.cpu().numpy(), xi_d.cpu().numpy()
+        truth = P.truth_fit(dim, xk_h, fk_h, nk_d.cpu().numpy(), xi_h, fi0, np.full(n, order, np.int32),
+                            kn_d.cpu().numpy(), wm_d.cpu().numpy())
+        P.assert_parity(fi_b.cpu().numpy(), fi_a.cpu().numpy(), truth, "index-based vs dense (moment) path")
+    else:
+        assert torch.equal(fi_a, fi_b)
     # extras (sensitivities + iterative refinement) go through the generic kernel on both paths
     sens_a = torch.zeros((n, K, no), dtype=torch.float64, device=dev); sens_b = torch.zeros_like(sens_a)
     fi_a = t(fi0); fi_b = t(fi0)
