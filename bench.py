@@ -168,18 +168,22 @@ def cpu_baseline(oracle, cfg, xk_d, fk_d, xi_d, F, n, no):
     xk_h = xk_d[:ns].cpu().numpy(); fk_h = fk_d[:ns].cpu().numpy(); xi_h = xi_d[:ns].cpu().numpy()
     meta = (np.full(ns, nk, np.int32), np.full(ns, order, np.int32), np.full(ns, cfg["knowns"], np.int64),
             np.full(ns, cfg["wm"], np.int32))
-    best, reps, t_all = 0.0, 0, time.perf_counter()
-    while True:
-        fi = np.zeros((ns, no)); fi[:, 0] = F[:ns]
-        t0 = time.perf_counter()
-        oracle.fit_many(dim, xk_h, fk_h, meta[0], xi_h, fi, None, 0, meta[1], meta[2], meta[3], ntasks=cores)
-        dt = time.perf_counter() - t0
-        best = max(best, ns / dt); reps += 1
-        if reps >= 3 and time.perf_counter() - t_all > 5.0 or reps >= 20:
-            break
+    def rate(threads, budget_s):
+        best, reps, t_all = 0.0, 0, time.perf_counter()
+        while True:
+            fi = np.zeros((ns, no)); fi[:, 0] = F[:ns]
+            t0 = time.perf_counter()
+            oracle.fit_many(dim, xk_h, fk_h, meta[0], xi_h, fi, None, 0, meta[1], meta[2], meta[3], ntasks=threads)
+            dt = time.perf_counter() - t0
+            best = max(best, ns / dt); reps += 1
+            if (reps >= 3 and time.perf_counter() - t_all > budget_s) or reps >= 20:
+                return best, reps
+    best, reps = rate(cores, 5.0)
+    best8, reps8 = rate(min(8, cores), 5.0)       # the thread count the reference was timed with
     return {"value": best, "unit": "fits/s", "cores": cores, "kind": "port",
             "sample": "%d cases of the same workload, best of %d passes, OpenMP static schedule over %d threads"
-                      % (ns, reps, cores)}
+                      % (ns, reps, cores),
+            "value_8_threads": best8}
 
 
 if __name__ == "__main__":

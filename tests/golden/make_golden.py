@@ -329,6 +329,36 @@ def gen_edge(outdir):
     print("edge: %d arrays" % len(out))
 
 
+def gen_testmany2d(outdir):
+    """The harness pattern of examples/wlsqm_example.py:55-187 (testmany2d): neighbourhoods from a radius query
+    (ragged nk, capped at max_nk), order 4, knowns = b2_F, WEIGHT_CENTER; driver call and ExpertSolver."""
+    import wlsqm
+    from scipy.spatial import cKDTree
+    N, r, max_nk = 1024, 0.14, 100
+    S = synth.halton(N, 2)
+    F = synth.field(S)
+    tree = cKDTree(S)
+    lists = tree.query_ball_point(S, r)
+    hoods = np.full((N, max_nk), -1, np.int32); nk = np.zeros(N, np.int32)
+    for i, L in enumerate(lists):
+        L = [j for j in L if j != i][:max_nk]
+        nk[i] = len(L); hoods[i, :len(L)] = L
+    assert nk.min() >= 15, nk.min()
+    hp = np.where(hoods >= 0, hoods, 0)
+    xk = S[hp]; fk = F[hp]
+    o = np.full(N, 4, np.int32); kn = np.full(N, wlsqm.b2_F, np.int64); w = np.full(N, wlsqm.WEIGHT_CENTER, np.int32)
+    fi = np.zeros((N, 15)); fi[:, 0] = F
+    wlsqm.fit_2D_many_parallel(xk=xk, fk=fk, nk=nk, xi=S, fi=fi, sens=None, do_sens=0, order=o, knowns=kn,
+                               weighting_method=w, ntasks=8)
+    s = wlsqm.ExpertSolver(dimension=2, nk=nk, order=o, knowns=kn, weighting_method=w, ntasks=8)
+    s.prepare(xi=S, xk=xk)
+    fi2 = np.zeros((N, 15)); fi2[:, 0] = F
+    s.solve(fk=fk, fi=fi2)
+    assert np.allclose(fi, fi2, rtol=1e-13, atol=1e-13)
+    np.savez_compressed(os.path.join(outdir, "testmany2d.npz"), hoods=hoods, nk=nk, fi=fi, N=N, r=r)
+    print("testmany2d: nk in [%d, %d]" % (nk.min(), nk.max()))
+
+
 def gen_interp(outdir):
     """interpolate_fit (interp.pyx:34-143) for every (dimension, order, diff), and ExpertSolver.interpolate
     (expert.pyx:687-781) in both modes on a small 2D cloud."""
@@ -383,6 +413,9 @@ def main():
     if a.only == "interp":
         gen_interp(a.out)
         return
+    if a.only == "testmany2d":
+        gen_testmany2d(a.out)
+        return
     gen_remap(a.out)
     for dim in (1, 2, 3):
         gen_sweep(dim, a.out)
@@ -394,6 +427,7 @@ def main():
     gen_config("X3", 3, 4, 100, wlsqm.WEIGHT_CENTER, wlsqm.b3_F, 32768, 64, a.out, extra_sens=4)
     gen_config("X2", 2, 3, 40, wlsqm.WEIGHT_CENTER, wlsqm.b2_F, 16384, 256, a.out)
     gen_interp(a.out)
+    gen_testmany2d(a.out)
 
 
 if __name__ == "__main__":

@@ -418,3 +418,28 @@ def test_expert_interpolate_vs_reference(wlsqm):
         assert np.allclose(v2, ref2, rtol=1e-8, atol=1e-8 * max(1.0, np.abs(ref2).max()))
         v3, _ = s.interpolate(g["ex_xq"], mode="nearest", diff=diff, I=I)  # re-use the model indices
         assert np.array_equal(v3, v)
+
+
+def test_example_harness_ragged_radius_neighbourhoods(wlsqm):
+    """examples/wlsqm_example.py testmany2d pattern: radius neighbourhoods (ragged nk, padded arrays), order 4,
+    F known, through the driver call and through ExpertSolver, against the reference's captured fi."""
+    import synth
+    g = K.golden("testmany2d.npz")
+    N = int(g["N"])
+    S = synth.halton(N, 2); F = synth.field(S)
+    hoods, nk = g["hoods"], g["nk"]
+    hp = np.where(hoods >= 0, hoods, 0)
+    xk = S[hp]; fk = F[hp]
+    xk[hoods < 0] = np.nan; fk[hoods < 0] = np.nan                  # padding must never be read
+    o = np.full(N, 4, np.int32); kn = np.full(N, wlsqm.b2_F, np.int64); w = np.full(N, wlsqm.WEIGHT_CENTER, np.int32)
+    fi0 = np.zeros((N, 15)); fi0[:, 0] = F
+    truth = P.truth_fit(2, xk, fk, nk, S, fi0, o, kn, w)
+    fi = fi0.copy()
+    wlsqm.fit_2D_many_parallel(xk=xk, fk=fk, nk=nk, xi=S, fi=fi, sens=None, do_sens=0, order=o, knowns=kn,
+                               weighting_method=w, ntasks=8)
+    P.assert_parity(fi, g["fi"], truth, "testmany2d driver")
+    s = wlsqm.ExpertSolver(dimension=2, nk=nk, order=o, knowns=kn, weighting_method=w, ntasks=8)
+    s.prepare(xi=S, xk=xk)
+    fi2 = fi0.copy()
+    s.solve(fk=fk, fi=fi2)
+    assert np.array_equal(fi, fi2)                                  # same kernels, same inputs

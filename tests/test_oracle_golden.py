@@ -152,3 +152,21 @@ def test_edge_strided_views():
     oracle.fit_many(2, xkv, fkv, nka, e["strided_xi"], fiv, None, 0, o, kn, w)
     assert np.allclose(big_fi, e["strided_big_fi_after"], rtol=1e-11, atol=1e-13)
     assert np.all(big_fi[1::2] == 0) and np.all(big_fi[:, 6:] == 0)   # nothing outside the view is touched
+
+
+def test_example_harness_ragged_radius_neighbourhoods():
+    """examples/wlsqm_example.py testmany2d pattern (ragged nk from a radius query, order 4, F known)."""
+    import synth
+    g = K.golden("testmany2d.npz")
+    N = int(g["N"])
+    S = synth.halton(N, 2); F = synth.field(S)
+    hoods, nk = g["hoods"], g["nk"]
+    hp = np.where(hoods >= 0, hoods, 0)
+    xk = S[hp]; fk = F[hp]
+    xk[hoods < 0] = np.nan; fk[hoods < 0] = np.nan
+    o = np.full(N, 4, np.int32); kn = np.ones(N, np.int64); w = np.full(N, 2, np.int32)
+    fi0 = np.zeros((N, 15)); fi0[:, 0] = F
+    fi = fi0.copy()
+    oracle.fit_many(2, xk, fk, nk, S, fi, None, 0, o, kn, w, ntasks=4)
+    truth = P.truth_fit(2, xk, fk, nk, S, fi0, o, kn, w)
+    P.assert_parity(fi, g["fi"], truth, "testmany2d")
