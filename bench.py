@@ -57,8 +57,8 @@ def build_problem(cfg, ncases, rank):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
     ap.add_argument("--ncases", type=int, default=1_000_000, help="local fits per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -104,6 +104,14 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # The GPU sat idle through the host-side neighbour search above and has dropped to its low power state; the
+    # first ~50 ms of kernels run at reduced clocks (measured: 0.214 ms vs 0.183 ms per step).  Bring it back to the
+    # clocks of a long-running job before the untimed warm-up, so a short --warmup does not measure the ramp.
+    t_wake = time.perf_counter()
+    while time.perf_counter() - t_wake < 0.3:
+        for _ in range(50):
+            whip.fit_many_device(*args)
+        torch.cuda.synchronize()
     for _ in range(a.warmup):
         whip.fit_many_device(*args)
     barrier()
@@ -118,7 +126,7 @@ def main():
         dt = float(t.item())
 
     # dominant kernel, timed live with HIP events on the stream it is launched on
-    ms_kernel = whip.time_fit_device(*args, reps=max(a.steps, 5))
+    ms_kernel = whip.time_fit_device(*args, reps=min(max(a.steps, 20), 500))
     B_fit = bytes_per_fit(dim, order, nk, cfg["knowns"])
     achieved = B_fit * n / (ms_kernel * 1e-3) / 1e9
 
