@@ -193,6 +193,26 @@ class ExpertSolver:
                                                  idx.ctypes.data, float(r), int(diff), out.ctypes.data))
         return out, np.asanyarray(None)
 
+    def solve_device(self, fk, fi, stream=None):
+        """Device-resident solve (extension): fk (ncases, max_nk) and fi (ncases, >= no) are torch CUDA tensors
+        (float64, contiguous last axis); the fit is enqueued on `stream` (default: torch's current stream) with no
+        host synchronisation and no PCIe traffic.  ALGO_BASIC, no sensitivities.  This is the time-stepping fast
+        path: fi can feed the next step's fk without leaving HBM."""
+        if not self.ready:
+            raise RuntimeError("Solver is not in the ready state; prepare() must be called before solve()")
+        import torch
+        for t, name in ((fk, "fk"), (fi, "fi")):
+            if t.dtype != torch.float64 or t.dim() != 2 or not t.is_cuda or t.stride(1) != 1:
+                raise ValueError("%s must be a 2-D float64 device tensor with a contiguous last axis" % name)
+        if fk.shape[0] < self.ncases or fi.shape[0] < self.ncases or fk.shape[1] < self._max_nk:
+            raise ValueError("fk/fi are too small")
+        if stream is None:
+            stream = torch.cuda.current_stream(fi.device).cuda_stream
+        B.check(B.lib().wlsqm_hip_expert_solve_device(self._handle, C.c_void_p(int(stream) if stream else 0),
+                                                      C.c_void_p(fk.data_ptr()), fk.stride(0),
+                                                      C.c_void_p(fi.data_ptr()), fi.stride(0)))
+        return 0
+
     def solve(self, fk, fi, sens=None):
         """Fit all cases to the data fk on the prepared geometry (expert.pyx:467-655).  Returns the maximum
         number of refinement iterations taken (0 for ALGO_BASIC)."""

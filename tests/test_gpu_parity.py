@@ -443,3 +443,23 @@ def test_example_harness_ragged_radius_neighbourhoods(wlsqm):
     fi2 = fi0.copy()
     s.solve(fk=fk, fi=fi2)
     assert np.array_equal(fi, fi2)                                  # same kernels, same inputs
+
+
+def test_expert_solve_device_time_stepping(wlsqm):
+    """ExpertSolver.solve_device: geometry prepared once, several right-hand sides solved without leaving HBM
+    (BASELINE config 4 pattern); identical to the host-array solve()."""
+    import torch
+    import synth
+    c = K.config("C2")
+    n = c["n"]
+    s = wlsqm.ExpertSolver(dimension=2, nk=c["nk_a"], order=c["order_a"], knowns=np.ones(n, np.int64),
+                           weighting_method=c["wm_a"])
+    s.prepare(xi=c["xi"], xk=c["xk"])
+    for t in range(3):
+        Ft = synth.field(c["S"], t=float(t))
+        fk = Ft[c["hoods"]]
+        fi_h = np.zeros((n, 6)); fi_h[:, 0] = Ft[:n]
+        fi_d = torch.from_numpy(fi_h.copy()).cuda()
+        s.solve_device(torch.from_numpy(fk).cuda(), fi_d)
+        s.solve(fk=fk, fi=fi_h)
+        assert np.array_equal(fi_d.cpu().numpy(), fi_h)
