@@ -2,12 +2,16 @@
 // reference file:line each entry point replaces).  Host logic only; kernels live in
 // fit_lane.hip / fit_tile.hip / fit_wave.hip.
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <ctime>
 #include <cstring>
 #include <new>
 #include <string>
 #include <vector>
 
 #include "wlsqm_internal.hpp"
+#include "hostio.hpp"
 
 namespace wlsqm {
 
@@ -151,8 +155,35 @@ int wlsqm_hip_fit_many_device(const wlsqm_batch* b, int device, void* stream, in
     return WLSQM_OK;
 }
 
-// Host-array entry point: stage -> device -> kernels -> commit.
+// Per-thread, per-device transfer context of the host-array entry points (never freed: it must not outlive
+// the HIP runtime at process exit, and a thread's buffers are reused by its next call).
+struct HostCtx {
+    Stager st;
+    GrowBuf xk, fk, xi, fi, nk, wm, kn, sens, it, idx;
+};
+static HostCtx* host_ctx(int device) {
+    static thread_local HostCtx* ctx[16] = {nullptr};
+    if (device < 0 || device >= 16) return nullptr;
+    if (!ctx[device]) ctx[device] = new HostCtx();
+    return ctx[device];
+}
+
+// Host-array entry point: pack -> device -> kernels -> commit.  Rows are packed by all host threads into pinned
+// staging buffers while the previous chunk is in flight (hostio.hpp); the arrays must provide max_nk neighbour
+// slots per case (entries k >= nk[j] are transferred but never used).
+static double now_s() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+
 int wlsqm_hip_fit_many_host(const wlsqm_batch* b, int device, int32_t* iterations_out) {
+    const bool trace = getenv("WLSQM_HIP_TRACE") != nullptr;
+    const double t_start = now_s();
+    double t_prev = t_start;
+    auto mark = [&](const char* what) {
+        if (!trace) return;
+        (void)hipDeviceSynchronize();
+        const double t = now_s();
+        fprintf(stderr, "[wlsqm_hip] %-28s %8.3f ms\n", what, (t - t_prev) * 1e3);
+        t_prev = t;
+    };
     int rc = validate_batch(b);
     if (rc != WLSQM_OK) return rc;
     const int dim = b->dimension;
@@ -160,65 +191,63 @@ int wlsqm_hip_fit_many_host(const wlsqm_batch* b, int device, int32_t* iteration
     // metadata (also validates order)
     std::vector<int32_t> h_nk(n), h_order(n), h_wm(n), h_no(n);
     std::vector<int64_t> h_kn(n);
-    int64_t max_nk = 0; int max_no = 0;
+    int64_t max_nk = 0; int max_no = 0; bool bad_order = false, bad_nk = false;
+#pragma omp parallel for schedule(static) num_threads(copy_threads()) reduction(max : max_nk) reduction(max : max_no) reduction(|| : bad_order) reduction(|| : bad_nk)
     for (int64_t j = 0; j < n; ++j) {
         h_nk[j] = b->nk[j * b->nk_stride];
         h_order[j] = b->order[j * b->order_stride];
         h_wm[j] = b->weighting_method[j * b->wm_stride];
         h_kn[j] = b->knowns[j * b->knowns_stride];
         const int no = wlsqm_hip_number_of_dofs(dim, h_order[j]);
-        if (no < 0) { set_error("order must be 0, 1, 2, 3 or 4"); return WLSQM_EVALUE; }
-        if (h_nk[j] < 0) { set_error("nk must be >= 0"); return WLSQM_EVALUE; }
+        if (no < 0) { bad_order = true; h_no[j] = 0; continue; }
+        if (h_nk[j] < 0) bad_nk = true;
         h_no[j] = no;
-        max_nk = std::max<int64_t>(max_nk, h_nk[j]);
-        max_no = std::max(max_no, no);
+        if (h_nk[j] > max_nk) max_nk = h_nk[j];
+        if (no > max_no) max_no = no;
     }
+    if (bad_order) { set_error("order must be 0, 1, 2, 3 or 4"); return WLSQM_EVALUE; }
+    if (bad_nk) { set_error("nk must be >= 0"); return WLSQM_EVALUE; }
+    if (b->max_nk > 0 && max_nk > b->max_nk) { set_error("max(nk) exceeds the neighbour axis (max_nk)"); return WLSQM_EVALUE; }
+    mark("metadata");
     rc = check_device(device);
     if (rc != WLSQM_OK) return rc;
+    HostCtx* cx = host_ctx(device);
+    if (!cx) { set_error("device ordinal out of range"); return WLSQM_ENODEVICE; }
+    if ((rc = cx->st.ensure(device))) return rc;
 
-    // contiguous host staging (only entries the reference would read: k < nk[j], n < no_j)
     const int64_t K = std::max<int64_t>(max_nk, 1);
-    std::vector<double> s_xk((size_t)n * K * dim, 0.0), s_fk((size_t)n * K, 0.0), s_xi((size_t)n * dim), s_fi((size_t)n * max_no, 0.0);
-#pragma omp parallel for schedule(static)
-    for (int64_t j = 0; j < n; ++j) {
-        const double* xr = b->xk + j * b->xk_stride_case;
-        const double* fr = b->fk + j * b->fk_stride_case;
-        for (int64_t k = 0; k < h_nk[j]; ++k) {
-            for (int m = 0; m < dim; ++m) s_xk[((size_t)j * K + k) * dim + m] = xr[k * b->xk_stride_k + m];
-            s_fk[(size_t)j * K + k] = fr[k * b->fk_stride_k];
-        }
-        for (int m = 0; m < dim; ++m) s_xi[(size_t)j * dim + m] = b->xi[j * b->xi_stride_case + m];
-        for (int a = 0; a < h_no[j]; ++a) s_fi[(size_t)j * max_no + a] = b->fi[j * b->fi_stride_case + a];
-    }
     const bool want_sens = b->do_sens && b->sens;
-    DevBuf d_xk, d_fk, d_xi, d_fi, d_nk, d_wm, d_kn, d_sens, d_it, d_idx;
-    if ((rc = d_xk.alloc(s_xk.size() * 8)) || (rc = d_fk.alloc(s_fk.size() * 8)) || (rc = d_xi.alloc(s_xi.size() * 8)) ||
-        (rc = d_fi.alloc(s_fi.size() * 8)) || (rc = d_nk.alloc(n * 4)) || (rc = d_wm.alloc(n * 4)) ||
-        (rc = d_kn.alloc(n * 8)) || (rc = d_it.alloc(4)))
+    if ((rc = cx->xk.need((size_t)n * K * dim * 8)) || (rc = cx->fk.need((size_t)n * K * 8)) ||
+        (rc = cx->xi.need((size_t)n * dim * 8)) || (rc = cx->fi.need((size_t)n * max_no * 8)) ||
+        (rc = cx->nk.need(n * 4)) || (rc = cx->wm.need(n * 4)) || (rc = cx->kn.need(n * 8)) || (rc = cx->it.need(4)))
         return rc;
-    if (want_sens && (rc = d_sens.alloc((size_t)n * K * max_no * 8))) return rc;
+    if (want_sens && (rc = cx->sens.need((size_t)n * K * max_no * 8))) return rc;
     hipStream_t s = nullptr;
-    WLSQM_HIP_CHECK(hipMemcpyAsync(d_xk.p, s_xk.data(), d_xk.n, hipMemcpyHostToDevice, s));
-    WLSQM_HIP_CHECK(hipMemcpyAsync(d_fk.p, s_fk.data(), d_fk.n, hipMemcpyHostToDevice, s));
-    WLSQM_HIP_CHECK(hipMemcpyAsync(d_xi.p, s_xi.data(), d_xi.n, hipMemcpyHostToDevice, s));
-    WLSQM_HIP_CHECK(hipMemcpyAsync(d_fi.p, s_fi.data(), d_fi.n, hipMemcpyHostToDevice, s));
-    WLSQM_HIP_CHECK(hipMemcpyAsync(d_nk.p, h_nk.data(), d_nk.n, hipMemcpyHostToDevice, s));
-    WLSQM_HIP_CHECK(hipMemcpyAsync(d_wm.p, h_wm.data(), d_wm.n, hipMemcpyHostToDevice, s));
-    WLSQM_HIP_CHECK(hipMemcpyAsync(d_kn.p, h_kn.data(), d_kn.n, hipMemcpyHostToDevice, s));
-    WLSQM_HIP_CHECK(hipMemsetAsync(d_it.p, 0, 4, s));
-    if (want_sens) WLSQM_HIP_CHECK(hipMemsetAsync(d_sens.p, 0, d_sens.n, s));
+    mark("buffers");
+    if (max_nk > 0) {
+        if ((rc = cx->st.upload_rows(cx->xk.b.p, b->xk, n, K * dim, b->xk_stride_case, b->xk_stride_k, dim, 8, s))) return rc;
+        if ((rc = cx->st.upload_rows(cx->fk.b.p, b->fk, n, K, b->fk_stride_case, b->fk_stride_k, 1, 8, s))) return rc;
+    }
+    if ((rc = cx->st.upload_rows(cx->xi.b.p, b->xi, n, dim, b->xi_stride_case, dim, dim, 8, s))) return rc;
+    if ((rc = cx->st.upload_rows(cx->fi.b.p, b->fi, n, max_no, b->fi_stride_case, max_no, max_no, 8, s))) return rc;
+    WLSQM_HIP_CHECK(hipMemcpyAsync(cx->nk.b.p, h_nk.data(), n * 4, hipMemcpyHostToDevice, s));
+    WLSQM_HIP_CHECK(hipMemcpyAsync(cx->wm.b.p, h_wm.data(), n * 4, hipMemcpyHostToDevice, s));
+    WLSQM_HIP_CHECK(hipMemcpyAsync(cx->kn.b.p, h_kn.data(), n * 8, hipMemcpyHostToDevice, s));
+    WLSQM_HIP_CHECK(hipMemsetAsync(cx->it.b.p, 0, 4, s));
+    if (want_sens) WLSQM_HIP_CHECK(hipMemsetAsync(cx->sens.b.p, 0, (size_t)n * K * max_no * 8, s));
 
+    mark("upload");
     KParams p{};
-    p.xk = d_xk.as<double>(); p.sxk_j = K * dim; p.sxk_k = dim;
-    p.fk = d_fk.as<double>(); p.sfk_j = K; p.sfk_k = 1;
-    p.nk = d_nk.as<int>(); p.snk = 1;
-    p.xi = d_xi.as<double>(); p.sxi_j = dim;
-    p.fi = d_fi.as<double>(); p.sfi_j = max_no;
-    p.sens = want_sens ? d_sens.as<double>() : nullptr; p.ss_j = K * max_no; p.ss_k = max_no;
-    p.knowns = d_kn.as<long long>(); p.sknowns = 1;
-    p.wm = d_wm.as<int>(); p.swm = 1;
+    p.xk = cx->xk.as<double>(); p.sxk_j = K * dim; p.sxk_k = dim;
+    p.fk = cx->fk.as<double>(); p.sfk_j = K; p.sfk_k = 1;
+    p.nk = cx->nk.as<int>(); p.snk = 1;
+    p.xi = cx->xi.as<double>(); p.sxi_j = dim;
+    p.fi = cx->fi.as<double>(); p.sfi_j = max_no;
+    p.sens = want_sens ? cx->sens.as<double>() : nullptr; p.ss_j = K * max_no; p.ss_k = max_no;
+    p.knowns = cx->kn.as<long long>(); p.sknowns = 1;
+    p.wm = cx->wm.as<int>(); p.swm = 1;
     p.do_sens = want_sens ? 1 : 0; p.iterative = b->iterative ? 1 : 0; p.max_iter = b->max_iter;
-    p.iters_out = d_it.as<int>();
+    p.iters_out = cx->it.as<int>();
 
     // bucket by order (the kernels are specialised per (dimension, order))
     const bool uniform_order = std::all_of(h_order.begin(), h_order.end(), [&](int o) { return o == h_order[0]; });
@@ -234,38 +263,43 @@ int wlsqm_hip_fit_many_host(const wlsqm_batch* b, int device, int32_t* iteration
             for (int64_t j = 0; j < n; ++j) if (h_order[j] == o) idx.push_back(j);
         }
         off[5] = (int64_t)idx.size();
-        if ((rc = d_idx.alloc(idx.size() * 8))) return rc;
-        WLSQM_HIP_CHECK(hipMemcpyAsync(d_idx.p, idx.data(), d_idx.n, hipMemcpyHostToDevice, s));
+        if ((rc = cx->idx.need(idx.size() * 8))) return rc;
+        WLSQM_HIP_CHECK(hipMemcpyAsync(cx->idx.b.p, idx.data(), idx.size() * 8, hipMemcpyHostToDevice, s));
+        WLSQM_HIP_CHECK(hipStreamSynchronize(s));      // idx is a local vector
         for (int o = 0; o <= 4; ++o) {
             if (off[o + 1] == off[o]) continue;
-            p.case_index = d_idx.as<long long>() + off[o]; p.ncases = off[o + 1] - off[o];
+            p.case_index = cx->idx.as<long long>() + off[o]; p.ncases = off[o + 1] - off[o];
             rc = launch_fit(dim, o, p, K, s);
             if (rc != WLSQM_OK) return rc;
         }
     }
+    mark("kernels");
     // commit: everything was read before anything is written back (simple.pyx:1010-1019)
-    std::vector<double> s_sens;
-    int h_it = 0;
-    WLSQM_HIP_CHECK(hipMemcpyAsync(s_fi.data(), d_fi.p, d_fi.n, hipMemcpyDeviceToHost, s));
-    if (want_sens) { s_sens.resize((size_t)n * K * max_no); WLSQM_HIP_CHECK(hipMemcpyAsync(s_sens.data(), d_sens.p, d_sens.n, hipMemcpyDeviceToHost, s)); }
-    WLSQM_HIP_CHECK(hipMemcpyAsync(&h_it, d_it.p, 4, hipMemcpyDeviceToHost, s));
-    WLSQM_HIP_CHECK(hipStreamSynchronize(s));
-#pragma omp parallel for schedule(static)
-    for (int64_t j = 0; j < n; ++j) {
-        if (wlsqm_hip_number_of_reduced_dofs(h_no[j], h_kn[j]) < 1) continue;   // nr < 1: reference leaves the case untouched
-        unsigned long long known, dropped;
-        effective_mask_host(h_no[j], h_kn[j], known, dropped);
-        for (int a = 0; a < h_no[j]; ++a) b->fi[j * b->fi_stride_case + a] = s_fi[(size_t)j * max_no + a];
-        if (want_sens) {
+    rc = cx->st.download_rows(cx->fi.b.p, n, max_no, 8, s, [&](int64_t j, const char* row) {
+        if (wlsqm_hip_number_of_reduced_dofs(h_no[j], h_kn[j]) < 1) return;     // nr < 1: the reference leaves the case untouched
+        std::memcpy(b->fi + j * b->fi_stride_case, row, (size_t)h_no[j] * 8);
+    });
+    if (rc != WLSQM_OK) return rc;
+    if (want_sens) {
+        rc = cx->st.download_rows(cx->sens.b.p, n, K * max_no, 8, s, [&](int64_t j, const char* row) {
+            if (wlsqm_hip_number_of_reduced_dofs(h_no[j], h_kn[j]) < 1) return;
+            unsigned long long known, dropped;
+            effective_mask_host(h_no[j], h_kn[j], known, dropped);
+            const double* r = reinterpret_cast<const double*>(row);
             double* sr = b->sens + j * b->sens_stride_case;
             for (int64_t k = 0; k < h_nk[j]; ++k)
                 for (int a = 0; a < h_no[j]; ++a) {
-                    if ((dropped >> a) & 1ull) continue;   // never written by the reference
-                    sr[k * b->sens_stride_k + a] = s_sens[((size_t)j * K + k) * max_no + a];
+                    if ((dropped >> a) & 1ull) continue;       // never written by the reference
+                    sr[k * b->sens_stride_k + a] = r[k * max_no + a];
                 }
-        }
+        });
+        if (rc != WLSQM_OK) return rc;
     }
+    int h_it = 0;
+    WLSQM_HIP_CHECK(hipMemcpyAsync(&h_it, cx->it.b.p, 4, hipMemcpyDeviceToHost, s));
+    WLSQM_HIP_CHECK(hipStreamSynchronize(s));
     if (iterations_out) *iterations_out = b->iterative ? h_it : 0;
+    mark("commit");
     return WLSQM_OK;
 }
 

@@ -13,6 +13,7 @@
 
 #include "wlsqm_internal.hpp"
 #include "wlsqm_interp.hpp"
+#include "hostio.hpp"
 
 struct wlsqm_expert {
     int device = 0, dimension = 0, algorithm = 1, do_sens = 0, max_iter = 10;
@@ -23,6 +24,7 @@ struct wlsqm_expert {
     std::vector<int64_t> kn;
     std::vector<long long> idx; int64_t off[6] = {0, 0, 0, 0, 0, 0};
     wlsqm::DevBuf d_nk, d_wm, d_kn, d_order, d_idx, d_xk, d_xi, d_fk, d_fi, d_sens, d_it;
+    wlsqm::Stager st;
     int64_t bytes() const {
         return (int64_t)(d_nk.n + d_wm.n + d_kn.n + d_order.n + d_idx.n + d_xk.n + d_xi.n + d_fk.n + d_fi.n + d_sens.n + d_it.n);
     }
@@ -129,16 +131,12 @@ int wlsqm_hip_expert_prepare(wlsqm_expert* h, const double* xi, int64_t xi_strid
     int rc = check_device(h->device);
     if (rc != WLSQM_OK) return rc;
     const int dim = h->dimension; const int64_t n = h->ncases, K = h->max_nk;
-    std::vector<double> s_xk((size_t)n * K * dim, 0.0), s_xi((size_t)n * dim);
-#pragma omp parallel for schedule(static)
-    for (int64_t j = 0; j < n; ++j) {
-        const double* xr = xk + j * xk_stride_case;
-        for (int64_t k = 0; k < h->nk[j]; ++k)
-            for (int m = 0; m < dim; ++m) s_xk[((size_t)j * K + k) * dim + m] = xr[k * xk_stride_k + m];
-        for (int m = 0; m < dim; ++m) s_xi[(size_t)j * dim + m] = xi[j * xi_stride_case + m];
-    }
-    WLSQM_HIP_CHECK(hipMemcpy(h->d_xk.p, s_xk.data(), h->d_xk.n, hipMemcpyHostToDevice));
-    WLSQM_HIP_CHECK(hipMemcpy(h->d_xi.p, s_xi.data(), h->d_xi.n, hipMemcpyHostToDevice));
+    if ((rc = h->st.ensure(h->device))) return rc;
+    hipStream_t s = nullptr;
+    if ((rc = h->st.upload_rows(h->d_xk.p, xk, n, K * dim, xk_stride_case, xk_stride_k, dim, 8, s))) return rc;
+    if ((rc = h->st.upload_rows(h->d_xi.p, xi, n, dim, xi_stride_case, dim, dim, 8, s))) return rc;
+    if ((rc = h->st.drain())) return rc;
+    WLSQM_HIP_CHECK(hipStreamSynchronize(s));
     h->ready = true;
     return WLSQM_OK;
 }
@@ -151,40 +149,41 @@ int wlsqm_hip_expert_solve(wlsqm_expert* h, const double* fk, int64_t fk_stride_
     int rc = check_device(h->device);
     if (rc != WLSQM_OK) return rc;
     const int64_t n = h->ncases, K = h->max_nk; const int NO = h->max_no;
-    std::vector<double> s_fk((size_t)n * K, 0.0), s_fi((size_t)n * NO, 0.0);
-#pragma omp parallel for schedule(static)
-    for (int64_t j = 0; j < n; ++j) {
-        for (int64_t k = 0; k < h->nk[j]; ++k) s_fk[(size_t)j * K + k] = fk[j * fk_stride_case + k * fk_stride_k];
-        for (int a = 0; a < h->no[j]; ++a) s_fi[(size_t)j * NO + a] = fi[j * fi_stride_case + a];
-    }
+    if ((rc = h->st.ensure(h->device))) return rc;
     hipStream_t s = nullptr;
     const bool want_sens = h->do_sens && sens;
-    WLSQM_HIP_CHECK(hipMemcpyAsync(h->d_fk.p, s_fk.data(), h->d_fk.n, hipMemcpyHostToDevice, s));
-    WLSQM_HIP_CHECK(hipMemcpyAsync(h->d_fi.p, s_fi.data(), h->d_fi.n, hipMemcpyHostToDevice, s));
+    if ((rc = h->st.upload_rows(h->d_fk.p, fk, n, K, fk_stride_case, fk_stride_k, 1, 8, s))) return rc;
+    if ((rc = h->st.upload_rows(h->d_fi.p, fi, n, NO, fi_stride_case, NO, NO, 8, s))) return rc;
     WLSQM_HIP_CHECK(hipMemsetAsync(h->d_it.p, 0, 4, s));
     KParams p = expert_params(h, h->d_fk.as<double>(), K, h->d_fi.as<double>(), NO);
-    if (want_sens) { p.sens = h->d_sens.as<double>(); p.ss_j = K * NO; p.ss_k = NO; p.do_sens = 1; }
+    if (want_sens) {
+        WLSQM_HIP_CHECK(hipMemsetAsync(h->d_sens.p, 0, h->d_sens.n, s));
+        p.sens = h->d_sens.as<double>(); p.ss_j = K * NO; p.ss_k = NO; p.do_sens = 1;
+    }
     rc = expert_launch(h, p, s);
     if (rc != WLSQM_OK) return rc;
-    std::vector<double> s_sens;
-    int h_it = 0;
-    WLSQM_HIP_CHECK(hipMemcpyAsync(s_fi.data(), h->d_fi.p, h->d_fi.n, hipMemcpyDeviceToHost, s));
-    if (want_sens) { s_sens.resize((size_t)n * K * NO); WLSQM_HIP_CHECK(hipMemcpyAsync(s_sens.data(), h->d_sens.p, h->d_sens.n, hipMemcpyDeviceToHost, s)); }
-    WLSQM_HIP_CHECK(hipMemcpyAsync(&h_it, h->d_it.p, 4, hipMemcpyDeviceToHost, s));
-    WLSQM_HIP_CHECK(hipStreamSynchronize(s));
-#pragma omp parallel for schedule(static)
-    for (int64_t j = 0; j < n; ++j) {
-        if (wlsqm_hip_number_of_reduced_dofs(h->no[j], h->kn[j]) < 1) continue;
-        unsigned long long known, dropped;
-        effective_mask_host(h->no[j], h->kn[j], known, dropped);
-        for (int a = 0; a < h->no[j]; ++a) fi[j * fi_stride_case + a] = s_fi[(size_t)j * NO + a];
-        if (want_sens)
+    rc = h->st.download_rows(h->d_fi.p, n, NO, 8, s, [&](int64_t j, const char* row) {
+        if (wlsqm_hip_number_of_reduced_dofs(h->no[j], h->kn[j]) < 1) return;
+        std::memcpy(fi + j * fi_stride_case, row, (size_t)h->no[j] * 8);
+    });
+    if (rc != WLSQM_OK) return rc;
+    if (want_sens) {
+        rc = h->st.download_rows(h->d_sens.p, n, K * NO, 8, s, [&](int64_t j, const char* row) {
+            if (wlsqm_hip_number_of_reduced_dofs(h->no[j], h->kn[j]) < 1) return;
+            unsigned long long known, dropped;
+            effective_mask_host(h->no[j], h->kn[j], known, dropped);
+            const double* r = reinterpret_cast<const double*>(row);
             for (int64_t k = 0; k < h->nk[j]; ++k)
                 for (int a = 0; a < h->no[j]; ++a) {
                     if ((dropped >> a) & 1ull) continue;
-                    sens[j * sens_stride_case + k * sens_stride_k + a] = s_sens[((size_t)j * K + k) * NO + a];
+                    sens[j * sens_stride_case + k * sens_stride_k + a] = r[k * NO + a];
                 }
+        });
+        if (rc != WLSQM_OK) return rc;
     }
+    int h_it = 0;
+    WLSQM_HIP_CHECK(hipMemcpyAsync(&h_it, h->d_it.p, 4, hipMemcpyDeviceToHost, s));
+    WLSQM_HIP_CHECK(hipStreamSynchronize(s));
     if (iterations_out) *iterations_out = (h->algorithm == WLSQM_ALGO_ITERATIVE) ? h_it : 0;
     h->solved = true;                  // d_fi now holds the coefficients interpolate() evaluates (case.fi in the reference)
     return WLSQM_OK;

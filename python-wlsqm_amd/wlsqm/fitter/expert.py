@@ -224,7 +224,7 @@ class ExpertSolver:
             raise ValueError("fk/fi have fewer rows than ncases")
         if fkv.shape[1] < self._max_nk:
             raise ValueError("max(nk) = %d exceeds the neighbour axis of fk" % self._max_nk)
-        max_no = max(number_of_dofs(self.dimension, int(o)) for o in np.unique(self.order))
+        max_no = number_of_dofs(self.dimension, int(np.max(self.order)))
         if fiv.shape[1] < max_no:
             raise ValueError("fi has %d columns, need at least %d" % (fiv.shape[1], max_no))
         sp, ssj, ssk = None, 0, 0

@@ -55,7 +55,7 @@ def _run_many(dimension, xk, fk, nk, xi, fi, sens, do_sens, order, knowns, weigh
     if np.any((order < 0) | (order > 4)):
         raise ValueError("order must be 0, 1, 2, 3 or 4")
     lib = B.lib()
-    max_no = max(lib.wlsqm_hip_number_of_dofs(dimension, int(o)) for o in np.unique(order))
+    max_no = lib.wlsqm_hip_number_of_dofs(dimension, int(order.max()))       # no grows with the order
     max_nk = int(nk.max())
     if max_nk > min(xk.shape[1], fk.shape[1]):
         raise ValueError("max(nk) = %d exceeds the neighbour axis of xk/fk" % max_nk)
