@@ -44,7 +44,7 @@ template <int DIM> __host__ __device__ constexpr int row_stride_x(int K) {
 }
 __host__ __device__ constexpr int row_stride_f(int K) { return round_up_mod(K, 2, 1); }
 
-template <int DIM, int ORDER, int K, int KSPLIT, int LPC>
+template <int DIM, int ORDER, int K, int KSPLIT, int LPC, bool FKD = false>
 struct TileGeom {
     static constexpr int NO = ndofs(DIM, ORDER);
     static constexpr int NE = NO * (NO + 1) / 2;
@@ -57,7 +57,7 @@ struct TileGeom {
     static constexpr int NX = (XCH + NT - 1) / NT, NF = (FCH + NT - 1) / NT;
     static constexpr int CPRX = K * DIM / 2, CPRF = K / 2;  // chunks per row
     static constexpr int NRED = NE + NO;                     // partial sums per case
-    static constexpr int LDS_TILE = TC * (RS + FS);
+    static constexpr int LDS_TILE = TC * (RS + (FKD ? 0 : FS));   // FKD: fk is read straight from global by its owner lane
     static constexpr int LDS_RED = (KSPLIT - 1) * NRED * TC;
     static constexpr int LDS_MAIN = LDS_TILE > LDS_RED ? LDS_TILE : LDS_RED;
     static constexpr size_t LDS_BYTES = sizeof(double) * (LDS_MAIN + SHARES * TC);
@@ -71,9 +71,11 @@ struct TileGeom {
 // (__launch_bounds__ 2nd argument).
 // GATHER: index-based ("cloud") input — the tile's rows are gathered from the point tables S/F through
 // hoods[ncases, K] instead of being read from dense xk/fk; everything after the LDS staging is identical.
-template <int DIM, int ORDER, int K, int KSPLIT, int LPC, int UNR, int MINW, bool GATHER>
+template <int DIM, int ORDER, int K, int KSPLIT, int LPC, int UNR, int MINW, bool GATHER, bool FKD = false>
 __global__ __launch_bounds__(WV * KSPLIT, MINW) void fit_tile_kernel(const KParams p, const long long ntiles) {
-    using G = TileGeom<DIM, ORDER, K, KSPLIT, LPC>;
+    using G = TileGeom<DIM, ORDER, K, KSPLIT, LPC, FKD>;
+    static_assert(!(FKD && GATHER), "direct fk loads are a dense-path option");
+    static_assert(!FKD || G::KPL % 2 == 0, "direct fk loads need an even share");
     constexpr int NO = G::NO, NE = G::NE, TC = G::TC, NT = G::NT, RS = G::RS, FS = G::FS;
     constexpr int NX = G::NX, NF = G::NF, CPRX = G::CPRX, CPRF = G::CPRF, KPL = G::KPL, NRED = G::NRED;
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -102,10 +104,11 @@ __global__ __launch_bounds__(WV * KSPLIT, MINW) void fit_tile_kernel(const KPara
         unsigned long long known, dropped;
         effective_mask<NO>(p.knowns[jc * p.sknowns], known, dropped);
         double xi[DIM];
+        double fdir[FKD ? KPL : 1];     // FKD: this lane's fk values, straight from global memory
 
         if constexpr (!GATHER) {
             // ---- stage 1: issue every global load of the tile (coalesced 16 B per lane)
-            double2_ bx[NX], bf[NF];
+            double2_ bx[NX], bf[FKD ? 1 : NF];
             {
                 const double2_* gx = reinterpret_cast<const double2_*>(p.xk + j0 * (long long)(K * DIM));
                 const double2_* gf = reinterpret_cast<const double2_*>(p.fk + j0 * (long long)K);
@@ -115,10 +118,17 @@ __global__ __launch_bounds__(WV * KSPLIT, MINW) void fit_tile_kernel(const KPara
                     const long long q = tid + (long long)i * NT;
                     bx[i] = gx[q < xlim ? q : xlim - 1];
                 }
+                if constexpr (!FKD) {
 #pragma unroll
-                for (int i = 0; i < NF; ++i) {
-                    const long long q = tid + (long long)i * NT;
-                    bf[i] = gf[q < flim ? q : flim - 1];
+                    for (int i = 0; i < NF; ++i) {
+                        const long long q = tid + (long long)i * NT;
+                        bf[i] = gf[q < flim ? q : flim - 1];
+                    }
+                } else {
+                    // this lane's KPL values of its own case: KPL*8 contiguous bytes of row jc
+                    const double2_* gr = reinterpret_cast<const double2_*>(p.fk + jc * (long long)K + k0);
+#pragma unroll
+                    for (int i = 0; i < KPL / 2; ++i) { const double2_ v = gr[i]; fdir[2 * i] = v.x; fdir[2 * i + 1] = v.y; }
                 }
             }
 #pragma unroll
@@ -135,13 +145,15 @@ __global__ __launch_bounds__(WV * KSPLIT, MINW) void fit_tile_kernel(const KPara
                     else { d[0] = bx[i].x; d[1] = bx[i].y; }
                 }
             }
+            if constexpr (!FKD) {
 #pragma unroll
-            for (int i = 0; i < NF; ++i) {
-                const int q = tid + i * NT;
-                if (G::FCH % NT == 0 || q < G::FCH) {
-                    const int r = q / CPRF, c2 = q - r * CPRF;
-                    double* d = sF + r * FS + 2 * c2;
-                    d[0] = bf[i].x; d[1] = bf[i].y;
+                for (int i = 0; i < NF; ++i) {
+                    const int q = tid + i * NT;
+                    if (G::FCH % NT == 0 || q < G::FCH) {
+                        const int r = q / CPRF, c2 = q - r * CPRF;
+                        double* d = sF + r * FS + 2 * c2;
+                        d[0] = bf[i].x; d[1] = bf[i].y;
+                    }
                 }
             }
         } else {
@@ -238,7 +250,8 @@ __global__ __launch_bounds__(WV * KSPLIT, MINW) void fit_tile_kernel(const KPara
             for (int m = 0; m < DIM; ++m) d[m] = live ? d[m] : 0.0;
             const double d2 = monomials<DIM, ORDER>(d, cc);
             const double w = live ? weight(d2, inv_max, uniform) : 0.0;
-            const double f = live ? fr[k] : 0.0;
+            const double fv = FKD ? fdir[k - k0] : fr[k];
+            const double f = live ? fv : 0.0;
             accumulate<NO>(M, g, cc, w, f);
         };
         if (__all(nkc >= K)) {
@@ -308,13 +321,13 @@ __global__ __launch_bounds__(WV * KSPLIT, MINW) void fit_tile_kernel(const KPara
 template <int DIM, int ORDER, int K, int KSPLIT, int LPC = 1, int UNR = 2, int MINW = 2>
 static int launch_tile_any(const KParams& p, hipStream_t stream, bool gather);
 
-template <int DIM, int ORDER, int K, int KSPLIT, int LPC, int UNR, int MINW, bool GATHER>
+template <int DIM, int ORDER, int K, int KSPLIT, int LPC, int UNR, int MINW, bool GATHER, bool FKD = false>
 static int launch_tile_impl(const KParams& p, hipStream_t stream) {
-    using G = TileGeom<DIM, ORDER, K, KSPLIT, LPC>;
+    using G = TileGeom<DIM, ORDER, K, KSPLIT, LPC, FKD>;
     constexpr size_t lds_bytes = G::LDS_BYTES;
     const long long ntiles = (p.ncases + G::TC - 1) / G::TC;
     static int per_cu = 0, cus = 0;
-    auto kern = fit_tile_kernel<DIM, ORDER, K, KSPLIT, LPC, UNR, MINW, GATHER>;
+    auto kern = fit_tile_kernel<DIM, ORDER, K, KSPLIT, LPC, UNR, MINW, GATHER, FKD>;
     if (!cus) {
         int dev = 0;
         WLSQM_HIP_CHECK(hipGetDevice(&dev));
@@ -379,6 +392,10 @@ int launch_fit_tile(int dimension, int order, const KParams& p, long long max_nk
             case 4: return launch_tile_any<2, 2, 32, 2, 2, 8, 2>(p, stream, gather);
             case 5: return launch_tile_any<2, 2, 32, 4, 2, 4, 2>(p, stream, gather);
             case 6: return launch_tile_any<2, 2, 32, 1, 2, 4, 2>(p, stream, gather);
+            case 7: return launch_tile_impl<2, 2, 32, 2, 1, 4, 2, false, true>(p, stream);
+            case 8: return launch_tile_impl<2, 2, 32, 2, 1, 8, 2, false, true>(p, stream);
+            case 9: return launch_tile_impl<2, 2, 32, 4, 1, 8, 2, false, true>(p, stream);
+            case 10: return launch_tile_impl<2, 2, 32, 2, 1, 2, 2, false, true>(p, stream);
             default: return launch_tile_any<2, 2, 32, 4, 1, 8, 2>(p, stream, gather);   // best of the round-1 A/B
         }
     }
