@@ -31,6 +31,7 @@ int launch_fit_lane(int dimension, int order, const KParams& p, hipStream_t stre
 int launch_fit_tile(int dimension, int order, const KParams& p, long long max_nk, hipStream_t stream, bool* handled);
 int launch_fit_wave(int dimension, int order, const KParams& p, hipStream_t stream);
 int launch_fit_moment(int dimension, int order, const KParams& p, long long max_nk, hipStream_t stream, bool* handled);
+int launch_fit_tilek(int dimension, int order, const KParams& p, long long max_nk, hipStream_t stream, bool* handled);
 
 int launch_fit(int dimension, int order, const KParams& p, long long max_nk, hipStream_t stream) {
     const int no = wlsqm_hip_number_of_dofs(dimension, order);
@@ -41,6 +42,8 @@ int launch_fit(int dimension, int order, const KParams& p, long long max_nk, hip
     int rc = launch_fit_moment(dimension, order, p, max_nk, stream, &handled);
     if (rc != WLSQM_OK || handled) return rc;
     rc = launch_fit_tile(dimension, order, p, max_nk, stream, &handled);
+    if (rc != WLSQM_OK || handled) return rc;
+    rc = launch_fit_tilek(dimension, order, p, max_nk, stream, &handled);
     if (rc != WLSQM_OK || handled) return rc;
     if (no <= 15) return launch_fit_lane(dimension, order, p, stream);
     return launch_fit_wave(dimension, order, p, stream);
@@ -215,7 +218,8 @@ int wlsqm_hip_fit_many_host(const wlsqm_batch* b, int device, int32_t* iteration
     if (!cx) { set_error("device ordinal out of range"); return WLSQM_ENODEVICE; }
     if ((rc = cx->st.ensure(device))) return rc;
 
-    const int64_t K = std::max<int64_t>(max_nk, 1);
+    // device rows hold an even number of neighbour slots (16-byte rows for the tiled kernels); the pad slot is never used
+    const int64_t K = std::max<int64_t>(max_nk + (max_nk & 1), 2);
     const bool want_sens = b->do_sens && b->sens;
     if ((rc = cx->xk.need((size_t)n * K * dim * 8)) || (rc = cx->fk.need((size_t)n * K * 8)) ||
         (rc = cx->xi.need((size_t)n * dim * 8)) || (rc = cx->fi.need((size_t)n * max_no * 8)) ||
@@ -225,8 +229,8 @@ int wlsqm_hip_fit_many_host(const wlsqm_batch* b, int device, int32_t* iteration
     hipStream_t s = nullptr;
     mark("buffers");
     if (max_nk > 0) {
-        if ((rc = cx->st.upload_rows(cx->xk.b.p, b->xk, n, K * dim, b->xk_stride_case, b->xk_stride_k, dim, 8, s))) return rc;
-        if ((rc = cx->st.upload_rows(cx->fk.b.p, b->fk, n, K, b->fk_stride_case, b->fk_stride_k, 1, 8, s))) return rc;
+        if ((rc = cx->st.upload_rows(cx->xk.b.p, b->xk, n, max_nk * dim, b->xk_stride_case, b->xk_stride_k, dim, 8, s, K * dim))) return rc;
+        if ((rc = cx->st.upload_rows(cx->fk.b.p, b->fk, n, max_nk, b->fk_stride_case, b->fk_stride_k, 1, 8, s, K))) return rc;
     }
     if ((rc = cx->st.upload_rows(cx->xi.b.p, b->xi, n, dim, b->xi_stride_case, dim, dim, 8, s))) return rc;
     if ((rc = cx->st.upload_rows(cx->fi.b.p, b->fi, n, max_no, b->fi_stride_case, max_no, max_no, 8, s))) return rc;

@@ -1,0 +1,213 @@
+// fit_tilek.hip — the LDS-tiled fit (fit_tile.hip) for ANY neighbour-axis extent K.
+//
+// fit_tile.hip is specialised per (dim, order, K) for the benchmark shapes; a user batch with
+// K = 20, 25, 30, 50 ... would otherwise fall to the generic row-per-lane kernel at ~1/6 of the speed.
+// This variant keeps K at run time: row strides, chunk counts and the neighbour split are computed by
+// the host, staging runs in rounds of R 16-byte chunks per lane (all R loads of a round in flight), and
+// the neighbour loops are rolled.  Same arithmetic and the same parity as fit_tile / fit_lane.
+// Mapping: 4 waves per 64-case tile, wave w owns neighbours [w*KPW, (w+1)*KPW).
+#include <cstdlib>
+
+#include "wlsqm_internal.hpp"
+#include "wlsqm_kernels.hpp"
+
+namespace wlsqm {
+
+constexpr int KW = 64, KSP = 4, KNT = KW * KSP, KROUND = 6;
+typedef double kd2_ __attribute__((ext_vector_type(2)));
+
+struct TileKGeom {
+    int K, KPW;            // neighbour slots per case; per wave
+    int RS, FS;            // LDS row strides (doubles)
+    int XCH, FCH;          // 16-byte chunks of the tile's xk / fk blocks
+    int CPRX, CPRF;        // chunks per row
+    int lds_main;          // doubles shared by the tile image and the reduction buffer
+};
+
+template <int DIM, int ORDER>
+__global__ __launch_bounds__(KNT, 2) void fit_tilek_kernel(const KParams p, const long long ntiles, const TileKGeom G) {
+    constexpr int NO = ndofs(DIM, ORDER), NE = NO * (NO + 1) / 2, NRED = NE + NO, TC = KW;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* sX = lds;
+    double* sF = lds + TC * G.RS;
+    double* sMax = lds + G.lds_main;
+
+    const int tid = threadIdx.x, lane = tid & (KW - 1), wave = tid / KW;
+    const int k0 = wave * G.KPW;
+
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long j0 = tile * TC, j = j0 + lane;
+        const bool valid = j < p.ncases;
+        const long long jc = valid ? j : p.ncases - 1;
+        const long long nvalid = (p.ncases - j0 < TC) ? (p.ncases - j0) : TC;
+
+        const int nkc = min(p.nk[jc * p.snk], G.K);
+        const bool uniform = (p.wm[jc * p.swm] == WLSQM_WEIGHT_UNIFORM);
+        unsigned long long known, dropped;
+        effective_mask<NO>(p.knowns[jc * p.sknowns], known, dropped);
+        double xi[DIM];
+#pragma unroll
+        for (int m = 0; m < DIM; ++m) xi[m] = p.xi[jc * p.sxi_j + m];
+
+        // ---- staging in rounds of KROUND chunks per lane: xk block, then fk block
+        {
+            const kd2_* gx = reinterpret_cast<const kd2_*>(p.xk + j0 * (long long)(G.K * DIM));
+            const long long xlim = nvalid * G.CPRX;
+            for (int q0 = tid; q0 < G.XCH; q0 += KNT * KROUND) {
+                kd2_ b[KROUND];
+#pragma unroll
+                for (int i = 0; i < KROUND; ++i) { const long long q = q0 + i * KNT; b[i] = gx[q < xlim ? q : xlim - 1]; }
+#pragma unroll
+                for (int i = 0; i < KROUND; ++i) {
+                    const int q = q0 + i * KNT;
+                    if (q < G.XCH) {
+                        const int r = q / G.CPRX, c2 = q - r * G.CPRX;
+                        double* d = sX + r * G.RS + 2 * c2;
+                        d[0] = b[i].x; d[1] = b[i].y;
+                    }
+                }
+            }
+            const kd2_* gf = reinterpret_cast<const kd2_*>(p.fk + j0 * (long long)G.K);
+            const long long flim = nvalid * G.CPRF;
+            for (int q0 = tid; q0 < G.FCH; q0 += KNT * KROUND) {
+                kd2_ b[KROUND];
+#pragma unroll
+                for (int i = 0; i < KROUND; ++i) { const long long q = q0 + i * KNT; b[i] = gf[q < flim ? q : flim - 1]; }
+#pragma unroll
+                for (int i = 0; i < KROUND; ++i) {
+                    const int q = q0 + i * KNT;
+                    if (q < G.FCH) {
+                        const int r = q / G.CPRF, c2 = q - r * G.CPRF;
+                        double* d = sF + r * G.FS + 2 * c2;
+                        d[0] = b[i].x; d[1] = b[i].y;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        const double* xr = sX + lane * G.RS;
+        const double* fr = sF + lane * G.FS;
+        const int k1 = min(k0 + G.KPW, nkc);
+
+        double max_d2 = 0.0;
+        for (int k = k0; k < k1; ++k) {
+            double d2 = 0.0;
+#pragma unroll
+            for (int m = 0; m < DIM; ++m) { const double dd = xr[k * DIM + m] - xi[m]; d2 += dd * dd; }
+            max_d2 = d2 > max_d2 ? d2 : max_d2;
+        }
+        sMax[wave * TC + lane] = max_d2;
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < KSP; ++s) { const double o = sMax[s * TC + lane]; max_d2 = o > max_d2 ? o : max_d2; }
+        const double inv_max = inverse_max(max_d2);
+
+        double M[NE], g[NO];
+#pragma unroll
+        for (int e = 0; e < NE; ++e) M[e] = 0.0;
+#pragma unroll
+        for (int a = 0; a < NO; ++a) g[a] = 0.0;
+#pragma unroll 2
+        for (int k = k0; k < k1; ++k) {
+            double d[DIM], cc[NO];
+#pragma unroll
+            for (int m = 0; m < DIM; ++m) d[m] = xr[k * DIM + m] - xi[m];
+            const double d2 = monomials<DIM, ORDER>(d, cc);
+            accumulate<NO>(M, g, cc, weight(d2, inv_max, uniform), fr[k]);
+        }
+
+        __syncthreads();
+        double* red = lds;
+        if (wave > 0) {
+            double* mine = red + (wave - 1) * (NRED * TC) + lane;
+#pragma unroll
+            for (int e = 0; e < NE; ++e) mine[e * TC] = M[e];
+#pragma unroll
+            for (int a = 0; a < NO; ++a) mine[(NE + a) * TC] = g[a];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int w = 1; w < KSP; ++w) {
+                const double* other = red + (w - 1) * (NRED * TC) + lane;
+#pragma unroll
+                for (int e = 0; e < NE; ++e) M[e] += other[e * TC];
+#pragma unroll
+                for (int a = 0; a < NO; ++a) g[a] += other[(NE + a) * TC];
+            }
+            constexpr unsigned long long FULL = (1ull << NO) - 1ull;
+            if (valid && known != FULL) {
+                double* fio = p.fi + j * p.sfi_j;
+                if (known) {
+                    double val[NO];
+#pragma unroll
+                    for (int a = 0; a < NO; ++a) val[a] = (((known & ~dropped) >> a) & 1ull) ? fio[a] : 0.0;
+                    eliminate_knowns<NO>(M, g, known, val);
+                }
+                ldlt_factor<NO>(M);
+                ldlt_solve<NO>(M, g);
+#pragma unroll
+                for (int a = 0; a < NO; ++a)
+                    if (!((known >> a) & 1ull)) fio[a] = g[a];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+static int rup(int v, int m, int r) { return v + ((r - v % m) % m + m) % m; }
+
+template <int DIM, int ORDER>
+static int launch_tilek(const KParams& p, long long K, hipStream_t stream, bool* handled) {
+    constexpr int NO = ndofs(DIM, ORDER), NE = NO * (NO + 1) / 2, NRED = NE + NO;
+    TileKGeom G;
+    G.K = (int)K; G.KPW = (int)((K + KSP - 1) / KSP);
+    G.RS = rup((int)K * DIM, 2, 1); G.FS = rup((int)K, 2, 1);       // odd strides: conflict-free ds_read_b64
+    G.XCH = KW * (int)K * DIM / 2; G.FCH = KW * (int)K / 2;
+    G.CPRX = (int)K * DIM / 2; G.CPRF = (int)K / 2;
+    const int lds_tile = KW * (G.RS + G.FS), lds_red = (KSP - 1) * NRED * KW;
+    G.lds_main = lds_tile > lds_red ? lds_tile : lds_red;
+    const size_t lds_bytes = sizeof(double) * (size_t)(G.lds_main + KSP * KW);
+    if (lds_bytes > 80 * 1024) return WLSQM_OK;                     // keep >= 2 workgroups per CU; larger K: generic kernel
+    *handled = true;
+    const long long ntiles = (p.ncases + KW - 1) / KW;
+    auto kern = fit_tilek_kernel<DIM, ORDER>;
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        WLSQM_HIP_CHECK(hipGetDevice(&dev));
+        hipDeviceProp_t prop;
+        WLSQM_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+        WLSQM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        cus = prop.multiProcessorCount;
+    }
+    int per_cu = 0;
+    WLSQM_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, KNT, lds_bytes));
+    if (per_cu < 1) per_cu = 1;
+    long long grid = (long long)per_cu * cus;
+    if (grid > ntiles) grid = ntiles;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(KNT), lds_bytes, stream, p, ntiles, G);
+    WLSQM_HIP_CHECK(hipGetLastError());
+    note_kernel("tilek");
+    return WLSQM_OK;
+}
+
+// Runtime-K tile path: dense contiguous arrays with 16-byte rows (K*dim and K even), no extras, no bucketing.
+int launch_fit_tilek(int dimension, int order, const KParams& p, long long K, hipStream_t stream, bool* handled) {
+    *handled = false;
+    const char* off = getenv("WLSQM_HIP_DISABLE_TILE");
+    if (off && off[0] == '1') return WLSQM_OK;
+    if (p.do_sens || p.iterative || p.case_index || p.hoods) return WLSQM_OK;
+    if (K < 4 || (K % 2) != 0) return WLSQM_OK;
+    if (p.sxk_k != dimension || p.sxk_j != K * dimension || p.sfk_k != 1 || p.sfk_j != K) return WLSQM_OK;
+    if ((reinterpret_cast<uintptr_t>(p.xk) | reinterpret_cast<uintptr_t>(p.fk)) & 15u) return WLSQM_OK;
+#define KCASE(D, O) if (dimension == D && order == O) return launch_tilek<D, O>(p, K, stream, handled);
+    KCASE(1, 0) KCASE(1, 1) KCASE(1, 2) KCASE(1, 3) KCASE(1, 4)
+    KCASE(2, 0) KCASE(2, 1) KCASE(2, 2) KCASE(2, 3)
+    KCASE(3, 0) KCASE(3, 1) KCASE(3, 2)
+#undef KCASE
+    return WLSQM_OK;
+}
+
+}  // namespace wlsqm

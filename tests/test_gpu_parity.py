@@ -254,7 +254,8 @@ def test_sens_reconstructs_solution(wlsqm):
 
 @pytest.mark.parametrize("dim,order,K,ncases", [(2, 2, 32, 64), (2, 2, 32, 1000), (2, 2, 32, 4097), (1, 2, 8, 777),
                                                  (3, 2, 40, 1500), (2, 3, 40, 515), (2, 1, 16, 300), (3, 2, 32, 130),
-                                                 (2, 4, 64, 700)])
+                                                 (2, 4, 64, 700), (2, 2, 20, 900), (2, 2, 25, 333), (2, 3, 30, 200),
+                                                 (3, 2, 50, 300), (1, 4, 12, 500), (3, 1, 14, 129)])
 def test_tile_path_equals_lane_path(wlsqm, dim, order, K, ncases, monkeypatch):
     """The LDS-tiled fast path (contiguous, curated K) against the generic lane kernel on the same inputs:
     ragged nk <= K, mixed weightings and knowns, tail tiles.  Same arithmetic except for the split of the

@@ -11,7 +11,8 @@ import wlsqm.hip as whip
 
 cfgname = sys.argv[1]; n = int(sys.argv[2]); variants = sys.argv[3:]
 cfg = bench.CONFIGS[cfgname]
-dim, order, nk = cfg["dim"], cfg["order"], cfg["nk"]
+dim, order, nk = cfg["dim"], cfg["order"], int(os.environ.get("TUNE_NK", cfg["nk"]))
+cfg = dict(cfg, nk=nk)
 no = bench.NDOF[dim][order]
 dev = torch.device("cuda", 0)
 S, F, hoods = bench.build_problem(cfg, n, 0)
