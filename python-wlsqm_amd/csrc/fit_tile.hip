@@ -26,6 +26,7 @@
 
 #include "wlsqm_internal.hpp"
 #include "wlsqm_kernels.hpp"
+#include "wlsqm_moments.hpp"
 
 namespace wlsqm {
 
@@ -44,7 +45,7 @@ template <int DIM> __host__ __device__ constexpr int row_stride_x(int K) {
 }
 __host__ __device__ constexpr int row_stride_f(int K) { return round_up_mod(K, 2, 1); }
 
-template <int DIM, int ORDER, int K, int KSPLIT, int LPC, bool FKD = false>
+template <int DIM, int ORDER, int K, int KSPLIT, int LPC, bool FKD = false, bool MOM = false>
 struct TileGeom {
     static constexpr int NO = ndofs(DIM, ORDER);
     static constexpr int NE = NO * (NO + 1) / 2;
@@ -56,7 +57,8 @@ struct TileGeom {
     static constexpr int XCH = TC * K * DIM / 2, FCH = TC * K / 2;      // 16-byte chunks per tile
     static constexpr int NX = (XCH + NT - 1) / NT, NF = (FCH + NT - 1) / NT;
     static constexpr int CPRX = K * DIM / 2, CPRF = K / 2;  // chunks per row
-    static constexpr int NRED = NE + NO;                     // partial sums per case
+    static constexpr int NA = MOM ? mom_count<DIM>(2 * ORDER) : NE;   // matrix accumulators: distinct moments or unique entries
+    static constexpr int NRED = NA + NO;                     // partial sums per case
     static constexpr int LDS_TILE = TC * (RS + (FKD ? 0 : FS));   // FKD: fk is read straight from global by its owner lane
     static constexpr int LDS_RED = (KSPLIT - 1) * NRED * TC;
     static constexpr int LDS_MAIN = LDS_TILE > LDS_RED ? LDS_TILE : LDS_RED;
@@ -71,13 +73,18 @@ struct TileGeom {
 // (__launch_bounds__ 2nd argument).
 // GATHER: index-based ("cloud") input — the tile's rows are gathered from the point tables S/F through
 // hoods[ncases, K] instead of being read from dense xk/fk; everything after the LDS staging is identical.
-template <int DIM, int ORDER, int K, int KSPLIT, int LPC, int UNR, int MINW, bool GATHER, bool FKD = false>
+// MOM: accumulate the distinct moments (wlsqm_moments.hpp) instead of the matrix entries; wave 0 expands them.
+// SPLIT: stop after the reduction and park the moments in the workspace p.ws (fit_moment.hip solves them in a second
+//        kernel): for systems whose expanded matrix does not fit the register file next to the accumulators.
+template <int DIM, int ORDER, int K, int KSPLIT, int LPC, int UNR, int MINW, bool GATHER, bool FKD = false, bool MOM = false,
+          bool SPLIT = false>
 __global__ __launch_bounds__(WV * KSPLIT, MINW) void fit_tile_kernel(const KParams p, const long long ntiles) {
-    using G = TileGeom<DIM, ORDER, K, KSPLIT, LPC, FKD>;
+    using G = TileGeom<DIM, ORDER, K, KSPLIT, LPC, FKD, MOM>;
+    static_assert(!SPLIT || MOM, "the workspace holds moments");
     static_assert(!(FKD && GATHER), "direct fk loads are a dense-path option");
     static_assert(!FKD || G::KPL % 2 == 0, "direct fk loads need an even share");
     constexpr int NO = G::NO, NE = G::NE, TC = G::TC, NT = G::NT, RS = G::RS, FS = G::FS;
-    constexpr int NX = G::NX, NF = G::NF, CPRX = G::CPRX, CPRF = G::CPRF, KPL = G::KPL, NRED = G::NRED;
+    constexpr int NX = G::NX, NF = G::NF, CPRX = G::CPRX, CPRF = G::CPRF, KPL = G::KPL, NRED = G::NRED, NA = G::NA;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* sX = lds;                                      // [TC][RS]
     double* sF = lds + TC * RS;                            // [TC][FS]
@@ -232,13 +239,13 @@ __global__ __launch_bounds__(WV * KSPLIT, MINW) void fit_tile_kernel(const KPara
 
         // ---- pass 2: this lane's share of the neighbours.  A wave whose cases all use the full K
         // neighbours (the common case) runs the loop without the per-neighbour `live` selects.
-        double M[NE], g[NO];
+        double A[NA], g[NO];               // MOM: moments mu / nu (graded order); else: packed upper triangle of M / g
 #pragma unroll
-        for (int e = 0; e < NE; ++e) M[e] = 0.0;
+        for (int e = 0; e < NA; ++e) A[e] = 0.0;
 #pragma unroll
         for (int a = 0; a < NO; ++a) g[a] = 0.0;
         auto neighbour = [&](int k, bool live) {
-            double d[DIM], cc[NO];
+            double d[DIM];
             if constexpr (DIM == 2) {
                 const double2_ xy = *reinterpret_cast<const double2_*>(xr + 2 * k);   // ds_read_b128
                 d[0] = xy.x - xi[0]; d[1] = xy.y - xi[1];
@@ -248,11 +255,20 @@ __global__ __launch_bounds__(WV * KSPLIT, MINW) void fit_tile_kernel(const KPara
             }
 #pragma unroll
             for (int m = 0; m < DIM; ++m) d[m] = live ? d[m] : 0.0;
-            const double d2 = monomials<DIM, ORDER>(d, cc);
-            const double w = live ? weight(d2, inv_max, uniform) : 0.0;
             const double fv = FKD ? fdir[k - k0] : fr[k];
             const double f = live ? fv : 0.0;
-            accumulate<NO>(M, g, cc, w, f);
+            if constexpr (MOM) {
+                double d2 = 0.0;
+#pragma unroll
+                for (int m = 0; m < DIM; ++m) d2 += d[m] * d[m];
+                const double w = live ? weight(d2, inv_max, uniform) : 0.0;
+                accumulate_moments<DIM, ORDER>(A, g, d, w, f);
+            } else {
+                double cc[NO];
+                const double d2 = monomials<DIM, ORDER>(d, cc);
+                const double w = live ? weight(d2, inv_max, uniform) : 0.0;
+                accumulate<NO>(A, g, cc, w, f);
+            }
         };
         if (__all(nkc >= K)) {
 #pragma unroll UNR
@@ -267,7 +283,7 @@ __global__ __launch_bounds__(WV * KSPLIT, MINW) void fit_tile_kernel(const KPara
 #pragma unroll
             for (int off = TC; off < WV; off <<= 1) {
 #pragma unroll
-                for (int e = 0; e < NE; ++e) M[e] += __shfl_xor(M[e], off, WV);
+                for (int e = 0; e < NA; ++e) A[e] += __shfl_xor(A[e], off, WV);
 #pragma unroll
                 for (int a = 0; a < NO; ++a) g[a] += __shfl_xor(g[a], off, WV);
             }
@@ -279,9 +295,9 @@ __global__ __launch_bounds__(WV * KSPLIT, MINW) void fit_tile_kernel(const KPara
             if (wave > 0 && h == 0) {
                 double* mine = red + (wave - 1) * (NRED * TC) + c;
 #pragma unroll
-                for (int e = 0; e < NE; ++e) mine[e * TC] = M[e];
+                for (int e = 0; e < NA; ++e) mine[e * TC] = A[e];
 #pragma unroll
-                for (int a = 0; a < NO; ++a) mine[(NE + a) * TC] = g[a];
+                for (int a = 0; a < NO; ++a) mine[(NA + a) * TC] = g[a];
             }
             __syncthreads();
             if (wave == 0) {
@@ -289,45 +305,63 @@ __global__ __launch_bounds__(WV * KSPLIT, MINW) void fit_tile_kernel(const KPara
                 for (int w = 1; w < KSPLIT; ++w) {
                     const double* other = red + (w - 1) * (NRED * TC) + c;
 #pragma unroll
-                    for (int e = 0; e < NE; ++e) M[e] += other[e * TC];
+                    for (int e = 0; e < NA; ++e) A[e] += other[e * TC];
 #pragma unroll
-                    for (int a = 0; a < NO; ++a) g[a] += other[(NE + a) * TC];
+                    for (int a = 0; a < NO; ++a) g[a] += other[(NA + a) * TC];
                 }
             }
         }
 
-        // ---- wave 0: knowns elimination, LDL^T, substitution, store
-        if (wave == 0) {
+        // ---- wave 0: [expand the moments,] knowns elimination, LDL^T, substitution, store
+        if constexpr (SPLIT) {
+            if (wave == 0 && valid && h == 0) {
+                double* w = p.ws + j;
+#pragma unroll
+                for (int e = 0; e < NA; ++e) w[e * p.ws_stride] = A[e];
+#pragma unroll
+                for (int a = 0; a < NO; ++a) w[(NA + a) * p.ws_stride] = g[a];
+            }
+        } else if (wave == 0) {
             constexpr unsigned long long FULL = (1ull << NO) - 1ull;
             if (valid && h == 0 && known != FULL) {
                 double* fio = p.fi + j * p.sfi_j;
-                if (known) {
-                    double val[NO];
+                auto finish = [&](double (&M)[NE], double (&rhs)[NO]) {
+                    if (known) {
+                        double val[NO];
 #pragma unroll
-                    for (int a = 0; a < NO; ++a) val[a] = (((known & ~dropped) >> a) & 1ull) ? fio[a] : 0.0;
-                    eliminate_knowns<NO>(M, g, known, val);
+                        for (int a = 0; a < NO; ++a) val[a] = (((known & ~dropped) >> a) & 1ull) ? fio[a] : 0.0;
+                        eliminate_knowns<NO>(M, rhs, known, val);
+                    }
+                    ldlt_factor<NO>(M);
+                    ldlt_solve<NO>(M, rhs);
+#pragma unroll
+                    for (int a = 0; a < NO; ++a)
+                        if (!((known >> a) & 1ull)) fio[a] = rhs[a];
+                };
+                if constexpr (MOM) {
+                    double M[NE], rhs[NO];
+                    expand_moments<DIM, ORDER>(A, g, M, rhs);
+                    finish(M, rhs);
+                } else {
+                    finish(A, g);
                 }
-                ldlt_factor<NO>(M);
-                ldlt_solve<NO>(M, g);
-#pragma unroll
-                for (int a = 0; a < NO; ++a)
-                    if (!((known >> a) & 1ull)) fio[a] = g[a];
             }
         }
         __syncthreads();   // the next tile overwrites LDS
     }
 }
 
-template <int DIM, int ORDER, int K, int KSPLIT, int LPC = 1, int UNR = 2, int MINW = 2>
+template <int DIM, int ORDER, int K, int KSPLIT, int LPC = 1, int UNR = 2, int MINW = 2, bool FKD = false, bool MOM = false>
 static int launch_tile_any(const KParams& p, hipStream_t stream, bool gather);
 
-template <int DIM, int ORDER, int K, int KSPLIT, int LPC, int UNR, int MINW, bool GATHER, bool FKD = false>
+template <int DIM, int ORDER, int K, int KSPLIT, int LPC, int UNR, int MINW, bool GATHER, bool FKD = false, bool MOM = false,
+          bool SPLIT = false>
 static int launch_tile_impl(const KParams& p, hipStream_t stream) {
-    using G = TileGeom<DIM, ORDER, K, KSPLIT, LPC, FKD>;
+    using G = TileGeom<DIM, ORDER, K, KSPLIT, LPC, FKD, MOM>;
     constexpr size_t lds_bytes = G::LDS_BYTES;
     const long long ntiles = (p.ncases + G::TC - 1) / G::TC;
     static int per_cu = 0, cus = 0;
-    auto kern = fit_tile_kernel<DIM, ORDER, K, KSPLIT, LPC, UNR, MINW, GATHER, FKD>;
+    auto kern = fit_tile_kernel<DIM, ORDER, K, KSPLIT, LPC, UNR, MINW, GATHER, FKD, MOM, SPLIT>;
     if (!cus) {
         int dev = 0;
         WLSQM_HIP_CHECK(hipGetDevice(&dev));
@@ -344,18 +378,19 @@ static int launch_tile_impl(const KParams& p, hipStream_t stream) {
     if (grid > ntiles) grid = ntiles;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G::NT), lds_bytes, stream, p, ntiles);
     WLSQM_HIP_CHECK(hipGetLastError());
-    note_kernel(GATHER ? "tile-gather" : "tile");
+    if (!SPLIT) note_kernel(GATHER ? "tile-gather" : "tile");
     return WLSQM_OK;
 }
 
-template <int DIM, int ORDER, int K, int KSPLIT, int LPC, int UNR, int MINW>
+// FKD (fk read straight from global memory) only exists for dense input; the index-based mode stages F[hoods].
+template <int DIM, int ORDER, int K, int KSPLIT, int LPC, int UNR, int MINW, bool FKD, bool MOM>
 static int launch_tile_any(const KParams& p, hipStream_t stream, bool gather) {
     if constexpr (K % 4 == 0) {
-        if (gather) return launch_tile_impl<DIM, ORDER, K, KSPLIT, LPC, UNR, MINW, true>(p, stream);
+        if (gather) return launch_tile_impl<DIM, ORDER, K, KSPLIT, LPC, UNR, MINW, true, false, MOM>(p, stream);
     } else {
         if (gather) { set_error("index-based tile path needs K % 4 == 0"); return WLSQM_EVALUE; }
     }
-    return launch_tile_impl<DIM, ORDER, K, KSPLIT, LPC, UNR, MINW, false>(p, stream);
+    return launch_tile_impl<DIM, ORDER, K, KSPLIT, LPC, UNR, MINW, false, FKD, MOM>(p, stream);
 }
 
 // The tile path needs: no extras, all cases in order, dense contiguous arrays, 16-byte aligned bases
@@ -369,6 +404,37 @@ static bool tile_eligible(int dim, const KParams& p, long long K) {
     if (p.sxk_k != dim || p.sxk_j != K * dim || p.sfk_k != 1 || p.sfk_j != K) return false;
     if ((reinterpret_cast<uintptr_t>(p.xk) | reinterpret_cast<uintptr_t>(p.fk)) & 15u) return false;
     return true;
+}
+
+// First kernel of the two-kernel moment path (fit_moment.hip): tile pass that leaves the moments in p.ws.
+// `handled` stays false when no instantiation covers (dimension, order, max_nk) or the input is not tile-eligible.
+bool tile_moments_supported(int dimension, int order, const KParams& p, long long max_nk) {
+    return dimension == 2 && order == 4 && max_nk == 64 && tile_eligible(dimension, p, max_nk);
+}
+
+int launch_tile_moments(int dimension, int order, const KParams& p, long long max_nk, hipStream_t stream, bool* handled) {
+    *handled = false;
+    if (!tile_moments_supported(dimension, order, p, max_nk)) return WLSQM_OK;
+    const char* v = getenv("WLSQM_TILE_VARIANT");
+    const int var = v ? atoi(v) : 0;
+    const bool gather = p.hoods != nullptr;
+    if (dimension == 2 && order == 4 && max_nk == 64) {      // C3
+        *handled = true;
+        if (gather) return launch_tile_impl<2, 4, 64, 2, 2, 4, 2, true, false, true, true>(p, stream);
+        switch (var) {
+            case 1: return launch_tile_impl<2, 4, 64, 2, 2, 4, 2, false, false, true, true>(p, stream);   // round-1 shape
+            case 2: return launch_tile_impl<2, 4, 64, 2, 2, 4, 2, false, true, true, true>(p, stream);
+            case 3: return launch_tile_impl<2, 4, 64, 1, 4, 4, 2, false, true, true, true>(p, stream);
+            case 4: return launch_tile_impl<2, 4, 64, 1, 4, 2, 2, false, true, true, true>(p, stream);
+            case 5: return launch_tile_impl<2, 4, 64, 1, 4, 8, 2, false, true, true, true>(p, stream);
+            case 6: return launch_tile_impl<2, 4, 64, 2, 4, 4, 2, false, true, true, true>(p, stream);
+            case 7: return launch_tile_impl<2, 4, 64, 2, 4, 8, 2, false, true, true, true>(p, stream);
+            case 8: return launch_tile_impl<2, 4, 64, 1, 4, 4, 2, false, false, true, true>(p, stream);
+            case 9: return launch_tile_impl<2, 4, 64, 4, 2, 4, 2, false, true, true, true>(p, stream);
+            default: return launch_tile_impl<2, 4, 64, 2, 2, 4, 2, false, false, true, true>(p, stream);   // best A/B; FKD and one-wave tiles lose (spills)
+        }
+    }
+    return WLSQM_OK;
 }
 
 int launch_fit_tile(int dimension, int order, const KParams& p, long long max_nk, hipStream_t stream, bool* handled) {
@@ -385,6 +451,16 @@ int launch_fit_tile(int dimension, int order, const KParams& p, long long max_nk
     if (dimension == D && order == O && max_nk == KK) { *handled = true; return launch_tile_any<D, O, KK, __VA_ARGS__>(p, stream, gather); }
     if (dimension == 2 && order == 2 && max_nk == 32) {      // C2
         *handled = true;
+        if (gather) {
+            // index-based input has no direct-fk option (F is gathered too), and without it the one-wave tiles lose
+            // (0.205 vs 0.170 ms per 1M cases): keep four waves per 64-case tile
+            switch (var) {
+                case 30: return launch_tile_impl<2, 2, 32, 4, 1, 8, 2, true>(p, stream);                 // entry form
+                case 32: return launch_tile_impl<2, 2, 32, 4, 1, 4, 3, true, false, true>(p, stream);
+                case 33: return launch_tile_impl<2, 2, 32, 1, 4, 8, 2, true, false, true>(p, stream);
+                default: return launch_tile_impl<2, 2, 32, 4, 1, 8, 2, true, false, true>(p, stream);
+            }
+        }
         switch (var) {
             case 1: return launch_tile_any<2, 2, 32, 4, 1, 1, 3>(p, stream, gather);
             case 2: return launch_tile_any<2, 2, 32, 4, 1, 4, 3>(p, stream, gather);
@@ -396,7 +472,27 @@ int launch_fit_tile(int dimension, int order, const KParams& p, long long max_nk
             case 8: return launch_tile_impl<2, 2, 32, 2, 1, 8, 2, false, true>(p, stream);
             case 9: return launch_tile_impl<2, 2, 32, 4, 1, 8, 2, false, true>(p, stream);
             case 10: return launch_tile_impl<2, 2, 32, 2, 1, 2, 2, false, true>(p, stream);
-            default: return launch_tile_any<2, 2, 32, 4, 1, 8, 2>(p, stream, gather);   // best of the round-1 A/B
+            case 11: return launch_tile_impl<2, 2, 32, 4, 1, 8, 2, false, false, true>(p, stream);
+            case 12: return launch_tile_impl<2, 2, 32, 4, 1, 4, 3, false, false, true>(p, stream);
+            case 13: return launch_tile_impl<2, 2, 32, 2, 1, 4, 2, false, false, true>(p, stream);
+            case 14: return launch_tile_impl<2, 2, 32, 2, 1, 4, 3, false, false, true>(p, stream);
+            case 15: return launch_tile_impl<2, 2, 32, 4, 1, 4, 4, false, false, true>(p, stream);
+            case 16: return launch_tile_impl<2, 2, 32, 8, 1, 4, 2, false, false, true>(p, stream);
+            case 17: return launch_tile_impl<2, 2, 32, 2, 2, 4, 3, false, false, true>(p, stream);
+            case 18: return launch_tile_impl<2, 2, 32, 4, 1, 8, 2, false, true, true>(p, stream);
+            case 19: return launch_tile_impl<2, 2, 32, 2, 1, 8, 3, false, true, true>(p, stream);
+            case 20: return launch_tile_impl<2, 2, 32, 1, 4, 8, 2, false, true, true>(p, stream);
+            case 21: return launch_tile_impl<2, 2, 32, 1, 4, 4, 3, false, false, true>(p, stream);
+            case 22: return launch_tile_impl<2, 2, 32, 1, 2, 8, 2, false, false, true>(p, stream);
+            case 23: return launch_tile_impl<2, 2, 32, 1, 2, 4, 3, false, false, true>(p, stream);
+            case 24: return launch_tile_impl<2, 2, 32, 1, 4, 8, 4, false, false, true>(p, stream);
+            case 25: return launch_tile_impl<2, 2, 32, 1, 4, 4, 2, false, true, true>(p, stream);
+            case 26: return launch_tile_impl<2, 2, 32, 1, 4, 2, 2, false, true, true>(p, stream);
+            case 27: return launch_tile_impl<2, 2, 32, 1, 4, 8, 3, false, true, true>(p, stream);
+            case 28: return launch_tile_impl<2, 2, 32, 1, 2, 8, 2, false, true, true>(p, stream);
+            case 29: return launch_tile_impl<2, 2, 32, 1, 4, 8, 2, false, false, true>(p, stream);
+            case 30: return launch_tile_any<2, 2, 32, 4, 1, 8, 2>(p, stream, gather);   // entry form, 4 waves per 64-case tile (before the moment form)
+            default: return launch_tile_any<2, 2, 32, 1, 4, 8, 2, true, true>(p, stream, gather);   // moments, one wave per 16-case tile, direct fk
         }
     }
     if (dimension == 3 && order == 2 && max_nk == 40) {      // C5
@@ -404,7 +500,32 @@ int launch_fit_tile(int dimension, int order, const KParams& p, long long max_nk
         switch (var) {
             case 1: return launch_tile_any<3, 2, 40, 4, 2, 1, 2>(p, stream, gather);
             case 2: return launch_tile_any<3, 2, 40, 4, 2, 5, 2>(p, stream, gather);
-            default: return launch_tile_any<3, 2, 40, 2, 2, 2, 2>(p, stream, gather);   // best of the round-1 A/B
+            case 3: return launch_tile_any<3, 2, 40, 4, 1, 2, 2>(p, stream, gather);
+            case 4: return launch_tile_impl<3, 2, 40, 4, 1, 2, 2, false, true>(p, stream);
+            case 5: return launch_tile_impl<3, 2, 40, 2, 2, 2, 2, false, true>(p, stream);
+            case 6: return launch_tile_any<3, 2, 40, 2, 2, 10, 2>(p, stream, gather);
+            case 7: return launch_tile_any<3, 2, 40, 2, 2, 5, 2>(p, stream, gather);
+            case 8: return launch_tile_any<3, 2, 40, 2, 2, 2, 1>(p, stream, gather);
+            case 9: return launch_tile_impl<3, 2, 40, 2, 2, 2, 2, false, false, true>(p, stream);
+            case 10: return launch_tile_impl<3, 2, 40, 2, 2, 2, 2, false, true, true>(p, stream);
+            case 11: return launch_tile_impl<3, 2, 40, 4, 1, 2, 2, false, true, true>(p, stream);
+            case 12: return launch_tile_impl<3, 2, 40, 4, 2, 5, 2, false, false, true>(p, stream);
+            case 13: return launch_tile_impl<3, 2, 40, 2, 2, 4, 3, false, true, true>(p, stream);
+            case 14: return launch_tile_impl<3, 2, 40, 4, 1, 2, 2, false, false, true>(p, stream);
+            case 15: return launch_tile_impl<3, 2, 40, 2, 2, 5, 2, false, true, true>(p, stream);
+            case 16: return launch_tile_impl<3, 2, 40, 2, 2, 1, 2, false, true, true>(p, stream);
+            case 17: return launch_tile_impl<3, 2, 40, 1, 4, 2, 2, false, true, true>(p, stream);
+            case 18: return launch_tile_impl<3, 2, 40, 2, 4, 5, 2, false, false, true>(p, stream);
+            case 19: return launch_tile_impl<3, 2, 40, 1, 2, 4, 2, false, true, true>(p, stream);
+            case 20: return launch_tile_impl<3, 2, 40, 1, 4, 5, 3, false, true, true>(p, stream);
+            case 21: return launch_tile_impl<3, 2, 40, 2, 2, 10, 2, false, true, true>(p, stream);
+            case 22: return launch_tile_any<3, 2, 40, 2, 2, 2, 2>(p, stream, gather);   // entry-form accumulators (before the moment form)
+            case 23: return launch_tile_impl<3, 2, 40, 1, 4, 5, 2, false, true, true>(p, stream);
+            case 24: return launch_tile_impl<3, 2, 40, 1, 4, 10, 2, false, true, true>(p, stream);
+            case 25: return launch_tile_impl<3, 2, 40, 1, 2, 4, 2, false, false, true>(p, stream);
+            case 26: return launch_tile_impl<3, 2, 40, 1, 4, 2, 2, false, false, true>(p, stream);
+            case 27: return launch_tile_impl<3, 2, 40, 1, 4, 1, 2, false, true, true>(p, stream);
+            default: return launch_tile_any<3, 2, 40, 1, 4, 2, 2, true, true>(p, stream, gather);   // moments, one wave per 16-case tile, direct fk
         }
     }
     // C3 (2D order 4, 64 neighbours): every tile variant tried (KSPLIT x LPC in {1x4, 2x4, 4x2, 2x2}) lost to the

@@ -6,10 +6,12 @@
 // the host, staging runs in rounds of R 16-byte chunks per lane (all R loads of a round in flight), and
 // the neighbour loops are rolled.  Same arithmetic and the same parity as fit_tile / fit_lane.
 // Mapping: 4 waves per 64-case tile, wave w owns neighbours [w*KPW, (w+1)*KPW).
+// MOM: accumulate the distinct moments (wlsqm_moments.hpp) instead of the matrix entries; wave 0 expands them.
 #include <cstdlib>
 
 #include "wlsqm_internal.hpp"
 #include "wlsqm_kernels.hpp"
+#include "wlsqm_moments.hpp"
 
 namespace wlsqm {
 
@@ -24,9 +26,10 @@ struct TileKGeom {
     int lds_main;          // doubles shared by the tile image and the reduction buffer
 };
 
-template <int DIM, int ORDER>
+template <int DIM, int ORDER, bool MOM>
 __global__ __launch_bounds__(KNT, 2) void fit_tilek_kernel(const KParams p, const long long ntiles, const TileKGeom G) {
-    constexpr int NO = ndofs(DIM, ORDER), NE = NO * (NO + 1) / 2, NRED = NE + NO, TC = KW;
+    constexpr int NO = ndofs(DIM, ORDER), NE = NO * (NO + 1) / 2, NA = MOM ? mom_count<DIM>(2 * ORDER) : NE;
+    constexpr int NRED = NA + NO, TC = KW;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* sX = lds;
     double* sF = lds + TC * G.RS;
@@ -103,18 +106,26 @@ __global__ __launch_bounds__(KNT, 2) void fit_tilek_kernel(const KParams p, cons
         for (int s = 0; s < KSP; ++s) { const double o = sMax[s * TC + lane]; max_d2 = o > max_d2 ? o : max_d2; }
         const double inv_max = inverse_max(max_d2);
 
-        double M[NE], g[NO];
+        double A[NA], g[NO];               // MOM: moments mu / nu; else the packed upper triangle of M / g
 #pragma unroll
-        for (int e = 0; e < NE; ++e) M[e] = 0.0;
+        for (int e = 0; e < NA; ++e) A[e] = 0.0;
 #pragma unroll
         for (int a = 0; a < NO; ++a) g[a] = 0.0;
 #pragma unroll 2
         for (int k = k0; k < k1; ++k) {
-            double d[DIM], cc[NO];
+            double d[DIM];
 #pragma unroll
             for (int m = 0; m < DIM; ++m) d[m] = xr[k * DIM + m] - xi[m];
-            const double d2 = monomials<DIM, ORDER>(d, cc);
-            accumulate<NO>(M, g, cc, weight(d2, inv_max, uniform), fr[k]);
+            if constexpr (MOM) {
+                double d2 = 0.0;
+#pragma unroll
+                for (int m = 0; m < DIM; ++m) d2 += d[m] * d[m];
+                accumulate_moments<DIM, ORDER>(A, g, d, weight(d2, inv_max, uniform), fr[k]);
+            } else {
+                double cc[NO];
+                const double d2 = monomials<DIM, ORDER>(d, cc);
+                accumulate<NO>(A, g, cc, weight(d2, inv_max, uniform), fr[k]);
+            }
         }
 
         __syncthreads();
@@ -122,9 +133,9 @@ __global__ __launch_bounds__(KNT, 2) void fit_tilek_kernel(const KParams p, cons
         if (wave > 0) {
             double* mine = red + (wave - 1) * (NRED * TC) + lane;
 #pragma unroll
-            for (int e = 0; e < NE; ++e) mine[e * TC] = M[e];
+            for (int e = 0; e < NA; ++e) mine[e * TC] = A[e];
 #pragma unroll
-            for (int a = 0; a < NO; ++a) mine[(NE + a) * TC] = g[a];
+            for (int a = 0; a < NO; ++a) mine[(NA + a) * TC] = g[a];
         }
         __syncthreads();
         if (wave == 0) {
@@ -132,24 +143,33 @@ __global__ __launch_bounds__(KNT, 2) void fit_tilek_kernel(const KParams p, cons
             for (int w = 1; w < KSP; ++w) {
                 const double* other = red + (w - 1) * (NRED * TC) + lane;
 #pragma unroll
-                for (int e = 0; e < NE; ++e) M[e] += other[e * TC];
+                for (int e = 0; e < NA; ++e) A[e] += other[e * TC];
 #pragma unroll
-                for (int a = 0; a < NO; ++a) g[a] += other[(NE + a) * TC];
+                for (int a = 0; a < NO; ++a) g[a] += other[(NA + a) * TC];
             }
             constexpr unsigned long long FULL = (1ull << NO) - 1ull;
             if (valid && known != FULL) {
                 double* fio = p.fi + j * p.sfi_j;
-                if (known) {
-                    double val[NO];
+                auto finish = [&](double (&M)[NE], double (&rhs)[NO]) {
+                    if (known) {
+                        double val[NO];
 #pragma unroll
-                    for (int a = 0; a < NO; ++a) val[a] = (((known & ~dropped) >> a) & 1ull) ? fio[a] : 0.0;
-                    eliminate_knowns<NO>(M, g, known, val);
+                        for (int a = 0; a < NO; ++a) val[a] = (((known & ~dropped) >> a) & 1ull) ? fio[a] : 0.0;
+                        eliminate_knowns<NO>(M, rhs, known, val);
+                    }
+                    ldlt_factor<NO>(M);
+                    ldlt_solve<NO>(M, rhs);
+#pragma unroll
+                    for (int a = 0; a < NO; ++a)
+                        if (!((known >> a) & 1ull)) fio[a] = rhs[a];
+                };
+                if constexpr (MOM) {
+                    double M[NE], rhs[NO];
+                    expand_moments<DIM, ORDER>(A, g, M, rhs);
+                    finish(M, rhs);
+                } else {
+                    finish(A, g);
                 }
-                ldlt_factor<NO>(M);
-                ldlt_solve<NO>(M, g);
-#pragma unroll
-                for (int a = 0; a < NO; ++a)
-                    if (!((known >> a) & 1ull)) fio[a] = g[a];
             }
         }
         __syncthreads();
@@ -158,9 +178,9 @@ __global__ __launch_bounds__(KNT, 2) void fit_tilek_kernel(const KParams p, cons
 
 static int rup(int v, int m, int r) { return v + ((r - v % m) % m + m) % m; }
 
-template <int DIM, int ORDER>
+template <int DIM, int ORDER, bool MOM>
 static int launch_tilek(const KParams& p, long long K, hipStream_t stream, bool* handled) {
-    constexpr int NO = ndofs(DIM, ORDER), NE = NO * (NO + 1) / 2, NRED = NE + NO;
+    constexpr int NO = ndofs(DIM, ORDER), NE = NO * (NO + 1) / 2, NRED = (MOM ? mom_count<DIM>(2 * ORDER) : NE) + NO;
     TileKGeom G;
     G.K = (int)K; G.KPW = (int)((K + KSP - 1) / KSP);
     G.RS = rup((int)K * DIM, 2, 1); G.FS = rup((int)K, 2, 1);       // odd strides: conflict-free ds_read_b64
@@ -172,7 +192,7 @@ static int launch_tilek(const KParams& p, long long K, hipStream_t stream, bool*
     if (lds_bytes > 80 * 1024) return WLSQM_OK;                     // keep >= 2 workgroups per CU; larger K: generic kernel
     *handled = true;
     const long long ntiles = (p.ncases + KW - 1) / KW;
-    auto kern = fit_tilek_kernel<DIM, ORDER>;
+    auto kern = fit_tilek_kernel<DIM, ORDER, MOM>;
     static int cus = 0;
     if (!cus) {
         int dev = 0;
@@ -202,7 +222,14 @@ int launch_fit_tilek(int dimension, int order, const KParams& p, long long K, hi
     if (K < 4 || (K % 2) != 0) return WLSQM_OK;
     if (p.sxk_k != dimension || p.sxk_j != K * dimension || p.sfk_k != 1 || p.sfk_j != K) return WLSQM_OK;
     if ((reinterpret_cast<uintptr_t>(p.xk) | reinterpret_cast<uintptr_t>(p.fk)) & 15u) return WLSQM_OK;
-#define KCASE(D, O) if (dimension == D && order == O) return launch_tilek<D, O>(p, K, stream, handled);
+    // moment form from order 2 up (fewer accumulators and operations); WLSQM_TILEK_MOM=0 keeps the entry form (A/B)
+    const char* mv = getenv("WLSQM_TILEK_MOM");
+    const bool mom = !(mv && mv[0] == '0');
+#define KCASE(D, O)                                                                   \
+    if (dimension == D && order == O) {                                               \
+        if (O >= 2 && mom) return launch_tilek<D, O, (O >= 2)>(p, K, stream, handled); \
+        return launch_tilek<D, O, false>(p, K, stream, handled);                      \
+    }
     KCASE(1, 0) KCASE(1, 1) KCASE(1, 2) KCASE(1, 3) KCASE(1, 4)
     KCASE(2, 0) KCASE(2, 1) KCASE(2, 2) KCASE(2, 3)
     KCASE(3, 0) KCASE(3, 1) KCASE(3, 2)

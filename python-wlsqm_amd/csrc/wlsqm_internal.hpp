@@ -27,7 +27,27 @@ struct KParams {
     long long ncases;              // cases this launch processes
     int do_sens, iterative, max_iter;
     int* iters_out;                // device int (atomicMax), nullable
+    // Two-kernel moment path (fit_moment.hip): the tile kernel parks the reduced moments of case j at
+    // ws[e * ws_stride + j] (structure of arrays) and the solve kernel picks them up.
+    double* ws;        long long ws_stride;
 };
+
+// The sub-batch [j0, j0 + n) of a launch (dense or index-based input, no case_index).
+inline KParams slice_cases(const KParams& p, long long j0, long long n) {
+    KParams q = p;
+    if (p.xk) q.xk = p.xk + j0 * p.sxk_j;
+    if (p.fk) q.fk = p.fk + j0 * p.sfk_j;
+    q.nk = p.nk + j0 * p.snk;
+    if (p.xi) q.xi = p.xi + j0 * p.sxi_j;
+    q.fi = p.fi + j0 * p.sfi_j;
+    if (p.sens) q.sens = p.sens + j0 * p.ss_j;
+    q.knowns = p.knowns + j0 * p.sknowns;
+    q.wm = p.wm + j0 * p.swm;
+    if (p.hoods) q.hoods = p.hoods + j0 * p.shoods_j;
+    if (p.pidx) q.pidx = p.pidx + j0;
+    q.ncases = n;
+    return q;
+}
 
 void set_error(const std::string& msg);
 int hip_fail(hipError_t e, const char* what);

@@ -1,0 +1,112 @@
+// wlsqm_moments.hpp — moment form of the normal equations.
+//
+//   M[a,b] = sum_k w_k c_a(k) c_b(k) = mu(P_a + P_b) / (P_a! P_b!)      mu(P) = sum_k w_k d^P
+//   g[a]   = sum_k w_k f_k c_a(k)    = nu(P_a) / P_a!                   nu(P) = sum_k w_k f_k d^P
+// with c_a = d^{P_a} / P_a! (impl.pyx:102-157, 319-349, 476-489; M as impl.pyx:601, g as :774).  The
+// no(no+1)/2 matrix entries are only C(2*order + dim, dim) distinct moments (2D order 2: 15 of 21,
+// 3D order 2: 35 of 55, 2D order 4: 45 of 120), accumulated with one multiply per monomial
+// (t(P) = t(P - e_m) d_m) and one add; the top degree is folded into an FMA.
+#pragma once
+#include "wlsqm_kernels.hpp"
+
+namespace wlsqm {
+
+__host__ __device__ constexpr int mtri(int d) { return d * (d + 1) / 2; }
+__host__ __device__ constexpr int mtet(int d) { return d * (d + 1) * (d + 2) / 6; }
+// number of monomials of total degree <= deg
+template <int DIM> __host__ __device__ constexpr int mom_count(int deg) {
+    return DIM == 1 ? deg + 1 : DIM == 2 ? mtri(deg + 1) : mtet(deg + 1);
+}
+// graded index of x^p y^q z^r: degrees ascending; inside a degree by (q + r) ascending, then r ascending
+template <int DIM> __host__ __device__ constexpr int mom_index(int p, int q, int r) {
+    return DIM == 1 ? p : DIM == 2 ? mtri(p + q) + q : mtet(p + q + r) + mtri(q + r) + r;
+}
+__host__ __device__ constexpr double mom_inv_fact(int n) {
+    return n <= 1 ? 1.0 : n == 2 ? 0.5 : n == 3 ? 1.0 / 6.0 : 1.0 / 24.0;
+}
+
+// One neighbour into the accumulators: mu over degrees 0..2*ORDER, nu over degrees 0..ORDER (both in graded order).
+template <int DIM, int ORDER>
+__device__ __forceinline__ void accumulate_moments(double (&mu)[mom_count<DIM>(2 * ORDER)], double (&nu)[mom_count<DIM>(ORDER)],
+                                                   const double (&d)[DIM], double w, double f) {
+    constexpr int D = 2 * ORDER;
+    constexpr int W = DIM == 1 ? 1 : DIM == 2 ? D + 1 : mtri(D + 1);   // monomials in the widest degree kept
+    double prev[W], cur[W];
+    prev[0] = w;
+    mu[0] += w;
+    nu[0] = fma(w, f, nu[0]);
+#pragma unroll
+    for (int deg = 1; deg <= D; ++deg) {
+        const int base = mom_count<DIM>(deg - 1);                      // index of the first monomial of this degree
+        // enumerate the monomials of this degree in graded order; `pos` is the position inside the degree
+        const int smax = (DIM == 1) ? 0 : deg;
+#pragma unroll
+        for (int s = 0; s <= smax; ++s) {                              // s = q + r  (DIM == 2: s = q)
+            const int rmax = (DIM == 3) ? s : 0;
+#pragma unroll
+            for (int r = 0; r <= rmax; ++r) {
+                const int q = s - r;
+                const int pos = (DIM == 3) ? mtri(s) + r : s;
+                // parent monomial (degree deg-1) and the variable that takes it here
+                int ppos; int var;
+                if (DIM == 3 && r > 0) { ppos = mtri(s - 1) + (r - 1); var = 2; }          // (p, q, r-1) * z
+                else if (DIM >= 2 && q > 0) { ppos = (DIM == 3) ? mtri(s - 1) : s - 1; var = 1; }   // (p, q-1, 0) * y
+                else { ppos = (DIM == 3) ? mtri(s) + r : s; var = 0; }                      // (p-1, q, r) * x
+                // for var == 0 the parent has the same (q, r), i.e. the same position in the previous degree
+                if (deg < D) {
+                    const double t = prev[ppos] * d[var];
+                    cur[pos] = t;
+                    mu[base + pos] += t;
+                    if (deg <= ORDER) nu[base + pos] = fma(t, f, nu[base + pos]);
+                } else {
+                    mu[base + pos] = fma(prev[ppos], d[var], mu[base + pos]);
+                }
+            }
+        }
+        if (deg < D) {
+            const int cnt = mom_count<DIM>(deg) - base;
+#pragma unroll
+            for (int i = 0; i < W; ++i) if (i < cnt) prev[i] = cur[i];
+        }
+    }
+}
+
+// Expand the packed upper triangle of M and the right-hand side g (DOF order) from the moments.
+// `mu_at(i)` / `nu_at(i)` deliver moment i (graded index); each is asked for exactly once, in ascending order,
+// so a caller may fetch (and sum) them from LDS on demand and never hold the whole moment vector in registers.
+template <int DIM, int ORDER, class MuAt, class NuAt>
+__device__ __forceinline__ void expand_moments_from(MuAt mu_at, NuAt nu_at,
+                                                    double (&M)[ndofs(DIM, ORDER) * (ndofs(DIM, ORDER) + 1) / 2],
+                                                    double (&g)[ndofs(DIM, ORDER)]) {
+    constexpr int NO = ndofs(DIM, ORDER), NM = mom_count<DIM>(2 * ORDER);
+#pragma unroll
+    for (int i = 0; i < NM; ++i) {
+        const double m = mu_at(i);
+#pragma unroll
+        for (int a = 0; a < NO; ++a) {
+            const int pa = Mono<DIM>::P[a], qa = Mono<DIM>::Q[a], ra = Mono<DIM>::R[a];
+            const double fa = mom_inv_fact(pa) * mom_inv_fact(qa) * mom_inv_fact(ra);
+#pragma unroll
+            for (int b = a; b < NO; ++b) {
+                const int pb = Mono<DIM>::P[b], qb = Mono<DIM>::Q[b], rb = Mono<DIM>::R[b];
+                const double fb = mom_inv_fact(pb) * mom_inv_fact(qb) * mom_inv_fact(rb);
+                if (mom_index<DIM>(pa + pb, qa + qb, ra + rb) == i) M[tri<NO>(a, b)] = m * (fa * fb);
+            }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < NO; ++a) {
+        const int pa = Mono<DIM>::P[a], qa = Mono<DIM>::Q[a], ra = Mono<DIM>::R[a];
+        g[a] = nu_at(mom_index<DIM>(pa, qa, ra)) * (mom_inv_fact(pa) * mom_inv_fact(qa) * mom_inv_fact(ra));
+    }
+}
+
+template <int DIM, int ORDER>
+__device__ __forceinline__ void expand_moments(const double (&mu)[mom_count<DIM>(2 * ORDER)],
+                                               const double (&nu)[mom_count<DIM>(ORDER)],
+                                               double (&M)[ndofs(DIM, ORDER) * (ndofs(DIM, ORDER) + 1) / 2],
+                                               double (&g)[ndofs(DIM, ORDER)]) {
+    expand_moments_from<DIM, ORDER>([&](int i) { return mu[i]; }, [&](int i) { return nu[i]; }, M, g);
+}
+
+}  // namespace wlsqm

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Interleaved A/B timing of kernel variants in ONE process (cdna_hip_programming.md §5.4 rule 24).
-usage: python tools/tune.py CONFIG ncases var0 var1 ...   (variants = values of WLSQM_TILE_VARIANT; 'lane' = generic kernel)"""
+usage: python tools/tune.py CONFIG ncases var0 var1 ...   (variants = values of WLSQM_TILE_VARIANT; 'lane' = generic kernel; k0/k1 = WLSQM_TILEK_MOM with TUNE_NK set)"""
 import os, sys, json
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -31,6 +31,8 @@ for rnd in range(5):
     for v in variants:
         if v == "lane":
             os.environ["WLSQM_HIP_DISABLE_TILE"] = "1"
+        elif v in ("k0", "k1"):            # runtime-K kernel: entry form / moment form
+            os.environ.pop("WLSQM_HIP_DISABLE_TILE", None); os.environ["WLSQM_TILEK_MOM"] = v[1]
         else:
             os.environ.pop("WLSQM_HIP_DISABLE_TILE", None); os.environ["WLSQM_TILE_VARIANT"] = v
         ms = whip.time_fit_device(*args, reps=20)
