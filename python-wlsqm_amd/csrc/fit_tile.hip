@@ -16,12 +16,14 @@
 //     (reusing the tile's storage); wave 0 does knowns elimination + LDL^T + substitution and
 //     writes the `no` results.
 //
-// LDS per workgroup is TC * K * (dim+1) * 8 B plus padding (50.7 KB for 2D/32 neighbours with
-// TC = 64), so three workgroups share a CU's 160 KB; while one workgroup computes, the others
-// have their ~48 KB of loads in flight, which is what keeps HBM busy.  Measured and rejected (C2, 1M cases,
-// tools/tune.py): software prefetch of the next tile through registers, early (-15 %) or late, during the solve
-// (-12 %): both cost the third resident workgroup; 4 lanes per case without barriers (-28 %: the shuffle
-// reduction and the redundant solves cost more VALU than the barriers they remove).
+// Shapes (KSPLIT waves x LPC lanes per case) are picked per configuration by A/B measurement, see launch_fit_tile.
+// What the round-1 measurements say (1M cases, tools/tune.py):
+//   * moment form (MOM, wlsqm_moments.hpp): fewer accumulators and operations per neighbour from order 2 up;
+//   * one wave per 16-case tile (KSPLIT 1, LPC 4) with fk read straight from global memory (FKD) is the fastest dense
+//     shape for 2D order 2 and 3D order 2: no barriers between waves, 8-16 KB of LDS per wave, and the fk loads are
+//     consumed only after the distance pass.  Without FKD the same shape loses to four waves per 64-case tile;
+//   * rejected for C2: software prefetch of the next tile through registers, early (-15 %) or late, during the solve
+//     (-12 %): both cost a resident workgroup; expanding the moments from LDS in wave 0 (-5 %).
 #include <cstdlib>
 
 #include "wlsqm_internal.hpp"
@@ -421,17 +423,11 @@ int launch_tile_moments(int dimension, int order, const KParams& p, long long ma
     if (dimension == 2 && order == 4 && max_nk == 64) {      // C3
         *handled = true;
         if (gather) return launch_tile_impl<2, 4, 64, 2, 2, 4, 2, true, false, true, true>(p, stream);
+        // A/B at 1M cases: two waves per 32-case tile 0.73 ms (with the solve kernel); direct fk the same; one wave per
+        // 16-case tile spills (60 accumulators + 16 fk values per lane) 0.85 ms; (2 or 4 waves) x 4 lanes per case 0.85 ms.
         switch (var) {
-            case 1: return launch_tile_impl<2, 4, 64, 2, 2, 4, 2, false, false, true, true>(p, stream);   // round-1 shape
-            case 2: return launch_tile_impl<2, 4, 64, 2, 2, 4, 2, false, true, true, true>(p, stream);
-            case 3: return launch_tile_impl<2, 4, 64, 1, 4, 4, 2, false, true, true, true>(p, stream);
-            case 4: return launch_tile_impl<2, 4, 64, 1, 4, 2, 2, false, true, true, true>(p, stream);
-            case 5: return launch_tile_impl<2, 4, 64, 1, 4, 8, 2, false, true, true, true>(p, stream);
-            case 6: return launch_tile_impl<2, 4, 64, 2, 4, 4, 2, false, true, true, true>(p, stream);
-            case 7: return launch_tile_impl<2, 4, 64, 2, 4, 8, 2, false, true, true, true>(p, stream);
-            case 8: return launch_tile_impl<2, 4, 64, 1, 4, 4, 2, false, false, true, true>(p, stream);
-            case 9: return launch_tile_impl<2, 4, 64, 4, 2, 4, 2, false, true, true, true>(p, stream);
-            default: return launch_tile_impl<2, 4, 64, 2, 2, 4, 2, false, false, true, true>(p, stream);   // best A/B; FKD and one-wave tiles lose (spills)
+            case 1: return launch_tile_impl<2, 4, 64, 2, 2, 4, 2, false, true, true, true>(p, stream);
+            default: return launch_tile_impl<2, 4, 64, 2, 2, 4, 2, false, false, true, true>(p, stream);
         }
     }
     return WLSQM_OK;
@@ -442,6 +438,8 @@ int launch_fit_tile(int dimension, int order, const KParams& p, long long max_nk
     // WLSQM_HIP_DISABLE_TILE=1 forces the generic kernels (A/B measurements and the tile-vs-lane parity test)
     const char* off = getenv("WLSQM_HIP_DISABLE_TILE");
     if (off && off[0] == '1') return WLSQM_OK;
+    const char* nofix = getenv("WLSQM_HIP_DISABLE_FIXEDK");     // A/B: send the curated shapes to the runtime-K kernels too
+    if (nofix && nofix[0] == '1' && !p.hoods) return WLSQM_OK;
     if (!tile_eligible(dimension, p, max_nk)) return WLSQM_OK;
     // WLSQM_TILE_VARIANT selects a tuning variant of the BASELINE configs (tools/tune.py); default = best measured
     const char* v = getenv("WLSQM_TILE_VARIANT");
@@ -454,94 +452,44 @@ int launch_fit_tile(int dimension, int order, const KParams& p, long long max_nk
         if (gather) {
             // index-based input has no direct-fk option (F is gathered too), and without it the one-wave tiles lose
             // (0.205 vs 0.170 ms per 1M cases): keep four waves per 64-case tile
-            switch (var) {
-                case 30: return launch_tile_impl<2, 2, 32, 4, 1, 8, 2, true>(p, stream);                 // entry form
-                case 32: return launch_tile_impl<2, 2, 32, 4, 1, 4, 3, true, false, true>(p, stream);
-                case 33: return launch_tile_impl<2, 2, 32, 1, 4, 8, 2, true, false, true>(p, stream);
-                default: return launch_tile_impl<2, 2, 32, 4, 1, 8, 2, true, false, true>(p, stream);
-            }
+            return var == 3 ? launch_tile_impl<2, 2, 32, 4, 1, 8, 2, true>(p, stream)
+                            : launch_tile_impl<2, 2, 32, 4, 1, 8, 2, true, false, true>(p, stream);
         }
+        // A/B at 1M cases (tools/tune.py), ms per launch: one wave per 16-case tile + moments + direct fk 0.167;
+        // the same with two lanes per case 0.173; without direct fk 0.233; four waves per 64-case tile: moments
+        // 0.181, entry form 0.186 (the round-1 kernel); eight waves 0.43.
         switch (var) {
-            case 1: return launch_tile_any<2, 2, 32, 4, 1, 1, 3>(p, stream, gather);
-            case 2: return launch_tile_any<2, 2, 32, 4, 1, 4, 3>(p, stream, gather);
-            case 3: return launch_tile_any<2, 2, 32, 2, 1, 4, 2>(p, stream, gather);
-            case 4: return launch_tile_any<2, 2, 32, 2, 2, 8, 2>(p, stream, gather);
-            case 5: return launch_tile_any<2, 2, 32, 4, 2, 4, 2>(p, stream, gather);
-            case 6: return launch_tile_any<2, 2, 32, 1, 2, 4, 2>(p, stream, gather);
-            case 7: return launch_tile_impl<2, 2, 32, 2, 1, 4, 2, false, true>(p, stream);
-            case 8: return launch_tile_impl<2, 2, 32, 2, 1, 8, 2, false, true>(p, stream);
-            case 9: return launch_tile_impl<2, 2, 32, 4, 1, 8, 2, false, true>(p, stream);
-            case 10: return launch_tile_impl<2, 2, 32, 2, 1, 2, 2, false, true>(p, stream);
-            case 11: return launch_tile_impl<2, 2, 32, 4, 1, 8, 2, false, false, true>(p, stream);
-            case 12: return launch_tile_impl<2, 2, 32, 4, 1, 4, 3, false, false, true>(p, stream);
-            case 13: return launch_tile_impl<2, 2, 32, 2, 1, 4, 2, false, false, true>(p, stream);
-            case 14: return launch_tile_impl<2, 2, 32, 2, 1, 4, 3, false, false, true>(p, stream);
-            case 15: return launch_tile_impl<2, 2, 32, 4, 1, 4, 4, false, false, true>(p, stream);
-            case 16: return launch_tile_impl<2, 2, 32, 8, 1, 4, 2, false, false, true>(p, stream);
-            case 17: return launch_tile_impl<2, 2, 32, 2, 2, 4, 3, false, false, true>(p, stream);
-            case 18: return launch_tile_impl<2, 2, 32, 4, 1, 8, 2, false, true, true>(p, stream);
-            case 19: return launch_tile_impl<2, 2, 32, 2, 1, 8, 3, false, true, true>(p, stream);
-            case 20: return launch_tile_impl<2, 2, 32, 1, 4, 8, 2, false, true, true>(p, stream);
-            case 21: return launch_tile_impl<2, 2, 32, 1, 4, 4, 3, false, false, true>(p, stream);
-            case 22: return launch_tile_impl<2, 2, 32, 1, 2, 8, 2, false, false, true>(p, stream);
-            case 23: return launch_tile_impl<2, 2, 32, 1, 2, 4, 3, false, false, true>(p, stream);
-            case 24: return launch_tile_impl<2, 2, 32, 1, 4, 8, 4, false, false, true>(p, stream);
-            case 25: return launch_tile_impl<2, 2, 32, 1, 4, 4, 2, false, true, true>(p, stream);
-            case 26: return launch_tile_impl<2, 2, 32, 1, 4, 2, 2, false, true, true>(p, stream);
-            case 27: return launch_tile_impl<2, 2, 32, 1, 4, 8, 3, false, true, true>(p, stream);
-            case 28: return launch_tile_impl<2, 2, 32, 1, 2, 8, 2, false, true, true>(p, stream);
-            case 29: return launch_tile_impl<2, 2, 32, 1, 4, 8, 2, false, false, true>(p, stream);
-            case 30: return launch_tile_any<2, 2, 32, 4, 1, 8, 2>(p, stream, gather);   // entry form, 4 waves per 64-case tile (before the moment form)
-            default: return launch_tile_any<2, 2, 32, 1, 4, 8, 2, true, true>(p, stream, gather);   // moments, one wave per 16-case tile, direct fk
+            case 1: return launch_tile_impl<2, 2, 32, 1, 2, 8, 2, false, true, true>(p, stream);
+            case 2: return launch_tile_impl<2, 2, 32, 4, 1, 4, 3, false, false, true>(p, stream);
+            case 3: return launch_tile_any<2, 2, 32, 4, 1, 8, 2>(p, stream, gather);
+            default: return launch_tile_any<2, 2, 32, 1, 4, 8, 2, true, true>(p, stream, gather);
         }
     }
     if (dimension == 3 && order == 2 && max_nk == 40) {      // C5
         *handled = true;
+        // A/B at 1M cases, ms per launch: one wave per 16-case tile + moments + direct fk 0.349; two waves per
+        // 32-case tile: moments + direct fk 0.359, moments 0.395, entry form + direct fk 0.477, entry form 0.567 (the
+        // round-1 kernel); four waves (4 x 1 lanes per case) spill.
         switch (var) {
-            case 1: return launch_tile_any<3, 2, 40, 4, 2, 1, 2>(p, stream, gather);
-            case 2: return launch_tile_any<3, 2, 40, 4, 2, 5, 2>(p, stream, gather);
-            case 3: return launch_tile_any<3, 2, 40, 4, 1, 2, 2>(p, stream, gather);
-            case 4: return launch_tile_impl<3, 2, 40, 4, 1, 2, 2, false, true>(p, stream);
-            case 5: return launch_tile_impl<3, 2, 40, 2, 2, 2, 2, false, true>(p, stream);
-            case 6: return launch_tile_any<3, 2, 40, 2, 2, 10, 2>(p, stream, gather);
-            case 7: return launch_tile_any<3, 2, 40, 2, 2, 5, 2>(p, stream, gather);
-            case 8: return launch_tile_any<3, 2, 40, 2, 2, 2, 1>(p, stream, gather);
-            case 9: return launch_tile_impl<3, 2, 40, 2, 2, 2, 2, false, false, true>(p, stream);
-            case 10: return launch_tile_impl<3, 2, 40, 2, 2, 2, 2, false, true, true>(p, stream);
-            case 11: return launch_tile_impl<3, 2, 40, 4, 1, 2, 2, false, true, true>(p, stream);
-            case 12: return launch_tile_impl<3, 2, 40, 4, 2, 5, 2, false, false, true>(p, stream);
-            case 13: return launch_tile_impl<3, 2, 40, 2, 2, 4, 3, false, true, true>(p, stream);
-            case 14: return launch_tile_impl<3, 2, 40, 4, 1, 2, 2, false, false, true>(p, stream);
-            case 15: return launch_tile_impl<3, 2, 40, 2, 2, 5, 2, false, true, true>(p, stream);
-            case 16: return launch_tile_impl<3, 2, 40, 2, 2, 1, 2, false, true, true>(p, stream);
-            case 17: return launch_tile_impl<3, 2, 40, 1, 4, 2, 2, false, true, true>(p, stream);
-            case 18: return launch_tile_impl<3, 2, 40, 2, 4, 5, 2, false, false, true>(p, stream);
-            case 19: return launch_tile_impl<3, 2, 40, 1, 2, 4, 2, false, true, true>(p, stream);
-            case 20: return launch_tile_impl<3, 2, 40, 1, 4, 5, 3, false, true, true>(p, stream);
-            case 21: return launch_tile_impl<3, 2, 40, 2, 2, 10, 2, false, true, true>(p, stream);
-            case 22: return launch_tile_any<3, 2, 40, 2, 2, 2, 2>(p, stream, gather);   // entry-form accumulators (before the moment form)
-            case 23: return launch_tile_impl<3, 2, 40, 1, 4, 5, 2, false, true, true>(p, stream);
-            case 24: return launch_tile_impl<3, 2, 40, 1, 4, 10, 2, false, true, true>(p, stream);
-            case 25: return launch_tile_impl<3, 2, 40, 1, 2, 4, 2, false, false, true>(p, stream);
-            case 26: return launch_tile_impl<3, 2, 40, 1, 4, 2, 2, false, false, true>(p, stream);
-            case 27: return launch_tile_impl<3, 2, 40, 1, 4, 1, 2, false, true, true>(p, stream);
-            default: return launch_tile_any<3, 2, 40, 1, 4, 2, 2, true, true>(p, stream, gather);   // moments, one wave per 16-case tile, direct fk
+            case 1: return launch_tile_impl<3, 2, 40, 2, 2, 2, 2, false, true, true>(p, stream);
+            case 2: return launch_tile_impl<3, 2, 40, 1, 4, 10, 2, false, true, true>(p, stream);
+            case 3: return launch_tile_any<3, 2, 40, 2, 2, 2, 2>(p, stream, gather);
+            default: return launch_tile_any<3, 2, 40, 1, 4, 2, 2, true, true>(p, stream, gather);
         }
     }
-    // C3 (2D order 4, 64 neighbours): every tile variant tried (KSPLIT x LPC in {1x4, 2x4, 4x2, 2x2}) lost to the
-    // generic lane kernel (2.1-3.5 ms vs 1.27 ms per 1M cases): 136 accumulators per lane leave no registers for
-    // the staging/shuffle traffic.  It stays on fit_lane until the moment-based assembly lands.
-    TILE_CASE(2, 2, 16, 4, 1, 4, 2)
-    TILE_CASE(2, 2, 24, 2, 1, 4, 2)
-    TILE_CASE(2, 2, 48, 4, 1, 4, 2)
-    TILE_CASE(2, 2, 64, 4, 1, 4, 2)
+    // Curated shapes for other common (dim, order, K): best of {entry form, moment form} x {four waves per 64-case tile,
+    // two waves per 32, one wave per 16 cases with direct fk}, tools/tune.py at 1M cases; anything else -> fit_tilek.hip.
+    TILE_CASE(2, 2, 16, 1, 4, 4, 2, true, true)
+    TILE_CASE(2, 2, 24, 2, 1, 4, 2, false, true)
+    TILE_CASE(2, 2, 48, 4, 1, 4, 2, false, true)
+    TILE_CASE(2, 2, 64, 1, 4, 4, 2, true, true)
     TILE_CASE(2, 1, 16, 4, 1, 4, 2)
     TILE_CASE(2, 1, 32, 4, 1, 4, 2)
     TILE_CASE(1, 2, 8, 2, 1, 4, 2)
-    TILE_CASE(1, 2, 16, 4, 1, 4, 2)
+    TILE_CASE(1, 2, 16, 1, 4, 4, 2, true, true)
     TILE_CASE(3, 1, 32, 4, 1, 4, 2)
-    TILE_CASE(3, 2, 32, 4, 2, 4, 2)
-    TILE_CASE(2, 3, 40, 4, 2, 5, 2)
+    TILE_CASE(3, 2, 32, 1, 4, 2, 2, true, true)
+    TILE_CASE(2, 3, 40, 2, 2, 2, 2, true, true)
 #undef TILE_CASE
     return WLSQM_OK;
 }

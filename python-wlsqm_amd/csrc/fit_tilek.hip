@@ -176,6 +176,164 @@ __global__ __launch_bounds__(KNT, 2) void fit_tilek_kernel(const KParams p, cons
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// One-wave variant (K <= 64): a 64-lane workgroup owns a tile of 16 cases, 4 lanes per case, lane (c, h) takes the
+// neighbours [h*KPL, (h+1)*KPL).  Only xk goes through LDS; every lane reads its own fk values straight from global
+// memory into registers (they are consumed late, after the distance pass, so their latency is hidden), the four lanes
+// of a case meet through wave shuffles, and nothing needs a barrier between waves.  Measured on the benchmark shapes
+// (fit_tile.hip) this shape beats four waves per 64-case tile by 7 % (C2) and 38 % (C5).
+constexpr int K1_TC = 16, K1_LPC = 4, K1_FMAX = 16, K1_ROUND = 8;
+
+struct Tile1Geom {
+    int K, KPL;            // neighbour slots per case; per lane (<= FMAX)
+    int RS;                // LDS row stride (doubles)
+    int XCH, CPRX;         // 16-byte chunks of the tile's xk block; per row
+    float inv_cprx;        // 1 / CPRX: chunk -> row without an integer division (chunk numbers stay below 2^11)
+    int fvec;              // this lane's fk values are 16-byte aligned pairs (K and KPL even)
+};
+
+// FMAX: compile-time bound of the neighbours per lane (8 for K <= 32, 16 for K <= 64)
+template <int DIM, int ORDER, bool MOM, int FMAX>
+__global__ __launch_bounds__(KW, 2) void fit_tile1_kernel(const KParams p, const long long ntiles, const Tile1Geom G) {
+    constexpr int NO = ndofs(DIM, ORDER), NE = NO * (NO + 1) / 2, NA = MOM ? mom_count<DIM>(2 * ORDER) : NE, TC = K1_TC;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* sX = lds;
+    const int lane = threadIdx.x, c = lane % TC, h = lane / TC;
+    const int k0 = h * G.KPL;
+
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long j0 = tile * TC, j = j0 + c;
+        const bool valid = j < p.ncases;
+        const long long jc = valid ? j : p.ncases - 1;
+        const long long nvalid = (p.ncases - j0 < TC) ? (p.ncases - j0) : TC;
+
+        const int nkc = min(p.nk[jc * p.snk], G.K);
+        const bool uniform = (p.wm[jc * p.swm] == WLSQM_WEIGHT_UNIFORM);
+        unsigned long long known, dropped;
+        effective_mask<NO>(p.knowns[jc * p.sknowns], known, dropped);
+        double xi[DIM];
+#pragma unroll
+        for (int m = 0; m < DIM; ++m) xi[m] = p.xi[jc * p.sxi_j + m];
+
+        // ---- this lane's fk values (clamped inside the row; slots beyond nk[j] are masked below)
+        double fdir[FMAX];
+        {
+            const double* gr = p.fk + jc * (long long)G.K;
+            if (G.fvec) {
+                const kd2_* gv = reinterpret_cast<const kd2_*>(gr + (k0 < G.K ? k0 : 0));
+                const int npair = (min(k0 + G.KPL, G.K) - k0) / 2;      // <= 0 for a lane past the end of the row
+#pragma unroll
+                for (int i = 0; i < FMAX / 2; ++i)
+                    if (2 * i < G.KPL) { const kd2_ v = gv[i < npair ? i : 0]; fdir[2 * i] = v.x; fdir[2 * i + 1] = v.y; }
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < FMAX; ++kk)
+                    if (kk < G.KPL) { const int k = k0 + kk; fdir[kk] = gr[k < G.K ? k : G.K - 1]; }
+            }
+        }
+        // ---- the tile's xk block: coalesced 16 B per lane, K1_ROUND loads in flight, parked in padded LDS rows
+        {
+            const kd2_* gx = reinterpret_cast<const kd2_*>(p.xk + j0 * (long long)(G.K * DIM));
+            const long long xlim = nvalid * G.CPRX;
+            for (int q0 = lane; q0 < G.XCH; q0 += KW * K1_ROUND) {
+                kd2_ b[K1_ROUND];
+#pragma unroll
+                for (int i = 0; i < K1_ROUND; ++i) { const long long q = q0 + i * KW; b[i] = gx[q < xlim ? q : xlim - 1]; }
+#pragma unroll
+                for (int i = 0; i < K1_ROUND; ++i) {
+                    const int q = q0 + i * KW;
+                    if (q < G.XCH) {
+                        const int r = (int)(((float)q + 0.5f) * G.inv_cprx), c2 = q - r * G.CPRX;
+                        double* d = sX + r * G.RS + 2 * c2;
+                        if constexpr (DIM == 2) *reinterpret_cast<kd2_*>(d) = b[i];      // RS even for DIM == 2
+                        else { d[0] = b[i].x; d[1] = b[i].y; }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        const double* xr = sX + c * G.RS;
+        double max_d2 = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < FMAX; ++kk) {
+            if (kk < G.KPL) {              // wave-uniform
+                const int k = k0 + kk;
+                const int kc = k < nkc ? k : 0;
+                double d2 = 0.0;
+#pragma unroll
+                for (int m = 0; m < DIM; ++m) { const double dd = xr[kc * DIM + m] - xi[m]; d2 += dd * dd; }
+                d2 = k < nkc ? d2 : 0.0;
+                max_d2 = d2 > max_d2 ? d2 : max_d2;
+            }
+        }
+#pragma unroll
+        for (int off = TC; off < KW; off <<= 1) { const double o = __shfl_xor(max_d2, off, KW); max_d2 = o > max_d2 ? o : max_d2; }
+        const double inv_max = inverse_max(max_d2);
+
+        double A[NA], g[NO];               // MOM: moments mu / nu; else the packed upper triangle of M / g
+#pragma unroll
+        for (int e = 0; e < NA; ++e) A[e] = 0.0;
+#pragma unroll
+        for (int a = 0; a < NO; ++a) g[a] = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < FMAX; ++kk) {
+            if (kk < G.KPL) {              // wave-uniform
+                const int k = k0 + kk;
+                const bool live = k < nkc;
+                const int kc = live ? k : 0;
+                double d[DIM];
+#pragma unroll
+                for (int m = 0; m < DIM; ++m) d[m] = live ? xr[kc * DIM + m] - xi[m] : 0.0;
+                const double f = live ? fdir[kk] : 0.0;
+                if constexpr (MOM) {
+                    double d2 = 0.0;
+#pragma unroll
+                    for (int m = 0; m < DIM; ++m) d2 += d[m] * d[m];
+                    accumulate_moments<DIM, ORDER>(A, g, d, live ? weight(d2, inv_max, uniform) : 0.0, f);
+                } else {
+                    double cc[NO];
+                    const double d2 = monomials<DIM, ORDER>(d, cc);
+                    accumulate<NO>(A, g, cc, live ? weight(d2, inv_max, uniform) : 0.0, f);
+                }
+            }
+        }
+        // ---- the four lanes of a case
+#pragma unroll
+        for (int off = TC; off < KW; off <<= 1) {
+#pragma unroll
+            for (int e = 0; e < NA; ++e) A[e] += __shfl_xor(A[e], off, KW);
+#pragma unroll
+            for (int a = 0; a < NO; ++a) g[a] += __shfl_xor(g[a], off, KW);
+        }
+        constexpr unsigned long long FULL = (1ull << NO) - 1ull;
+        if (valid && h == 0 && known != FULL) {
+            double* fio = p.fi + j * p.sfi_j;
+            auto finish = [&](double (&M)[NE], double (&rhs)[NO]) {
+                if (known) {
+                    double val[NO];
+#pragma unroll
+                    for (int a = 0; a < NO; ++a) val[a] = (((known & ~dropped) >> a) & 1ull) ? fio[a] : 0.0;
+                    eliminate_knowns<NO>(M, rhs, known, val);
+                }
+                ldlt_factor<NO>(M);
+                ldlt_solve<NO>(M, rhs);
+#pragma unroll
+                for (int a = 0; a < NO; ++a)
+                    if (!((known >> a) & 1ull)) fio[a] = rhs[a];
+            };
+            if constexpr (MOM) {
+                double M[NE], rhs[NO];
+                expand_moments<DIM, ORDER>(A, g, M, rhs);
+                finish(M, rhs);
+            } else {
+                finish(A, g);
+            }
+        }
+        __syncthreads();   // the next tile overwrites LDS
+    }
+}
+
 static int rup(int v, int m, int r) { return v + ((r - v % m) % m + m) % m; }
 
 template <int DIM, int ORDER, bool MOM>
@@ -213,22 +371,66 @@ static int launch_tilek(const KParams& p, long long K, hipStream_t stream, bool*
     return WLSQM_OK;
 }
 
+template <int DIM, int ORDER, bool MOM, int FMAX>
+static int launch_tile1(const KParams& p, long long K, hipStream_t stream, bool* handled) {
+    Tile1Geom G;
+    G.K = (int)K; G.KPL = (int)((K + K1_LPC - 1) / K1_LPC);
+    if (G.KPL > FMAX) return WLSQM_OK;
+    G.fvec = (K % 2 == 0 && G.KPL % 2 == 0) ? 1 : 0;
+    G.RS = DIM == 2 ? rup((int)K * DIM, 4, 2) : rup((int)K * DIM, 2, 1);   // conflict-free ds_read_b128 / b64
+    G.XCH = K1_TC * (int)K * DIM / 2; G.CPRX = (int)K * DIM / 2; G.inv_cprx = 1.0f / (float)G.CPRX;
+    const size_t lds_bytes = sizeof(double) * (size_t)(K1_TC * G.RS);
+    *handled = true;
+    const long long ntiles = (p.ncases + K1_TC - 1) / K1_TC;
+    auto kern = fit_tile1_kernel<DIM, ORDER, MOM, FMAX>;
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        WLSQM_HIP_CHECK(hipGetDevice(&dev));
+        hipDeviceProp_t prop;
+        WLSQM_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+        cus = prop.multiProcessorCount;
+    }
+    int per_cu = 0;
+    WLSQM_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, KW, lds_bytes));
+    if (per_cu < 1) per_cu = 1;
+    long long grid = (long long)per_cu * cus;
+    if (grid > ntiles) grid = ntiles;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(KW), lds_bytes, stream, p, ntiles, G);
+    WLSQM_HIP_CHECK(hipGetLastError());
+    note_kernel("tile1");
+    return WLSQM_OK;
+}
+
 // Runtime-K tile path: dense contiguous arrays with 16-byte rows (K*dim and K even), no extras, no bucketing.
 int launch_fit_tilek(int dimension, int order, const KParams& p, long long K, hipStream_t stream, bool* handled) {
     *handled = false;
     const char* off = getenv("WLSQM_HIP_DISABLE_TILE");
     if (off && off[0] == '1') return WLSQM_OK;
     if (p.do_sens || p.iterative || p.case_index || p.hoods) return WLSQM_OK;
-    if (K < 4 || (K % 2) != 0) return WLSQM_OK;
+    if (K < 4 || ((K * dimension) % 2) != 0) return WLSQM_OK;   // rows of xk are multiples of 16 bytes
     if (p.sxk_k != dimension || p.sxk_j != K * dimension || p.sfk_k != 1 || p.sfk_j != K) return WLSQM_OK;
     if ((reinterpret_cast<uintptr_t>(p.xk) | reinterpret_cast<uintptr_t>(p.fk)) & 15u) return WLSQM_OK;
-    // moment form from order 2 up (fewer accumulators and operations); WLSQM_TILEK_MOM=0 keeps the entry form (A/B)
-    const char* mv = getenv("WLSQM_TILEK_MOM");
-    const bool mom = !(mv && mv[0] == '0');
-#define KCASE(D, O)                                                                   \
-    if (dimension == D && order == O) {                                               \
-        if (O >= 2 && mom) return launch_tilek<D, O, (O >= 2)>(p, K, stream, handled); \
-        return launch_tilek<D, O, false>(p, K, stream, handled);                      \
+    // Two shapes (A/B over K = 16..64, tools/tune.py w1/w4): one wave per 16-case tile wins for 2D order 2 and 3D order 1
+    // (+5..+20 %) and is the only one whose LDS image fits for large K; four waves per 64-case tile wins for the
+    // register-heavy systems (3D order 2, 2D order 3: the one-wave kernel spills there) and for order <= 1 with few
+    // neighbours.  WLSQM_TILEK_SHAPE=1|4 forces a shape (A/B).
+    const char* sv = getenv("WLSQM_TILEK_SHAPE");
+    const bool can1 = K <= K1_LPC * K1_FMAX, can4 = (K % 2) == 0;       // the four-wave shape stages fk rows in 16-byte chunks
+    bool first1 = (dimension == 2 && order == 2) || (dimension == 3 && order == 1);
+    if (sv && sv[0] == '1') first1 = true;
+    if (sv && sv[0] == '4') first1 = false;
+#define KCASE(D, O)                                                                            \
+    if (dimension == D && order == O) {                                                        \
+        for (int attempt = 0; attempt < 2 && !*handled; ++attempt) {                           \
+            const bool one = (attempt == 0) == first1;                                         \
+            int rc = WLSQM_OK;                                                                 \
+            if (one && can1) rc = K <= 32 ? launch_tile1<D, O, (O >= 2), 8>(p, K, stream, handled)  \
+                                          : launch_tile1<D, O, (O >= 2), 16>(p, K, stream, handled); \
+            if (!one && can4) rc = launch_tilek<D, O, (O >= 2)>(p, K, stream, handled);        \
+            if (rc != WLSQM_OK) return rc;                                                     \
+        }                                                                                      \
+        return WLSQM_OK;                                                                       \
     }
     KCASE(1, 0) KCASE(1, 1) KCASE(1, 2) KCASE(1, 3) KCASE(1, 4)
     KCASE(2, 0) KCASE(2, 1) KCASE(2, 2) KCASE(2, 3)

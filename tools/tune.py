@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Interleaved A/B timing of kernel variants in ONE process (cdna_hip_programming.md §5.4 rule 24).
-usage: python tools/tune.py CONFIG ncases var0 var1 ...   (variants = values of WLSQM_TILE_VARIANT; 'lane' = generic kernel; k0/k1 = WLSQM_TILEK_MOM with TUNE_NK set)"""
+usage: python tools/tune.py CONFIG ncases var0 var1 ...   (variants = values of WLSQM_TILE_VARIANT; 'lane' = generic kernel; fix/w1/w4 = curated fixed-K shape / runtime-K one wave / four waves per tile)"""
 import os, sys, json
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,8 +11,8 @@ import wlsqm.hip as whip
 
 cfgname = sys.argv[1]; n = int(sys.argv[2]); variants = sys.argv[3:]
 cfg = bench.CONFIGS[cfgname]
-dim, order, nk = cfg["dim"], cfg["order"], int(os.environ.get("TUNE_NK", cfg["nk"]))
-cfg = dict(cfg, nk=nk)
+dim, order, nk = cfg["dim"], int(os.environ.get("TUNE_ORDER", cfg["order"])), int(os.environ.get("TUNE_NK", cfg["nk"]))
+cfg = dict(cfg, nk=nk, order=order)
 no = bench.NDOF[dim][order]
 dev = torch.device("cuda", 0)
 S, F, hoods = bench.build_problem(cfg, n, 0)
@@ -31,10 +31,14 @@ for rnd in range(5):
     for v in variants:
         if v == "lane":
             os.environ["WLSQM_HIP_DISABLE_TILE"] = "1"
-        elif v in ("k0", "k1"):            # runtime-K kernel: entry form / moment form
-            os.environ.pop("WLSQM_HIP_DISABLE_TILE", None); os.environ["WLSQM_TILEK_MOM"] = v[1]
+        elif v in ("w1", "w4"):            # runtime-K kernels (curated fixed-K shapes off): one wave / four waves per tile
+            os.environ.pop("WLSQM_HIP_DISABLE_TILE", None); os.environ["WLSQM_HIP_DISABLE_FIXEDK"] = "1"
+            os.environ["WLSQM_TILEK_SHAPE"] = v[1]
+        elif v == "fix":                   # curated fixed-K shape
+            os.environ.pop("WLSQM_HIP_DISABLE_TILE", None); os.environ.pop("WLSQM_HIP_DISABLE_FIXEDK", None)
         else:
-            os.environ.pop("WLSQM_HIP_DISABLE_TILE", None); os.environ["WLSQM_TILE_VARIANT"] = v
+            os.environ.pop("WLSQM_HIP_DISABLE_TILE", None); os.environ.pop("WLSQM_HIP_DISABLE_FIXEDK", None)
+            os.environ["WLSQM_TILE_VARIANT"] = v
         ms = whip.time_fit_device(*args, reps=20)
         res[v].append(ms)
         if rnd == 0:
