@@ -113,7 +113,13 @@ typedef struct wlsqm_expert wlsqm_expert;
 int wlsqm_hip_expert_create(wlsqm_expert** out, int device, int dimension, int64_t ncases,
                             const int32_t* nk, const int32_t* order, const int64_t* knowns,
                             const int32_t* weighting_method, int algorithm, int do_sens, int max_iter);
-/* expert.pyx:309-426 prepare(xi, xk): host arrays; geometry is uploaded and kept device-resident. */
+/* expert.pyx:92-93, 112-126, 163-189, 243-252 ExpertSolver(..., host=other): "guest mode".  The new solver shares the
+ * host's device-resident geometry and per-case metadata (nk, order, knowns, weighting_method) instead of holding a copy,
+ * and owns only its field buffers (fk, fi, sens).  The host must be prepared (WLSQM_ERUNTIME otherwise, as the
+ * reference's RuntimeError).  The shared state is reference-counted: destroying the host first is safe. */
+int wlsqm_hip_expert_create_guest(wlsqm_expert** out, wlsqm_expert* host, int algorithm, int do_sens, int max_iter);
+/* expert.pyx:309-426 prepare(xi, xk): host arrays; geometry is uploaded and kept device-resident.  On a guest the
+ * arrays are ignored (expert.pyx:350-352: the host's geometry is used) and only the host's ready state is checked. */
 int wlsqm_hip_expert_prepare(wlsqm_expert* h, const double* xi, int64_t xi_stride_case,
                              const double* xk, int64_t xk_stride_case, int64_t xk_stride_k, int64_t max_nk);
 /* expert.pyx:467-655 solve(fk, fi, sens): host arrays; returns max iterations via *iterations_out. */
@@ -134,7 +140,8 @@ int wlsqm_hip_expert_conds(wlsqm_expert* h, double* out);
  * CSR lists list_off[nx+1], list_idx[] of the models within radius r of each point (expert.pyx:898-985). */
 int wlsqm_hip_expert_interpolate(wlsqm_expert* h, const double* x, int64_t x_stride, int64_t nx, const int64_t* I,
                                  const int64_t* list_off, const int64_t* list_idx, double r, int diff, double* out);
-/* expert.pyx:289-306 memory_used(): (bytes in use, bytes reserved) of the device-side state. */
+/* expert.pyx:289-306 memory_used(): (bytes in use, bytes reserved) of the device-side state; a guest counts only
+ * what it owns (the shared geometry is the host's). */
 int wlsqm_hip_expert_memory_used(const wlsqm_expert* h, int64_t* used, int64_t* total);
 /* expert.pyx:267-286 __del__ */
 int wlsqm_hip_expert_destroy(wlsqm_expert* h);

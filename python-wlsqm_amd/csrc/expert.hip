@@ -8,6 +8,7 @@
 // reference's Case holds, infra.pxd:124-182) and the fit kernels are HBM-bound, so solve() re-runs
 // the fused assemble+factor+solve kernel on the resident geometry.
 #include <algorithm>
+#include <memory>
 #include <new>
 #include <vector>
 
@@ -15,18 +16,36 @@
 #include "wlsqm_interp.hpp"
 #include "hostio.hpp"
 
-struct wlsqm_expert {
-    int device = 0, dimension = 0, algorithm = 1, do_sens = 0, max_iter = 10;
+// Geometry + per-case metadata: what prepare() makes resident.  Shared (not copied) between a host solver and its
+// guests (expert.pyx:112-126 "guest mode": several fields on the exact same geometry); reference-counted, so unlike
+// the reference a guest stays valid if its host is destroyed first.
+struct wlsqm_expert_geometry {
+    int device = 0, dimension = 0;
     int64_t ncases = 0, max_nk = 1;
     int max_no = 0;
-    bool ready = false, solved = false, uniform_order = true;
+    bool ready = false, uniform_order = true;
     std::vector<int32_t> nk, order, wm, no;
     std::vector<int64_t> kn;
     std::vector<long long> idx; int64_t off[6] = {0, 0, 0, 0, 0, 0};
-    wlsqm::DevBuf d_nk, d_wm, d_kn, d_order, d_idx, d_xk, d_xi, d_fk, d_fi, d_sens, d_it;
+    wlsqm::DevBuf d_nk, d_wm, d_kn, d_order, d_idx, d_xk, d_xi;
+    int64_t bytes() const { return (int64_t)(d_nk.n + d_wm.n + d_kn.n + d_order.n + d_idx.n + d_xk.n + d_xi.n); }
+};
+
+struct wlsqm_expert {
+    std::shared_ptr<wlsqm_expert_geometry> g;
+    bool guest = false;
+    int algorithm = 1, do_sens = 0, max_iter = 10;
+    bool solved = false;
+    wlsqm::DevBuf d_fk, d_fi, d_sens, d_it;
     wlsqm::Stager st;
-    int64_t bytes() const {
-        return (int64_t)(d_nk.n + d_wm.n + d_kn.n + d_order.n + d_idx.n + d_xk.n + d_xi.n + d_fk.n + d_fi.n + d_sens.n + d_it.n);
+    int64_t own_bytes() const { return (int64_t)(d_fk.n + d_fi.n + d_sens.n + d_it.n); }
+    int64_t bytes() const { return own_bytes() + (guest ? 0 : g->bytes()); }
+    int alloc_fields() {
+        int rc;
+        if ((rc = d_it.alloc(4)) || (rc = d_fk.alloc((size_t)g->ncases * g->max_nk * 8)) ||
+            (rc = d_fi.alloc((size_t)g->ncases * g->max_no * 8))) return rc;
+        if (do_sens && (rc = d_sens.alloc((size_t)g->ncases * g->max_nk * g->max_no * 8))) return rc;
+        return WLSQM_OK;
     }
 };
 
@@ -40,28 +59,28 @@ int launch_conds(int dimension, int order, const KParams& p, const int* order_ar
 
 static KParams expert_params(const wlsqm_expert* h, const double* d_fk, int64_t sfk_j, double* d_fi, int64_t sfi_j) {
     KParams p{};
-    const int dim = h->dimension;
-    p.xk = h->d_xk.as<double>(); p.sxk_j = h->max_nk * dim; p.sxk_k = dim;
+    const int dim = h->g->dimension;
+    p.xk = h->g->d_xk.as<double>(); p.sxk_j = h->g->max_nk * dim; p.sxk_k = dim;
     p.fk = d_fk; p.sfk_j = sfk_j; p.sfk_k = 1;
-    p.nk = h->d_nk.as<int>(); p.snk = 1;
-    p.xi = h->d_xi.as<double>(); p.sxi_j = dim;
+    p.nk = h->g->d_nk.as<int>(); p.snk = 1;
+    p.xi = h->g->d_xi.as<double>(); p.sxi_j = dim;
     p.fi = d_fi; p.sfi_j = sfi_j;
     p.sens = nullptr; p.ss_j = 0; p.ss_k = 0;
-    p.knowns = h->d_kn.as<long long>(); p.sknowns = 1;
-    p.wm = h->d_wm.as<int>(); p.swm = 1;
-    p.case_index = nullptr; p.ncases = h->ncases;
+    p.knowns = h->g->d_kn.as<long long>(); p.sknowns = 1;
+    p.wm = h->g->d_wm.as<int>(); p.swm = 1;
+    p.case_index = nullptr; p.ncases = h->g->ncases;
     p.do_sens = 0; p.iterative = (h->algorithm == WLSQM_ALGO_ITERATIVE) ? 1 : 0; p.max_iter = h->max_iter;
     p.iters_out = h->d_it.as<int>();
     return p;
 }
 
 static int expert_launch(const wlsqm_expert* h, KParams p, hipStream_t s) {
-    if (h->uniform_order) return launch_fit(h->dimension, h->order[0], p, h->max_nk, s);
+    if (h->g->uniform_order) return launch_fit(h->g->dimension, h->g->order[0], p, h->g->max_nk, s);
     for (int o = 0; o <= 4; ++o) {
-        if (h->off[o + 1] == h->off[o]) continue;
-        p.case_index = h->d_idx.as<long long>() + h->off[o];
-        p.ncases = h->off[o + 1] - h->off[o];
-        int rc = launch_fit(h->dimension, o, p, h->max_nk, s);
+        if (h->g->off[o + 1] == h->g->off[o]) continue;
+        p.case_index = h->g->d_idx.as<long long>() + h->g->off[o];
+        p.ncases = h->g->off[o + 1] - h->g->off[o];
+        int rc = launch_fit(h->g->dimension, o, p, h->g->max_nk, s);
         if (rc != WLSQM_OK) return rc;
     }
     return WLSQM_OK;
@@ -80,42 +99,41 @@ int wlsqm_hip_expert_create(wlsqm_expert** out, int device, int dimension, int64
     if (!nk || !order || !knowns || !weighting_method) { set_error("null array"); return WLSQM_EVALUE; }
     wlsqm_expert* h = new (std::nothrow) wlsqm_expert();
     if (!h) { set_error("out of memory"); return WLSQM_EMEMORY; }
-    h->device = device; h->dimension = dimension; h->algorithm = algorithm; h->do_sens = do_sens ? 1 : 0;
-    h->max_iter = max_iter; h->ncases = ncases;
-    h->nk.assign(nk, nk + ncases); h->order.assign(order, order + ncases);
-    h->wm.assign(weighting_method, weighting_method + ncases); h->kn.assign(knowns, knowns + ncases);
-    h->no.resize(ncases);
+    h->g = std::make_shared<wlsqm_expert_geometry>();
+    wlsqm_expert_geometry& g = *h->g;
+    g.device = device; g.dimension = dimension; g.ncases = ncases;
+    h->algorithm = algorithm; h->do_sens = do_sens ? 1 : 0; h->max_iter = max_iter;
+    g.nk.assign(nk, nk + ncases); g.order.assign(order, order + ncases);
+    g.wm.assign(weighting_method, weighting_method + ncases); g.kn.assign(knowns, knowns + ncases);
+    g.no.resize(ncases);
     int64_t mk = 0;
     for (int64_t j = 0; j < ncases; ++j) {
         const int no = wlsqm_hip_number_of_dofs(dimension, order[j]);
         if (no < 0 || nk[j] < 0) { delete h; set_error("order must be 0..4 and nk >= 0"); return WLSQM_EVALUE; }
-        h->no[j] = no; h->max_no = std::max(h->max_no, no); mk = std::max<int64_t>(mk, nk[j]);
+        g.no[j] = no; g.max_no = std::max(g.max_no, no); mk = std::max<int64_t>(mk, nk[j]);
     }
-    h->max_nk = std::max<int64_t>(mk, 1);
-    h->uniform_order = std::all_of(h->order.begin(), h->order.end(), [&](int o) { return o == h->order[0]; });
+    g.max_nk = std::max<int64_t>(mk, 1);
+    g.uniform_order = std::all_of(g.order.begin(), g.order.end(), [&](int o) { return o == g.order[0]; });
     int rc = check_device(device);
     if (rc != WLSQM_OK) { delete h; return rc; }
-    if ((rc = h->d_nk.alloc(ncases * 4)) || (rc = h->d_wm.alloc(ncases * 4)) || (rc = h->d_kn.alloc(ncases * 8)) ||
-        (rc = h->d_order.alloc(ncases * 4)) ||
-        (rc = h->d_it.alloc(4)) || (rc = h->d_xk.alloc((size_t)ncases * h->max_nk * dimension * 8)) ||
-        (rc = h->d_xi.alloc((size_t)ncases * dimension * 8)) || (rc = h->d_fk.alloc((size_t)ncases * h->max_nk * 8)) ||
-        (rc = h->d_fi.alloc((size_t)ncases * h->max_no * 8))) { delete h; return rc; }
-    if (h->do_sens && (rc = h->d_sens.alloc((size_t)ncases * h->max_nk * h->max_no * 8))) { delete h; return rc; }
+    if ((rc = g.d_nk.alloc(ncases * 4)) || (rc = g.d_wm.alloc(ncases * 4)) || (rc = g.d_kn.alloc(ncases * 8)) ||
+        (rc = g.d_order.alloc(ncases * 4)) || (rc = g.d_xk.alloc((size_t)ncases * g.max_nk * dimension * 8)) ||
+        (rc = g.d_xi.alloc((size_t)ncases * dimension * 8)) || (rc = h->alloc_fields())) { delete h; return rc; }
     hipError_t e;
-    if ((e = hipMemcpy(h->d_nk.p, h->nk.data(), h->d_nk.n, hipMemcpyHostToDevice)) != hipSuccess ||
-        (e = hipMemcpy(h->d_wm.p, h->wm.data(), h->d_wm.n, hipMemcpyHostToDevice)) != hipSuccess ||
-        (e = hipMemcpy(h->d_kn.p, h->kn.data(), h->d_kn.n, hipMemcpyHostToDevice)) != hipSuccess ||
-        (e = hipMemcpy(h->d_order.p, h->order.data(), h->d_order.n, hipMemcpyHostToDevice)) != hipSuccess) {
+    if ((e = hipMemcpy(g.d_nk.p, g.nk.data(), g.d_nk.n, hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(g.d_wm.p, g.wm.data(), g.d_wm.n, hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(g.d_kn.p, g.kn.data(), g.d_kn.n, hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(g.d_order.p, g.order.data(), g.d_order.n, hipMemcpyHostToDevice)) != hipSuccess) {
         delete h; return hip_fail(e, "hipMemcpy(expert metadata)");
     }
-    if (!h->uniform_order) {
+    if (!g.uniform_order) {
         for (int o = 0; o <= 4; ++o) {
-            h->off[o] = (int64_t)h->idx.size();
-            for (int64_t j = 0; j < ncases; ++j) if (h->order[j] == o) h->idx.push_back(j);
+            g.off[o] = (int64_t)g.idx.size();
+            for (int64_t j = 0; j < ncases; ++j) if (g.order[j] == o) g.idx.push_back(j);
         }
-        h->off[5] = (int64_t)h->idx.size();
-        if ((rc = h->d_idx.alloc(h->idx.size() * 8))) { delete h; return rc; }
-        if ((e = hipMemcpy(h->d_idx.p, h->idx.data(), h->d_idx.n, hipMemcpyHostToDevice)) != hipSuccess) {
+        g.off[5] = (int64_t)g.idx.size();
+        if ((rc = g.d_idx.alloc(g.idx.size() * 8))) { delete h; return rc; }
+        if ((e = hipMemcpy(g.d_idx.p, g.idx.data(), g.d_idx.n, hipMemcpyHostToDevice)) != hipSuccess) {
             delete h; return hip_fail(e, "hipMemcpy(expert idx)");
         }
     }
@@ -123,21 +141,46 @@ int wlsqm_hip_expert_create(wlsqm_expert** out, int device, int dimension, int64
     return WLSQM_OK;
 }
 
+int wlsqm_hip_expert_create_guest(wlsqm_expert** out, wlsqm_expert* host, int algorithm, int do_sens, int max_iter) {
+    if (!out) { set_error("null out"); return WLSQM_EVALUE; }
+    *out = nullptr;
+    if (!host) { set_error("null host"); return WLSQM_EVALUE; }
+    if (algorithm != WLSQM_ALGO_BASIC && algorithm != WLSQM_ALGO_ITERATIVE) { set_error("Unknown algorithm specifier"); return WLSQM_EVALUE; }
+    if (!host->g->ready) {                                                                                       // expert.pyx:165-166
+        set_error("In guest mode, host must be in the ready state (host.prepare() must have been called first)");
+        return WLSQM_ERUNTIME;
+    }
+    int rc = check_device(host->g->device);
+    if (rc != WLSQM_OK) return rc;
+    wlsqm_expert* h = new (std::nothrow) wlsqm_expert();
+    if (!h) { set_error("out of memory"); return WLSQM_EMEMORY; }
+    h->g = host->g; h->guest = true;
+    h->algorithm = algorithm; h->do_sens = do_sens ? 1 : 0; h->max_iter = max_iter;
+    if ((rc = h->alloc_fields())) { delete h; return rc; }
+    *out = h;
+    return WLSQM_OK;
+}
+
 int wlsqm_hip_expert_prepare(wlsqm_expert* h, const double* xi, int64_t xi_stride_case,
                              const double* xk, int64_t xk_stride_case, int64_t xk_stride_k, int64_t max_nk) {
-    if (!h || !xi || !xk) { set_error("null argument"); return WLSQM_EVALUE; }
-    h->ready = false;
-    if (max_nk < h->max_nk && h->max_nk > 1) { set_error("xk has fewer neighbour slots than max(nk)"); return WLSQM_EVALUE; }
-    int rc = check_device(h->device);
+    if (!h) { set_error("null argument"); return WLSQM_EVALUE; }
+    if (h->guest) {       // the geometry is the host's (expert.pyx:350-352): nothing to upload
+        if (!h->g->ready) { set_error("In guest mode, host must be in the ready state"); return WLSQM_ERUNTIME; }
+        return WLSQM_OK;
+    }
+    if (!xi || !xk) { set_error("null argument"); return WLSQM_EVALUE; }
+    h->g->ready = false;
+    if (max_nk < h->g->max_nk && h->g->max_nk > 1) { set_error("xk has fewer neighbour slots than max(nk)"); return WLSQM_EVALUE; }
+    int rc = check_device(h->g->device);
     if (rc != WLSQM_OK) return rc;
-    const int dim = h->dimension; const int64_t n = h->ncases, K = h->max_nk;
-    if ((rc = h->st.ensure(h->device))) return rc;
+    const int dim = h->g->dimension; const int64_t n = h->g->ncases, K = h->g->max_nk;
+    if ((rc = h->st.ensure(h->g->device))) return rc;
     hipStream_t s = nullptr;
-    if ((rc = h->st.upload_rows(h->d_xk.p, xk, n, K * dim, xk_stride_case, xk_stride_k, dim, 8, s))) return rc;
-    if ((rc = h->st.upload_rows(h->d_xi.p, xi, n, dim, xi_stride_case, dim, dim, 8, s))) return rc;
+    if ((rc = h->st.upload_rows(h->g->d_xk.p, xk, n, K * dim, xk_stride_case, xk_stride_k, dim, 8, s))) return rc;
+    if ((rc = h->st.upload_rows(h->g->d_xi.p, xi, n, dim, xi_stride_case, dim, dim, 8, s))) return rc;
     if ((rc = h->st.drain())) return rc;
     WLSQM_HIP_CHECK(hipStreamSynchronize(s));
-    h->ready = true;
+    h->g->ready = true;
     return WLSQM_OK;
 }
 
@@ -145,11 +188,11 @@ int wlsqm_hip_expert_solve(wlsqm_expert* h, const double* fk, int64_t fk_stride_
                            double* fi, int64_t fi_stride_case,
                            double* sens, int64_t sens_stride_case, int64_t sens_stride_k, int32_t* iterations_out) {
     if (!h || !fk || !fi) { set_error("null argument"); return WLSQM_EVALUE; }
-    if (!h->ready) { set_error("Solver is not in the ready state; prepare() must be called before solve()"); return WLSQM_ERUNTIME; }   // expert.pyx:493-494
-    int rc = check_device(h->device);
+    if (!h->g->ready) { set_error("Solver is not in the ready state; prepare() must be called before solve()"); return WLSQM_ERUNTIME; }   // expert.pyx:493-494
+    int rc = check_device(h->g->device);
     if (rc != WLSQM_OK) return rc;
-    const int64_t n = h->ncases, K = h->max_nk; const int NO = h->max_no;
-    if ((rc = h->st.ensure(h->device))) return rc;
+    const int64_t n = h->g->ncases, K = h->g->max_nk; const int NO = h->g->max_no;
+    if ((rc = h->st.ensure(h->g->device))) return rc;
     hipStream_t s = nullptr;
     const bool want_sens = h->do_sens && sens;
     if ((rc = h->st.upload_rows(h->d_fk.p, fk, n, K, fk_stride_case, fk_stride_k, 1, 8, s))) return rc;
@@ -163,18 +206,18 @@ int wlsqm_hip_expert_solve(wlsqm_expert* h, const double* fk, int64_t fk_stride_
     rc = expert_launch(h, p, s);
     if (rc != WLSQM_OK) return rc;
     rc = h->st.download_rows(h->d_fi.p, n, NO, 8, s, [&](int64_t j, const char* row) {
-        if (wlsqm_hip_number_of_reduced_dofs(h->no[j], h->kn[j]) < 1) return;
-        std::memcpy(fi + j * fi_stride_case, row, (size_t)h->no[j] * 8);
+        if (wlsqm_hip_number_of_reduced_dofs(h->g->no[j], h->g->kn[j]) < 1) return;
+        std::memcpy(fi + j * fi_stride_case, row, (size_t)h->g->no[j] * 8);
     });
     if (rc != WLSQM_OK) return rc;
     if (want_sens) {
         rc = h->st.download_rows(h->d_sens.p, n, K * NO, 8, s, [&](int64_t j, const char* row) {
-            if (wlsqm_hip_number_of_reduced_dofs(h->no[j], h->kn[j]) < 1) return;
+            if (wlsqm_hip_number_of_reduced_dofs(h->g->no[j], h->g->kn[j]) < 1) return;
             unsigned long long known, dropped;
-            effective_mask_host(h->no[j], h->kn[j], known, dropped);
+            effective_mask_host(h->g->no[j], h->g->kn[j], known, dropped);
             const double* r = reinterpret_cast<const double*>(row);
-            for (int64_t k = 0; k < h->nk[j]; ++k)
-                for (int a = 0; a < h->no[j]; ++a) {
+            for (int64_t k = 0; k < h->g->nk[j]; ++k)
+                for (int a = 0; a < h->g->no[j]; ++a) {
                     if ((dropped >> a) & 1ull) continue;
                     sens[j * sens_stride_case + k * sens_stride_k + a] = r[k * NO + a];
                 }
@@ -192,8 +235,8 @@ int wlsqm_hip_expert_solve(wlsqm_expert* h, const double* fk, int64_t fk_stride_
 int wlsqm_hip_expert_solve_device(wlsqm_expert* h, void* stream, const double* fk, int64_t fk_stride_case,
                                   double* fi, int64_t fi_stride_case) {
     if (!h || !fk || !fi) { set_error("null argument"); return WLSQM_EVALUE; }
-    if (!h->ready) { set_error("Solver is not in the ready state; prepare() must be called before solve()"); return WLSQM_ERUNTIME; }
-    int rc = check_device(h->device);
+    if (!h->g->ready) { set_error("Solver is not in the ready state; prepare() must be called before solve()"); return WLSQM_ERUNTIME; }
+    int rc = check_device(h->g->device);
     if (rc != WLSQM_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     KParams p = expert_params(h, fk, fk_stride_case, fi, fi_stride_case);
@@ -207,12 +250,12 @@ int wlsqm_hip_expert_solve_device(wlsqm_expert* h, void* stream, const double* f
 int wlsqm_hip_expert_interpolate(wlsqm_expert* h, const double* x, int64_t x_stride, int64_t nx, const int64_t* I,
                                  const int64_t* list_off, const int64_t* list_idx, double r, int diff, double* out) {
     if (!h || !x || !out) { set_error("null argument"); return WLSQM_EVALUE; }
-    if (!h->ready || !h->solved) { set_error("interpolate() needs prepare() and solve() first"); return WLSQM_ERUNTIME; }
+    if (!h->g->ready || !h->solved) { set_error("interpolate() needs prepare() and solve() first"); return WLSQM_ERUNTIME; }
     if (!I && !list_off) { set_error("either I or the neighbour lists must be given"); return WLSQM_EVALUE; }
-    int rc = check_device(h->device);
+    int rc = check_device(h->g->device);
     if (rc != WLSQM_OK) return rc;
     if (nx <= 0) return WLSQM_OK;
-    const int dim = h->dimension;
+    const int dim = h->g->dimension;
     std::vector<double> sx((size_t)nx * dim);
     for (int64_t m = 0; m < nx; ++m)
         for (int c = 0; c < dim; ++c) sx[(size_t)m * dim + c] = x[m * x_stride + c];
@@ -221,8 +264,8 @@ int wlsqm_hip_expert_interpolate(wlsqm_expert* h, const double* x, int64_t x_str
     if ((rc = d_x.alloc(sx.size() * 8)) || (rc = d_out.alloc((size_t)nx * 8))) return rc;
     WLSQM_HIP_CHECK(hipMemcpyAsync(d_x.p, sx.data(), d_x.n, hipMemcpyHostToDevice, s));
     InterpParams q{};
-    q.xi = h->d_xi.as<double>(); q.sxi = dim; q.fi = h->d_fi.as<double>(); q.sfi = h->max_no;
-    q.order = h->d_order.as<int>(); q.sorder = 1; q.nmodels = h->ncases;
+    q.xi = h->g->d_xi.as<double>(); q.sxi = dim; q.fi = h->d_fi.as<double>(); q.sfi = h->g->max_no;
+    q.order = h->g->d_order.as<int>(); q.sorder = 1; q.nmodels = h->g->ncases;
     q.x = d_x.as<double>(); q.sx = dim; q.nx = nx; q.diff = diff; q.out = d_out.as<double>();
     if (list_off) {
         const int64_t nlist = list_off[nx];
@@ -244,21 +287,21 @@ int wlsqm_hip_expert_interpolate(wlsqm_expert* h, const double* x, int64_t x_str
 
 int wlsqm_hip_expert_conds(wlsqm_expert* h, double* out) {
     if (!h || !out) { set_error("null argument"); return WLSQM_EVALUE; }
-    if (!h->ready) { set_error("Solver is not in the ready state; prepare() must be called before conds()"); return WLSQM_ERUNTIME; }   // expert.pyx:438-439
-    int rc = check_device(h->device);
+    if (!h->g->ready) { set_error("Solver is not in the ready state; prepare() must be called before conds()"); return WLSQM_ERUNTIME; }   // expert.pyx:438-439
+    int rc = check_device(h->g->device);
     if (rc != WLSQM_OK) return rc;
-    const int64_t n = h->ncases;
+    const int64_t n = h->g->ncases;
     const long long CH = std::min<int64_t>(n, 32768);
     DevBuf ws, d_out;
-    if ((rc = ws.alloc((size_t)CH * cond_workspace_doubles(h->max_no) * 8)) || (rc = d_out.alloc((size_t)n * 8))) return rc;
+    if ((rc = ws.alloc((size_t)CH * cond_workspace_doubles(h->g->max_no) * 8)) || (rc = d_out.alloc((size_t)n * 8))) return rc;
     KParams p = expert_params(h, nullptr, 0, nullptr, 0);
     hipStream_t s = nullptr;
     bool present[5] = {false, false, false, false, false};
-    for (int64_t j = 0; j < n; ++j) present[h->order[j]] = true;
+    for (int64_t j = 0; j < n; ++j) present[h->g->order[j]] = true;
     for (long long c0 = 0; c0 < n; c0 += CH)
         for (int o = 0; o <= 4; ++o) {
             if (!present[o]) continue;
-            rc = launch_conds(h->dimension, o, p, h->uniform_order ? nullptr : h->d_order.as<int>(), ws.as<double>(), CH, c0,
+            rc = launch_conds(h->g->dimension, o, p, h->g->uniform_order ? nullptr : h->g->d_order.as<int>(), ws.as<double>(), CH, c0,
                               d_out.as<double>(), s);
             if (rc != WLSQM_OK) return rc;
         }
@@ -276,7 +319,7 @@ int wlsqm_hip_expert_memory_used(const wlsqm_expert* h, int64_t* used, int64_t* 
 
 int wlsqm_hip_expert_destroy(wlsqm_expert* h) {
     if (!h) return WLSQM_OK;
-    (void)hipSetDevice(h->device);
+    (void)hipSetDevice(h->g->device);
     delete h;
     return WLSQM_OK;
 }

@@ -70,11 +70,18 @@ class ExpertSolver:
         self.nk, self.order, self.knowns, self.weighting_method = nk, order, knowns, weighting_method
         self._max_nk = int(nk.max()) if ncases else 0
         h = C.c_void_p()
-        B.check(B.lib().wlsqm_hip_expert_create(
-            C.byref(h), B.default_device(), self.dimension, ncases,
-            np.ascontiguousarray(nk).ctypes.data, np.ascontiguousarray(order).ctypes.data,
-            np.ascontiguousarray(knowns).ctypes.data, np.ascontiguousarray(weighting_method).ctypes.data,
-            self.algorithm, int(self.do_sens), self.max_iter))
+        if host is not None:
+            # guest mode: share the host's device-resident geometry and metadata, own only the field buffers
+            if not getattr(host, "_handle", None):
+                raise RuntimeError("In guest mode, the host ExpertSolver has been closed")
+            B.check(B.lib().wlsqm_hip_expert_create_guest(C.byref(h), host._handle, self.algorithm,
+                                                          int(self.do_sens), self.max_iter))
+        else:
+            B.check(B.lib().wlsqm_hip_expert_create(
+                C.byref(h), B.default_device(), self.dimension, ncases,
+                np.ascontiguousarray(nk).ctypes.data, np.ascontiguousarray(order).ctypes.data,
+                np.ascontiguousarray(knowns).ctypes.data, np.ascontiguousarray(weighting_method).ctypes.data,
+                self.algorithm, int(self.do_sens), self.max_iter))
         self._handle = h
         if host is not None:
             self.tree = host.tree
@@ -99,10 +106,14 @@ class ExpertSolver:
         return (int(used.value), int(total.value))
 
     def prepare(self, xi, xk):
-        """Upload the geometry (expert.pyx:309-426).  In guest mode the host's xi/xk are used (:350-352)."""
+        """Upload the geometry (expert.pyx:309-426).  In guest mode the host's geometry is used (:350-352): nothing is
+        uploaded, the arguments are ignored and the host's device-resident copy is shared."""
         self.ready = False
         if self.host is not None:
-            xi, xk = self.host.xi, self.host.xk
+            B.check(B.lib().wlsqm_hip_expert_prepare(self._handle, None, 0, None, 0, 0, 0))
+            self.xk, self.xi = self.host.xk, self.host.xi
+            self.ready = True
+            return
         if self.dimension == 1:
             xiv = B.view(xi, np.float64, 1, "xi")
             xkv = B.view(xk, np.float64, 2, "xk")

@@ -488,3 +488,42 @@ def test_moment_path_chunking_is_invisible(wlsqm, monkeypatch):
     whip.fit_many_device(*args, fi_b, kn, wm)
     torch.cuda.synchronize()
     assert torch.equal(fi_a, fi_b)
+
+
+def test_expert_guest_mode_shares_geometry(wlsqm):
+    """ExpertSolver(host=...) (expert.pyx:112-126, 163-189): a guest fits another field on the host's geometry,
+    bit-identical to a stand-alone solver, without a second device copy of the geometry."""
+    import synth
+    c = K.config("C2")
+    n, dim = c["n"], c["dim"]
+    mk = lambda **kw: wlsqm.ExpertSolver(dimension=dim, nk=c["nk_a"], order=c["order_a"], knowns=c["knowns_a"],
+                                         weighting_method=c["wm_a"], algorithm=wlsqm.ALGO_BASIC, do_sens=False, **kw)
+    host = mk()
+    with pytest.raises(RuntimeError):
+        mk(host=host)                                               # host not prepared (expert.pyx:165-166)
+    host.prepare(xi=c["xi"], xk=c["xk"])
+    with pytest.raises(ValueError):
+        wlsqm.ExpertSolver(dimension=dim, nk=c["nk_a"], order=c["order_a"], knowns=c["knowns_a"] + 2,
+                           weighting_method=c["wm_a"], host=host)   # metadata must match element by element (:181-189)
+    guest = mk(host=host)
+    with pytest.raises(RuntimeError):
+        guest.solve(fk=c["fk"], fi=c["fi0"].copy())                 # a guest needs its own prepare() too (:122)
+    guest.prepare(xi=None, xk=None)
+    alone = mk()
+    alone.prepare(xi=c["xi"], xk=c["xk"])
+    used_host, _ = host.memory_used(); used_guest, _ = guest.memory_used(); used_alone, _ = alone.memory_used()
+    assert used_alone == used_host and used_guest < used_host - n * c["nkv"] * dim * 8 + 1   # no second copy of xk
+    F2 = synth.field(c["S"], t=3.0)
+    fk2 = F2[c["hoods"]]
+    fi_g = np.zeros((n, c["no"])); fi_g[:, 0] = F2[:n]
+    fi_a = fi_g.copy(); fi_h = c["fi0"].copy()
+    assert guest.solve(fk=fk2, fi=fi_g) == 0 and alone.solve(fk=fk2, fi=fi_a) == 0
+    assert np.array_equal(fi_g, fi_a)
+    host.solve(fk=c["fk"], fi=fi_h)                                 # the host keeps working on its own field
+    truth = P.truth_fit(dim, c["xk"], c["fk"], c["nk_a"], c["xi"], c["fi0"], c["order_a"], c["knowns_a"], c["wm_a"])
+    P.assert_parity(fi_h, c["g"]["fi"], truth, "host after guest solve")
+    host.close()                                                    # shared geometry is reference-counted
+    fi_g2 = np.zeros((n, c["no"])); fi_g2[:, 0] = F2[:n]
+    guest.solve(fk=fk2, fi=fi_g2)
+    assert np.array_equal(fi_g2, fi_a)
+    guest.close(); alone.close()
