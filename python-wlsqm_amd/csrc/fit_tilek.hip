@@ -193,7 +193,12 @@ struct Tile1Geom {
 };
 
 // FMAX: compile-time bound of the neighbours per lane (8 for K <= 32, 16 for K <= 64)
-template <int DIM, int ORDER, bool MOM, int FMAX>
+// EXTRAS: sensitivities (impl.pyx:776-778, 821-846) and iterative refinement (impl.pyx:986-1083) on the same tile.  After
+//   the shuffle butterfly the four lanes of a case hold bit-identical sums (fp addition commutes), so each of them
+//   factors the matrix for itself at no extra cost (the instructions run for the whole wave anyway) and then handles
+//   ITS neighbours: one substitution per neighbour for the sensitivities, its share of the residual and of the
+//   correction's right-hand side per refinement sweep (met again through the butterfly).
+template <int DIM, int ORDER, bool MOM, int FMAX, bool EXTRAS = false>
 __global__ __launch_bounds__(KW, 2) void fit_tile1_kernel(const KParams p, const long long ntiles, const Tile1Geom G) {
     constexpr int NO = ndofs(DIM, ORDER), NE = NO * (NO + 1) / 2, NA = MOM ? mom_count<DIM>(2 * ORDER) : NE, TC = K1_TC;
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -307,27 +312,188 @@ __global__ __launch_bounds__(KW, 2) void fit_tile1_kernel(const KParams p, const
             for (int a = 0; a < NO; ++a) g[a] += __shfl_xor(g[a], off, KW);
         }
         constexpr unsigned long long FULL = (1ull << NO) - 1ull;
-        if (valid && h == 0 && known != FULL) {
-            double* fio = p.fi + j * p.sfi_j;
-            auto finish = [&](double (&M)[NE], double (&rhs)[NO]) {
-                if (known) {
-                    double val[NO];
+        if constexpr (!EXTRAS) {
+            if (valid && h == 0 && known != FULL) {
+                double* fio = p.fi + j * p.sfi_j;
+                auto finish = [&](double (&M)[NE], double (&rhs)[NO]) {
+                    if (known) {
+                        double val[NO];
 #pragma unroll
-                    for (int a = 0; a < NO; ++a) val[a] = (((known & ~dropped) >> a) & 1ull) ? fio[a] : 0.0;
-                    eliminate_knowns<NO>(M, rhs, known, val);
+                        for (int a = 0; a < NO; ++a) val[a] = (((known & ~dropped) >> a) & 1ull) ? fio[a] : 0.0;
+                        eliminate_knowns<NO>(M, rhs, known, val);
+                    }
+                    ldlt_factor<NO>(M);
+                    ldlt_solve<NO>(M, rhs);
+#pragma unroll
+                    for (int a = 0; a < NO; ++a)
+                        if (!((known >> a) & 1ull)) fio[a] = rhs[a];
+                };
+                if constexpr (MOM) {
+                    double M[NE], rhs[NO];
+                    expand_moments<DIM, ORDER>(A, g, M, rhs);
+                    finish(M, rhs);
+                } else {
+                    finish(A, g);
                 }
-                ldlt_factor<NO>(M);
-                ldlt_solve<NO>(M, rhs);
+            }
+        } else {
+            // every lane factors its case (all four lanes of a case: same bits) and keeps the factor for the extras
+            double* fio = p.fi + jc * p.sfi_j;
+            const bool store = valid && known != FULL;             // nr < 1: no-op (impl.pyx:574, 636, 742)
+            double M[NE], sol[NO], val[NO];
+            if constexpr (MOM) expand_moments<DIM, ORDER>(A, g, M, sol);
+            else {
+#pragma unroll
+                for (int e = 0; e < NE; ++e) M[e] = A[e];
+#pragma unroll
+                for (int a = 0; a < NO; ++a) sol[a] = g[a];
+            }
+#pragma unroll
+            for (int a = 0; a < NO; ++a) val[a] = (((known & ~dropped) >> a) & 1ull) ? fio[a] : 0.0;
+            eliminate_knowns<NO>(M, sol, known, val);
+            ldlt_factor<NO>(M);
+            ldlt_solve<NO>(M, sol);
+
+            // monomials and weight of this lane's neighbour slot kk (rows are still in LDS)
+            auto neighbour = [&](int kk, double (&cc)[NO], double& w) {
+                const int k = k0 + kk;
+                const int kc = k < nkc ? k : 0;
+                double d[DIM];
+#pragma unroll
+                for (int m = 0; m < DIM; ++m) d[m] = xr[kc * DIM + m] - xi[m];
+                const double d2 = monomials<DIM, ORDER>(d, cc);
+                w = weight(d2, inv_max, uniform);
+                return k < nkc;
+            };
+
+            // ---- sensitivities: sens[k, a] = d fi[a] / d fk[k]; NaN for knowns (impl.pyx:821-823)
+            if (p.do_sens && p.sens) {
+                double* sr = p.sens + jc * p.ss_j;
+                auto sens_row = [&](int k, double (&sv)[NO]) {        // the row of neighbour k (clamped) of this lane's case
+                    const int kc = k < nkc ? k : 0;
+                    double d[DIM], cc[NO];
+#pragma unroll
+                    for (int m = 0; m < DIM; ++m) d[m] = xr[kc * DIM + m] - xi[m];
+                    const double d2 = monomials<DIM, ORDER>(d, cc);
+                    const double w = weight(d2, inv_max, uniform);
+#pragma unroll
+                    for (int a = 0; a < NO; ++a) sv[a] = ((known >> a) & 1ull) ? 0.0 : ((a == 0) ? w : w * cc[a]);
+                    ldlt_solve<NO>(M, sv);
+                };
+                // dense output (rows of exactly `no` doubles, K rows per case): a case's rows are one contiguous run, so
+                // the tile's rows go through LDS in slabs of 8 consecutive neighbours per case (lane (c, h) takes
+                // neighbour 4*kk + h here) and leave as full-line stores of 8 B per lane.  Direct 8-byte stores from
+                // the owner lanes touch 64 lines per instruction and cost 0.73 ms per 1M C2 cases against 0.45 ms for
+                // everything else in this kernel.
+                const bool dense = p.ss_k == NO && p.ss_j == (long long)G.K * NO && !__any(dropped != 0);
+                if (dense) {
+                    constexpr int SL = 2, E = SL * K1_LPC * NO, CS = E + 1;      // elements per case and slab; padded stride
+                    double* sS = lds + TC * G.RS;                                // [TC][CS]
+                    int* sNk = reinterpret_cast<int*>(sS + TC * CS);             // rows each case stores (0: none)
+                    if (h == 0) sNk[c] = store ? nkc : 0;
+                    const int nslab = (G.KPL + SL - 1) / SL;
+                    double* out0 = p.sens + j0 * p.ss_j;
+                    for (int slab = 0; slab < nslab; ++slab) {
+#pragma unroll
+                        for (int i = 0; i < SL; ++i) {
+                            double sv[NO];
+                            sens_row((slab * SL + i) * K1_LPC + h, sv);
+                            double* q = sS + c * CS + (i * K1_LPC + h) * NO;
+#pragma unroll
+                            for (int a = 0; a < NO; ++a) q[a] = ((known >> a) & 1ull) ? __longlong_as_double(0x7ff8000000000000LL) : sv[a];
+                        }
+                        __syncthreads();
+                        const int kbase = slab * SL * K1_LPC;
+#pragma unroll
+                        for (int q0 = 0; q0 < TC * E; q0 += KW) {
+                            const int q = q0 + lane;
+                            if ((TC * E) % KW == 0 || q < TC * E) {
+                                const int cs = q / E, e = q - cs * E, k = kbase + e / NO;       // compile-time divisors
+                                if (k < sNk[cs]) out0[(long long)cs * p.ss_j + (long long)kbase * NO + e] = sS[cs * CS + e];
+                            }
+                        }
+                        __syncthreads();
+                    }
+                } else {
+#pragma unroll
+                    for (int kk = 0; kk < FMAX; ++kk) {
+                        if (kk < G.KPL) {              // wave-uniform
+                            double sv[NO];
+                            sens_row(k0 + kk, sv);
+                            if (k0 + kk < nkc && store) {
+                                double* row = sr + (long long)(k0 + kk) * p.ss_k;
+#pragma unroll
+                                for (int a = 0; a < NO; ++a) {
+                                    if (!((known >> a) & 1ull)) row[a] = sv[a];
+                                    else if (!((dropped >> a) & 1ull)) row[a] = __longlong_as_double(0x7ff8000000000000LL);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+
+            // ---- iterative refinement: every sweep re-evaluates the model at the neighbours, solves for a correction
+            // from the residual and stops when the residual's max-norm repeats exactly (impl.pyx:1037-1057)
+            int iters = 0;
+            if (p.iterative) {
+                double fi[NO];
+#pragma unroll
+                for (int a = 0; a < NO; ++a) fi[a] = ((known >> a) & 1ull) ? val[a] : sol[a];
+#pragma unroll
+                for (int a = 0; a < NO; ++a) if ((dropped >> a) & 1ull) fi[a] = fio[a];   // Case_set_fi copies all `no`
+                double prev_norm = -1.0;
+                bool running = true, broke = false;
+                int i = 0;
+                for (i = 0; i < p.max_iter; ++i) {
+                    if (!__any(running)) break;
+                    double norm = 0.0, r[NO];
+#pragma unroll
+                    for (int a = 0; a < NO; ++a) r[a] = 0.0;
+#pragma unroll
+                    for (int kk = 0; kk < FMAX; ++kk) {
+                        if (kk < G.KPL) {
+                            double cc[NO], w;
+                            const bool live = neighbour(kk, cc, w);
+                            double model = fi[0];
+#pragma unroll
+                            for (int a = 1; a < NO; ++a) model += cc[a] * fi[a];
+                            const double res = live ? fdir[kk] - model : 0.0;
+                            const double ar = fabs(res);
+                            norm = ar > norm ? ar : norm;
+                            const double wr = w * res;
+#pragma unroll
+                            for (int a = 0; a < NO; ++a) r[a] += (a == 0) ? wr : wr * cc[a];
+                        }
+                    }
+#pragma unroll
+                    for (int off = TC; off < KW; off <<= 1) {
+                        const double o = __shfl_xor(norm, off, KW);
+                        norm = o > norm ? o : norm;
+#pragma unroll
+                        for (int a = 0; a < NO; ++a) r[a] += __shfl_xor(r[a], off, KW);
+                    }
+                    if (running) {
+                        if (norm == prev_norm) { running = false; broke = true; iters = i; }
+                        else {
+                            prev_norm = norm;
+#pragma unroll
+                            for (int a = 0; a < NO; ++a) if ((known >> a) & 1ull) r[a] = 0.0;
+                            ldlt_solve<NO>(M, r);
+#pragma unroll
+                            for (int a = 0; a < NO; ++a) if (!((known >> a) & 1ull)) fi[a] += r[a];
+                        }
+                    }
+                }
+                if (!broke) iters = p.max_iter > 0 ? p.max_iter : 1;   // for/else, impl.pyx:1080-1081
+#pragma unroll
+                for (int a = 0; a < NO; ++a) sol[a] = fi[a];
+            }
+            if (store && h == 0) {
 #pragma unroll
                 for (int a = 0; a < NO; ++a)
-                    if (!((known >> a) & 1ull)) fio[a] = rhs[a];
-            };
-            if constexpr (MOM) {
-                double M[NE], rhs[NO];
-                expand_moments<DIM, ORDER>(A, g, M, rhs);
-                finish(M, rhs);
-            } else {
-                finish(A, g);
+                    if (!((known >> a) & 1ull)) fio[a] = sol[a];
+                if (p.iterative && p.iters_out) atomicMax(p.iters_out, iters);
             }
         }
         __syncthreads();   // the next tile overwrites LDS
@@ -371,7 +537,7 @@ static int launch_tilek(const KParams& p, long long K, hipStream_t stream, bool*
     return WLSQM_OK;
 }
 
-template <int DIM, int ORDER, bool MOM, int FMAX>
+template <int DIM, int ORDER, bool MOM, int FMAX, bool EXTRAS = false>
 static int launch_tile1(const KParams& p, long long K, hipStream_t stream, bool* handled) {
     Tile1Geom G;
     G.K = (int)K; G.KPL = (int)((K + K1_LPC - 1) / K1_LPC);
@@ -379,10 +545,12 @@ static int launch_tile1(const KParams& p, long long K, hipStream_t stream, bool*
     G.fvec = (K % 2 == 0 && G.KPL % 2 == 0) ? 1 : 0;
     G.RS = DIM == 2 ? rup((int)K * DIM, 4, 2) : rup((int)K * DIM, 2, 1);   // conflict-free ds_read_b128 / b64
     G.XCH = K1_TC * (int)K * DIM / 2; G.CPRX = (int)K * DIM / 2; G.inv_cprx = 1.0f / (float)G.CPRX;
-    const size_t lds_bytes = sizeof(double) * (size_t)(K1_TC * G.RS);
+    constexpr int NO_ = ndofs(DIM, ORDER);
+    // EXTRAS: + the sensitivities' staging slab [TC][2*4*no + 1] and 16 ints
+    const size_t lds_bytes = sizeof(double) * (size_t)(K1_TC * G.RS + (EXTRAS ? K1_TC * (2 * K1_LPC * NO_ + 1) + K1_TC / 2 : 0));
     *handled = true;
     const long long ntiles = (p.ncases + K1_TC - 1) / K1_TC;
-    auto kern = fit_tile1_kernel<DIM, ORDER, MOM, FMAX>;
+    auto kern = fit_tile1_kernel<DIM, ORDER, MOM, FMAX, EXTRAS>;
     static int cus = 0;
     if (!cus) {
         int dev = 0;
@@ -398,7 +566,7 @@ static int launch_tile1(const KParams& p, long long K, hipStream_t stream, bool*
     if (grid > ntiles) grid = ntiles;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(KW), lds_bytes, stream, p, ntiles, G);
     WLSQM_HIP_CHECK(hipGetLastError());
-    note_kernel("tile1");
+    note_kernel(EXTRAS ? "tile1-extras" : "tile1");
     return WLSQM_OK;
 }
 
@@ -407,7 +575,7 @@ int launch_fit_tilek(int dimension, int order, const KParams& p, long long K, hi
     *handled = false;
     const char* off = getenv("WLSQM_HIP_DISABLE_TILE");
     if (off && off[0] == '1') return WLSQM_OK;
-    if (p.do_sens || p.iterative || p.case_index || p.hoods) return WLSQM_OK;
+    if (p.case_index || p.hoods) return WLSQM_OK;
     if (K < 4 || ((K * dimension) % 2) != 0) return WLSQM_OK;   // rows of xk are multiples of 16 bytes
     if (p.sxk_k != dimension || p.sxk_j != K * dimension || p.sfk_k != 1 || p.sfk_j != K) return WLSQM_OK;
     if ((reinterpret_cast<uintptr_t>(p.xk) | reinterpret_cast<uintptr_t>(p.fk)) & 15u) return WLSQM_OK;
@@ -415,6 +583,21 @@ int launch_fit_tilek(int dimension, int order, const KParams& p, long long K, hi
     // (+5..+20 %) and is the only one whose LDS image fits for large K; four waves per 64-case tile wins for the
     // register-heavy systems (3D order 2, 2D order 3: the one-wave kernel spills there) and for order <= 1 with few
     // neighbours.  WLSQM_TILEK_SHAPE=1|4 forces a shape (A/B).
+    const bool extras = p.do_sens || p.iterative;
+    if (extras) {
+        // sensitivities / iterative refinement: the one-wave kernel with EXTRAS (K <= 64), else the generic kernel
+        const char* ex = getenv("WLSQM_HIP_DISABLE_TILE_EXTRAS");
+        if ((ex && ex[0] == '1') || K > K1_LPC * K1_FMAX) return WLSQM_OK;
+#define XCASE(D, O)                                                                                   \
+    if (dimension == D && order == O)                                                                 \
+        return K <= 32 ? launch_tile1<D, O, (O >= 2), 8, true>(p, K, stream, handled)                 \
+                       : launch_tile1<D, O, (O >= 2), K1_FMAX, true>(p, K, stream, handled);
+        XCASE(1, 0) XCASE(1, 1) XCASE(1, 2) XCASE(1, 3) XCASE(1, 4)
+        XCASE(2, 0) XCASE(2, 1) XCASE(2, 2) XCASE(2, 3)
+        XCASE(3, 0) XCASE(3, 1) XCASE(3, 2)
+#undef XCASE
+        return WLSQM_OK;
+    }
     const char* sv = getenv("WLSQM_TILEK_SHAPE");
     const bool can1 = K <= K1_LPC * K1_FMAX, can4 = (K % 2) == 0;       // the four-wave shape stages fk rows in 16-byte chunks
     bool first1 = (dimension == 2 && order == 2) || (dimension == 3 && order == 1);

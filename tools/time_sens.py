@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Device-resident timing of the sensitivities / iterative paths: python tools/time_sens.py [ncases]"""
+"""Device-resident timing of the sensitivities / iterative paths: python tools/time_sens.py [ncases [lane]]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -22,6 +22,8 @@ def timeit(f, reps=10):
     f(); torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(reps): f()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / reps * 1e3
+if len(sys.argv) > 2 and sys.argv[2] == "lane":
+    os.environ["WLSQM_HIP_DISABLE_TILE_EXTRAS"] = "1"
 ms = timeit(lambda: whip.fit_many_device(dim, order, xk, fk, nk_d, S_d, fi, kn, wm, sens=sens))
 print("do_sens  : %.3f ms -> %.3e fits/s, %.0f GB/s (852 B in + 1536 B sens out per fit)" % (ms, n / ms * 1e3, 2388 * n / ms / 1e6))
 ms = timeit(lambda: whip.fit_many_device(dim, order, xk, fk, nk_d, S_d, fi, kn, wm, iterative=True, max_iter=10))
