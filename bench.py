@@ -30,6 +30,8 @@ CONFIGS = {
     "C2": dict(dim=2, order=2, nk=32, wm=2, knowns=0, desc="2D order-2, Halton, 32 neighbours, WEIGHT_CENTER, all DOFs unknown"),
     "C3": dict(dim=2, order=4, nk=64, wm=2, knowns=1, desc="2D order-4, Halton, 64 neighbours, WEIGHT_CENTER, F known"),
     "C5": dict(dim=3, order=2, nk=40, wm=2, knowns=0, desc="3D order-2, Halton, 40 neighbours, WEIGHT_CENTER, all DOFs unknown"),
+    # BASELINE configs[3]: the C2 geometry prepared once in an ExpertSolver, then many right-hand sides (run_c4 below)
+    "C4": dict(dim=2, order=2, nk=32, wm=2, knowns=0, desc="ExpertSolver, 2D order-2, Halton, 32 neighbours: prepare once + stacked right-hand sides"),
 }
 NDOF = {1: [1, 2, 3, 4, 5], 2: [1, 3, 6, 10, 15], 3: [1, 4, 10, 20, 35]}
 HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
@@ -62,6 +64,7 @@ def main():
     ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
     ap.add_argument("--ncases", type=int, default=1_000_000, help="local fits per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--nrhs", type=int, default=64, help="C4: right-hand sides stacked per step (256 = 4 steps)")
     a = ap.parse_args()
 
     import torch
@@ -82,6 +85,8 @@ def main():
     dim, order, nk, n = cfg["dim"], cfg["order"], cfg["nk"], a.ncases
     no = NDOF[dim][order]
     S, F, hoods = build_problem(cfg, n, rank)
+    if a.config == "C4":
+        return run_c4(a, cfg, S, F, hoods, dev, dist, rank, world)
 
     # device-resident inputs in the reference's dense layout: xk = S[hoods], fk = F[hoods]  (gathered on the GPU)
     S_d = torch.from_numpy(np.ascontiguousarray(S)).to(dev)
@@ -167,6 +172,101 @@ def main():
                          "within_1e-10_plus_8x_noise": bool(np.all(E <= 1e-10 + 8.0 * N))}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(oracle, cfg, xk_d, fk_d, xi_d, F, n, no)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_c4(a, cfg, S, F, hoods, dev, dist, rank, world):
+    """BASELINE configs[3]: ExpertSolver on the C2 geometry, prepare once, then right-hand sides F_t = sin(pi x + 0.01 t)
+    cos(pi y).  A step = ONE solve_many_device call over --nrhs stacked fields (256 right-hand
+    sides = 4 steps at the default 64); a fit = one (case, field) pair.  Algorithmic bytes per fit: fk 8 nk + fi 8 no
+    + the geometry (8 nk dim + 8 dim + 20) shared by the nrhs fields of a step.  The time-stepping rate (one fused
+    solve_device launch per field, 852 B per fit) is reported beside it."""
+    import torch
+    import wlsqm
+    dim, order, nk, n, R = cfg["dim"], cfg["order"], cfg["nk"], a.ncases, a.nrhs
+    no = NDOF[dim][order]
+    solver = wlsqm.ExpertSolver(dimension=dim, nk=np.full(n, nk, np.int32), order=np.full(n, order, np.int32),
+                                knowns=np.full(n, cfg["knowns"], np.int64),
+                                weighting_method=np.full(n, cfg["wm"], np.int32))
+    t0 = time.perf_counter()
+    solver.prepare(xi=S, xk=S[hoods])
+    t_prepare = time.perf_counter() - t0
+    S_d = torch.from_numpy(S).to(dev)
+    h_d = torch.from_numpy(hoods.astype(np.int64)).to(dev)
+    fk = torch.empty((R, n, nk), dtype=torch.float64, device=dev)
+    for r in range(R):
+        fk[r] = (torch.sin(np.pi * S_d[:, 0] + 0.01 * r) * torch.cos(np.pi * S_d[:, 1]))[h_d]
+    fi = torch.zeros((R, n, no), dtype=torch.float64, device=dev)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    t_wake = time.perf_counter()
+    while time.perf_counter() - t_wake < 0.3:
+        solver.solve_many_device(fk, fi)
+        torch.cuda.synchronize()
+    for _ in range(a.warmup):
+        solver.solve_many_device(fk, fi)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        solver.solve_many_device(fk, fi)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    # the kernel alone, events on the stream it is launched on (torch's current stream is passed to the launch)
+    reps = min(max(a.steps, 5), 50)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        solver.solve_many_device(fk, fi)
+    e1.record(); torch.cuda.synchronize()
+    ms_kernel = e0.elapsed_time(e1) / reps
+    # time stepping: one fused launch per field
+    fi_seq = torch.zeros_like(fi[0])
+    e0.record()
+    for r in range(R):
+        solver.solve_device(fk[r], fi_seq)
+    e1.record(); torch.cuda.synchronize()
+    ms_step_field = e0.elapsed_time(e1) / R
+    B_fit = 8 * nk + 8 * no + (8 * nk * dim + 8 * dim + 20) / R
+    achieved = B_fit * n * R / (ms_kernel * 1e-3) / 1e9
+    if rank == 0:
+        out = {
+            "metric": "local fits/s (whole node)", "value": world * n * R * a.steps / dt, "unit": "fits/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C4: %s; %d cases x %d stacked fields per GPU per step (a fit = one case of one field), "
+                                   "geometry and fields device-resident" % (cfg["desc"], n, R),
+                       "fits_per_gpu": n * R, "bytes_per_fit": B_fit, "prepare_ms_host_arrays": t_prepare * 1e3},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel_ms": ms_kernel},
+            "time_stepping": {"ms_per_field": ms_step_field, "fits_per_s": n / (ms_step_field * 1e-3),
+                              "bytes_per_fit": bytes_per_fit(dim, order, nk, cfg["knowns"])},
+        }
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from oracle import oracle
+        import _parity
+        ns = min(n, 1024)
+        r = R - 1
+        xk_h = S[hoods[:ns]]; fk_h = fk[r, :ns].cpu().numpy(); xi_h = S[:ns]
+        fi_o = np.zeros((ns, no)); fi_in = fi_o.copy()
+        meta = (np.full(ns, nk, np.int32), np.full(ns, order, np.int32), np.full(ns, cfg["knowns"], np.int64),
+                np.full(ns, cfg["wm"], np.int32))
+        oracle.fit_many(dim, xk_h, fk_h, meta[0], xi_h, fi_o, None, 0, meta[1], meta[2], meta[3], ntasks=8)
+        truth = _parity.truth_fit(dim, xk_h, fk_h, meta[0], xi_h, fi_in, meta[1], meta[2], meta[3])
+        E = _parity.column_metric(fi[r, :ns].cpu().numpy(), fi_o); N = _parity.column_metric(fi_o, truth)
+        out["parity"] = {"cases": ns, "field": r, "colmax_vs_oracle": float(E.max()), "oracle_fp64_noise_floor": float(N.max()),
+                         "within_1e-10_plus_8x_noise": bool(np.all(E <= 1e-10 + 8.0 * N))}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

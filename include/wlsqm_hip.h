@@ -131,6 +131,18 @@ int wlsqm_hip_expert_solve(wlsqm_expert* h, const double* fk, int64_t fk_stride_
  * pointers (contiguous k axis); enqueued on `stream`; no host synchronisation. */
 int wlsqm_hip_expert_solve_device(wlsqm_expert* h, void* stream, const double* fk, int64_t fk_stride_case,
                                   double* fi, int64_t fi_stride_case);
+/* Extension (no reference counterpart; BASELINE config 4 "prepare once + 256 RHS solves"): nrhs fields on the prepared
+ * geometry in one call.  Equivalent to nrhs calls of expert.pyx:467-655 solve() with ALGO_BASIC and no sensitivities,
+ * but the geometry work (weights, monomials, normal matrix, factorisation) is shared between the fields where a
+ * shape has the fast kernel (no <= 6, max_nk <= 32; csrc/solve_many.hip).  Device variant: fk[nrhs][ncases][max_nk]
+ * and fi[nrhs][ncases][fi_stride_case] are device pointers with the given element strides (k contiguous), enqueued on
+ * `stream`.  Host variant: strided host arrays, transferred in chunks of right-hand sides. */
+int wlsqm_hip_expert_solve_many_device(wlsqm_expert* h, void* stream, int64_t nrhs,
+                                       const double* fk, int64_t fk_stride_rhs, int64_t fk_stride_case,
+                                       double* fi, int64_t fi_stride_rhs, int64_t fi_stride_case);
+int wlsqm_hip_expert_solve_many(wlsqm_expert* h, int64_t nrhs,
+                                const double* fk, int64_t fk_stride_rhs, int64_t fk_stride_case, int64_t fk_stride_k,
+                                double* fi, int64_t fi_stride_rhs, int64_t fi_stride_case);
 /* expert.pyx:429-464 conds(): 2-norm condition number of the Ruiz-scaled reduced matrix of every case
  * (impl.pyx:662-682), out[ncases] on the host.  Diagnostics path (one-sided Jacobi SVD per case). */
 int wlsqm_hip_expert_conds(wlsqm_expert* h, double* out);

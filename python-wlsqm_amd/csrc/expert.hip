@@ -37,8 +37,9 @@ struct wlsqm_expert {
     int algorithm = 1, do_sens = 0, max_iter = 10;
     bool solved = false;
     wlsqm::DevBuf d_fk, d_fi, d_sens, d_it;
+    wlsqm::GrowBuf d_fkm, d_fim;        // solve_many: a chunk of stacked right-hand sides / solutions
     wlsqm::Stager st;
-    int64_t own_bytes() const { return (int64_t)(d_fk.n + d_fi.n + d_sens.n + d_it.n); }
+    int64_t own_bytes() const { return (int64_t)(d_fk.n + d_fi.n + d_sens.n + d_it.n + d_fkm.b.n + d_fim.b.n); }
     int64_t bytes() const { return own_bytes() + (guest ? 0 : g->bytes()); }
     int alloc_fields() {
         int rc;
@@ -52,6 +53,9 @@ struct wlsqm_expert {
 using namespace wlsqm;
 
 namespace wlsqm {
+int launch_solve_many(int dimension, int order, const KParams& p, long long K, long long nrhs,
+                      const double* fk, long long sfk_r, long long sfk_j, double* fi, long long sfi_r, long long sfi_j,
+                      hipStream_t stream, bool* handled);
 long long cond_workspace_doubles(int no);
 int launch_conds(int dimension, int order, const KParams& p, const int* order_arr, double* ws, long long CH,
                  long long case0, double* out, hipStream_t stream);
@@ -242,6 +246,77 @@ int wlsqm_hip_expert_solve_device(wlsqm_expert* h, void* stream, const double* f
     KParams p = expert_params(h, fk, fk_stride_case, fi, fi_stride_case);
     p.iters_out = nullptr;
     return expert_launch(h, p, s);
+}
+
+// Many fields on the prepared geometry, device-resident (extension; BASELINE config 4).  Fast path: one launch that
+// shares the geometry work between the fields (solve_many.hip); otherwise nrhs launches of the fused kernel.
+static int solve_many_on_device(wlsqm_expert* h, hipStream_t s, int64_t nrhs, const double* fk, int64_t sfk_r, int64_t sfk_j,
+                                double* fi, int64_t sfi_r, int64_t sfi_j) {
+    const wlsqm_expert_geometry& g = *h->g;
+    bool handled = false;
+    if (g.uniform_order && h->algorithm == WLSQM_ALGO_BASIC) {
+        KParams p = expert_params(h, nullptr, 0, nullptr, 0);
+        int rc = launch_solve_many(g.dimension, g.order[0], p, g.max_nk, nrhs, fk, sfk_r, sfk_j, fi, sfi_r, sfi_j, s, &handled);
+        if (rc != WLSQM_OK) return rc;
+    }
+    if (handled) return WLSQM_OK;
+    for (int64_t r = 0; r < nrhs; ++r) {
+        KParams p = expert_params(h, fk + r * sfk_r, sfk_j, fi + r * sfi_r, sfi_j);
+        p.iters_out = nullptr;
+        int rc = expert_launch(h, p, s);
+        if (rc != WLSQM_OK) return rc;
+    }
+    return WLSQM_OK;
+}
+
+int wlsqm_hip_expert_solve_many_device(wlsqm_expert* h, void* stream, int64_t nrhs,
+                                       const double* fk, int64_t fk_stride_rhs, int64_t fk_stride_case,
+                                       double* fi, int64_t fi_stride_rhs, int64_t fi_stride_case) {
+    if (!h || !fk || !fi) { set_error("null argument"); return WLSQM_EVALUE; }
+    if (nrhs < 1) { set_error("nrhs must be >= 1"); return WLSQM_EVALUE; }
+    if (!h->g->ready) { set_error("Solver is not in the ready state; prepare() must be called before solve()"); return WLSQM_ERUNTIME; }
+    if (h->do_sens) { set_error("solve_many does not compute sensitivities"); return WLSQM_EVALUE; }
+    int rc = check_device(h->g->device);
+    if (rc != WLSQM_OK) return rc;
+    return solve_many_on_device(h, (hipStream_t)stream, nrhs, fk, fk_stride_rhs, fk_stride_case, fi, fi_stride_rhs, fi_stride_case);
+}
+
+int wlsqm_hip_expert_solve_many(wlsqm_expert* h, int64_t nrhs,
+                                const double* fk, int64_t fk_stride_rhs, int64_t fk_stride_case, int64_t fk_stride_k,
+                                double* fi, int64_t fi_stride_rhs, int64_t fi_stride_case) {
+    if (!h || !fk || !fi) { set_error("null argument"); return WLSQM_EVALUE; }
+    if (nrhs < 1) { set_error("nrhs must be >= 1"); return WLSQM_EVALUE; }
+    if (!h->g->ready) { set_error("Solver is not in the ready state; prepare() must be called before solve()"); return WLSQM_ERUNTIME; }
+    if (h->do_sens) { set_error("solve_many does not compute sensitivities"); return WLSQM_EVALUE; }
+    const wlsqm_expert_geometry& g = *h->g;
+    int rc = check_device(g.device);
+    if (rc != WLSQM_OK) return rc;
+    const int64_t n = g.ncases, K = g.max_nk; const int NO = g.max_no;
+    if ((rc = h->st.ensure(g.device))) return rc;
+    hipStream_t s = nullptr;
+    // right-hand sides travel in chunks of at most ~1 GiB of fk
+    int64_t chunk = std::max<int64_t>(1, (int64_t(1) << 30) / std::max<int64_t>(1, n * K * 8));
+    chunk = std::min(chunk, nrhs);
+    if ((rc = h->d_fkm.need((size_t)chunk * n * K * 8)) || (rc = h->d_fim.need((size_t)chunk * n * NO * 8))) return rc;
+    double* d_fk = h->d_fkm.as<double>(); double* d_fi = h->d_fim.as<double>();
+    for (int64_t r0 = 0; r0 < nrhs; r0 += chunk) {
+        const int64_t nr = std::min(chunk, nrhs - r0);
+        for (int64_t r = 0; r < nr; ++r) {
+            if ((rc = h->st.upload_rows(d_fk + r * n * K, fk + (r0 + r) * fk_stride_rhs, n, K, fk_stride_case, fk_stride_k, 1, 8, s))) return rc;
+            if ((rc = h->st.upload_rows(d_fi + r * n * NO, fi + (r0 + r) * fi_stride_rhs, n, NO, fi_stride_case, NO, NO, 8, s))) return rc;
+        }
+        if ((rc = solve_many_on_device(h, s, nr, d_fk, n * K, K, d_fi, n * NO, NO))) return rc;
+        for (int64_t r = 0; r < nr; ++r) {
+            double* out = fi + (r0 + r) * fi_stride_rhs;
+            rc = h->st.download_rows(d_fi + r * n * NO, n, NO, 8, s, [&](int64_t j, const char* row) {
+                if (wlsqm_hip_number_of_reduced_dofs(g.no[j], g.kn[j]) < 1) return;
+                std::memcpy(out + j * fi_stride_case, row, (size_t)g.no[j] * 8);
+            });
+            if (rc != WLSQM_OK) return rc;
+        }
+    }
+    WLSQM_HIP_CHECK(hipStreamSynchronize(s));
+    return WLSQM_OK;
 }
 
 // ExpertSolver.interpolate (expert.pyx:687-781): evaluate the models of the last solve() at nx host points.

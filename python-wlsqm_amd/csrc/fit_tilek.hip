@@ -12,6 +12,7 @@
 #include "wlsqm_internal.hpp"
 #include "wlsqm_kernels.hpp"
 #include "wlsqm_moments.hpp"
+#include "wlsqm_tile1.hpp"
 
 namespace wlsqm {
 
@@ -182,16 +183,6 @@ __global__ __launch_bounds__(KNT, 2) void fit_tilek_kernel(const KParams p, cons
 // memory into registers (they are consumed late, after the distance pass, so their latency is hidden), the four lanes
 // of a case meet through wave shuffles, and nothing needs a barrier between waves.  Measured on the benchmark shapes
 // (fit_tile.hip) this shape beats four waves per 64-case tile by 7 % (C2) and 38 % (C5).
-constexpr int K1_TC = 16, K1_LPC = 4, K1_FMAX = 16, K1_ROUND = 8;
-
-struct Tile1Geom {
-    int K, KPL;            // neighbour slots per case; per lane (<= FMAX)
-    int RS;                // LDS row stride (doubles)
-    int XCH, CPRX;         // 16-byte chunks of the tile's xk block; per row
-    float inv_cprx;        // 1 / CPRX: chunk -> row without an integer division (chunk numbers stay below 2^11)
-    int fvec;              // this lane's fk values are 16-byte aligned pairs (K and KPL even)
-};
-
 // FMAX: compile-time bound of the neighbours per lane (8 for K <= 32, 16 for K <= 64)
 // EXTRAS: sensitivities (impl.pyx:776-778, 821-846) and iterative refinement (impl.pyx:986-1083) on the same tile.  After
 //   the shuffle butterfly the four lanes of a case hold bit-identical sums (fp addition commutes), so each of them
@@ -222,58 +213,13 @@ __global__ __launch_bounds__(KW, 2) void fit_tile1_kernel(const KParams p, const
 
         // ---- this lane's fk values (clamped inside the row; slots beyond nk[j] are masked below)
         double fdir[FMAX];
-        {
-            const double* gr = p.fk + jc * (long long)G.K;
-            if (G.fvec) {
-                const kd2_* gv = reinterpret_cast<const kd2_*>(gr + (k0 < G.K ? k0 : 0));
-                const int npair = (min(k0 + G.KPL, G.K) - k0) / 2;      // <= 0 for a lane past the end of the row
-#pragma unroll
-                for (int i = 0; i < FMAX / 2; ++i)
-                    if (2 * i < G.KPL) { const kd2_ v = gv[i < npair ? i : 0]; fdir[2 * i] = v.x; fdir[2 * i + 1] = v.y; }
-            } else {
-#pragma unroll
-                for (int kk = 0; kk < FMAX; ++kk)
-                    if (kk < G.KPL) { const int k = k0 + kk; fdir[kk] = gr[k < G.K ? k : G.K - 1]; }
-            }
-        }
+        tile1_load_f<FMAX>(fdir, p.fk + jc * (long long)G.K, k0, G);
         // ---- the tile's xk block: coalesced 16 B per lane, K1_ROUND loads in flight, parked in padded LDS rows
-        {
-            const kd2_* gx = reinterpret_cast<const kd2_*>(p.xk + j0 * (long long)(G.K * DIM));
-            const long long xlim = nvalid * G.CPRX;
-            for (int q0 = lane; q0 < G.XCH; q0 += KW * K1_ROUND) {
-                kd2_ b[K1_ROUND];
-#pragma unroll
-                for (int i = 0; i < K1_ROUND; ++i) { const long long q = q0 + i * KW; b[i] = gx[q < xlim ? q : xlim - 1]; }
-#pragma unroll
-                for (int i = 0; i < K1_ROUND; ++i) {
-                    const int q = q0 + i * KW;
-                    if (q < G.XCH) {
-                        const int r = (int)(((float)q + 0.5f) * G.inv_cprx), c2 = q - r * G.CPRX;
-                        double* d = sX + r * G.RS + 2 * c2;
-                        if constexpr (DIM == 2) *reinterpret_cast<kd2_*>(d) = b[i];      // RS even for DIM == 2
-                        else { d[0] = b[i].x; d[1] = b[i].y; }
-                    }
-                }
-            }
-        }
+        tile1_stage_x<DIM>(sX, p.xk + j0 * (long long)(G.K * DIM), nvalid, lane, G);
         __syncthreads();
 
         const double* xr = sX + c * G.RS;
-        double max_d2 = 0.0;
-#pragma unroll
-        for (int kk = 0; kk < FMAX; ++kk) {
-            if (kk < G.KPL) {              // wave-uniform
-                const int k = k0 + kk;
-                const int kc = k < nkc ? k : 0;
-                double d2 = 0.0;
-#pragma unroll
-                for (int m = 0; m < DIM; ++m) { const double dd = xr[kc * DIM + m] - xi[m]; d2 += dd * dd; }
-                d2 = k < nkc ? d2 : 0.0;
-                max_d2 = d2 > max_d2 ? d2 : max_d2;
-            }
-        }
-#pragma unroll
-        for (int off = TC; off < KW; off <<= 1) { const double o = __shfl_xor(max_d2, off, KW); max_d2 = o > max_d2 ? o : max_d2; }
+        const double max_d2 = tile1_max_d2<DIM, FMAX>(xr, xi, k0, nkc, G);
         const double inv_max = inverse_max(max_d2);
 
         double A[NA], g[NO];               // MOM: moments mu / nu; else the packed upper triangle of M / g
@@ -540,11 +486,7 @@ static int launch_tilek(const KParams& p, long long K, hipStream_t stream, bool*
 template <int DIM, int ORDER, bool MOM, int FMAX, bool EXTRAS = false>
 static int launch_tile1(const KParams& p, long long K, hipStream_t stream, bool* handled) {
     Tile1Geom G;
-    G.K = (int)K; G.KPL = (int)((K + K1_LPC - 1) / K1_LPC);
-    if (G.KPL > FMAX) return WLSQM_OK;
-    G.fvec = (K % 2 == 0 && G.KPL % 2 == 0) ? 1 : 0;
-    G.RS = DIM == 2 ? rup((int)K * DIM, 4, 2) : rup((int)K * DIM, 2, 1);   // conflict-free ds_read_b128 / b64
-    G.XCH = K1_TC * (int)K * DIM / 2; G.CPRX = (int)K * DIM / 2; G.inv_cprx = 1.0f / (float)G.CPRX;
+    if (!tile1_geometry<DIM>(K, FMAX, G)) return WLSQM_OK;
     constexpr int NO_ = ndofs(DIM, ORDER);
     // EXTRAS: + the sensitivities' staging slab [TC][2*4*no + 1] and 16 ints
     const size_t lds_bytes = sizeof(double) * (size_t)(K1_TC * G.RS + (EXTRAS ? K1_TC * (2 * K1_LPC * NO_ + 1) + K1_TC / 2 : 0));

@@ -224,6 +224,48 @@ class ExpertSolver:
                                                       C.c_void_p(fi.data_ptr()), fi.stride(0)))
         return 0
 
+    def solve_many_device(self, fk, fi, stream=None):
+        """Many fields on the prepared geometry, device-resident (extension; no reference counterpart).
+
+        fk (nrhs, ncases, max_nk) and fi (nrhs, ncases, >= no) are torch CUDA tensors (float64, contiguous last axis);
+        field r is fitted from fk[r] into fi[r] exactly as solve_device(fk[r], fi[r]) would (ALGO_BASIC, no
+        sensitivities; knowns are read from fi[r]), but in ONE launch that shares the geometry work between the fields
+        where the shape allows (no <= 6, max_nk <= 32): per case and field only fk[r] is read and fi[r] written."""
+        if not self.ready:
+            raise RuntimeError("Solver is not in the ready state; prepare() must be called before solve()")
+        import torch
+        for t, name in ((fk, "fk"), (fi, "fi")):
+            if t.dtype != torch.float64 or t.dim() != 3 or not t.is_cuda or t.stride(2) != 1:
+                raise ValueError("%s must be a 3-D float64 device tensor with a contiguous last axis" % name)
+        if fk.shape[0] != fi.shape[0] or fk.shape[0] < 1:
+            raise ValueError("fk and fi must hold the same number (>= 1) of right-hand sides")
+        if fk.shape[1] < self.ncases or fi.shape[1] < self.ncases or fk.shape[2] < self._max_nk:
+            raise ValueError("fk/fi are too small")
+        if stream is None:
+            stream = torch.cuda.current_stream(fi.device).cuda_stream
+        B.check(B.lib().wlsqm_hip_expert_solve_many_device(
+            self._handle, C.c_void_p(int(stream) if stream else 0), fk.shape[0],
+            C.c_void_p(fk.data_ptr()), fk.stride(0), fk.stride(1), C.c_void_p(fi.data_ptr()), fi.stride(0), fi.stride(1)))
+        return 0
+
+    def solve_many(self, fk, fi):
+        """Many fields on the prepared geometry, numpy in/out (extension): fk (nrhs, ncases, >= max_nk),
+        fi (nrhs, ncases, >= no) in/out; same result as nrhs calls of solve() with ALGO_BASIC.  Returns 0."""
+        if not self.ready:
+            raise RuntimeError("Solver is not in the ready state; prepare() must be called before solve()")
+        fkv = B.view(fk, np.float64, 3, "fk")
+        fiv = B.view(fi, np.float64, 3, "fi", contiguous_last=True, writable=True)
+        if fkv.shape[0] != fiv.shape[0] or fkv.shape[0] < 1:
+            raise ValueError("fk and fi must hold the same number (>= 1) of right-hand sides")
+        if fkv.shape[1] < self.ncases or fiv.shape[1] < self.ncases:
+            raise ValueError("fk/fi have fewer rows than ncases")
+        if fkv.shape[2] < self._max_nk:
+            raise ValueError("max(nk) = %d exceeds the neighbour axis of fk" % self._max_nk)
+        B.check(B.lib().wlsqm_hip_expert_solve_many(
+            self._handle, fkv.shape[0], fkv.ctypes.data, B.es(fkv, 0), B.es(fkv, 1), B.es(fkv, 2),
+            fiv.ctypes.data, B.es(fiv, 0), B.es(fiv, 1)))
+        return 0
+
     def solve(self, fk, fi, sens=None):
         """Fit all cases to the data fk on the prepared geometry (expert.pyx:467-655).  Returns the maximum
         number of refinement iterations taken (0 for ALGO_BASIC)."""

@@ -539,3 +539,48 @@ def test_expert_guest_mode_shares_geometry(wlsqm):
     guest.solve(fk=fk2, fi=fi_g2)
     assert np.array_equal(fi_g2, fi_a)
     guest.close(); alone.close()
+
+
+@pytest.mark.parametrize("name,knowns", [("C2", 0), ("C2", 0b010001), ("C1", 0), ("C5", 0)])
+def test_expert_solve_many_matches_sequential_solves(wlsqm, name, knowns):
+    """solve_many (extension, BASELINE config 4): R fields in one call == R solve() calls, to rounding (the shared-geometry
+    kernel sums in a different order); known DOFs are read per field and stay bit-identical.  C5 (no = 10) has no
+    shared-geometry instantiation and takes R fused launches: bit-identical there."""
+    import torch
+    import synth
+    c = K.config(name)
+    n, dim, no, nk = c["n"], c["dim"], c["no"], c["nkv"]
+    rng = np.random.default_rng(5)
+    kn = np.full(n, knowns, np.int64)
+    nk_a = rng.integers(max(no + 1, nk // 2), nk + 1, n).astype(np.int32)          # ragged neighbour counts
+    s = wlsqm.ExpertSolver(dimension=dim, nk=nk_a, order=c["order_a"], knowns=kn, weighting_method=c["wm_a"],
+                           algorithm=wlsqm.ALGO_BASIC, do_sens=False)
+    s.prepare(xi=c["xi"], xk=c["xk"])
+    R = 5
+    fks = np.stack([synth.field(c["S"], t=0.3 * r)[c["hoods"]] if dim > 1 else np.sin((2 + r) * np.pi * c["S"])[c["hoods"]]
+                    for r in range(R)])
+    fi0 = rng.uniform(-1, 1, (R, n, no))
+    for r in range(R):
+        fi0[r, :, 0] = fks[r].mean(axis=1)
+    ref = fi0.copy()
+    for r in range(R):
+        s.solve(fk=fks[r], fi=ref[r])
+    got = fi0.copy()
+    assert s.solve_many(fk=fks, fi=got) == 0
+    dev = torch.device("cuda", 0)
+    fk_d = torch.from_numpy(np.ascontiguousarray(fks[:, :, :int(nk_a.max())])).to(dev)
+    got_d = torch.from_numpy(fi0.copy()).to(dev)
+    s.solve_many_device(fk_d, got_d)
+    torch.cuda.synchronize()
+    got_d = got_d.cpu().numpy()
+    for r in range(R):
+        for a in range(no):
+            if (knowns >> a) & 1:
+                assert np.array_equal(got[r, :, a], fi0[r, :, a]) and np.array_equal(got_d[r, :, a], fi0[r, :, a])
+        if name == "C5":
+            assert np.array_equal(got[r], ref[r]) and np.array_equal(got_d[r], ref[r])
+        else:
+            truth = P.truth_fit(dim, c["xk"], fks[r], nk_a, c["xi"], fi0[r], c["order_a"], kn, c["wm_a"])
+            P.assert_parity(got[r], ref[r], truth, "%s solve_many host, field %d" % (name, r))
+            P.assert_parity(got_d[r], ref[r], truth, "%s solve_many device, field %d" % (name, r))
+    s.close()
