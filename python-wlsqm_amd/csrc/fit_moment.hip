@@ -8,11 +8,10 @@
 //   B. moment_solve_kernel (here): one lane per case expands M and g from the moments (compile-time factorial
 //      constants), eliminates knowns, runs the in-register LDL^T and substitution and stores fi.
 // The extra 960 B/case of workspace traffic is affordable because this configuration is fp64-VALU-bound.  Batches
-// beyond 4M cases run in chunks, which bounds the workspace at 1.9 GB.  (Measured and rejected: chunks small enough
+// beyond 4M cases run in chunks, which bounds the workspace (stream-ordered allocation, hipMallocAsync) at 1.9 GB.  (Measured and rejected: chunks small enough
 // to keep the workspace in the Infinity Cache, 32K-256K cases: 1M C3 cases took 1.10-0.77 ms instead of 0.73 ms —
 // the launch boundaries and kernel tails cost more than the HBM round trip.)
 #include <cstdlib>
-#include <mutex>
 
 #include "wlsqm_internal.hpp"
 #include "wlsqm_kernels.hpp"
@@ -52,10 +51,6 @@ __global__ __launch_bounds__(64) void moment_solve_kernel(const KParams p) {
         if (!((known >> a) & 1ull)) fio[a] = g[a];
 }
 
-// per-device workspace for the moments, grown on demand (not freed until process exit)
-static std::mutex g_ws_mutex;
-static DevBuf g_ws[16];
-
 // cases per chunk
 static long long chunk_cases() {
     const char* e = getenv("WLSQM_HIP_MOMENT_CHUNK");             // tuning override
@@ -66,32 +61,34 @@ static long long chunk_cases() {
 template <int DIM, int ORDER>
 static int launch_moment(const KParams& p0, long long max_nk, hipStream_t stream, bool* handled) {
     constexpr int NO = ndofs(DIM, ORDER), NACC = mom_count<DIM>(2 * ORDER) + NO;
-    int dev = 0;
-    WLSQM_HIP_CHECK(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 16) { set_error("device ordinal out of range"); return WLSQM_EVALUE; }
     long long chunk = chunk_cases();
     if (chunk > p0.ncases) chunk = p0.ncases;
-    double* ws = nullptr;
-    {
-        std::lock_guard<std::mutex> lock(g_ws_mutex);
-        const size_t need = (size_t)NACC * (size_t)chunk * sizeof(double);
-        if (g_ws[dev].n < need) {
-            WLSQM_HIP_CHECK(hipStreamSynchronize(stream));      // the old buffer may still be in use by earlier launches
-            int rc = g_ws[dev].alloc(need);
-            if (rc != WLSQM_OK) return rc;
-        }
-        ws = g_ws[dev].as<double>();
+    // stream-ordered workspace: concurrent launches on other streams get their own block, and the pool hands the same
+    // memory back to the next call on this stream without a device synchronisation
+    static bool pool_kept[16] = {};
+    int dev = 0;
+    WLSQM_HIP_CHECK(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 16 && !pool_kept[dev]) {      // keep freed blocks in the pool across synchronisations
+        hipMemPool_t pool;
+        WLSQM_HIP_CHECK(hipDeviceGetDefaultMemPool(&pool, dev));
+        uint64_t keep = ~0ull;
+        WLSQM_HIP_CHECK(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep));
+        pool_kept[dev] = true;
     }
+    double* ws = nullptr;
+    WLSQM_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&ws), (size_t)NACC * (size_t)chunk * sizeof(double), stream));
     for (long long j0 = 0; j0 < p0.ncases; j0 += chunk) {
         const long long n = (p0.ncases - j0 < chunk) ? (p0.ncases - j0) : chunk;
         KParams p = slice_cases(p0, j0, n);
         p.ws = ws; p.ws_stride = chunk;
         int rc = launch_tile_moments(DIM, ORDER, p, max_nk, stream, handled);
-        if (rc != WLSQM_OK || !*handled) return rc;              // not handled can only happen on the first chunk
+        if (rc != WLSQM_OK || !*handled) { (void)hipFreeAsync(ws, stream); return rc; }
         const long long blocks = (n + 63) / 64;
         hipLaunchKernelGGL((moment_solve_kernel<DIM, ORDER>), dim3((unsigned)blocks), dim3(64), 0, stream, p);
-        WLSQM_HIP_CHECK(hipGetLastError());
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { (void)hipFreeAsync(ws, stream); return hip_fail(e, "moment_solve_kernel"); }
     }
+    WLSQM_HIP_CHECK(hipFreeAsync(ws, stream));
     note_kernel(p0.hoods ? "moment-gather" : "moment");
     return WLSQM_OK;
 }
