@@ -408,6 +408,8 @@ static bool tile_eligible(int dim, const KParams& p, long long K) {
     return true;
 }
 
+int launch_fit_glds(int dimension, int order, const KParams& p, long long max_nk, int variant, hipStream_t stream, bool* handled);
+
 // First kernel of the two-kernel moment path (fit_moment.hip): tile pass that leaves the moments in p.ws.
 // `handled` stays false when no instantiation covers (dimension, order, max_nk) or the input is not tile-eligible.
 bool tile_moments_supported(int dimension, int order, const KParams& p, long long max_nk) {
@@ -457,7 +459,9 @@ int launch_fit_tile(int dimension, int order, const KParams& p, long long max_nk
         }
         // A/B at 1M cases (tools/tune.py), ms per launch: one wave per 16-case tile + moments + direct fk 0.167;
         // the same with two lanes per case 0.173; without direct fk 0.233; four waves per 64-case tile: moments
-        // 0.181, entry form 0.186 (the round-1 kernel); eight waves 0.43.
+        // 0.181, entry form 0.186 (the round-1 kernel); eight waves 0.43; the default shape squeezed to 128 VGPRs (four
+        // waves per SIMD, small spills) 0.182-0.199, with unroll 4 or 2 at three waves per SIMD 0.176-0.180.
+        if (var >= 40 && var < 50) return launch_fit_glds(dimension, order, p, max_nk, var, stream, handled);   // LDS-DMA ring (fit_glds.hip)
         switch (var) {
             case 1: return launch_tile_impl<2, 2, 32, 1, 2, 8, 2, false, true, true>(p, stream);
             case 2: return launch_tile_impl<2, 2, 32, 4, 1, 4, 3, false, false, true>(p, stream);
