@@ -23,7 +23,10 @@
 //     shape for 2D order 2 and 3D order 2: no barriers between waves, 8-16 KB of LDS per wave, and the fk loads are
 //     consumed only after the distance pass.  Without FKD the same shape loses to four waves per 64-case tile;
 //   * rejected for C2: software prefetch of the next tile through registers, early (-15 %) or late, during the solve
-//     (-12 %): both cost a resident workgroup; expanding the moments from LDS in wave 0 (-5 %).
+//     (-12 %): both cost a resident workgroup; expanding the moments from LDS in wave 0 (-5 %); bringing the NEXT tile's
+//     xk in by LDS-DMA (global_load_lds_dwordx4 into a two-tile ring, rows rotated on the source side for conflict-free
+//     reads, next tile's fk and scalars in a second register set; git history: fit_glds.hip): 0.193 vs 0.177 ms — the
+//     second register set costs the third wave per SIMD, and at this occupancy the other waves already hide the wait.
 #include <cstdlib>
 
 #include "wlsqm_internal.hpp"
@@ -408,8 +411,6 @@ static bool tile_eligible(int dim, const KParams& p, long long K) {
     return true;
 }
 
-int launch_fit_glds(int dimension, int order, const KParams& p, long long max_nk, int variant, hipStream_t stream, bool* handled);
-
 // First kernel of the two-kernel moment path (fit_moment.hip): tile pass that leaves the moments in p.ws.
 // `handled` stays false when no instantiation covers (dimension, order, max_nk) or the input is not tile-eligible.
 bool tile_moments_supported(int dimension, int order, const KParams& p, long long max_nk) {
@@ -461,7 +462,6 @@ int launch_fit_tile(int dimension, int order, const KParams& p, long long max_nk
         // the same with two lanes per case 0.173; without direct fk 0.233; four waves per 64-case tile: moments
         // 0.181, entry form 0.186 (the round-1 kernel); eight waves 0.43; the default shape squeezed to 128 VGPRs (four
         // waves per SIMD, small spills) 0.182-0.199, with unroll 4 or 2 at three waves per SIMD 0.176-0.180.
-        if (var >= 40 && var < 50) return launch_fit_glds(dimension, order, p, max_nk, var, stream, handled);   // LDS-DMA ring (fit_glds.hip)
         switch (var) {
             case 1: return launch_tile_impl<2, 2, 32, 1, 2, 8, 2, false, true, true>(p, stream);
             case 2: return launch_tile_impl<2, 2, 32, 4, 1, 4, 3, false, false, true>(p, stream);
