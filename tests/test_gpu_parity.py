@@ -255,7 +255,10 @@ def test_sens_reconstructs_solution(wlsqm):
 @pytest.mark.parametrize("dim,order,K,ncases", [(2, 2, 32, 64), (2, 2, 32, 1000), (2, 2, 32, 4097), (1, 2, 8, 777),
                                                  (3, 2, 40, 1500), (2, 3, 40, 515), (2, 1, 16, 300), (3, 2, 32, 130),
                                                  (2, 4, 64, 700), (2, 2, 20, 900), (2, 2, 25, 333), (2, 3, 30, 200),
-                                                 (3, 2, 50, 300), (1, 4, 12, 500), (3, 1, 14, 129)])
+                                                 (3, 2, 50, 300), (1, 4, 12, 500), (3, 1, 14, 129), (2, 2, 7, 200),
+                                                 (2, 2, 64, 300), (2, 2, 70, 200), (3, 1, 9, 150), (1, 2, 5, 100),
+                                                 (2, 0, 16, 100), (3, 0, 8, 100), (2, 2, 48, 300), (2, 2, 16, 300),
+                                                 (3, 2, 56, 200), (2, 3, 64, 150)])
 def test_tile_path_equals_lane_path(wlsqm, dim, order, K, ncases, monkeypatch):
     """The LDS-tiled fast path (contiguous, curated K) against the generic lane kernel on the same inputs:
     ragged nk <= K, mixed weightings and knowns, tail tiles.  Same arithmetic except for the split of the
@@ -266,7 +269,7 @@ def test_tile_path_equals_lane_path(wlsqm, dim, order, K, ncases, monkeypatch):
     xi = rng.uniform(0, 1, (ncases, dim))
     xk = xi[:, None, :] + 0.05 * rng.uniform(-1, 1, (ncases, K, dim))
     fk = np.sin(3 * xk[..., 0]) * np.cos(2 * xk[..., -1])
-    nk = rng.integers(max(no + 2, K // 3), K + 1, ncases).astype(np.int32); nk[0] = K
+    nk = rng.integers(min(K, max(no + 2, K // 3)), K + 1, ncases).astype(np.int32); nk[0] = K
     nk[ncases // 2:] = K                                         # whole tiles at full K take the unpredicated loop
     orders = np.full(ncases, order, np.int32)
     masks = [0, 0, 1, (1 << no) - 1] + ([1 << (no - 1), 1 | (1 << (no // 2))] if no >= 3 else [])
@@ -285,6 +288,51 @@ def test_tile_path_equals_lane_path(wlsqm, dim, order, K, ncases, monkeypatch):
     assert np.array_equal(fi_t == fi0, fi_l == fi0)
     truth = P.truth_fit(dim, xk, fk, nk, xi, fi0, orders, knowns, wm)
     P.assert_parity(fi_t, fi_l, truth, "tile vs lane")
+
+
+@pytest.mark.parametrize("dim,order,K,ncases,wide", [(2, 2, 32, 500, False), (2, 2, 32, 333, True), (2, 2, 20, 300, False),
+                                                      (1, 2, 8, 300, False), (3, 2, 40, 200, False), (2, 3, 30, 150, False),
+                                                      (3, 1, 14, 129, True), (2, 2, 50, 200, False), (2, 1, 9, 100, False)])
+def test_tile_extras_equal_lane_extras(wlsqm, dim, order, K, ncases, wide, monkeypatch):
+    """Sensitivities and iterative refinement on the one-wave tile kernel (fit_tile1_kernel<..., EXTRAS>) against the
+    generic lane kernel: ragged nk, mixed weightings and knowns (NaN rows), tail tiles; `wide`: sens/fi with spare
+    columns (strided output instead of the LDS-staged dense store); padding beyond nk / no must stay untouched."""
+    rng = np.random.default_rng(7 * ncases + K)
+    no = K_.NDOF[dim][order]
+    xi = rng.uniform(0, 1, (ncases, dim))
+    xk = xi[:, None, :] + 0.05 * rng.uniform(-1, 1, (ncases, K, dim))
+    fk = np.sin(3 * xk[..., 0]) * np.cos(2 * xk[..., -1])
+    nk = rng.integers(min(K, max(no + 2, K // 3)), K + 1, ncases).astype(np.int32); nk[0] = K
+    orders = np.full(ncases, order, np.int32)
+    masks = [0, 0, 1] + ([1 << (no - 1), 1 | (1 << (no // 2))] if no >= 3 else [])
+    knowns = rng.choice(np.array(masks, np.int64), ncases)
+    wm = rng.choice(np.array([1, 2], np.int32), ncases)
+    ncol = no + (3 if wide else 0)
+    fi0 = rng.uniform(-1, 1, (ncases, ncol)); fi0[:, 0] = np.sin(3 * xi[:, 0]) * np.cos(2 * xi[:, -1])
+    if dim == 1:
+        xi, xk = np.ascontiguousarray(xi[:, 0]), np.ascontiguousarray(xk[..., 0])
+    out = {}
+    for tag in ("tile", "lane"):
+        if tag == "lane":
+            monkeypatch.setenv("WLSQM_HIP_DISABLE_TILE", "1")
+        fi_s = fi0.copy(); sens = np.full((ncases, K, ncol), 777.0)
+        _many(wlsqm, dim, "_many")(xk, fk, nk, xi, fi_s, sens, 1, orders, knowns, wm)
+        fi_i = fi0.copy()
+        it = _many(wlsqm, dim, "_iterative_many")(xk, fk, nk, xi, fi_i, None, 0, orders, knowns, wm, max_iter=8)
+        out[tag] = (fi_s, sens, fi_i, it)
+    monkeypatch.delenv("WLSQM_HIP_DISABLE_TILE")
+    (fs_t, s_t, fi_t, it_t), (fs_l, s_l, fi_l, it_l) = out["tile"], out["lane"]
+    assert 1 <= it_t <= 8 and 1 <= it_l <= 8
+    _check_untouched(fs_t, fi0, orders, knowns, dim); _check_untouched(fi_t, fi0, orders, knowns, dim)
+    truth = P.truth_fit(dim, xk, fk, nk, xi, fi0[:, :no], orders, knowns, wm)
+    P.assert_parity(fs_t[:, :no], fs_l[:, :no], truth, "tile vs lane, do_sens")
+    P.assert_parity(fi_t[:, :no], fi_l[:, :no], truth, "tile vs lane, iterative")
+    assert np.array_equal(np.isnan(s_t), np.isnan(s_l))
+    assert np.array_equal(s_t == 777.0, s_l == 777.0)                     # k >= nk and spare columns untouched
+    a, b = np.nan_to_num(s_t), np.nan_to_num(s_l)
+    live = (b != 777.0)
+    scale = np.abs(np.where(live, b, 0.0)).max(axis=(1, 2), keepdims=True) + 1e-300
+    assert (np.abs(a - b) <= 1e-6 * scale).all(), float((np.abs(a - b) / scale).max())
 
 
 @pytest.mark.parametrize("name", ["C1", "C2", "C3", "C5", "X2", "X3"])
