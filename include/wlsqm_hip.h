@@ -131,6 +131,14 @@ int wlsqm_hip_expert_solve(wlsqm_expert* h, const double* fk, int64_t fk_stride_
  * pointers (contiguous k axis); enqueued on `stream`; no host synchronisation. */
 int wlsqm_hip_expert_solve_device(wlsqm_expert* h, void* stream, const double* fk, int64_t fk_stride_case,
                                   double* fi, int64_t fi_stride_case);
+/* Extension: the neighbour search the reference's examples run on the host before calling the fitter
+ * (examples/expertsolver_example.py:48-66: cKDTree(x).query(x, 1 + nk), the point itself dropped;
+ * examples/wlsqm_example.py:103-133).  For every point of the device-resident cloud S[npoints, dimension] the k nearest
+ * OTHER points, ascending by (distance, index), into the device array hoods[npoints, k] (int32) — the `hoods` argument of
+ * wlsqm_hip_fit_cloud_device.  Exact (uniform-grid search with a provable stop test).  1 <= k <= min(npoints - 1, 213).
+ * Synchronises `stream` before returning. */
+int wlsqm_hip_knn_device(int dimension, int64_t npoints, const double* S, int k, int32_t* hoods, int device, void* stream);
+
 /* Extension (no reference counterpart; BASELINE config 4 "prepare once + 256 RHS solves"): nrhs fields on the prepared
  * geometry in one call.  Equivalent to nrhs calls of expert.pyx:467-655 solve() with ALGO_BASIC and no sensitivities,
  * but the geometry work (weights, monomials, normal matrix, factorisation) is shared between the fields where a

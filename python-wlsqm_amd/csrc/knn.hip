@@ -1,0 +1,253 @@
+// knn.hip — k nearest neighbours of every point of a cloud, on the GPU (the step BEFORE the fit).
+//
+// The reference's examples build the neighbourhoods on the host with scipy.spatial.cKDTree
+// (examples/expertsolver_example.py:48-66: tree.query(x, 1 + nk), self dropped; examples/wlsqm_example.py:103-133) and
+// hand `hoods` / `x[hoods]` to the fitter.  For a device-resident cloud that search is the last host step; this file
+// replaces it with an exact uniform-grid search:
+//   1. bounding box (atomic min/max on order-preserving integer keys), grid of ~4 points per cell;
+//   2. points sorted by cell (hipcub radix sort), cell start offsets by binary search, coordinates gathered in cell order;
+//   3. one lane per query, in CELL order (the 64 lanes of a wave are spatial neighbours: same cells, coherent loops and
+//      cache lines): Chebyshev rings of cells around the query's cell, best-k candidates in LDS ([slot][lane], conflict
+//      free), until the k-th best distance is no larger than the distance to the unvisited region;
+//   4. the k results sorted by (distance, index) — cKDTree's order — and written to hoods[point, :].
+// Exact (no approximation): the stop test is a proof that no unvisited point can be closer.
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+
+#include <hipcub/hipcub.hpp>
+
+#include "wlsqm_internal.hpp"
+
+namespace wlsqm {
+
+struct KnnGrid {
+    double lo[3], inv_cell[3], cell[3];
+    int g[3];
+    int dim;
+};
+
+__device__ __forceinline__ unsigned long long key_of(double v) {      // order-preserving map double -> uint64
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+static inline double value_of(unsigned long long k) {
+    const unsigned long long u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    double v; memcpy(&v, &u, 8); return v;
+}
+
+__global__ void knn_bbox_kernel(const double* __restrict__ S, long long n, int dim, unsigned long long* mm /*[2][3]*/) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long ic = i < n ? i : n - 1;                       // tail lanes replay the last point
+    for (int m = 0; m < dim; ++m) {
+        double lo = S[ic * dim + m], hi = lo;
+        for (int off = 32; off > 0; off >>= 1) {                  // one pair of atomics per wave, not per point
+            const double a = __shfl_xor(lo, off, 64), b = __shfl_xor(hi, off, 64);
+            lo = (a < lo || a != a) ? a : lo;                     // NaN wins, so that it is reported
+            hi = (b > hi || b != b) ? b : hi;
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicMin(&mm[m], key_of(lo));
+            atomicMax(&mm[3 + m], key_of(hi));
+        }
+    }
+}
+
+__device__ __forceinline__ int cell_coord(double x, const KnnGrid& G, int m) {
+    int c = (int)((x - G.lo[m]) * G.inv_cell[m]);
+    return c < 0 ? 0 : (c >= G.g[m] ? G.g[m] - 1 : c);
+}
+
+__global__ void knn_cell_kernel(const double* __restrict__ S, long long n, KnnGrid G, unsigned* __restrict__ cell,
+                                int* __restrict__ idx) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned c = 0;
+    for (int m = G.dim - 1; m >= 0; --m) c = c * (unsigned)G.g[m] + (unsigned)cell_coord(S[i * G.dim + m], G, m);
+    cell[i] = c;
+    idx[i] = (int)i;
+}
+
+// start[c] = first sorted position whose cell id is >= c  (c = 0..ncells)
+__global__ void knn_start_kernel(const unsigned* __restrict__ sorted_cell, long long n, long long ncells, int* __restrict__ start) {
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > ncells) return;
+    long long lo = 0, hi = n;
+    while (lo < hi) { const long long mid = (lo + hi) >> 1; if ((long long)sorted_cell[mid] < c) lo = mid + 1; else hi = mid; }
+    start[c] = (int)lo;
+}
+
+__global__ void knn_gather_kernel(const double* __restrict__ S, const int* __restrict__ perm, long long n, int dim,
+                                  double* __restrict__ Ss) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long long src = perm[i];
+    for (int m = 0; m < dim; ++m) Ss[i * dim + m] = S[src * dim + m];
+}
+
+template <int DIM>
+__global__ __launch_bounds__(64) void knn_query_kernel(const double* __restrict__ Ss, const int* __restrict__ perm,
+                                                      const int* __restrict__ start, long long n, int k, KnnGrid G,
+                                                      int* __restrict__ hoods) {
+    extern __shared__ __attribute__((aligned(8))) unsigned char smem[];
+    double* bd = reinterpret_cast<double*>(smem) + threadIdx.x;                       // [k][64] best squared distances
+    int* bi = reinterpret_cast<int*>(smem + (size_t)k * 64 * sizeof(double)) + threadIdx.x;   // [k][64] their sorted positions
+    const long long q = (long long)blockIdx.x * 64 + threadIdx.x;
+    if (q >= n) return;
+    double x[DIM]; int cq[DIM];
+#pragma unroll
+    for (int m = 0; m < DIM; ++m) { x[m] = Ss[q * DIM + m]; cq[m] = cell_coord(x[m], G, m); }
+
+    int count = 0, worst_slot = 0;
+    double worst = -1.0;
+    int rmax = 0;
+#pragma unroll
+    for (int m = 0; m < DIM; ++m) rmax = max(rmax, max(cq[m], G.g[m] - 1 - cq[m]));
+
+    for (int r = 0; r <= rmax; ++r) {
+        // cells on the Chebyshev shell of radius r around the query's cell
+        const int z0 = DIM > 2 ? -r : 0, z1 = DIM > 2 ? r : 0, y0 = DIM > 1 ? -r : 0, y1 = DIM > 1 ? r : 0;
+        for (int dz = z0; dz <= z1; ++dz) {
+            const int cz = DIM > 2 ? cq[2] + dz : 0;
+            if (DIM > 2 && (cz < 0 || cz >= G.g[2])) continue;
+            for (int dy = y0; dy <= y1; ++dy) {
+                const int cy = DIM > 1 ? cq[1] + dy : 0;
+                if (DIM > 1 && (cy < 0 || cy >= G.g[1])) continue;
+                const bool face = (DIM > 2 && (dz == -r || dz == r)) || (DIM > 1 && (dy == -r || dy == r));
+                // on a face of the shell: the whole x-run; otherwise only its two ends
+                const int step = (face || r == 0) ? 1 : 2 * r;
+                for (int dx = -r; dx <= r; dx += step) {
+                    const int cx = cq[0] + dx;
+                    if (cx < 0 || cx >= G.g[0]) continue;
+                    long long cid = cx;
+                    if (DIM > 1) cid += (long long)G.g[0] * cy;
+                    if (DIM > 2) cid += (long long)G.g[0] * G.g[1] * cz;
+                    const int p0 = start[cid], p1 = start[cid + 1];
+                    for (int pos = p0; pos < p1; ++pos) {
+                        if (pos == q) continue;                                        // the point itself
+                        double d2 = 0.0;
+#pragma unroll
+                        for (int m = 0; m < DIM; ++m) { const double d = Ss[(long long)pos * DIM + m] - x[m]; d2 += d * d; }
+                        if (count < k) {
+                            bd[count * 64] = d2; bi[count * 64] = pos;
+                            if (d2 > worst) { worst = d2; worst_slot = count; }
+                            ++count;
+                        } else if (d2 < worst) {
+                            bd[worst_slot * 64] = d2; bi[worst_slot * 64] = pos;
+                            worst = -1.0;
+                            for (int s = 0; s < k; ++s) { const double v = bd[s * 64]; if (v > worst) { worst = v; worst_slot = s; } }
+                        }
+                    }
+                }
+            }
+        }
+        if (count == k) {
+            // every unvisited point lies outside the block of cells [cq - r, cq + r]: at least `reach` away
+            double reach = DBL_MAX;
+#pragma unroll
+            for (int m = 0; m < DIM; ++m) {
+                // (minus a sliver: a point's cell number and this boundary are rounded independently)
+                if (cq[m] - r > 0) reach = fmin(reach, x[m] - (G.lo[m] + (cq[m] - r) * G.cell[m]) - 1e-9 * G.cell[m]);
+                if (cq[m] + r < G.g[m] - 1) reach = fmin(reach, (G.lo[m] + (cq[m] + r + 1) * G.cell[m]) - x[m] - 1e-9 * G.cell[m]);
+            }
+            if (reach == DBL_MAX || (reach > 0.0 && worst <= reach * reach)) break;
+        }
+    }
+    // ascending (distance, original index): selection sort in place, then map sorted positions to point indices
+    const long long row = (long long)perm[q] * k;
+    for (int i = 0; i < count; ++i) bi[i * 64] = perm[bi[i * 64]];
+    for (int i = 0; i < count; ++i) {
+        int best = i; double bdv = bd[i * 64]; int bidx = bi[i * 64];
+        for (int s = i + 1; s < count; ++s) {
+            const double v = bd[s * 64]; const int vi = bi[s * 64];
+            if (v < bdv || (v == bdv && vi < bidx)) { best = s; bdv = v; bidx = vi; }
+        }
+        if (best != i) { bd[best * 64] = bd[i * 64]; bi[best * 64] = bi[i * 64]; }
+        hoods[row + i] = bidx;
+    }
+}
+
+}  // namespace wlsqm
+
+using namespace wlsqm;
+
+extern "C" int wlsqm_hip_knn_device(int dimension, int64_t npoints, const double* S, int k, int32_t* hoods, int device,
+                                    void* stream_) {
+    if (dimension < 1 || dimension > 3) { set_error("dimension must be 1, 2 or 3"); return WLSQM_EVALUE; }
+    if (!S || !hoods) { set_error("null array"); return WLSQM_EVALUE; }
+    if (k < 1 || npoints < 2 || (int64_t)k > npoints - 1) { set_error("k must be in 1 .. npoints - 1"); return WLSQM_EVALUE; }
+    if (npoints > 0x7fffffffLL) { set_error("at most 2^31 - 1 points"); return WLSQM_EVALUE; }
+    const size_t lds = (size_t)k * 64 * (sizeof(double) + sizeof(int));
+    if (lds > 160 * 1024) { set_error("k too large for the LDS-resident candidate lists (k <= 213)"); return WLSQM_EVALUE; }
+    int rc = check_device(device);
+    if (rc != WLSQM_OK) return rc;
+    hipStream_t s = (hipStream_t)stream_;
+    const long long n = npoints;
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+
+    // 1. bounding box
+    DevBuf d_mm;
+    if ((rc = d_mm.alloc(6 * sizeof(unsigned long long)))) return rc;
+    unsigned long long h_mm[6] = {~0ull, ~0ull, ~0ull, 0ull, 0ull, 0ull};
+    WLSQM_HIP_CHECK(hipMemcpyAsync(d_mm.p, h_mm, sizeof(h_mm), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(knn_bbox_kernel, dim3(blocks), dim3(256), 0, s, S, n, dimension, d_mm.as<unsigned long long>());
+    WLSQM_HIP_CHECK(hipMemcpyAsync(h_mm, d_mm.p, sizeof(h_mm), hipMemcpyDeviceToHost, s));
+    WLSQM_HIP_CHECK(hipStreamSynchronize(s));
+    KnnGrid G{};
+    G.dim = dimension;
+    double ext[3] = {0, 0, 0}, vol = 1.0;
+    int live = 0;
+    for (int m = 0; m < dimension; ++m) {
+        const double lo = value_of(h_mm[m]), hi = value_of(h_mm[3 + m]);
+        if (!(lo == lo) || !(hi == hi) || hi - lo > DBL_MAX) { set_error("non-finite coordinates"); return WLSQM_EVALUE; }
+        G.lo[m] = lo; ext[m] = hi - lo;
+        if (ext[m] > 0.0) { vol *= ext[m]; ++live; }
+    }
+    // ~4 points per cell over the non-degenerate axes, at most 2^27 cells
+    const double target_cells = std::min((double)n / 4.0, 134217728.0);
+    const double h = live ? std::pow(vol / std::max(target_cells, 1.0), 1.0 / live) : 1.0;
+    long long ncells = 1;
+    for (int m = 0; m < dimension; ++m) {
+        int g = ext[m] > 0.0 ? (int)std::min(std::max(ext[m] / h, 1.0), 4096.0 * 4096.0) : 1;
+        if (dimension == 3) g = std::min(g, 1024); else if (dimension == 2) g = std::min(g, 16384);
+        G.g[m] = std::max(g, 1);
+        G.cell[m] = ext[m] > 0.0 ? ext[m] / G.g[m] : 1.0;
+        G.inv_cell[m] = 1.0 / G.cell[m];
+        ncells *= G.g[m];
+    }
+    for (int m = dimension; m < 3; ++m) { G.g[m] = 1; G.cell[m] = 1.0; G.inv_cell[m] = 1.0; G.lo[m] = 0.0; }
+
+    // 2. sort by cell
+    DevBuf d_cell, d_cell2, d_idx, d_perm, d_start, d_Ss, d_tmp;
+    if ((rc = d_cell.alloc(n * 4)) || (rc = d_cell2.alloc(n * 4)) || (rc = d_idx.alloc(n * 4)) || (rc = d_perm.alloc(n * 4)) ||
+        (rc = d_start.alloc((ncells + 1) * 4)) || (rc = d_Ss.alloc((size_t)n * dimension * 8))) return rc;
+    hipLaunchKernelGGL(knn_cell_kernel, dim3(blocks), dim3(256), 0, s, S, n, G, d_cell.as<unsigned>(), d_idx.as<int>());
+    int bits = 1;
+    while ((1ll << bits) < ncells) ++bits;
+    size_t tmp_bytes = 0;
+    WLSQM_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_cell.as<unsigned>(), d_cell2.as<unsigned>(),
+                                                       d_idx.as<int>(), d_perm.as<int>(), (int)n, 0, bits, s));
+    if ((rc = d_tmp.alloc(tmp_bytes ? tmp_bytes : 16))) return rc;
+    WLSQM_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(d_tmp.p, tmp_bytes, d_cell.as<unsigned>(), d_cell2.as<unsigned>(),
+                                                       d_idx.as<int>(), d_perm.as<int>(), (int)n, 0, bits, s));
+    hipLaunchKernelGGL(knn_start_kernel, dim3((unsigned)((ncells + 1 + 255) / 256)), dim3(256), 0, s, d_cell2.as<unsigned>(), n,
+                       ncells, d_start.as<int>());
+    hipLaunchKernelGGL(knn_gather_kernel, dim3(blocks), dim3(256), 0, s, S, d_perm.as<int>(), n, dimension, d_Ss.as<double>());
+
+    // 3./4. query
+    const unsigned qblocks = (unsigned)((n + 63) / 64);
+#define KNN_LAUNCH(D)                                                                                                   \
+    {                                                                                                                   \
+        auto kern = knn_query_kernel<D>;                                                                                \
+        if (lds > 64 * 1024)                                                                                            \
+            WLSQM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(kern, dim3(qblocks), dim3(64), lds, s, d_Ss.as<double>(), d_perm.as<int>(), d_start.as<int>(), n, k, G, hoods); \
+    }
+    if (dimension == 1) KNN_LAUNCH(1) else if (dimension == 2) KNN_LAUNCH(2) else KNN_LAUNCH(3)
+#undef KNN_LAUNCH
+    WLSQM_HIP_CHECK(hipGetLastError());
+    WLSQM_HIP_CHECK(hipStreamSynchronize(s));      // the temporaries above are freed on return
+    return WLSQM_OK;
+}

@@ -10,7 +10,7 @@ import ctypes as C
 
 from . import _binding as B
 
-__all__ = ["fit_many_device", "time_fit_device", "fit_cloud_device", "time_fit_cloud_device", "device_count"]
+__all__ = ["fit_many_device", "time_fit_device", "fit_cloud_device", "time_fit_cloud_device", "device_count", "knn"]
 
 
 def device_count():
@@ -144,3 +144,26 @@ def time_fit_cloud_device(dimension, order, S, F, hoods, fi, nk, knowns, weighti
     ms = C.c_float(0.0)
     B.check(B.lib().wlsqm_hip_time_fit_cloud_device(*a, dev, s, int(reps), C.byref(ms)))
     return float(ms.value)
+
+
+def knn(S, k, stream=None):
+    """The k nearest OTHER points of every point of the device-resident cloud S (npoints, dim) [1D: (npoints,)], as an
+    int32 device tensor (npoints, k), ascending by (distance, index) — what the reference's examples get on the host from
+    ``cKDTree(S).query(S, 1 + k)[1][:, 1:]`` (examples/expertsolver_example.py:48-66).  Exact uniform-grid search on the
+    GPU; the result is the ``hoods`` argument of fit_cloud_device / ShardedCloudSolver, or of ``S[hoods]`` for the dense
+    API.  1 <= k <= min(npoints - 1, 213).  Synchronises the stream."""
+    import torch
+    if S.dim() == 1:
+        dim = 1
+    elif S.dim() == 2 and 1 <= S.shape[1] <= 3:
+        dim = int(S.shape[1])
+    else:
+        raise ValueError("S must be (npoints,) or (npoints, dim) with dim 1..3")
+    _check(S, "S", "float64", S.dim())
+    if not S.is_contiguous():
+        raise ValueError("S must be contiguous")
+    n = int(S.shape[0])
+    hoods = torch.empty((n, int(k)), dtype=torch.int32, device=S.device)
+    s, dev = _stream_and_device(S, stream)
+    B.check(B.lib().wlsqm_hip_knn_device(dim, n, _ptr(S), int(k), _ptr(hoods), dev, s))
+    return hoods

@@ -723,3 +723,82 @@ def test_full_size_properties(wlsqm, name):
     oracle.fit_many(dim, xk_h, fk_h, meta[0], xi_h, fi_o, None, 0, meta[1], meta[2], meta[3], ntasks=8)
     truth = P.truth_fit(dim, xk_h, fk_h, meta[0], xi_h, fi_in, meta[1], meta[2], meta[3])
     P.assert_parity(fi_f.cpu().numpy()[idx], fi_o, truth, name + " full size, strided sample")
+
+
+@pytest.mark.parametrize("case", ["halton2d", "halton3d", "line1d", "clustered2d", "duplicates2d", "tiny", "flat3d", "k100"])
+def test_gpu_knn_equals_ckdtree(wlsqm, case):
+    """wlsqm.hip.knn (exact grid search on the GPU) against scipy's cKDTree, the reference examples' neighbour search
+    (examples/expertsolver_example.py:48-66): same neighbour sets, same distances in ascending order; where distances
+    tie exactly the order inside the tie may differ (cKDTree's is unspecified), so ties are compared as sets."""
+    import torch
+    import synth
+    import wlsqm.hip as whip
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(3)
+    k = 32
+    if case == "halton2d":
+        S = synth.halton(50_000, 2)
+    elif case == "halton3d":
+        S = synth.halton(40_000, 3); k = 40
+    elif case == "line1d":
+        S = np.sort(rng.uniform(0, 1, 20_000)); k = 8
+    elif case == "clustered2d":        # strongly non-uniform density: many points per cell in the clusters, empty cells elsewhere
+        S = np.concatenate([0.5 + 1e-3 * rng.standard_normal((20_000, 2)), rng.uniform(0, 1, (2_000, 2)),
+                            np.array([[5.0, 5.0]])])
+    elif case == "duplicates2d":       # coincident points: distance-0 ties
+        base = rng.uniform(0, 1, (3_000, 2)); S = np.concatenate([base, base[:1500], base[:700]])
+    elif case == "tiny":
+        S = rng.uniform(0, 1, (9, 2)); k = 8
+    elif case == "flat3d":             # degenerate bounding box (all z equal)
+        S = np.concatenate([rng.uniform(0, 1, (5_000, 2)), np.full((5_000, 1), 0.25)], axis=1); k = 12
+    else:
+        S = synth.halton(6_000, 2); k = 100
+    S = np.ascontiguousarray(S)
+    got = whip.knn(torch.from_numpy(S).cuda(), k).cpu().numpy()
+    n = len(S)
+    X = S if S.ndim == 2 else S[:, None]
+    assert got.shape == (n, k) and got.dtype == np.int32
+    assert (got != np.arange(n)[:, None]).all() and got.min() >= 0 and got.max() < n
+    d_got = np.sqrt(((X[got] - X[:, None, :]) ** 2).sum(-1))
+    dd, ii = cKDTree(X).query(X, min(n, k + 2 + (2300 if case == "duplicates2d" else 0)))
+    # reference distances to the k nearest OTHER points (drop one zero-distance self entry per row)
+    d_ref = np.empty((n, k)); d_next = np.full(n, np.inf)       # d_next: the first neighbour NOT returned
+    for j in range(n):
+        row = list(ii[j]); pos = row.index(j) if j in row else 0
+        rest = np.delete(dd[j], pos)
+        d_ref[j] = rest[:k]
+        if len(rest) > k:
+            d_next[j] = rest[k]
+    assert np.all(np.diff(d_got, axis=1) >= 0)                                 # ascending
+    assert np.allclose(d_got, d_ref, rtol=1e-14, atol=0)                         # the same k smallest distances
+    for j in range(0, n, max(1, n // 500)):                                     # no index repeated in a row
+        assert len(set(got[j])) == k
+    if case in ("halton2d", "halton3d", "line1d"):                              # no ties there: identical index lists
+        ref = np.array([[i for i in ii[j] if i != j][:k] for j in range(n)])
+        same = (ref == got).all(axis=1)
+        ext = np.concatenate([d_ref, d_next[:, None]], axis=1)
+        tie = np.isclose(ext[:, 1:], ext[:, :-1], rtol=1e-12, atol=0).any(axis=1)       # Halton lattices tie to the last ulp
+        assert (same | tie).all()
+
+
+def test_gpu_knn_feeds_the_fit(wlsqm):
+    """End to end on the device: neighbour search, then the index-based fit, equal to the host-searched fit."""
+    import torch
+    import synth
+    import wlsqm.hip as whip
+    n, k = 20_000, 32
+    S = synth.halton(n, 2); F = synth.field(S)
+    dev = torch.device("cuda", 0)
+    S_d, F_d = torch.from_numpy(S).to(dev), torch.from_numpy(F).to(dev)
+    h_gpu = whip.knn(S_d, k)
+    h_ref = torch.from_numpy(synth.knn(S, k, workers=1)).to(dev)
+    same = (h_gpu == h_ref).all(dim=1)          # rows differ only where Halton distances tie to the last ulp
+    assert float(same.double().mean()) > 0.98
+    nk = torch.full((n,), k, dtype=torch.int32, device=dev); kn = torch.zeros(n, dtype=torch.int64, device=dev)
+    wm = torch.full((n,), 2, dtype=torch.int32, device=dev)
+    fi = torch.zeros((n, 6), dtype=torch.float64, device=dev); fi[:, 0] = F_d
+    whip.fit_cloud_device(2, 2, S_d, F_d, h_gpu, fi, nk, kn, wm)
+    torch.cuda.synchronize()
+    inner = (np.abs(S - 0.5) < 0.45).all(axis=1)
+    dfdx = np.pi * np.cos(np.pi * S[:, 0]) * np.cos(np.pi * S[:, 1])
+    assert np.abs(fi.cpu().numpy()[inner, 1] - dfdx[inner]).max() < 5e-3        # truncation error of the order-2 model at this spacing
