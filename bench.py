@@ -44,13 +44,21 @@ def bytes_per_fit(dim, order, nk, knowns):
     return 8 * nk * (dim + 1) + 8 * dim + 8 * no + 8 * bin(knowns).count("1") + 20
 
 
-def build_problem(cfg, ncases, rank):
+def build_problem(cfg, ncases, rank, device=None):
+    """Synthetic inputs of SURVEY.md section 8d: Halton points, nk nearest neighbours (self excluded), smooth field.
+    With `device` (a torch device) the neighbour search runs on that GPU (wlsqm.hip.knn, exact, same neighbours as
+    cKDTree up to the order inside last-ulp distance ties); otherwise scipy's cKDTree on the host."""
     dim, nk = cfg["dim"], cfg["nk"]
     if dim == 1:
         p = synth.line_problem_1d(ncases, nk // 2, seed=rank)
         return p["S"], p["F"], p["hoods"]
     S = synth.halton(ncases, dim, skip=1 + rank * ncases)       # each rank owns a different stretch of the sequence
     F = synth.field(S)
+    if device is not None:
+        import torch
+        import wlsqm.hip as whip
+        hoods = whip.knn(torch.from_numpy(S).to(device), nk).cpu().numpy()
+        return S, F, hoods
     world = int(os.environ.get("WORLD_SIZE", "1"))
     hoods = synth.knn(S, nk, workers=max(1, len(os.sched_getaffinity(0)) // world))
     return S, F, hoods
@@ -84,7 +92,7 @@ def main():
     cfg = CONFIGS[a.config]
     dim, order, nk, n = cfg["dim"], cfg["order"], cfg["nk"], a.ncases
     no = NDOF[dim][order]
-    S, F, hoods = build_problem(cfg, n, rank)
+    S, F, hoods = build_problem(cfg, n, rank, device=dev)
     if a.config == "C4":
         return run_c4(a, cfg, S, F, hoods, dev, dist, rank, world)
 
