@@ -32,6 +32,7 @@ int launch_fit_tile(int dimension, int order, const KParams& p, long long max_nk
 int launch_fit_wave(int dimension, int order, const KParams& p, hipStream_t stream);
 int launch_fit_moment(int dimension, int order, const KParams& p, long long max_nk, hipStream_t stream, bool* handled);
 int launch_fit_tilek(int dimension, int order, const KParams& p, long long max_nk, hipStream_t stream, bool* handled);
+long long preferred_slots(int dimension, int order, long long max_nk);
 
 int launch_fit(int dimension, int order, const KParams& p, long long max_nk, hipStream_t stream) {
     const int no = wlsqm_hip_number_of_dofs(dimension, order);
@@ -218,8 +219,10 @@ int wlsqm_hip_fit_many_host(const wlsqm_batch* b, int device, int32_t* iteration
     if (!cx) { set_error("device ordinal out of range"); return WLSQM_ENODEVICE; }
     if ((rc = cx->st.ensure(device))) return rc;
 
-    // device rows hold an even number of neighbour slots (16-byte rows for the tiled kernels); the pad slot is never used
-    const int64_t K = std::max<int64_t>(max_nk + (max_nk & 1), 2);
+    // device rows hold an even number of neighbour slots (16-byte rows for the tiled kernels), for some shapes a few more
+    // (the next size with a specialised kernel); pad slots are staged but masked by k < nk[j]
+    const bool uniform_order = std::all_of(h_order.begin(), h_order.end(), [&](int o) { return o == h_order[0]; });
+    const int64_t K = preferred_slots(dim, uniform_order ? h_order[0] : -1, max_nk);
     const bool want_sens = b->do_sens && b->sens;
     if ((rc = cx->xk.need((size_t)n * K * dim * 8)) || (rc = cx->fk.need((size_t)n * K * 8)) ||
         (rc = cx->xi.need((size_t)n * dim * 8)) || (rc = cx->fi.need((size_t)n * max_no * 8)) ||
@@ -254,7 +257,6 @@ int wlsqm_hip_fit_many_host(const wlsqm_batch* b, int device, int32_t* iteration
     p.iters_out = cx->it.as<int>();
 
     // bucket by order (the kernels are specialised per (dimension, order))
-    const bool uniform_order = std::all_of(h_order.begin(), h_order.end(), [&](int o) { return o == h_order[0]; });
     if (uniform_order) {
         p.case_index = nullptr; p.ncases = n;
         rc = launch_fit(dim, h_order[0], p, K, s);

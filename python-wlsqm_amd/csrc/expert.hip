@@ -22,6 +22,7 @@
 struct wlsqm_expert_geometry {
     int device = 0, dimension = 0;
     int64_t ncases = 0, max_nk = 1;
+    int64_t slots = 2;                 // neighbour slots per device row (>= max_nk; preferred_slots in fit_tile.hip)
     int max_no = 0;
     bool ready = false, uniform_order = true;
     std::vector<int32_t> nk, order, wm, no;
@@ -43,9 +44,9 @@ struct wlsqm_expert {
     int64_t bytes() const { return own_bytes() + (guest ? 0 : g->bytes()); }
     int alloc_fields() {
         int rc;
-        if ((rc = d_it.alloc(4)) || (rc = d_fk.alloc((size_t)g->ncases * g->max_nk * 8)) ||
+        if ((rc = d_it.alloc(4)) || (rc = d_fk.alloc((size_t)g->ncases * g->slots * 8)) ||
             (rc = d_fi.alloc((size_t)g->ncases * g->max_no * 8))) return rc;
-        if (do_sens && (rc = d_sens.alloc((size_t)g->ncases * g->max_nk * g->max_no * 8))) return rc;
+        if (do_sens && (rc = d_sens.alloc((size_t)g->ncases * g->slots * g->max_no * 8))) return rc;
         return WLSQM_OK;
     }
 };
@@ -53,6 +54,7 @@ struct wlsqm_expert {
 using namespace wlsqm;
 
 namespace wlsqm {
+long long preferred_slots(int dimension, int order, long long max_nk);
 int launch_solve_many(int dimension, int order, const KParams& p, long long K, long long nrhs,
                       const double* fk, long long sfk_r, long long sfk_j, double* fi, long long sfi_r, long long sfi_j,
                       hipStream_t stream, bool* handled);
@@ -64,7 +66,7 @@ int launch_conds(int dimension, int order, const KParams& p, const int* order_ar
 static KParams expert_params(const wlsqm_expert* h, const double* d_fk, int64_t sfk_j, double* d_fi, int64_t sfi_j) {
     KParams p{};
     const int dim = h->g->dimension;
-    p.xk = h->g->d_xk.as<double>(); p.sxk_j = h->g->max_nk * dim; p.sxk_k = dim;
+    p.xk = h->g->d_xk.as<double>(); p.sxk_j = h->g->slots * dim; p.sxk_k = dim;
     p.fk = d_fk; p.sfk_j = sfk_j; p.sfk_k = 1;
     p.nk = h->g->d_nk.as<int>(); p.snk = 1;
     p.xi = h->g->d_xi.as<double>(); p.sxi_j = dim;
@@ -79,12 +81,12 @@ static KParams expert_params(const wlsqm_expert* h, const double* d_fk, int64_t 
 }
 
 static int expert_launch(const wlsqm_expert* h, KParams p, hipStream_t s) {
-    if (h->g->uniform_order) return launch_fit(h->g->dimension, h->g->order[0], p, h->g->max_nk, s);
+    if (h->g->uniform_order) return launch_fit(h->g->dimension, h->g->order[0], p, h->g->slots, s);
     for (int o = 0; o <= 4; ++o) {
         if (h->g->off[o + 1] == h->g->off[o]) continue;
         p.case_index = h->g->d_idx.as<long long>() + h->g->off[o];
         p.ncases = h->g->off[o + 1] - h->g->off[o];
-        int rc = launch_fit(h->g->dimension, o, p, h->g->max_nk, s);
+        int rc = launch_fit(h->g->dimension, o, p, h->g->slots, s);
         if (rc != WLSQM_OK) return rc;
     }
     return WLSQM_OK;
@@ -118,10 +120,11 @@ int wlsqm_hip_expert_create(wlsqm_expert** out, int device, int dimension, int64
     }
     g.max_nk = std::max<int64_t>(mk, 1);
     g.uniform_order = std::all_of(g.order.begin(), g.order.end(), [&](int o) { return o == g.order[0]; });
+    g.slots = preferred_slots(dimension, g.uniform_order ? g.order[0] : -1, g.max_nk);
     int rc = check_device(device);
     if (rc != WLSQM_OK) { delete h; return rc; }
     if ((rc = g.d_nk.alloc(ncases * 4)) || (rc = g.d_wm.alloc(ncases * 4)) || (rc = g.d_kn.alloc(ncases * 8)) ||
-        (rc = g.d_order.alloc(ncases * 4)) || (rc = g.d_xk.alloc((size_t)ncases * g.max_nk * dimension * 8)) ||
+        (rc = g.d_order.alloc(ncases * 4)) || (rc = g.d_xk.alloc((size_t)ncases * g.slots * dimension * 8)) ||
         (rc = g.d_xi.alloc((size_t)ncases * dimension * 8)) || (rc = h->alloc_fields())) { delete h; return rc; }
     hipError_t e;
     if ((e = hipMemcpy(g.d_nk.p, g.nk.data(), g.d_nk.n, hipMemcpyHostToDevice)) != hipSuccess ||
@@ -177,10 +180,10 @@ int wlsqm_hip_expert_prepare(wlsqm_expert* h, const double* xi, int64_t xi_strid
     if (max_nk < h->g->max_nk && h->g->max_nk > 1) { set_error("xk has fewer neighbour slots than max(nk)"); return WLSQM_EVALUE; }
     int rc = check_device(h->g->device);
     if (rc != WLSQM_OK) return rc;
-    const int dim = h->g->dimension; const int64_t n = h->g->ncases, K = h->g->max_nk;
+    const int dim = h->g->dimension; const int64_t n = h->g->ncases, K = h->g->slots, mk = h->g->max_nk;
     if ((rc = h->st.ensure(h->g->device))) return rc;
     hipStream_t s = nullptr;
-    if ((rc = h->st.upload_rows(h->g->d_xk.p, xk, n, K * dim, xk_stride_case, xk_stride_k, dim, 8, s))) return rc;
+    if ((rc = h->st.upload_rows(h->g->d_xk.p, xk, n, mk * dim, xk_stride_case, xk_stride_k, dim, 8, s, K * dim))) return rc;
     if ((rc = h->st.upload_rows(h->g->d_xi.p, xi, n, dim, xi_stride_case, dim, dim, 8, s))) return rc;
     if ((rc = h->st.drain())) return rc;
     WLSQM_HIP_CHECK(hipStreamSynchronize(s));
@@ -195,11 +198,11 @@ int wlsqm_hip_expert_solve(wlsqm_expert* h, const double* fk, int64_t fk_stride_
     if (!h->g->ready) { set_error("Solver is not in the ready state; prepare() must be called before solve()"); return WLSQM_ERUNTIME; }   // expert.pyx:493-494
     int rc = check_device(h->g->device);
     if (rc != WLSQM_OK) return rc;
-    const int64_t n = h->g->ncases, K = h->g->max_nk; const int NO = h->g->max_no;
+    const int64_t n = h->g->ncases, K = h->g->slots; const int NO = h->g->max_no;
     if ((rc = h->st.ensure(h->g->device))) return rc;
     hipStream_t s = nullptr;
     const bool want_sens = h->do_sens && sens;
-    if ((rc = h->st.upload_rows(h->d_fk.p, fk, n, K, fk_stride_case, fk_stride_k, 1, 8, s))) return rc;
+    if ((rc = h->st.upload_rows(h->d_fk.p, fk, n, h->g->max_nk, fk_stride_case, fk_stride_k, 1, 8, s, K))) return rc;
     if ((rc = h->st.upload_rows(h->d_fi.p, fi, n, NO, fi_stride_case, NO, NO, 8, s))) return rc;
     WLSQM_HIP_CHECK(hipMemsetAsync(h->d_it.p, 0, 4, s));
     KParams p = expert_params(h, h->d_fk.as<double>(), K, h->d_fi.as<double>(), NO);
@@ -256,7 +259,7 @@ static int solve_many_on_device(wlsqm_expert* h, hipStream_t s, int64_t nrhs, co
     bool handled = false;
     if (g.uniform_order && h->algorithm == WLSQM_ALGO_BASIC) {
         KParams p = expert_params(h, nullptr, 0, nullptr, 0);
-        int rc = launch_solve_many(g.dimension, g.order[0], p, g.max_nk, nrhs, fk, sfk_r, sfk_j, fi, sfi_r, sfi_j, s, &handled);
+        int rc = launch_solve_many(g.dimension, g.order[0], p, g.slots, nrhs, fk, sfk_r, sfk_j, fi, sfi_r, sfi_j, s, &handled);
         if (rc != WLSQM_OK) return rc;
     }
     if (handled) return WLSQM_OK;
@@ -291,7 +294,7 @@ int wlsqm_hip_expert_solve_many(wlsqm_expert* h, int64_t nrhs,
     const wlsqm_expert_geometry& g = *h->g;
     int rc = check_device(g.device);
     if (rc != WLSQM_OK) return rc;
-    const int64_t n = g.ncases, K = g.max_nk; const int NO = g.max_no;
+    const int64_t n = g.ncases, K = g.slots; const int NO = g.max_no;
     if ((rc = h->st.ensure(g.device))) return rc;
     hipStream_t s = nullptr;
     // right-hand sides travel in chunks of at most ~1 GiB of fk
@@ -302,7 +305,7 @@ int wlsqm_hip_expert_solve_many(wlsqm_expert* h, int64_t nrhs,
     for (int64_t r0 = 0; r0 < nrhs; r0 += chunk) {
         const int64_t nr = std::min(chunk, nrhs - r0);
         for (int64_t r = 0; r < nr; ++r) {
-            if ((rc = h->st.upload_rows(d_fk + r * n * K, fk + (r0 + r) * fk_stride_rhs, n, K, fk_stride_case, fk_stride_k, 1, 8, s))) return rc;
+            if ((rc = h->st.upload_rows(d_fk + r * n * K, fk + (r0 + r) * fk_stride_rhs, n, g.max_nk, fk_stride_case, fk_stride_k, 1, 8, s, K))) return rc;
             if ((rc = h->st.upload_rows(d_fi + r * n * NO, fi + (r0 + r) * fi_stride_rhs, n, NO, fi_stride_case, NO, NO, 8, s))) return rc;
         }
         if ((rc = solve_many_on_device(h, s, nr, d_fk, n * K, K, d_fi, n * NO, NO))) return rc;

@@ -413,26 +413,40 @@ static bool tile_eligible(int dim, const KParams& p, long long K) {
 
 // First kernel of the two-kernel moment path (fit_moment.hip): tile pass that leaves the moments in p.ws.
 // `handled` stays false when no instantiation covers (dimension, order, max_nk) or the input is not tile-eligible.
+// Neighbour-slot counts with a two-kernel moment instantiation (2D order 4).  The host entry points round their device
+// rows up to the next of these (preferred_slots), so every host-array batch of 2D order-4 fits with <= 100 neighbours
+// takes this path (the reference's own example, examples/wlsqm_example.py:55-187, is order 4 with max_nk = 100).
+static bool moment_slots(long long K) { return K == 32 || K == 40 || K == 48 || K == 64 || K == 80 || K == 100; }
+
 bool tile_moments_supported(int dimension, int order, const KParams& p, long long max_nk) {
-    return dimension == 2 && order == 4 && max_nk == 64 && tile_eligible(dimension, p, max_nk);
+    return dimension == 2 && order == 4 && moment_slots(max_nk) && tile_eligible(dimension, p, max_nk);
+}
+
+// Device row length (neighbour slots) the host entry points should allocate for a batch whose largest neighbourhood has
+// max_nk members: even (16-byte rows for the tiled kernels), and for 2D order 4 the next size with a moment kernel.
+long long preferred_slots(int dimension, int order, long long max_nk) {
+    if (dimension == 2 && order == 4)
+        for (long long K : {32ll, 40ll, 48ll, 64ll, 80ll, 100ll})
+            if (max_nk <= K) return K;
+    const long long K = max_nk + (max_nk & 1);
+    return K < 2 ? 2 : K;
 }
 
 int launch_tile_moments(int dimension, int order, const KParams& p, long long max_nk, hipStream_t stream, bool* handled) {
     *handled = false;
     if (!tile_moments_supported(dimension, order, p, max_nk)) return WLSQM_OK;
-    const char* v = getenv("WLSQM_TILE_VARIANT");
-    const int var = v ? atoi(v) : 0;
     const bool gather = p.hoods != nullptr;
-    if (dimension == 2 && order == 4 && max_nk == 64) {      // C3
-        *handled = true;
-        if (gather) return launch_tile_impl<2, 4, 64, 2, 2, 4, 2, true, false, true, true>(p, stream);
-        // A/B at 1M cases: two waves per 32-case tile 0.73 ms (with the solve kernel); direct fk the same; one wave per
-        // 16-case tile spills (60 accumulators + 16 fk values per lane) 0.85 ms; (2 or 4 waves) x 4 lanes per case 0.85 ms.
-        switch (var) {
-            case 1: return launch_tile_impl<2, 4, 64, 2, 2, 4, 2, false, true, true, true>(p, stream);
-            default: return launch_tile_impl<2, 4, 64, 2, 2, 4, 2, false, false, true, true>(p, stream);
-        }
+    *handled = true;
+    // A/B at 1M cases, K = 64: two waves per 32-case tile 0.73 ms (with the solve kernel); direct fk the same; one wave per
+    // 16-case tile spills (60 accumulators + 16 fk values per lane) 0.85 ms; (2 or 4 waves) x 4 lanes per case 0.85 ms.
+#define MOMENT_CASE(KK)                                                                                             \
+    if (max_nk == KK) {                                                                                             \
+        if (gather) return launch_tile_impl<2, 4, KK, 2, 2, 4, 2, true, false, true, true>(p, stream);             \
+        return launch_tile_impl<2, 4, KK, 2, 2, 4, 2, false, false, true, true>(p, stream);                        \
     }
+    MOMENT_CASE(32) MOMENT_CASE(40) MOMENT_CASE(48) MOMENT_CASE(64) MOMENT_CASE(80) MOMENT_CASE(100)
+#undef MOMENT_CASE
+    *handled = false;
     return WLSQM_OK;
 }
 

@@ -120,8 +120,10 @@ __global__ __launch_bounds__(K1_WV, 2) void solve_many_kernel(const KParams p, c
 #pragma unroll
             for (int kk = 0; kk < FMAX; ++kk)
                 if (kk < G.KPL) {
+                    // slots beyond nk[j] may hold anything (padding of the device rows): 0 * NaN would poison the sum
+                    const double fv = (k0 + kk < nkc) ? f[kk] : 0.0;
 #pragma unroll
-                    for (int a = 0; a < NO; ++a) g[a] = fma(wc[kk][a], f[kk], g[a]);        // wc == 0 beyond nk[j]
+                    for (int a = 0; a < NO; ++a) g[a] = fma(wc[kk][a], fv, g[a]);
                 }
 #pragma unroll
             for (int off = TC; off < K1_WV; off <<= 1)

@@ -258,7 +258,7 @@ def test_sens_reconstructs_solution(wlsqm):
                                                  (3, 2, 50, 300), (1, 4, 12, 500), (3, 1, 14, 129), (2, 2, 7, 200),
                                                  (2, 2, 64, 300), (2, 2, 70, 200), (3, 1, 9, 150), (1, 2, 5, 100),
                                                  (2, 0, 16, 100), (3, 0, 8, 100), (2, 2, 48, 300), (2, 2, 16, 300),
-                                                 (3, 2, 56, 200), (2, 3, 64, 150)])
+                                                 (3, 2, 56, 200), (2, 3, 64, 150), (2, 4, 37, 300), (2, 4, 90, 150), (2, 4, 21, 200)])
 def test_tile_path_equals_lane_path(wlsqm, dim, order, K, ncases, monkeypatch):
     """The LDS-tiled fast path (contiguous, curated K) against the generic lane kernel on the same inputs:
     ragged nk <= K, mixed weightings and knowns, tail tiles.  Same arithmetic except for the split of the
