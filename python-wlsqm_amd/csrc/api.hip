@@ -33,6 +33,7 @@ int launch_fit_wave(int dimension, int order, const KParams& p, hipStream_t stre
 int launch_fit_moment(int dimension, int order, const KParams& p, long long max_nk, hipStream_t stream, bool* handled);
 int launch_fit_tilek(int dimension, int order, const KParams& p, long long max_nk, hipStream_t stream, bool* handled);
 long long preferred_slots(int dimension, int order, long long max_nk);
+int launch_fit_rows(int dimension, int order, const KParams& p, hipStream_t stream, bool* handled);
 
 int launch_fit(int dimension, int order, const KParams& p, long long max_nk, hipStream_t stream) {
     const int no = wlsqm_hip_number_of_dofs(dimension, order);
@@ -47,6 +48,8 @@ int launch_fit(int dimension, int order, const KParams& p, long long max_nk, hip
     rc = launch_fit_tilek(dimension, order, p, max_nk, stream, &handled);
     if (rc != WLSQM_OK || handled) return rc;
     if (no <= 15) return launch_fit_lane(dimension, order, p, stream);
+    rc = launch_fit_rows(dimension, order, p, stream, &handled);        // basic fit of the 3D order-3/4 systems
+    if (rc != WLSQM_OK || handled) return rc;
     return launch_fit_wave(dimension, order, p, stream);
 }
 

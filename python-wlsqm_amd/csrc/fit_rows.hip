@@ -1,0 +1,215 @@
+// fit_rows.hip — one wavefront per case for the large 3D systems (order 3: 20 unknowns, order 4: 35), basic fit.
+//
+// The no x no normal matrix does not fit one lane, so the 64 lanes of a wave share a case — but unlike fit_wave.hip
+// (the general version, which also does sensitivities and refinement and keeps the matrix in LDS) everything that is
+// touched repeatedly lives in registers and crosses lanes as wave-uniform broadcasts (v_readlane), not through LDS:
+//   1. lane k loads neighbour k, computes its weight and the power tables w dx^n, dy^n, dz^n (n <= 2*order) into LDS;
+//   2. ASSEMBLY IN MOMENT FORM (wlsqm_moments.hpp): the no(no+1)/2 = 630 matrix entries of order 4 are only 165 distinct
+//      moments sum_k w dx^p dy^q dz^r; they are dealt to the lanes (<= 3 each), every lane sums its moments over the
+//      neighbours with three table look-ups and two multiplies per moment and neighbour (one table row spans fewer than
+//      64 banks: conflict-free whatever the lanes pick); lane a < no also sums the right-hand-side moment of DOF a;
+//   3. ONE MATRIX ROW PER LANE IN REGISTERS: lane i expands row i from the moments (one pass over LDS), knowns become
+//      identity rows/columns (the mask is wave-uniform: one case per wave);
+//   4. left-looking LDL^T with the rows in place: at column c every lane i >= c updates v_i = A[i][c] - sum_m V_i[m]
+//      (V_c[m] / d_m), where V_c[m] comes from lane c by v_readlane — 2 readlanes + 2 fp64 operations per (c, m), no LDS,
+//      no barrier; 1/d_c is computed once per column by all lanes;
+//   5. forward substitution the same way; for the backward one the factor is parked in LDS once (column access).
+// Per case ~5.5k wave-instructions for order 4 with 64 neighbours, against ~25k (and ~100 LDS round trips on the critical
+// path of its rolled loops) in fit_wave.hip.
+#include "wlsqm_internal.hpp"
+#include "wlsqm_kernels.hpp"
+#include "wlsqm_moments.hpp"
+
+namespace wlsqm {
+
+constexpr int RW = 64;
+
+__device__ __forceinline__ double lane_bcast(double v, int l) {          // value of lane l (compile-time l), wave-uniform
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double inv_factorial(int n) { return n <= 1 ? 1.0 : n == 2 ? 0.5 : n == 3 ? 1.0 / 6.0 : 1.0 / 24.0; }
+
+template <int DIM, int ORDER>
+__global__ __launch_bounds__(RW) void fit_rows_kernel(const KParams p) {
+    static_assert(DIM == 3, "row-per-lane kernel is instantiated for the 3D systems");
+    constexpr int NO = ndofs(DIM, ORDER), NM = mom_count<DIM>(2 * ORDER), NP = 2 * ORDER + 1;
+    constexpr int TS = DIM * NP, TSP = TS | 1;                    // power-table row: [w dx^n | dy^n | dz^n], odd stride
+    constexpr int MPL = (NM + RW - 1) / RW;                       // moments per lane
+    constexpr int LDV = NO + 2;
+    static_assert(NO <= RW && TS <= 32, "one row per lane; one table row inside 64 banks");
+    __shared__ double sP[RW * TSP];                               // power tables of a chunk of 64 neighbours; later the factor
+    __shared__ double sF[RW];
+    __shared__ double sMu[NM];
+    __shared__ double sNu[NO];
+    static_assert(NO * LDV <= RW * TSP, "the factor reuses the table storage");
+
+    const int lane = threadIdx.x;
+    const long long t = blockIdx.x;
+    const long long j = p.case_index ? p.case_index[t] : t;
+    const int nk = p.nk[j * p.snk];
+    const bool uniform = (p.wm[j * p.swm] == WLSQM_WEIGHT_UNIFORM);
+    unsigned long long known, dropped;
+    effective_mask<NO>(p.knowns[j * p.sknowns], known, dropped);
+    constexpr unsigned long long FULL = (1ull << NO) - 1ull;
+    if (known == FULL) return;                                    // nr < 1: no-op (impl.pyx:574, 636, 742); whole wave exits
+
+    double xi[DIM];
+#pragma unroll
+    for (int m = 0; m < DIM; ++m) xi[m] = p.xi[j * p.sxi_j + m];
+    const double* xr = p.xk + j * p.sxk_j;
+    const double* fr = p.fk + j * p.sfk_j;
+    double* fio = p.fi + j * p.sfi_j;
+
+    // ---- per-lane bookkeeping: table offsets of this lane's moments and of its DOF
+    int off[MPL][DIM];
+#pragma unroll
+    for (int i = 0; i < MPL; ++i) {
+        int e = lane + RW * i;
+        if (e >= NM) e = NM - 1;                                  // clamp: harmless duplicate, never stored
+        int s = 0;
+        while (mtet(s + 1) <= e) ++s;                             // total degree
+        int rem = e - mtet(s), tq = 0;
+        while (mtri(tq + 1) <= rem) ++tq;                         // q + r
+        const int r = rem - mtri(tq), q = tq - r, pp = s - tq;
+        off[i][0] = pp; off[i][1] = NP + q; off[i][2] = 2 * NP + r;
+    }
+    const int me = lane < NO ? lane : NO - 1;
+    const int pi = Mono<DIM>::P[me], qi = Mono<DIM>::Q[me], ri = Mono<DIM>::R[me];
+
+    // ---- pass 1: largest squared distance (impl.pyx:389-391)
+    double max_d2 = 0.0;
+    if (!uniform) {
+        for (int k = lane; k < nk; k += RW) {
+            double d2 = 0.0;
+#pragma unroll
+            for (int m = 0; m < DIM; ++m) { const double dd = xr[k * p.sxk_k + m] - xi[m]; d2 += dd * dd; }
+            max_d2 = d2 > max_d2 ? d2 : max_d2;
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { const double v = __shfl_xor(max_d2, o, RW); max_d2 = v > max_d2 ? v : max_d2; }
+    }
+    const double inv_max = inverse_max(max_d2);
+
+    // ---- pass 2: moments, chunks of 64 neighbours
+    double acc[MPL], nacc = 0.0;
+#pragma unroll
+    for (int i = 0; i < MPL; ++i) acc[i] = 0.0;
+    for (int kb = 0; kb < nk; kb += RW) {
+        const int kc = min(RW, nk - kb);
+        __syncthreads();                                          // previous chunk fully consumed
+        if (lane < kc) {
+            double d[DIM], d2 = 0.0;
+#pragma unroll
+            for (int m = 0; m < DIM; ++m) { d[m] = xr[(kb + lane) * p.sxk_k + m] - xi[m]; d2 += d[m] * d[m]; }
+            double* row = sP + lane * TSP;
+            double v = weight(d2, inv_max, uniform);
+#pragma unroll
+            for (int m = 0; m < DIM; ++m) {
+                if (m > 0) v = 1.0;
+#pragma unroll
+                for (int n = 0; n < NP; ++n) { row[m * NP + n] = v; v *= d[m]; }
+            }
+            sF[lane] = fr[(kb + lane) * p.sfk_k];
+        }
+        __syncthreads();
+        const double* tab = sP;
+#pragma unroll 4
+        for (int k = 0; k < kc; ++k, tab += TSP) {
+#pragma unroll
+            for (int i = 0; i < MPL; ++i) acc[i] = fma(tab[off[i][0]] * tab[off[i][1]], tab[off[i][2]], acc[i]);
+            nacc = fma((tab[pi] * tab[NP + qi]) * tab[2 * NP + ri], sF[k], nacc);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MPL; ++i)
+        if (lane + RW * i < NM) sMu[lane + RW * i] = acc[i];
+    if (lane < NO) sNu[lane] = nacc;
+    __syncthreads();
+
+    // ---- row i of the normal matrix and of the right-hand side, from the moments (factorial constants as impl.pyx:331-349)
+    const double fi_ = inv_factorial(pi) * inv_factorial(qi) * inv_factorial(ri);
+    double V[NO];
+#pragma unroll
+    for (int b = 0; b < NO; ++b) {
+        constexpr int dummy = 0; (void)dummy;
+        const int pb = Mono<DIM>::P[b], qb = Mono<DIM>::Q[b], rb = Mono<DIM>::R[b];
+        const double fb = mom_inv_fact(pb) * mom_inv_fact(qb) * mom_inv_fact(rb);
+        const int s = pi + qi + ri + pb + qb + rb, tq = qi + ri + qb + rb, r = ri + rb;
+        V[b] = sMu[mtet(s) + mtri(tq) + r] * (fi_ * fb);
+    }
+    double g = sNu[me] * fi_;
+
+    // ---- knowns (impl.pyx:792-818): the mask is wave-uniform
+    const bool kn_me = (known >> me) & 1ull;
+    if (known) {
+#pragma unroll
+        for (int b = 0; b < NO; ++b)
+            if ((known >> b) & 1ull) {
+                const double val = ((dropped >> b) & 1ull) ? 0.0 : fio[b];
+                g -= V[b] * val;
+            }
+#pragma unroll
+        for (int b = 0; b < NO; ++b)
+            if (kn_me || ((known >> b) & 1ull)) V[b] = (b == me) ? 1.0 : 0.0;
+        if (kn_me) g = 0.0;
+    }
+
+    // ---- left-looking LDL^T, row i in lane i: V[m] = L[i][m] d_m below the diagonal, V[i] = d_i
+    double dinv[NO], my_dinv = 1.0;
+#pragma unroll
+    for (int c = 0; c < NO; ++c) {
+        double v = V[c];
+#pragma unroll
+        for (int m = 0; m < c; ++m) v = fma(-V[m], lane_bcast(V[m], c) * dinv[m], v);
+        V[c] = v;
+        dinv[c] = recip(lane_bcast(v, c));
+        my_dinv = (lane == c) ? dinv[c] : my_dinv;
+    }
+    // ---- forward substitution and the diagonal
+#pragma unroll
+    for (int m = 0; m < NO; ++m) {
+        const double tm = lane_bcast(g, m) * dinv[m];
+        g = (lane > m) ? fma(-V[m], tm, g) : g;
+    }
+    g *= my_dinv;
+    // ---- backward substitution: the factor by columns through LDS (the tables are dead)
+    __syncthreads();
+    double* sV = sP;
+    if (lane < NO) {
+#pragma unroll
+        for (int m = 0; m < NO; ++m) sV[lane * LDV + m] = V[m];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int jj = NO - 1; jj >= 1; --jj) {
+        const double xj = lane_bcast(g, jj);
+        const double l = sV[jj * LDV + me] * my_dinv;            // L[jj][i] = V_jj[i] / d_i
+        g = (lane < jj) ? fma(-l, xj, g) : g;
+    }
+    if (lane < NO && !kn_me) fio[lane] = g;
+}
+
+template <int DIM, int ORDER>
+static int launch_rows(const KParams& p, hipStream_t stream) {
+    if (p.ncases > 0x7fffffffLL) { set_error("too many cases for one launch"); return WLSQM_EVALUE; }
+    hipLaunchKernelGGL((fit_rows_kernel<DIM, ORDER>), dim3((unsigned)p.ncases), dim3(RW), 0, stream, p);
+    WLSQM_HIP_CHECK(hipGetLastError());
+    note_kernel("rows");
+    return WLSQM_OK;
+}
+
+// Basic fit (no sensitivities, no refinement) of the 3D order-3/4 systems on dense (possibly strided) input.
+int launch_fit_rows(int dimension, int order, const KParams& p, hipStream_t stream, bool* handled) {
+    *handled = false;
+    const char* off = getenv("WLSQM_HIP_DISABLE_ROWS");          // A/B against fit_wave.hip
+    if (off && off[0] == '1') return WLSQM_OK;
+    if (p.do_sens || p.iterative || p.hoods) return WLSQM_OK;
+    if (dimension == 3 && order == 3) { *handled = true; return launch_rows<3, 3>(p, stream); }
+    if (dimension == 3 && order == 4) { *handled = true; return launch_rows<3, 4>(p, stream); }
+    return WLSQM_OK;
+}
+
+}  // namespace wlsqm
