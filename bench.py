@@ -44,6 +44,17 @@ def bytes_per_fit(dim, order, nk, knowns):
     return 8 * nk * (dim + 1) + 8 * dim + 8 * no + 8 * bin(knowns).count("1") + 20
 
 
+def load_traffic(config, units_per_launch):
+    """HBM bytes per launch from the committed PMC summary (profiles/traffic_<config>.json, tools/make_traffic.py), or None
+    when there is none for this config / launch size."""
+    tfile = os.path.join(ROOT, "profiles", "traffic_%s.json" % config)
+    try:
+        t = json.load(open(tfile))
+        return t.get("hbm_bytes_per_launch") if int(t.get("cases_per_launch", -1)) == int(units_per_launch) else None
+    except Exception:
+        return None
+
+
 def build_problem(cfg, ncases, rank, device=None):
     """Synthetic inputs of SURVEY.md section 8d: Halton points, nk nearest neighbours (self excluded), smooth field.
     With `device` (a torch device) the neighbour search runs on that GPU (wlsqm.hip.knn, exact, same neighbours as
@@ -145,13 +156,7 @@ def main():
 
     out = None
     if rank == 0:
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "traffic_%s.json" % a.config)
-        if os.path.exists(tfile):
-            try:
-                traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic = load_traffic(a.config, n)
         out = {
             "metric": "local fits/s (whole node)", "value": world * n * a.steps / dt, "unit": "fits/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
@@ -257,7 +262,7 @@ def run_c4(a, cfg, S, F, hoods, dev, dist, rank, world):
                                    "geometry and fields device-resident" % (cfg["desc"], n, R),
                        "fits_per_gpu": n * R, "bytes_per_fit": B_fit, "prepare_ms_host_arrays": t_prepare * 1e3},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel_ms": ms_kernel},
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": load_traffic("C4", n * R), "kernel_ms": ms_kernel},
             "time_stepping": {"ms_per_field": ms_step_field, "fits_per_s": n / (ms_step_field * 1e-3),
                               "bytes_per_fit": bytes_per_fit(dim, order, nk, cfg["knowns"])},
         }
