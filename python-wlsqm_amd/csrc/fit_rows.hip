@@ -134,7 +134,6 @@ __global__ __launch_bounds__(RW) void fit_rows_kernel(const KParams p) {
     double V[NO];
 #pragma unroll
     for (int b = 0; b < NO; ++b) {
-        constexpr int dummy = 0; (void)dummy;
         const int pb = Mono<DIM>::P[b], qb = Mono<DIM>::Q[b], rb = Mono<DIM>::R[b];
         const double fb = mom_inv_fact(pb) * mom_inv_fact(qb) * mom_inv_fact(rb);
         const int s = pi + qi + ri + pb + qb + rb, tq = qi + ri + qb + rb, r = ri + rb;
