@@ -151,3 +151,23 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".sh", ".cpp")):
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "oracle" not in text.lower() or f == "nothing", "%s mentions the oracle" % os.path.join(dirpath, f)
+
+
+def test_package_surface_matches_the_reference():
+    """Import graph and flat re-exports a user of the reference relies on (reference tests/test_package.py:10-57):
+    version string, the fitter submodules (impl / infra / polyeval expose no Python-callable API in the reference either),
+    the public names, number_of_dofs for every (dimension, order), and the bit-exact remap contract."""
+    import re
+    import wlsqm
+    assert re.match(r"^\d+\.\d+\.\d+(\.(dev|a|b|rc|post)\d+)?$", wlsqm.__version__)
+    from wlsqm.fitter import defs, expert, impl, infra, interp, polyeval, simple  # noqa: F401
+    for name in ("fit_1D", "fit_2D", "fit_3D", "fit_1D_many_parallel", "fit_2D_many_parallel", "fit_3D_many_parallel",
+                 "fit_2D_iterative_many_parallel", "ExpertSolver", "WEIGHT_UNIFORM", "WEIGHT_CENTER", "ALGO_BASIC",
+                 "ALGO_ITERATIVE", "number_of_dofs", "interpolate_fit", "lambdify_fit", "b2_F", "i3_XY"):
+        assert hasattr(wlsqm, name), name
+    assert [wlsqm.number_of_dofs(1, k) for k in range(5)] == [1, 2, 3, 4, 5]
+    assert [wlsqm.number_of_dofs(2, k) for k in range(5)] == [1, 3, 6, 10, 15]
+    assert [wlsqm.number_of_dofs(3, k) for k in range(5)] == [1, 4, 10, 20, 35]
+    nr, o2r, r2o = infra.remap(6, 0b010010)
+    assert nr == 4 and o2r.tolist() == [0, -1, 1, 2, -1, 3] and r2o.tolist() == [0, 2, 3, 5, -1, -1]
+    assert infra.number_of_reduced_dofs(6, 0b010010) == 4

@@ -802,3 +802,38 @@ def test_gpu_knn_feeds_the_fit(wlsqm):
     inner = (np.abs(S - 0.5) < 0.45).all(axis=1)
     dfdx = np.pi * np.cos(np.pi * S[:, 0]) * np.cos(np.pi * S[:, 1])
     assert np.abs(fi.cpu().numpy()[inner, 1] - dfdx[inner]).max() < 5e-3        # truncation error of the order-2 model at this spacing
+
+
+def test_derivatives_robust_to_noise(wlsqm):
+    """Scenarios of the reference's tests/test_noise_robustness.py:25-106: 1 % Gaussian noise on 200 samples of a linear
+    (order-1 fit) and of a quadratic (order-2 fit) function; the gradient at the origin comes out within 0.02 / 0.05."""
+    rng = np.random.default_rng(42)
+    xk = rng.uniform(-1.0, 1.0, size=(200, 2))
+    fk = 2.0 * xk[:, 0] + 3.0 * xk[:, 1] + rng.normal(0.0, 0.01, 200)
+    fi = np.zeros(wlsqm.number_of_dofs(2, 1))
+    wlsqm.fit_2D(xk=xk, fk=fk, xi=np.array([0.0, 0.0]), fi=fi, sens=None, do_sens=False, order=1, knowns=0,
+                 weighting_method=wlsqm.WEIGHT_UNIFORM, debug=False)
+    assert abs(fi[wlsqm.i2_X] - 2.0) < 0.02 and abs(fi[wlsqm.i2_Y] - 3.0) < 0.02 and abs(fi[wlsqm.i2_F]) < 0.02
+    fq = 1.0 + 2.0 * xk[:, 0] - 1.5 * xk[:, 1] + 0.5 * xk[:, 0] ** 2 + xk[:, 0] * xk[:, 1] - 0.25 * xk[:, 1] ** 2
+    fi = np.zeros(wlsqm.number_of_dofs(2, 2))
+    wlsqm.fit_2D(xk=xk, fk=fq + rng.normal(0.0, 0.01, 200), xi=np.array([0.0, 0.0]), fi=fi, sens=None, do_sens=False,
+                 order=2, knowns=0, weighting_method=wlsqm.WEIGHT_UNIFORM, debug=False)
+    assert abs(fi[wlsqm.i2_X] - 2.0) < 0.05 and abs(fi[wlsqm.i2_Y] + 1.5) < 0.05
+
+
+def test_parallel_variants_equal_serial_variants(wlsqm):
+    """fit_*D_many_parallel == fit_*D_many (reference tests/test_parallel.py:35-130; here both are the same launch)."""
+    rng = np.random.default_rng(42)
+    for dim in (1, 2):
+        n, K = 300, 12
+        xi = rng.uniform(-1, 1, (n, dim)); xk = xi[:, None, :] + 0.1 * rng.uniform(-1, 1, (n, K, dim))
+        fk = np.sin(xk[..., 0]) * (1.0 + xk[..., -1])
+        args = dict(nk=np.full(n, K, np.int32), order=np.full(n, 2, np.int32), knowns=np.zeros(n, np.int64),
+                    weighting_method=np.full(n, wlsqm.WEIGHT_UNIFORM, np.int32), sens=None, do_sens=False)
+        if dim == 1:
+            xi, xk = np.ascontiguousarray(xi[:, 0]), np.ascontiguousarray(xk[..., 0])
+        no = wlsqm.number_of_dofs(dim, 2)
+        a, b = np.zeros((n, no)), np.zeros((n, no))
+        getattr(wlsqm, "fit_%dD_many" % dim)(xk=xk, fk=fk, xi=xi, fi=a, **args)
+        getattr(wlsqm, "fit_%dD_many_parallel" % dim)(xk=xk, fk=fk, xi=xi, fi=b, ntasks=4, **args)
+        assert np.array_equal(a, b) and np.isfinite(a).all()
