@@ -26,7 +26,8 @@
 //     (-12 %): both cost a resident workgroup; expanding the moments from LDS in wave 0 (-5 %); bringing the NEXT tile's
 //     xk in by LDS-DMA (global_load_lds_dwordx4 into a two-tile ring, rows rotated on the source side for conflict-free
 //     reads, next tile's fk and scalars in a second register set; git history: fit_glds.hip): 0.193 vs 0.177 ms — the
-//     second register set costs the third wave per SIMD, and at this occupancy the other waves already hide the wait.
+//     second register set costs the third wave per SIMD, and at this occupancy the other waves already hide the wait;
+//     non-temporal loads (__builtin_nontemporal_load) for the streamed-once xk / fk: -2..-3 % on C2, C5 and C3.
 #include <cstdlib>
 
 #include "wlsqm_internal.hpp"
