@@ -305,12 +305,17 @@ def cpu_baseline(oracle, cfg, xk_d, fk_d, xi_d, F, n, no):
             best = max(best, ns / dt); reps += 1
             if (reps >= 3 and time.perf_counter() - t_all > budget_s) or reps >= 20:
                 return best, reps
-    best, reps = rate(cores, 5.0)
-    best8, reps8 = rate(min(8, cores), 5.0)       # the thread count the reference was timed with
-    return {"value": best, "unit": "fits/s", "cores": cores, "kind": "port",
-            "sample": "%d cases of the same workload, best of %d passes, OpenMP static schedule over %d threads"
-                      % (ns, reps, cores),
-            "value_8_threads": best8}
+    # The restated algorithm keeps the reference's four malloc/free per case (lapackdrivers.pyx:557-560), which stops scaling
+    # long before a 256-thread host is full: time a ladder of team sizes and report the best one as the baseline.
+    ladder = sorted({t for t in (8, 16, 32, 64, 128, cores) if t <= cores})
+    rates = {}
+    for t in ladder:
+        rates[t], _ = rate(t, 2.5)
+    best_t = max(rates, key=rates.get)
+    return {"value": rates[best_t], "unit": "fits/s", "cores": best_t, "kind": "port",
+            "sample": "%d cases of the same workload, best pass per team size, OpenMP static schedule; team sizes tried: %s "
+                      "(host has %d hardware threads)" % (ns, ", ".join("%d: %.3g" % (t, rates[t]) for t in ladder), cores),
+            "value_8_threads": rates.get(8, rates[ladder[0]]), "value_all_threads": rates[cores]}
 
 
 if __name__ == "__main__":
