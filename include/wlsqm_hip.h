@@ -138,6 +138,11 @@ int wlsqm_hip_expert_solve_device(wlsqm_expert* h, void* stream, const double* f
  * wlsqm_hip_fit_cloud_device.  Exact (uniform-grid search with a provable stop test).  1 <= k <= min(npoints - 1, 213).
  * Synchronises `stream` before returning. */
 int wlsqm_hip_knn_device(int dimension, int64_t npoints, const double* S, int k, int32_t* hoods, int device, void* stream);
+/* Extension: the radius form of the same search (examples/wlsqm_example.py:103-133: query_ball_point(x, r), at most
+ * max_nk neighbours kept).  For every point the other points within `radius`, nearest first, at most max_nk of them:
+ * hoods[npoints, max_nk] (int32; unused slots hold the point's own index) and nk[npoints] (int32, the counts). */
+int wlsqm_hip_ball_device(int dimension, int64_t npoints, const double* S, double radius, int max_nk,
+                          int32_t* hoods, int32_t* nk, int device, void* stream);
 
 /* Extension (no reference counterpart; BASELINE config 4 "prepare once + 256 RHS solves"): nrhs fields on the prepared
  * geometry in one call.  Equivalent to nrhs calls of expert.pyx:467-655 solve() with ALGO_BASIC and no sensitivities,

@@ -90,7 +90,8 @@ __global__ void knn_gather_kernel(const double* __restrict__ S, const int* __res
 template <int DIM>
 __global__ __launch_bounds__(64) void knn_query_kernel(const double* __restrict__ Ss, const int* __restrict__ perm,
                                                       const int* __restrict__ start, long long n, int k, KnnGrid G,
-                                                      int* __restrict__ hoods) {
+                                                      double r2max, int row_stride, int* __restrict__ hoods,
+                                                      int* __restrict__ counts) {
     extern __shared__ __attribute__((aligned(8))) unsigned char smem[];
     double* bd = reinterpret_cast<double*>(smem) + threadIdx.x;                       // [k][64] best squared distances
     int* bi = reinterpret_cast<int*>(smem + (size_t)k * 64 * sizeof(double)) + threadIdx.x;   // [k][64] their sorted positions
@@ -130,6 +131,7 @@ __global__ __launch_bounds__(64) void knn_query_kernel(const double* __restrict_
                         double d2 = 0.0;
 #pragma unroll
                         for (int m = 0; m < DIM; ++m) { const double d = Ss[(long long)pos * DIM + m] - x[m]; d2 += d * d; }
+                        if (d2 > r2max) continue;                                      // ball search: outside the radius
                         if (count < k) {
                             bd[count * 64] = d2; bi[count * 64] = pos;
                             if (d2 > worst) { worst = d2; worst_slot = count; }
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(64) void knn_query_kernel(const double* __restrict_
                 }
             }
         }
-        if (count == k) {
+        {
             // every unvisited point lies outside the block of cells [cq - r, cq + r]: at least `reach` away
             double reach = DBL_MAX;
 #pragma unroll
@@ -152,11 +154,15 @@ __global__ __launch_bounds__(64) void knn_query_kernel(const double* __restrict_
                 if (cq[m] - r > 0) reach = fmin(reach, x[m] - (G.lo[m] + (cq[m] - r) * G.cell[m]) - 1e-9 * G.cell[m]);
                 if (cq[m] + r < G.g[m] - 1) reach = fmin(reach, (G.lo[m] + (cq[m] + r + 1) * G.cell[m]) - x[m] - 1e-9 * G.cell[m]);
             }
-            if (reach == DBL_MAX || (reach > 0.0 && worst <= reach * reach)) break;
+            if (reach == DBL_MAX) break;                                   // the whole grid has been visited
+            if (reach > 0.0 && ((count == k && worst <= reach * reach) || reach * reach > r2max)) break;
         }
     }
     // ascending (distance, original index): selection sort in place, then map sorted positions to point indices
-    const long long row = (long long)perm[q] * k;
+    const int self = perm[q];
+    const long long row = (long long)self * row_stride;
+    if (counts) counts[self] = count;
+    for (int i = count; i < row_stride; ++i) hoods[row + i] = self;       // unused slots: a valid index, masked by the count
     for (int i = 0; i < count; ++i) bi[i * 64] = perm[bi[i * 64]];
     for (int i = 0; i < count; ++i) {
         int best = i; double bdv = bd[i * 64]; int bidx = bi[i * 64];
@@ -173,8 +179,9 @@ __global__ __launch_bounds__(64) void knn_query_kernel(const double* __restrict_
 
 using namespace wlsqm;
 
-extern "C" int wlsqm_hip_knn_device(int dimension, int64_t npoints, const double* S, int k, int32_t* hoods, int device,
-                                    void* stream_) {
+// k nearest other points within squared distance r2max of every point; row_stride slots per row of hoods
+static int neighbour_search(int dimension, int64_t npoints, const double* S, int k, double r2max, int row_stride,
+                            int32_t* hoods, int32_t* counts, int device, void* stream_) {
     if (dimension < 1 || dimension > 3) { set_error("dimension must be 1, 2 or 3"); return WLSQM_EVALUE; }
     if (!S || !hoods) { set_error("null array"); return WLSQM_EVALUE; }
     if (k < 1 || npoints < 2 || (int64_t)k > npoints - 1) { set_error("k must be in 1 .. npoints - 1"); return WLSQM_EVALUE; }
@@ -243,11 +250,25 @@ extern "C" int wlsqm_hip_knn_device(int dimension, int64_t npoints, const double
         auto kern = knn_query_kernel<D>;                                                                                \
         if (lds > 64 * 1024)                                                                                            \
             WLSQM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL(kern, dim3(qblocks), dim3(64), lds, s, d_Ss.as<double>(), d_perm.as<int>(), d_start.as<int>(), n, k, G, hoods); \
+        hipLaunchKernelGGL(kern, dim3(qblocks), dim3(64), lds, s, d_Ss.as<double>(), d_perm.as<int>(), d_start.as<int>(), n, k, G, \
+                           r2max, row_stride, hoods, counts);                                                                 \
     }
     if (dimension == 1) KNN_LAUNCH(1) else if (dimension == 2) KNN_LAUNCH(2) else KNN_LAUNCH(3)
 #undef KNN_LAUNCH
     WLSQM_HIP_CHECK(hipGetLastError());
     WLSQM_HIP_CHECK(hipStreamSynchronize(s));      // the temporaries above are freed on return
     return WLSQM_OK;
+}
+
+extern "C" int wlsqm_hip_knn_device(int dimension, int64_t npoints, const double* S, int k, int32_t* hoods, int device,
+                                    void* stream) {
+    return neighbour_search(dimension, npoints, S, k, DBL_MAX, k, hoods, nullptr, device, stream);
+}
+
+extern "C" int wlsqm_hip_ball_device(int dimension, int64_t npoints, const double* S, double radius, int max_nk,
+                                     int32_t* hoods, int32_t* nk, int device, void* stream) {
+    if (!(radius > 0.0)) { set_error("radius must be positive"); return WLSQM_EVALUE; }
+    if (max_nk < 1 || !nk) { set_error("max_nk must be >= 1 and nk non-null"); return WLSQM_EVALUE; }
+    const int k = (int)std::min<int64_t>(max_nk, npoints - 1);
+    return neighbour_search(dimension, npoints, S, k, radius * radius, max_nk, hoods, nk, device, stream);
 }

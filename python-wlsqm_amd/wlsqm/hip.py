@@ -10,7 +10,7 @@ import ctypes as C
 
 from . import _binding as B
 
-__all__ = ["fit_many_device", "time_fit_device", "fit_cloud_device", "time_fit_cloud_device", "device_count", "knn"]
+__all__ = ["fit_many_device", "time_fit_device", "fit_cloud_device", "time_fit_cloud_device", "device_count", "knn", "ball"]
 
 
 def device_count():
@@ -167,3 +167,23 @@ def knn(S, k, stream=None):
     s, dev = _stream_and_device(S, stream)
     B.check(B.lib().wlsqm_hip_knn_device(dim, n, _ptr(S), int(k), _ptr(hoods), dev, s))
     return hoods
+
+
+def ball(S, radius, max_nk, stream=None):
+    """All OTHER points within `radius` of every point of the device-resident cloud S, nearest first, at most max_nk of
+    them: returns (hoods, nk) = int32 device tensors (npoints, max_nk) and (npoints,).  The radius form of knn(): what
+    the reference's examples/wlsqm_example.py:103-133 builds with ``cKDTree.query_ball_point`` (unused slots of a row
+    hold the point's own index, so the rows stay valid for fit_cloud_device with the returned nk)."""
+    import torch
+    dim = 1 if S.dim() == 1 else int(S.shape[1])
+    if S.dim() not in (1, 2) or not 1 <= dim <= 3:
+        raise ValueError("S must be (npoints,) or (npoints, dim) with dim 1..3")
+    _check(S, "S", "float64", S.dim())
+    if not S.is_contiguous():
+        raise ValueError("S must be contiguous")
+    n = int(S.shape[0])
+    hoods = torch.empty((n, int(max_nk)), dtype=torch.int32, device=S.device)
+    nk = torch.empty((n,), dtype=torch.int32, device=S.device)
+    s, dev = _stream_and_device(S, stream)
+    B.check(B.lib().wlsqm_hip_ball_device(dim, n, _ptr(S), float(radius), int(max_nk), _ptr(hoods), _ptr(nk), dev, s))
+    return hoods, nk

@@ -837,3 +837,35 @@ def test_parallel_variants_equal_serial_variants(wlsqm):
         getattr(wlsqm, "fit_%dD_many" % dim)(xk=xk, fk=fk, xi=xi, fi=a, **args)
         getattr(wlsqm, "fit_%dD_many_parallel" % dim)(xk=xk, fk=fk, xi=xi, fi=b, ntasks=4, **args)
         assert np.array_equal(a, b) and np.isfinite(a).all()
+
+
+@pytest.mark.parametrize("dim,n,r,max_nk", [(2, 20_000, 0.02, 60), (2, 20_000, 0.02, 12), (3, 15_000, 0.08, 100), (1, 5_000, 0.003, 40)])
+def test_gpu_ball_search_equals_ckdtree(wlsqm, dim, n, r, max_nk):
+    """wlsqm.hip.ball (radius search on the GPU) against cKDTree.query_ball_point, the neighbourhood construction of the
+    reference's examples/wlsqm_example.py:103-133: same members where a ball holds at most max_nk points, the nearest
+    max_nk otherwise; rows sorted by distance; unused slots hold the point's own index."""
+    import torch
+    import wlsqm.hip as whip
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(dim * 7 + max_nk)
+    S = rng.uniform(0, 1, (n, dim)) if dim > 1 else np.sort(rng.uniform(0, 1, n))
+    X = S if S.ndim == 2 else S[:, None]
+    hoods, nk = whip.ball(torch.from_numpy(np.ascontiguousarray(S)).cuda(), r, max_nk)
+    hoods, nk = hoods.cpu().numpy(), nk.cpu().numpy()
+    ref = cKDTree(X).query_ball_point(X, r)
+    assert hoods.shape == (n, max_nk) and nk.shape == (n,)
+    truncated = 0
+    for j in range(n):
+        want = [i for i in ref[j] if i != j]
+        got = hoods[j, :nk[j]]
+        d = np.sqrt(((X[got] - X[j]) ** 2).sum(-1))
+        assert np.all(np.diff(d) >= 0) and (d <= r * (1 + 1e-14)).all()
+        assert (hoods[j, nk[j]:] == j).all()
+        if len(want) <= max_nk:
+            assert nk[j] == len(want) and set(got) == set(want), j
+        else:
+            truncated += 1
+            dw = np.sort(np.sqrt(((X[want] - X[j]) ** 2).sum(-1)))[:max_nk]
+            assert nk[j] == max_nk and np.allclose(d, dw, rtol=1e-14, atol=0)
+    if max_nk == 12:
+        assert truncated > 0          # this parametrisation is meant to exercise the truncation
