@@ -268,7 +268,7 @@ __global__ __launch_bounds__(WV * KSPLIT, MINW) void fit_tile_kernel(const KPara
 #pragma unroll
                 for (int m = 0; m < DIM; ++m) d2 += d[m] * d[m];
                 const double w = live ? weight(d2, inv_max, uniform) : 0.0;
-                accumulate_moments<DIM, ORDER>(A, g, d, w, f);
+                accumulate_moments_best<DIM, ORDER>(A, g, d, w, f);
             } else {
                 double cc[NO];
                 const double d2 = monomials<DIM, ORDER>(d, cc);

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(KNT, 2) void fit_tilek_kernel(const KParams p, cons
                 double d2 = 0.0;
 #pragma unroll
                 for (int m = 0; m < DIM; ++m) d2 += d[m] * d[m];
-                accumulate_moments<DIM, ORDER>(A, g, d, weight(d2, inv_max, uniform), fr[k]);
+                accumulate_moments_best<DIM, ORDER>(A, g, d, weight(d2, inv_max, uniform), fr[k]);
             } else {
                 double cc[NO];
                 const double d2 = monomials<DIM, ORDER>(d, cc);
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(KW, 2) void fit_tile1_kernel(const KParams p, const
                     double d2 = 0.0;
 #pragma unroll
                     for (int m = 0; m < DIM; ++m) d2 += d[m] * d[m];
-                    accumulate_moments<DIM, ORDER>(A, g, d, live ? weight(d2, inv_max, uniform) : 0.0, f);
+                    accumulate_moments_best<DIM, ORDER>(A, g, d, live ? weight(d2, inv_max, uniform) : 0.0, f);
                 } else {
                     double cc[NO];
                     const double d2 = monomials<DIM, ORDER>(d, cc);

@@ -71,6 +71,44 @@ __device__ __forceinline__ void accumulate_moments(double (&mu)[mom_count<DIM>(2
     }
 }
 
+// 2D alternative: outer-product form.  With X[p] = dx^p and Yw[q] = w dy^q every moment is ONE fma,
+// mu(p,q) += X[p] * Yw[q], and nu(p,q) += X[p] * (f Yw[q]); the chain form above spends a multiply AND an add on every
+// monomial below the top degree.  Operations per neighbour, order 4: 45 + 15 fma + 21 multiplies = 81 against 96;
+// order 2: 31 against 30 (no gain: used from order 3 up, see accumulate_moments_best).
+template <int ORDER>
+__device__ __forceinline__ void accumulate_moments_outer2d(double (&mu)[mom_count<2>(2 * ORDER)], double (&nu)[mom_count<2>(ORDER)],
+                                                           const double (&d)[2], double w, double f) {
+    constexpr int D = 2 * ORDER;
+    double X[D + 1], Yw[D + 1], Yf[ORDER + 1];
+    X[1] = d[0];
+#pragma unroll
+    for (int p = 2; p <= D; ++p) X[p] = X[p - 1] * d[0];
+    Yw[0] = w;
+#pragma unroll
+    for (int q = 1; q <= D; ++q) Yw[q] = Yw[q - 1] * d[1];
+#pragma unroll
+    for (int q = 0; q <= ORDER; ++q) Yf[q] = Yw[q] * f;
+#pragma unroll
+    for (int deg = 0; deg <= D; ++deg) {
+#pragma unroll
+        for (int q = 0; q <= deg; ++q) {
+            const int p = deg - q, i = mtri(deg) + q;
+            if (p == 0) { mu[i] += Yw[q]; if (deg <= ORDER) nu[i] += Yf[q]; }
+            else { mu[i] = fma(X[p], Yw[q], mu[i]); if (deg <= ORDER) nu[i] = fma(X[p], Yf[q], nu[i]); }
+        }
+    }
+}
+
+// The cheaper of the two forms for (DIM, ORDER).
+template <int DIM, int ORDER>
+__device__ __forceinline__ void accumulate_moments_best(double (&mu)[mom_count<DIM>(2 * ORDER)], double (&nu)[mom_count<DIM>(ORDER)],
+                                                        const double (&d)[DIM], double w, double f) {
+#ifndef WLSQM_NO_OUTER_MOMENTS
+    if constexpr (DIM == 2 && ORDER >= 3) { accumulate_moments_outer2d<ORDER>(mu, nu, d, w, f); return; }
+#endif
+    accumulate_moments<DIM, ORDER>(mu, nu, d, w, f);
+}
+
 // Expand the packed upper triangle of M and the right-hand side g (DOF order) from the moments.
 // `mu_at(i)` / `nu_at(i)` deliver moment i (graded index); each is asked for exactly once, in ascending order,
 // so a caller may fetch (and sum) them from LDS on demand and never hold the whole moment vector in registers.
