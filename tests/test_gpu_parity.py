@@ -869,3 +869,37 @@ def test_gpu_ball_search_equals_ckdtree(wlsqm, dim, n, r, max_nk):
             assert nk[j] == max_nk and np.allclose(d, dw, rtol=1e-14, atol=0)
     if max_nk == 12:
         assert truncated > 0          # this parametrisation is meant to exercise the truncation
+
+
+@pytest.mark.parametrize("dim,order,K", [(2, 2, 32), (2, 4, 64), (3, 2, 40), (3, 4, 64), (1, 4, 12), (2, 3, 30)])
+@pytest.mark.parametrize("scale", [1e-6, 1e4])
+def test_fit_is_invariant_to_the_length_scale(wlsqm, dim, order, K, scale):
+    """The reference equilibrates every matrix (Ruiz scaling) before a pivoted LU; the GPU path factors the unscaled
+    normal matrix with an unpivoted LDL^T, which is scale-invariant by construction.  Check it: the same cloud with all
+    coordinates multiplied by `scale` gives the same DOFs up to the exact factors scale^-|P| (and the moment form's
+    powers dx^p, up to p = 8, stay far from overflow and underflow)."""
+    rng = np.random.default_rng(int(100 * dim + order))
+    n = 400
+    no = K_.NDOF[dim][order]
+    xi = rng.uniform(0, 1, (n, dim))
+    xk = xi[:, None, :] + 0.05 * rng.uniform(-1, 1, (n, K, dim))
+    fk = np.sin(3 * xk[..., 0]) * np.cos(2 * xk[..., -1]) + xk[..., 0] ** 2
+    nk = np.full(n, K, np.int32); orders = np.full(n, order, np.int32)
+    knowns = np.zeros(n, np.int64); wm = np.full(n, wlsqm.WEIGHT_CENTER, np.int32)
+    def run(s):
+        a, b = xk * s, xi * s
+        if dim == 1:
+            a, b = np.ascontiguousarray(a[..., 0]), np.ascontiguousarray(b[:, 0])
+        fi = np.zeros((n, no))
+        _many(wlsqm, dim)(a, fk, nk, b, fi, None, 0, orders, knowns, wm)
+        return fi
+    base, scaled = run(1.0), run(scale)
+    ex = P.exponents(dim, order)
+    for a, e in enumerate(ex):
+        back = scaled[:, a] * scale ** sum(e)
+        ref = np.abs(base[:, a]).max()
+        assert np.isfinite(back).all()
+        # rounding differs between the two runs; it is amplified by the conditioning of the local systems (35 unknowns from
+        # 64 neighbours in 3D order 4 is the worst here)
+        tol = 1e-7 * 10.0 ** max(0, order - 2) * (10.0 if dim == 3 else 1.0)
+        assert np.abs(back - base[:, a]).max() <= tol * ref, (e, np.abs(back - base[:, a]).max() / ref)
