@@ -27,7 +27,9 @@
 //     xk in by LDS-DMA (global_load_lds_dwordx4 into a two-tile ring, rows rotated on the source side for conflict-free
 //     reads, next tile's fk and scalars in a second register set; git history: fit_glds.hip): 0.193 vs 0.177 ms — the
 //     second register set costs the third wave per SIMD, and at this occupancy the other waves already hide the wait;
-//     non-temporal loads (__builtin_nontemporal_load) for the streamed-once xk / fk: -2..-3 % on C2, C5 and C3.
+//     non-temporal loads (__builtin_nontemporal_load) for the streamed-once xk / fk: -2..-3 % on C2, C5 and C3;
+//     XCD-aware tile order for the index-based path (each XCD's workgroups stride through one contiguous eighth of the
+//     tiles, so that the point rows shared by neighbouring tiles meet in one L2): +1 %, inside the noise — left out.
 #include <cstdlib>
 
 #include "wlsqm_internal.hpp"
