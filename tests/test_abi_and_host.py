@@ -171,3 +171,21 @@ def test_package_surface_matches_the_reference():
     nr, o2r, r2o = infra.remap(6, 0b010010)
     assert nr == 4 and o2r.tolist() == [0, -1, 1, 2, -1, 3] and r2o.tolist() == [0, 2, 3, 5, -1, -1]
     assert infra.number_of_reduced_dofs(6, 0b010010) == 4
+
+
+def test_product_never_touches_the_oracle_or_the_reference():
+    """The oracle is test infrastructure: nothing under python-wlsqm_amd/ or include/ (the product) may mention it, and
+    nothing there may read the reference tree at run time."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bad = []
+    for top in ("python-wlsqm_amd", "include"):
+        for d, _, files in os.walk(os.path.join(root, top)):
+            if "build" in d.split(os.sep) or "__pycache__" in d:
+                continue
+            for f in files:
+                if f.endswith((".py", ".hip", ".hpp", ".h", ".sh")):
+                    text = open(os.path.join(d, f), errors="replace").read()
+                    if "oracle" in text.lower() or "/root/reference" in text:
+                        bad.append(os.path.join(d, f))
+    assert not bad, bad
