@@ -183,7 +183,9 @@ __global__ __launch_bounds__(KNT, 2) void fit_tilek_kernel(const KParams p, cons
 // memory into registers (they are consumed late, after the distance pass, so their latency is hidden), the four lanes
 // of a case meet through wave shuffles, and nothing needs a barrier between waves.  Measured on the benchmark shapes
 // (fit_tile.hip) this shape beats four waves per 64-case tile by 7 % (C2) and 38 % (C5).
-// FMAX: compile-time bound of the neighbours per lane (8 for K <= 32, 16 for K <= 64)
+// FMAX: compile-time bound of the neighbours per lane (8 for K <= 32, 16 for K <= 64).  Every iteration sits under its own
+//   wave-uniform `kk < KPL` branch; grouping four iterations per branch (straight-line code for the scheduler) was measured
+//   and rejected: the extra scheduling freedom costs 40 VGPRs and a wave per SIMD (C2 at K = 32: 0.247 vs 0.221 ms).
 // EXTRAS: sensitivities (impl.pyx:776-778, 821-846) and iterative refinement (impl.pyx:986-1083) on the same tile.  After
 //   the shuffle butterfly the four lanes of a case hold bit-identical sums (fp addition commutes), so each of them
 //   factors the matrix for itself at no extra cost (the instructions run for the whole wave anyway) and then handles
