@@ -190,3 +190,22 @@ def test_product_never_touches_the_oracle_or_the_reference():
                     if "oracle" in text.lower() or (f.endswith((".py", ".sh")) and "/root/reference" in text):
                         bad.append(os.path.join(d, f))
     assert not bad, bad
+
+
+def _build_c_example(tmp_path):
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "python-wlsqm_amd", "wlsqm", "_lib")
+    exe = str(tmp_path / "fit_quadratic")
+    subprocess.check_call(["gcc", "-O2", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "c", "fit_quadratic.c"),
+                           "-o", exe, "-L", lib, "-lwlsqm_hip", "-Wl,-rpath," + lib, "-lm"])
+    return exe
+
+
+def test_c_abi_links_from_plain_c(tmp_path):
+    """include/wlsqm_hip.h is a real C header and the library a real C ABI: examples/c/fit_quadratic.c compiles with gcc
+    and links against libwlsqm_hip.so (on a machine without a GPU it then reports 'no HIP device' and exits with 2)."""
+    import subprocess
+    exe = _build_c_example(tmp_path)
+    rc = subprocess.call([exe])
+    assert rc in (0, 2)

@@ -903,3 +903,12 @@ def test_fit_is_invariant_to_the_length_scale(wlsqm, dim, order, K, scale):
         # 64 neighbours in 3D order 4 is the worst here)
         tol = 1e-7 * 10.0 ** max(0, order - 2) * (10.0 if dim == 3 else 1.0)
         assert np.abs(back - base[:, a]).max() <= tol * ref, (e, np.abs(back - base[:, a]).max() / ref)
+
+
+def test_c_abi_example_runs_from_plain_c(wlsqm, tmp_path):
+    """examples/c/fit_quadratic.c (plain C, no Python, no torch): 1000 quadratic fits through wlsqm_hip_fit_many_host."""
+    import subprocess
+    from test_abi_and_host import _build_c_example
+    out = subprocess.run([_build_c_example(tmp_path)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "max |error|" in out.stdout
