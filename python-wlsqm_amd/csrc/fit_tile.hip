@@ -29,7 +29,10 @@
 //     second register set costs the third wave per SIMD, and at this occupancy the other waves already hide the wait;
 //     non-temporal loads (__builtin_nontemporal_load) for the streamed-once xk / fk: -2..-3 % on C2, C5 and C3;
 //     XCD-aware tile order for the index-based path (each XCD's workgroups stride through one contiguous eighth of the
-//     tiles, so that the point rows shared by neighbouring tiles meet in one L2): +1 %, inside the noise — left out.
+//     tiles, so that the point rows shared by neighbouring tiles meet in one L2): +1 %, inside the noise — left out;
+//     squeezing C5 into 168 VGPRs for a third wave per SIMD (solving lane parks its moments in LDS and expands from
+//     there; unroll 1-5): 320 B of spills remain (45 accumulators + chain temporaries + 10 fk values) and the kernel
+//     runs 2.4x slower; the same for C2 at 128 VGPRs (four waves): -15 %.
 #include <cstdlib>
 
 #include "wlsqm_internal.hpp"
