@@ -99,6 +99,35 @@ class ExpertSolver:
         except Exception:
             pass
 
+    # ---- persistence (extension: copying / pickling are on the reference's TODO list).  The device-side state is a
+    # function of the constructor arguments and of the geometry handed to prepare(), both of which the object keeps, so a
+    # copy or an unpickled solver is rebuilt from them; the fitted coefficients of the last solve() are not carried over.
+    def __getstate__(self):
+        return dict(dimension=self.dimension, nk=np.asarray(self.nk), order=np.asarray(self.order),
+                    knowns=np.asarray(self.knowns), weighting_method=np.asarray(self.weighting_method),
+                    algorithm=self.algorithm, do_sens=self.do_sens, max_iter=self.max_iter, ntasks=self.ntasks,
+                    debug=self.debug, host=self.host, ready=self.ready,
+                    xi=None if self.xi is None else np.asarray(self.xi), xk=None if self.xk is None else np.asarray(self.xk))
+
+    def __setstate__(self, st):
+        ready, xi, xk = st.pop("ready"), st.pop("xi"), st.pop("xk")
+        self.__init__(**st)
+        if ready:
+            self.prepare(xi=xi, xk=xk)
+
+    def __copy__(self):
+        new = ExpertSolver.__new__(ExpertSolver)
+        new.__setstate__(self.__getstate__())
+        return new
+
+    def __deepcopy__(self, memo):
+        import copy
+        st = self.__getstate__()
+        st["host"] = copy.deepcopy(st["host"], memo)
+        new = ExpertSolver.__new__(ExpertSolver)
+        new.__setstate__(st)
+        return new
+
     def memory_used(self):
         """(bytes in use, bytes reserved) of the device-side state (expert.pyx:289-306)."""
         used, total = C.c_int64(0), C.c_int64(0)

@@ -912,3 +912,28 @@ def test_c_abi_example_runs_from_plain_c(wlsqm, tmp_path):
     out = subprocess.run([_build_c_example(tmp_path)], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "max |error|" in out.stdout
+
+
+def test_expert_solver_copy_and_pickle(wlsqm):
+    """Extension (copy / pickle are on the reference's TODO list): a pickled or copied prepared solver comes back prepared
+    and gives bit-identical fits; a pickled guest brings its host along."""
+    import copy, pickle
+    c = K.config("C2")
+    s = wlsqm.ExpertSolver(dimension=c["dim"], nk=c["nk_a"], order=c["order_a"], knowns=c["knowns_a"],
+                           weighting_method=c["wm_a"])
+    s2 = pickle.loads(pickle.dumps(s))
+    assert not s2.ready                                            # unprepared stays unprepared
+    s.prepare(xi=c["xi"], xk=c["xk"])
+    fi = c["fi0"].copy(); s.solve(fk=c["fk"], fi=fi)
+    for clone in (pickle.loads(pickle.dumps(s)), copy.copy(s), copy.deepcopy(s)):
+        assert clone.ready and clone is not s
+        fi2 = c["fi0"].copy(); clone.solve(fk=c["fk"], fi=fi2)
+        assert np.array_equal(fi, fi2)
+        clone.close()
+    guest = wlsqm.ExpertSolver(dimension=c["dim"], nk=c["nk_a"], order=c["order_a"], knowns=c["knowns_a"],
+                               weighting_method=c["wm_a"], host=s)
+    guest.prepare(xi=None, xk=None)
+    g2 = pickle.loads(pickle.dumps(guest))
+    assert g2.ready and g2.host is not None and g2.host is not s and g2.host.ready
+    fi3 = c["fi0"].copy(); g2.solve(fk=c["fk"], fi=fi3)
+    assert np.array_equal(fi, fi3)
