@@ -98,7 +98,7 @@ int wlsqm_hip_fit_many_device(const wlsqm_batch* b, int device, void* stream, in
  * F[npoints] through hoods[ncases, max_nk] (int32), which cuts the algorithmic HBM bytes per fit from
  * 8 nk (dim+1) to 4 nk.  xi of case j is S[point_index ? point_index[j] : j].  All cases have polynomial order
  * `order`; nk / knowns / weighting_method are per-case device arrays (unit stride); fi is in/out as usual.
- * Supported for systems with no <= 15 DOFs (everything except 3D order 3/4). */
+ * Every (dimension, order); with sensitivities or refinement only systems with no <= 15 DOFs (not 3D order 3/4). */
 int wlsqm_hip_fit_cloud_device(int dimension, int order, int64_t ncases, int64_t max_nk,
                                const double* S, const double* F, const int32_t* hoods, int64_t hoods_stride_case,
                                const int32_t* point_index, const int32_t* nk, const int64_t* knowns,

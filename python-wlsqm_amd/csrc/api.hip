@@ -39,7 +39,10 @@ int launch_fit(int dimension, int order, const KParams& p, long long max_nk, hip
     const int no = wlsqm_hip_number_of_dofs(dimension, order);
     if (no < 0) { set_error("bad dimension/order"); return WLSQM_EVALUE; }
     if (p.ncases <= 0) return WLSQM_OK;
-    if (p.hoods && no > 15) { set_error("the index-based path supports systems with at most 15 DOFs"); return WLSQM_EVALUE; }
+    if (p.hoods && no > 15 && (p.do_sens || p.iterative)) {
+        set_error("index-based input with sensitivities or refinement supports systems with at most 15 DOFs");
+        return WLSQM_EVALUE;
+    }
     bool handled = false;
     int rc = launch_fit_moment(dimension, order, p, max_nk, stream, &handled);
     if (rc != WLSQM_OK || handled) return rc;

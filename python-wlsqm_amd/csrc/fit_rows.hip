@@ -56,11 +56,18 @@ __global__ __launch_bounds__(RW) void fit_rows_kernel(const KParams p) {
     constexpr unsigned long long FULL = (1ull << NO) - 1ull;
     if (known == FULL) return;                                    // nr < 1: no-op (impl.pyx:574, 636, 742); whole wave exits
 
+    // dense rows (xk / fk with strides) or index-based: rows hoods[j, k] of the point tables S / F
+    const int* hr = p.hoods ? p.hoods + j * p.shoods_j : nullptr;
+    const double* xr = hr ? nullptr : p.xk + j * p.sxk_j;
+    const double* fr = hr ? nullptr : p.fk + j * p.sfk_j;
+    auto coord = [&](int k, int m) { return hr ? p.S[(long long)hr[k] * DIM + m] : xr[k * p.sxk_k + m]; };
+    auto value = [&](int k) { return hr ? p.F[hr[k]] : fr[k * p.sfk_k]; };
     double xi[DIM];
+    {
+        const long long pj = hr ? (p.pidx ? (long long)p.pidx[j] : j) : 0;
 #pragma unroll
-    for (int m = 0; m < DIM; ++m) xi[m] = p.xi[j * p.sxi_j + m];
-    const double* xr = p.xk + j * p.sxk_j;
-    const double* fr = p.fk + j * p.sfk_j;
+        for (int m = 0; m < DIM; ++m) xi[m] = hr ? p.S[pj * DIM + m] : p.xi[j * p.sxi_j + m];
+    }
     double* fio = p.fi + j * p.sfi_j;
 
     // ---- per-lane bookkeeping: table offsets of this lane's moments and of its DOF
@@ -85,7 +92,7 @@ __global__ __launch_bounds__(RW) void fit_rows_kernel(const KParams p) {
         for (int k = lane; k < nk; k += RW) {
             double d2 = 0.0;
 #pragma unroll
-            for (int m = 0; m < DIM; ++m) { const double dd = xr[k * p.sxk_k + m] - xi[m]; d2 += dd * dd; }
+            for (int m = 0; m < DIM; ++m) { const double dd = coord(k, m) - xi[m]; d2 += dd * dd; }
             max_d2 = d2 > max_d2 ? d2 : max_d2;
         }
 #pragma unroll
@@ -103,7 +110,7 @@ __global__ __launch_bounds__(RW) void fit_rows_kernel(const KParams p) {
         if (lane < kc) {
             double d[DIM], d2 = 0.0;
 #pragma unroll
-            for (int m = 0; m < DIM; ++m) { d[m] = xr[(kb + lane) * p.sxk_k + m] - xi[m]; d2 += d[m] * d[m]; }
+            for (int m = 0; m < DIM; ++m) { d[m] = coord(kb + lane, m) - xi[m]; d2 += d[m] * d[m]; }
             double* row = sP + lane * TSP;
             double v = weight(d2, inv_max, uniform);
 #pragma unroll
@@ -112,7 +119,7 @@ __global__ __launch_bounds__(RW) void fit_rows_kernel(const KParams p) {
 #pragma unroll
                 for (int n = 0; n < NP; ++n) { row[m * NP + n] = v; v *= d[m]; }
             }
-            sF[lane] = fr[(kb + lane) * p.sfk_k];
+            sF[lane] = value(kb + lane);
         }
         __syncthreads();
         const double* tab = sP;
@@ -200,12 +207,12 @@ static int launch_rows(const KParams& p, hipStream_t stream) {
     return WLSQM_OK;
 }
 
-// Basic fit (no sensitivities, no refinement) of the 3D order-3/4 systems on dense (possibly strided) input.
+// Basic fit (no sensitivities, no refinement) of the 3D order-3/4 systems on dense (possibly strided) or index-based input.
 int launch_fit_rows(int dimension, int order, const KParams& p, hipStream_t stream, bool* handled) {
     *handled = false;
     const char* off = getenv("WLSQM_HIP_DISABLE_ROWS");          // A/B against fit_wave.hip
     if (off && off[0] == '1') return WLSQM_OK;
-    if (p.do_sens || p.iterative || p.hoods) return WLSQM_OK;
+    if (p.do_sens || p.iterative) return WLSQM_OK;
     if (dimension == 3 && order == 3) { *handled = true; return launch_rows<3, 3>(p, stream); }
     if (dimension == 3 && order == 4) { *handled = true; return launch_rows<3, 4>(p, stream); }
     return WLSQM_OK;

@@ -358,7 +358,8 @@ def test_expert_conds_vs_reference(wlsqm, name):
         s2.conds()                                                 # not in debug mode (expert.pyx:440-441)
 
 
-@pytest.mark.parametrize("dim,order,K,n", [(2, 2, 32, 3000), (3, 2, 40, 1500), (2, 4, 64, 700), (1, 2, 8, 999), (2, 3, 20, 500)])
+@pytest.mark.parametrize("dim,order,K,n", [(2, 2, 32, 3000), (3, 2, 40, 1500), (2, 4, 64, 700), (1, 2, 8, 999), (2, 3, 20, 500),
+                                           (3, 3, 40, 300), (3, 4, 64, 200)])
 def test_index_based_path_equals_dense_path(wlsqm, dim, order, K, n):
     """wlsqm.hip.fit_cloud_device (the kernels gather S[hoods], F[hoods] themselves) against the dense
     device-resident path on the gathered arrays: same arithmetic, so bit-identical; plus knowns and sens."""
@@ -397,6 +398,8 @@ def test_index_based_path_equals_dense_path(wlsqm, dim, order, K, n):
         P.assert_parity(fi_b.cpu().numpy(), fi_a.cpu().numpy(), truth, "index-based vs dense (moment) path")
     else:
         assert torch.equal(fi_a, fi_b)
+    if no > 15:
+        return                                   # 3D order 3/4: index-based input is for the basic fit only
     # extras (sensitivities + iterative refinement): the index-based launch takes the generic kernel, the dense one the
     # one-wave tile kernel with EXTRAS where it has an instantiation (no <= 10): equal to rounding there
     sens_a = torch.zeros((n, K, no), dtype=torch.float64, device=dev); sens_b = torch.zeros_like(sens_a)
