@@ -200,9 +200,11 @@ __global__ __launch_bounds__(KW, 2) void fit_tile1_kernel(const KParams p, const
     const int k0 = h * G.KPL;
 
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const long long j0 = tile * TC, j = j0 + c;
-        const bool valid = j < p.ncases;
-        const long long jc = valid ? j : p.ncases - 1;
+        // position in the launch -> case number: all cases in order, or the index list of an order bucket (p.case_index)
+        const long long j0 = tile * TC, pos = j0 + c;
+        const bool valid = pos < p.ncases;
+        const long long posc = valid ? pos : p.ncases - 1;
+        const long long jc = p.case_index ? p.case_index[posc] : posc, j = jc;
         const long long nvalid = (p.ncases - j0 < TC) ? (p.ncases - j0) : TC;
 
         const int nkc = min(p.nk[jc * p.snk], G.K);
@@ -217,7 +219,8 @@ __global__ __launch_bounds__(KW, 2) void fit_tile1_kernel(const KParams p, const
         double fdir[FMAX];
         tile1_load_f<FMAX>(fdir, p.fk + jc * (long long)G.K, k0, G);
         // ---- the tile's xk block: coalesced 16 B per lane, K1_ROUND loads in flight, parked in padded LDS rows
-        tile1_stage_x<DIM>(sX, p.xk + j0 * (long long)(G.K * DIM), nvalid, lane, G);
+        if (p.case_index) tile1_stage_x_indexed<DIM>(sX, p.xk, jc, nvalid, lane, G);
+        else tile1_stage_x<DIM>(sX, p.xk + j0 * (long long)(G.K * DIM), nvalid, lane, G);
         __syncthreads();
 
         const double* xr = sX + c * G.RS;
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(KW, 2) void fit_tile1_kernel(const KParams p, const
                 // neighbour 4*kk + h here) and leave as full-line stores of 8 B per lane.  Direct 8-byte stores from
                 // the owner lanes touch 64 lines per instruction and cost 0.73 ms per 1M C2 cases against 0.45 ms for
                 // everything else in this kernel.
-                const bool dense = p.ss_k == NO && p.ss_j == (long long)G.K * NO && !__any(dropped != 0);
+                const bool dense = p.ss_k == NO && p.ss_j == (long long)G.K * NO && !p.case_index && !__any(dropped != 0);
                 if (dense) {
                     constexpr int SL = 2, E = SL * K1_LPC * NO, CS = E + 1;      // elements per case and slab; padded stride
                     double* sS = lds + TC * G.RS;                                // [TC][CS]
@@ -519,7 +522,7 @@ int launch_fit_tilek(int dimension, int order, const KParams& p, long long K, hi
     *handled = false;
     const char* off = getenv("WLSQM_HIP_DISABLE_TILE");
     if (off && off[0] == '1') return WLSQM_OK;
-    if (p.case_index || p.hoods) return WLSQM_OK;
+    if (p.hoods) return WLSQM_OK;
     if (K < 4 || ((K * dimension) % 2) != 0) return WLSQM_OK;   // rows of xk are multiples of 16 bytes
     if (p.sxk_k != dimension || p.sxk_j != K * dimension || p.sfk_k != 1 || p.sfk_j != K) return WLSQM_OK;
     if ((reinterpret_cast<uintptr_t>(p.xk) | reinterpret_cast<uintptr_t>(p.fk)) & 15u) return WLSQM_OK;
@@ -543,7 +546,8 @@ int launch_fit_tilek(int dimension, int order, const KParams& p, long long K, hi
         return WLSQM_OK;
     }
     const char* sv = getenv("WLSQM_TILEK_SHAPE");
-    const bool can1 = K <= K1_LPC * K1_FMAX, can4 = (K % 2) == 0;       // the four-wave shape stages fk rows in 16-byte chunks
+    // the four-wave shape stages fk rows in 16-byte chunks and takes whole batches only (no index list)
+    const bool can1 = K <= K1_LPC * K1_FMAX, can4 = (K % 2) == 0 && !p.case_index;
     bool first1 = (dimension == 2 && order == 2) || (dimension == 3 && order == 1);
     if (sv && sv[0] == '1') first1 = true;
     if (sv && sv[0] == '4') first1 = false;

@@ -69,6 +69,37 @@ __device__ __forceinline__ void tile1_stage_x(double* sX, const double* gx0, lon
     }
 }
 
+// The same for a tile whose 16 cases are picked by an index list (order buckets of a heterogeneous batch): row r of the
+// tile is case `mycase` of lane r (every lane passes the case number of ITS row c = lane % 16; rows >= nvalid replay the last
+// valid one).  Each row is still one contiguous run of K*DIM doubles, so the loads stay 16 B per lane and line-sized.
+template <int DIM>
+__device__ __forceinline__ void tile1_stage_x_indexed(double* sX, const double* xk, long long mycase, long long nvalid, int lane,
+                                                      const Tile1Geom& G) {
+    const long long row_doubles = (long long)G.K * DIM;
+    for (int q0 = lane; q0 < G.XCH; q0 += K1_WV * K1_ROUND) {
+        k1d2_ b[K1_ROUND];
+#pragma unroll
+        for (int i = 0; i < K1_ROUND; ++i) {
+            const int q = min(q0 + i * K1_WV, G.XCH - 1);
+            int r = (int)(((float)q + 0.5f) * G.inv_cprx);
+            const int c2 = q - r * G.CPRX;
+            r = r < nvalid ? r : (int)nvalid - 1;
+            const long long src_case = __shfl(mycase, r, K1_WV);          // lane r holds row r's case number
+            b[i] = *reinterpret_cast<const k1d2_*>(xk + src_case * row_doubles + 2 * c2);
+        }
+#pragma unroll
+        for (int i = 0; i < K1_ROUND; ++i) {
+            const int q = q0 + i * K1_WV;
+            if (q < G.XCH) {
+                const int r = (int)(((float)q + 0.5f) * G.inv_cprx), c2 = q - r * G.CPRX;
+                double* d = sX + r * G.RS + 2 * c2;
+                if constexpr (DIM == 2) *reinterpret_cast<k1d2_*>(d) = b[i];
+                else { d[0] = b[i].x; d[1] = b[i].y; }
+            }
+        }
+    }
+}
+
 // Largest squared distance of the case (impl.pyx:389-391) over all four lanes; neighbours k >= nkc count as 0.
 template <int DIM, int FMAX>
 __device__ __forceinline__ double tile1_max_d2(const double* xr, const double (&xi)[DIM], int k0, int nkc, const Tile1Geom& G) {
