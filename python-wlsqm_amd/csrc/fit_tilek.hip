@@ -212,15 +212,35 @@ __global__ __launch_bounds__(KW, 2) void fit_tile1_kernel(const KParams p, const
         unsigned long long known, dropped;
         effective_mask<NO>(p.knowns[jc * p.sknowns], known, dropped);
         double xi[DIM];
-#pragma unroll
-        for (int m = 0; m < DIM; ++m) xi[m] = p.xi[jc * p.sxi_j + m];
-
-        // ---- this lane's fk values (clamped inside the row; slots beyond nk[j] are masked below)
         double fdir[FMAX];
-        tile1_load_f<FMAX>(fdir, p.fk + jc * (long long)G.K, k0, G);
-        // ---- the tile's xk block: coalesced 16 B per lane, K1_ROUND loads in flight, parked in padded LDS rows
-        if (p.case_index) tile1_stage_x_indexed<DIM>(sX, p.xk, jc, nvalid, lane, G);
-        else tile1_stage_x<DIM>(sX, p.xk + j0 * (long long)(G.K * DIM), nvalid, lane, G);
+        if (p.hoods) {
+            // ---- index-based input: this lane gathers ITS neighbours' rows of the point tables S / F through hoods[j, k]
+            // and parks the coordinates in the same padded LDS image the dense path builds (its own slots of row c)
+            const long long pj = p.pidx ? (long long)p.pidx[jc] : jc;
+#pragma unroll
+            for (int m = 0; m < DIM; ++m) xi[m] = p.S[pj * DIM + m];
+            const int* hr = p.hoods + jc * p.shoods_j;
+            double* row = sX + c * G.RS;
+#pragma unroll
+            for (int kk = 0; kk < FMAX; ++kk)
+                if (kk < G.KPL) {
+                    const int k = k0 + kk;
+                    const long long idx = hr[k < G.K ? k : G.K - 1];
+                    fdir[kk] = p.F[idx];
+                    if (k < G.K) {
+#pragma unroll
+                        for (int m = 0; m < DIM; ++m) row[k * DIM + m] = p.S[idx * DIM + m];
+                    }
+                }
+        } else {
+#pragma unroll
+            for (int m = 0; m < DIM; ++m) xi[m] = p.xi[jc * p.sxi_j + m];
+            // ---- this lane's fk values (clamped inside the row; slots beyond nk[j] are masked below)
+            tile1_load_f<FMAX>(fdir, p.fk + jc * (long long)G.K, k0, G);
+            // ---- the tile's xk block: coalesced 16 B per lane, K1_ROUND loads in flight, parked in padded LDS rows
+            if (p.case_index) tile1_stage_x_indexed<DIM>(sX, p.xk, jc, nvalid, lane, G);
+            else tile1_stage_x<DIM>(sX, p.xk + j0 * (long long)(G.K * DIM), nvalid, lane, G);
+        }
         __syncthreads();
 
         const double* xr = sX + c * G.RS;
@@ -522,10 +542,13 @@ int launch_fit_tilek(int dimension, int order, const KParams& p, long long K, hi
     *handled = false;
     const char* off = getenv("WLSQM_HIP_DISABLE_TILE");
     if (off && off[0] == '1') return WLSQM_OK;
-    if (p.hoods) return WLSQM_OK;
-    if (K < 4 || ((K * dimension) % 2) != 0) return WLSQM_OK;   // rows of xk are multiples of 16 bytes
-    if (p.sxk_k != dimension || p.sxk_j != K * dimension || p.sfk_k != 1 || p.sfk_j != K) return WLSQM_OK;
-    if ((reinterpret_cast<uintptr_t>(p.xk) | reinterpret_cast<uintptr_t>(p.fk)) & 15u) return WLSQM_OK;
+    if (p.hoods) {                                               // index-based input: the one-wave kernel gathers per lane
+        if (K < 4 || p.shoods_j != K) return WLSQM_OK;
+    } else {
+        if (K < 4 || ((K * dimension) % 2) != 0) return WLSQM_OK;   // rows of xk are multiples of 16 bytes
+        if (p.sxk_k != dimension || p.sxk_j != K * dimension || p.sfk_k != 1 || p.sfk_j != K) return WLSQM_OK;
+        if ((reinterpret_cast<uintptr_t>(p.xk) | reinterpret_cast<uintptr_t>(p.fk)) & 15u) return WLSQM_OK;
+    }
     // Two shapes (A/B over K = 16..64, tools/tune.py w1/w4): one wave per 16-case tile wins for 2D order 2 and 3D order 1
     // (+5..+20 %) and is the only one whose LDS image fits for large K; four waves per 64-case tile wins for the
     // register-heavy systems (3D order 2, 2D order 3: the one-wave kernel spills there) and for order <= 1 with few
@@ -547,7 +570,7 @@ int launch_fit_tilek(int dimension, int order, const KParams& p, long long K, hi
     }
     const char* sv = getenv("WLSQM_TILEK_SHAPE");
     // the four-wave shape stages fk rows in 16-byte chunks and takes whole batches only (no index list)
-    const bool can1 = K <= K1_LPC * K1_FMAX, can4 = (K % 2) == 0 && !p.case_index;
+    const bool can1 = K <= K1_LPC * K1_FMAX, can4 = (K % 2) == 0 && !p.case_index && !p.hoods;
     bool first1 = (dimension == 2 && order == 2) || (dimension == 3 && order == 1);
     if (sv && sv[0] == '1') first1 = true;
     if (sv && sv[0] == '4') first1 = false;

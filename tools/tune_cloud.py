@@ -8,7 +8,7 @@ import torch
 import bench, synth
 import wlsqm.hip as whip
 cfg = bench.CONFIGS[sys.argv[1]]; n = int(sys.argv[2]); mode = sys.argv[3] if len(sys.argv) > 3 else "sorted"
-dim, order, nk = cfg["dim"], cfg["order"], cfg["nk"]; no = bench.NDOF[dim][order]
+dim, order, nk = cfg["dim"], int(os.environ.get("TUNE_ORDER", cfg["order"])), int(os.environ.get("TUNE_NK", cfg["nk"])); no = bench.NDOF[dim][order]
 dev = torch.device("cuda", 0)
 S = synth.halton(n, dim)
 if mode == "sorted":
