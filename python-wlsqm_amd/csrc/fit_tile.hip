@@ -32,7 +32,11 @@
 //     tiles, so that the point rows shared by neighbouring tiles meet in one L2): +1 %, inside the noise — left out;
 //     squeezing C5 into 168 VGPRs for a third wave per SIMD (solving lane parks its moments in LDS and expands from
 //     there; unroll 1-5): 320 B of spills remain (45 accumulators + chain temporaries + 10 fk values) and the kernel
-//     runs 2.4x slower; the same for C2 at 128 VGPRs (four waves): -15 %.
+//     runs 2.4x slower; the same for C2 at 128 VGPRs (four waves): -15 %;
+//     gfx950's v_permlane16_swap / v_permlane32_swap instead of the ds_bpermute butterflies (2 moves + 1 add per double
+//     and step, no LDS crossbar): correct, but C5 0.46 instead of 0.36 ms and do_sens 0.82 instead of 0.70 ms (both
+//     operands are overwritten, so every value needs two copies first); wave-shuffle instead of LDS for the per-case
+//     maximum of the one-wave shapes: no difference.
 #include <cstdlib>
 
 #include "wlsqm_internal.hpp"
