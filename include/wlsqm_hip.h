@@ -143,6 +143,11 @@ int wlsqm_hip_knn_device(int dimension, int64_t npoints, const double* S, int k,
  * hoods[npoints, max_nk] (int32; unused slots hold the point's own index) and nk[npoints] (int32, the counts). */
 int wlsqm_hip_ball_device(int dimension, int64_t npoints, const double* S, double radius, int max_nk,
                           int32_t* hoods, int32_t* nk, int device, void* stream);
+/* Extension: nearest point of the device-resident cloud S[ndata, dimension] for each of the device-resident query points
+ * X[nquery, x_stride] (queries are not members of the cloud): nearest[nquery] (int64 device array, indices into S; ties go
+ * to the smaller index).  What ExpertSolver.interpolate(mode='nearest') needs (cKDTree.query in expert.pyx:830-895). */
+int wlsqm_hip_nearest_device(int dimension, int64_t ndata, const double* S, int64_t nquery, const double* X,
+                             int64_t x_stride, int64_t* nearest, int device, void* stream);
 
 /* Extension (no reference counterpart; BASELINE config 4 "prepare once + 256 RHS solves"): nrhs fields on the prepared
  * geometry in one call.  Equivalent to nrhs calls of expert.pyx:467-655 solve() with ALGO_BASIC and no sensitivities,
@@ -165,6 +170,10 @@ int wlsqm_hip_expert_conds(wlsqm_expert* h, double* out);
  * CSR lists list_off[nx+1], list_idx[] of the models within radius r of each point (expert.pyx:898-985). */
 int wlsqm_hip_expert_interpolate(wlsqm_expert* h, const double* x, int64_t x_stride, int64_t nx, const int64_t* I,
                                  const int64_t* list_off, const int64_t* list_idx, double r, int diff, double* out);
+/* mode='nearest' with the nearest-origin search on the device too (the reference queries a cKDTree of the origins,
+ * expert.pyx:830-895): out[nx] the values, I_out[nx] (nullable) the model chosen for every point. */
+int wlsqm_hip_expert_interpolate_nearest(wlsqm_expert* h, const double* x, int64_t x_stride, int64_t nx, int diff,
+                                         double* out, int64_t* I_out);
 /* expert.pyx:289-306 memory_used(): (bytes in use, bytes reserved) of the device-side state; a guest counts only
  * what it owns (the shared geometry is the host's). */
 int wlsqm_hip_expert_memory_used(const wlsqm_expert* h, int64_t* used, int64_t* total);

@@ -54,6 +54,8 @@ struct wlsqm_expert {
 using namespace wlsqm;
 
 namespace wlsqm {
+int nearest_search(int dimension, int64_t ndata, const double* S, int64_t nquery, const double* X, int64_t x_stride,
+                   long long* out, hipStream_t s);
 long long preferred_slots(int dimension, int order, long long max_nk);
 int launch_solve_many(int dimension, int order, const KParams& p, long long K, long long nrhs,
                       const double* fk, long long sfk_r, long long sfk_j, double* fi, long long sfi_r, long long sfi_j,
@@ -359,6 +361,38 @@ int wlsqm_hip_expert_interpolate(wlsqm_expert* h, const double* x, int64_t x_str
     rc = launch_interp(dim, q, s);
     if (rc != WLSQM_OK) return rc;
     WLSQM_HIP_CHECK(hipMemcpyAsync(out, d_out.p, (size_t)nx * 8, hipMemcpyDeviceToHost, s));
+    WLSQM_HIP_CHECK(hipStreamSynchronize(s));
+    return WLSQM_OK;
+}
+
+// mode='nearest' without host-side search (expert.pyx:830-895 queries a cKDTree of the origins): the nearest origin of
+// every x is found on the device (knn.hip), then the model is evaluated as above.  I_out (host, nullable) receives the
+// model numbers, the second return value of the reference's interpolate().
+int wlsqm_hip_expert_interpolate_nearest(wlsqm_expert* h, const double* x, int64_t x_stride, int64_t nx, int diff,
+                                         double* out, int64_t* I_out) {
+    if (!h || !x || !out) { set_error("null argument"); return WLSQM_EVALUE; }
+    if (!h->g->ready || !h->solved) { set_error("interpolate() needs prepare() and solve() first"); return WLSQM_ERUNTIME; }
+    int rc = check_device(h->g->device);
+    if (rc != WLSQM_OK) return rc;
+    if (nx <= 0) return WLSQM_OK;
+    const int dim = h->g->dimension;
+    std::vector<double> sx((size_t)nx * dim);
+    for (int64_t m = 0; m < nx; ++m)
+        for (int c = 0; c < dim; ++c) sx[(size_t)m * dim + c] = x[m * x_stride + c];
+    DevBuf d_x, d_I, d_out;
+    hipStream_t s = nullptr;
+    if ((rc = d_x.alloc(sx.size() * 8)) || (rc = d_out.alloc((size_t)nx * 8)) || (rc = d_I.alloc((size_t)nx * 8))) return rc;
+    WLSQM_HIP_CHECK(hipMemcpyAsync(d_x.p, sx.data(), d_x.n, hipMemcpyHostToDevice, s));
+    if ((rc = nearest_search(dim, h->g->ncases, h->g->d_xi.as<double>(), nx, d_x.as<double>(), dim, d_I.as<long long>(), s))) return rc;
+    InterpParams q{};
+    q.xi = h->g->d_xi.as<double>(); q.sxi = dim; q.fi = h->d_fi.as<double>(); q.sfi = h->g->max_no;
+    q.order = h->g->d_order.as<int>(); q.sorder = 1; q.nmodels = h->g->ncases;
+    q.x = d_x.as<double>(); q.sx = dim; q.nx = nx; q.diff = diff; q.out = d_out.as<double>();
+    q.I = d_I.as<long long>();
+    rc = launch_interp(dim, q, s);
+    if (rc != WLSQM_OK) return rc;
+    WLSQM_HIP_CHECK(hipMemcpyAsync(out, d_out.p, (size_t)nx * 8, hipMemcpyDeviceToHost, s));
+    if (I_out) WLSQM_HIP_CHECK(hipMemcpyAsync(I_out, d_I.p, (size_t)nx * 8, hipMemcpyDeviceToHost, s));
     WLSQM_HIP_CHECK(hipStreamSynchronize(s));
     return WLSQM_OK;
 }

@@ -179,21 +179,18 @@ __global__ __launch_bounds__(64) void knn_query_kernel(const double* __restrict_
 
 using namespace wlsqm;
 
-// k nearest other points within squared distance r2max of every point; row_stride slots per row of hoods
-static int neighbour_search(int dimension, int64_t npoints, const double* S, int k, double r2max, int row_stride,
-                            int32_t* hoods, int32_t* counts, int device, void* stream_) {
-    if (dimension < 1 || dimension > 3) { set_error("dimension must be 1, 2 or 3"); return WLSQM_EVALUE; }
-    if (!S || !hoods) { set_error("null array"); return WLSQM_EVALUE; }
-    if (k < 1 || npoints < 2 || (int64_t)k > npoints - 1) { set_error("k must be in 1 .. npoints - 1"); return WLSQM_EVALUE; }
-    if (npoints > 0x7fffffffLL) { set_error("at most 2^31 - 1 points"); return WLSQM_EVALUE; }
-    const size_t lds = (size_t)k * 64 * (sizeof(double) + sizeof(int));
-    if (lds > 160 * 1024) { set_error("k too large for the LDS-resident candidate lists (k <= 213)"); return WLSQM_EVALUE; }
-    int rc = check_device(device);
-    if (rc != WLSQM_OK) return rc;
-    hipStream_t s = (hipStream_t)stream_;
+// Uniform grid over a device-resident cloud: bounding box, cells of ~4 points, points sorted by cell.
+struct GridIndex {
+    KnnGrid G{};
+    long long ncells = 1;
+    DevBuf d_perm, d_start, d_Ss;
+    int build(int dimension, int64_t npoints, const double* S, hipStream_t s);
+};
+
+int GridIndex::build(int dimension, int64_t npoints, const double* S, hipStream_t s) {
+    int rc;
     const long long n = npoints;
     const unsigned blocks = (unsigned)((n + 255) / 256);
-
     // 1. bounding box
     DevBuf d_mm;
     if ((rc = d_mm.alloc(6 * sizeof(unsigned long long)))) return rc;
@@ -202,7 +199,7 @@ static int neighbour_search(int dimension, int64_t npoints, const double* S, int
     hipLaunchKernelGGL(knn_bbox_kernel, dim3(blocks), dim3(256), 0, s, S, n, dimension, d_mm.as<unsigned long long>());
     WLSQM_HIP_CHECK(hipMemcpyAsync(h_mm, d_mm.p, sizeof(h_mm), hipMemcpyDeviceToHost, s));
     WLSQM_HIP_CHECK(hipStreamSynchronize(s));
-    KnnGrid G{};
+    G = KnnGrid{};
     G.dim = dimension;
     double ext[3] = {0, 0, 0}, vol = 1.0;
     int live = 0;
@@ -215,7 +212,7 @@ static int neighbour_search(int dimension, int64_t npoints, const double* S, int
     // ~4 points per cell over the non-degenerate axes, at most 2^27 cells
     const double target_cells = std::min((double)n / 4.0, 134217728.0);
     const double h = live ? std::pow(vol / std::max(target_cells, 1.0), 1.0 / live) : 1.0;
-    long long ncells = 1;
+    ncells = 1;
     for (int m = 0; m < dimension; ++m) {
         int g = ext[m] > 0.0 ? (int)std::min(std::max(ext[m] / h, 1.0), 4096.0 * 4096.0) : 1;
         if (dimension == 3) g = std::min(g, 1024); else if (dimension == 2) g = std::min(g, 16384);
@@ -227,7 +224,7 @@ static int neighbour_search(int dimension, int64_t npoints, const double* S, int
     for (int m = dimension; m < 3; ++m) { G.g[m] = 1; G.cell[m] = 1.0; G.inv_cell[m] = 1.0; G.lo[m] = 0.0; }
 
     // 2. sort by cell
-    DevBuf d_cell, d_cell2, d_idx, d_perm, d_start, d_Ss, d_tmp;
+    DevBuf d_cell, d_cell2, d_idx, d_tmp;
     if ((rc = d_cell.alloc(n * 4)) || (rc = d_cell2.alloc(n * 4)) || (rc = d_idx.alloc(n * 4)) || (rc = d_perm.alloc(n * 4)) ||
         (rc = d_start.alloc((ncells + 1) * 4)) || (rc = d_Ss.alloc((size_t)n * dimension * 8))) return rc;
     hipLaunchKernelGGL(knn_cell_kernel, dim3(blocks), dim3(256), 0, s, S, n, G, d_cell.as<unsigned>(), d_idx.as<int>());
@@ -242,23 +239,120 @@ static int neighbour_search(int dimension, int64_t npoints, const double* S, int
     hipLaunchKernelGGL(knn_start_kernel, dim3((unsigned)((ncells + 1 + 255) / 256)), dim3(256), 0, s, d_cell2.as<unsigned>(), n,
                        ncells, d_start.as<int>());
     hipLaunchKernelGGL(knn_gather_kernel, dim3(blocks), dim3(256), 0, s, S, d_perm.as<int>(), n, dimension, d_Ss.as<double>());
+    WLSQM_HIP_CHECK(hipGetLastError());
+    WLSQM_HIP_CHECK(hipStreamSynchronize(s));      // the sort's temporaries are freed on return
+    return WLSQM_OK;
+}
 
-    // 3./4. query
+// k nearest other points within squared distance r2max of every point; row_stride slots per row of hoods
+static int neighbour_search(int dimension, int64_t npoints, const double* S, int k, double r2max, int row_stride,
+                            int32_t* hoods, int32_t* counts, int device, void* stream_) {
+    if (dimension < 1 || dimension > 3) { set_error("dimension must be 1, 2 or 3"); return WLSQM_EVALUE; }
+    if (!S || !hoods) { set_error("null array"); return WLSQM_EVALUE; }
+    if (k < 1 || npoints < 2 || (int64_t)k > npoints - 1) { set_error("k must be in 1 .. npoints - 1"); return WLSQM_EVALUE; }
+    if (npoints > 0x7fffffffLL) { set_error("at most 2^31 - 1 points"); return WLSQM_EVALUE; }
+    const size_t lds = (size_t)k * 64 * (sizeof(double) + sizeof(int));
+    if (lds > 160 * 1024) { set_error("k too large for the LDS-resident candidate lists (k <= 213)"); return WLSQM_EVALUE; }
+    int rc = check_device(device);
+    if (rc != WLSQM_OK) return rc;
+    hipStream_t s = (hipStream_t)stream_;
+    const long long n = npoints;
+    GridIndex grid;
+    if ((rc = grid.build(dimension, npoints, S, s))) return rc;
+    const KnnGrid G = grid.G;
     const unsigned qblocks = (unsigned)((n + 63) / 64);
 #define KNN_LAUNCH(D)                                                                                                   \
     {                                                                                                                   \
         auto kern = knn_query_kernel<D>;                                                                                \
         if (lds > 64 * 1024)                                                                                            \
             WLSQM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL(kern, dim3(qblocks), dim3(64), lds, s, d_Ss.as<double>(), d_perm.as<int>(), d_start.as<int>(), n, k, G, \
-                           r2max, row_stride, hoods, counts);                                                                 \
+        hipLaunchKernelGGL(kern, dim3(qblocks), dim3(64), lds, s, grid.d_Ss.as<double>(), grid.d_perm.as<int>(),        \
+                           grid.d_start.as<int>(), n, k, G, r2max, row_stride, hoods, counts);                         \
     }
     if (dimension == 1) KNN_LAUNCH(1) else if (dimension == 2) KNN_LAUNCH(2) else KNN_LAUNCH(3)
 #undef KNN_LAUNCH
     WLSQM_HIP_CHECK(hipGetLastError());
-    WLSQM_HIP_CHECK(hipStreamSynchronize(s));      // the temporaries above are freed on return
+    WLSQM_HIP_CHECK(hipStreamSynchronize(s));      // the grid's buffers are freed on return
     return WLSQM_OK;
 }
+
+namespace wlsqm {
+
+// Nearest data point of every query point (queries are NOT part of the cloud: no self-exclusion): ExpertSolver.interpolate's
+// model lookup (expert.pyx:830-895 queries a cKDTree of the origins xi).  One lane per query; ties go to the smaller index.
+template <int DIM>
+__global__ __launch_bounds__(64) void nearest_kernel(const double* __restrict__ Ss, const int* __restrict__ perm,
+                                                     const int* __restrict__ start, const double* __restrict__ X, long long sx,
+                                                     long long nq, KnnGrid G, long long* __restrict__ out) {
+    const long long q = (long long)blockIdx.x * 64 + threadIdx.x;
+    if (q >= nq) return;
+    double x[DIM]; int cq[DIM];
+#pragma unroll
+    for (int m = 0; m < DIM; ++m) { x[m] = X[q * sx + m]; cq[m] = cell_coord(x[m], G, m); }
+    int rmax = 0;
+#pragma unroll
+    for (int m = 0; m < DIM; ++m) rmax = max(rmax, max(cq[m], G.g[m] - 1 - cq[m]));
+    double best = DBL_MAX; int best_idx = 0x7fffffff;
+    for (int r = 0; r <= rmax; ++r) {
+        const int z0 = DIM > 2 ? -r : 0, z1 = DIM > 2 ? r : 0, y0 = DIM > 1 ? -r : 0, y1 = DIM > 1 ? r : 0;
+        for (int dz = z0; dz <= z1; ++dz) {
+            const int cz = DIM > 2 ? cq[2] + dz : 0;
+            if (DIM > 2 && (cz < 0 || cz >= G.g[2])) continue;
+            for (int dy = y0; dy <= y1; ++dy) {
+                const int cy = DIM > 1 ? cq[1] + dy : 0;
+                if (DIM > 1 && (cy < 0 || cy >= G.g[1])) continue;
+                const bool face = (DIM > 2 && (dz == -r || dz == r)) || (DIM > 1 && (dy == -r || dy == r));
+                const int step = (face || r == 0) ? 1 : 2 * r;
+                for (int dx = -r; dx <= r; dx += step) {
+                    const int cx = cq[0] + dx;
+                    if (cx < 0 || cx >= G.g[0]) continue;
+                    long long cid = cx;
+                    if (DIM > 1) cid += (long long)G.g[0] * cy;
+                    if (DIM > 2) cid += (long long)G.g[0] * G.g[1] * cz;
+                    for (int pos = start[cid]; pos < start[cid + 1]; ++pos) {
+                        double d2 = 0.0;
+#pragma unroll
+                        for (int m = 0; m < DIM; ++m) { const double d = Ss[(long long)pos * DIM + m] - x[m]; d2 += d * d; }
+                        const int idx = perm[pos];
+                        if (d2 < best || (d2 == best && idx < best_idx)) { best = d2; best_idx = idx; }
+                    }
+                }
+            }
+        }
+        if (best < DBL_MAX) {
+            // unvisited points lie outside the block [cq - r, cq + r] of cells (the query itself may lie outside the grid)
+            double reach = DBL_MAX;
+#pragma unroll
+            for (int m = 0; m < DIM; ++m) {
+                if (cq[m] - r > 0) reach = fmin(reach, x[m] - (G.lo[m] + (cq[m] - r) * G.cell[m]) - 1e-9 * G.cell[m]);
+                if (cq[m] + r < G.g[m] - 1) reach = fmin(reach, (G.lo[m] + (cq[m] + r + 1) * G.cell[m]) - x[m] - 1e-9 * G.cell[m]);
+            }
+            if (reach == DBL_MAX || (reach > 0.0 && best <= reach * reach)) break;
+        }
+    }
+    out[q] = best_idx;
+}
+
+// nearest data point (index into S, int64) of each of the nquery device-resident points X[nquery, x_stride]
+int nearest_search(int dimension, int64_t ndata, const double* S, int64_t nquery, const double* X, int64_t x_stride,
+                   long long* out, hipStream_t s) {
+    if (ndata < 1 || ndata > 0x7fffffffLL) { set_error("1 .. 2^31 - 1 data points"); return WLSQM_EVALUE; }
+    if (nquery <= 0) return WLSQM_OK;
+    GridIndex grid;
+    int rc = grid.build(dimension, ndata, S, s);
+    if (rc != WLSQM_OK) return rc;
+    const unsigned qblocks = (unsigned)((nquery + 63) / 64);
+#define NEAREST_LAUNCH(D)                                                                                               \
+    hipLaunchKernelGGL(nearest_kernel<D>, dim3(qblocks), dim3(64), 0, s, grid.d_Ss.as<double>(), grid.d_perm.as<int>(),   \
+                       grid.d_start.as<int>(), X, (long long)x_stride, (long long)nquery, grid.G, out);
+    if (dimension == 1) NEAREST_LAUNCH(1) else if (dimension == 2) NEAREST_LAUNCH(2) else NEAREST_LAUNCH(3)
+#undef NEAREST_LAUNCH
+    WLSQM_HIP_CHECK(hipGetLastError());
+    WLSQM_HIP_CHECK(hipStreamSynchronize(s));
+    return WLSQM_OK;
+}
+
+}  // namespace wlsqm
 
 extern "C" int wlsqm_hip_knn_device(int dimension, int64_t npoints, const double* S, int k, int32_t* hoods, int device,
                                     void* stream) {
@@ -271,4 +365,13 @@ extern "C" int wlsqm_hip_ball_device(int dimension, int64_t npoints, const doubl
     if (max_nk < 1 || !nk) { set_error("max_nk must be >= 1 and nk non-null"); return WLSQM_EVALUE; }
     const int k = (int)std::min<int64_t>(max_nk, npoints - 1);
     return neighbour_search(dimension, npoints, S, k, radius * radius, max_nk, hoods, nk, device, stream);
+}
+
+extern "C" int wlsqm_hip_nearest_device(int dimension, int64_t ndata, const double* S, int64_t nquery, const double* X,
+                                        int64_t x_stride, int64_t* nearest, int device, void* stream) {
+    if (dimension < 1 || dimension > 3) { set_error("dimension must be 1, 2 or 3"); return WLSQM_EVALUE; }
+    if (!S || !X || !nearest) { set_error("null array"); return WLSQM_EVALUE; }
+    int rc = check_device(device);
+    if (rc != WLSQM_OK) return rc;
+    return nearest_search(dimension, ndata, S, nquery, X, x_stride, reinterpret_cast<long long*>(nearest), (hipStream_t)stream);
 }

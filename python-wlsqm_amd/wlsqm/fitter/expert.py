@@ -29,6 +29,8 @@ class ExpertSolver:
     def __init__(self, dimension, nk, order, knowns, weighting_method, algorithm=defs.ALGO_BASIC, do_sens=False,
                  max_iter=10, ntasks=1, debug=False, host=None):
         self._handle = None
+        self._tree = None
+        self._tree_points = None
         nk = B.view(nk, np.int32, 1, "nk")
         order = B.view(order, np.int32, 1, "order")
         knowns = B.view(knowns, np.int64, 1, "knowns")
@@ -84,7 +86,7 @@ class ExpertSolver:
                 self.algorithm, int(self.do_sens), self.max_iter))
         self._handle = h
         if host is not None:
-            self.tree = host.tree
+            self._tree, self._tree_points = host._tree, host._tree_points        # expert.pyx:263-264
 
     def close(self):
         """Release the device-side state now (also done by __del__; expert.pyx:267-286)."""
@@ -174,17 +176,32 @@ class ExpertSolver:
         B.check(B.lib().wlsqm_hip_expert_conds(self._handle, out.ctypes.data))
         return out
 
+    # `tree` (expert.pyx:247, 681: a scipy cKDTree of the origins xi) is built on first use: mode='nearest' finds the nearest
+    # origin on the GPU and never needs it; mode='continuous' (ball queries against the origins) does.
+    @property
+    def tree(self):
+        if self._tree is None and self._tree_points is not None:
+            import scipy.spatial
+            self._tree = scipy.spatial.cKDTree(data=self._tree_points)
+        return self._tree
+
+    @tree.setter
+    def tree(self, value):
+        self._tree = value
+        if value is None:
+            self._tree_points = None
+
     def prep_interpolate(self):
-        """Index the origins xi with a k-d tree so that interpolate() can find the nearest local model
-        (expert.pyx:658-681; the search runs on the host with scipy, as in the reference)."""
+        """Prepare interpolate() (expert.pyx:658-681: index the origins xi for the nearest-model search).  The k-d tree of
+        the reference is only built when something asks for it (`self.tree`, mode='continuous'); mode='nearest' searches
+        on the GPU."""
         if not self.ready:
             raise RuntimeError("Solver is not in the ready state; prepare() must be called before prep_interpolate()")
-        if self.host is not None:
-            self.tree = self.host.tree
+        if self.host is not None and self.host._tree_points is not None:
+            self._tree, self._tree_points = self.host._tree, self.host._tree_points
         else:
-            import scipy.spatial
             xi = np.asarray(self.xi)
-            self.tree = scipy.spatial.cKDTree(data=xi if self.dimension >= 2 else np.atleast_2d(xi).T)
+            self._tree, self._tree_points = None, (xi if self.dimension >= 2 else np.atleast_2d(xi).T)
 
     def interpolate(self, x, mode='nearest', r=None, diff=0, I=None):
         """Interpolate the global (patched) model or its derivative `diff` to the points x (expert.pyx:687-781).
@@ -197,7 +214,7 @@ class ExpertSolver:
             raise ValueError("r must be specified in mode='continuous'")
         if diff is None:
             raise ValueError("diff cannot be None")
-        if self.tree is None:
+        if self._tree is None and self._tree_points is None:
             raise RuntimeError("Points xi have not been indexed; prep_interpolate() must be called before interpolate()")
         if I is not None and len(I) != len(x):
             raise ValueError("When 'I' is specified, 'I' must have the same length as x; got len(I) = %d, len(x) = %d." % (len(I), len(x)))
@@ -211,10 +228,12 @@ class ExpertSolver:
         out = np.empty((nx,), dtype=np.float64)
         lib = B.lib()
         if mode == 'nearest':
-            if I is None:
-                _, I_out = self.tree.query(xq, k=1)
-            else:
-                I_out = I
+            if I is None:                                                        # nearest origin found on the device
+                I_out = np.empty((nx,), dtype=np.int64)
+                B.check(lib.wlsqm_hip_expert_interpolate_nearest(self._handle, xv.ctypes.data, B.es(xv, 0), nx, int(diff),
+                                                                 out.ctypes.data, I_out.ctypes.data))
+                return out, I_out
+            I_out = I
             Iv = np.ascontiguousarray(np.asarray(I_out, dtype=np.int64))
             if (Iv == self.ncases).any():                                        # expert.pyx:861-864
                 out[:] = np.nan

@@ -10,7 +10,7 @@ import ctypes as C
 
 from . import _binding as B
 
-__all__ = ["fit_many_device", "time_fit_device", "fit_cloud_device", "time_fit_cloud_device", "device_count", "knn", "ball"]
+__all__ = ["fit_many_device", "time_fit_device", "fit_cloud_device", "time_fit_cloud_device", "device_count", "knn", "ball", "nearest"]
 
 
 def device_count():
@@ -187,3 +187,17 @@ def ball(S, radius, max_nk, stream=None):
     s, dev = _stream_and_device(S, stream)
     B.check(B.lib().wlsqm_hip_ball_device(dim, n, _ptr(S), float(radius), int(max_nk), _ptr(hoods), _ptr(nk), dev, s))
     return hoods, nk
+
+
+def nearest(S, X, stream=None):
+    """Index (int64 device tensor, one per row of X) of the point of the device-resident cloud S nearest to each query
+    point X[j] (queries need not belong to the cloud; ties go to the smaller index): ``cKDTree(S).query(X)[1]`` on the GPU."""
+    import torch
+    dim = 1 if S.dim() == 1 else int(S.shape[1])
+    _check(S, "S", "float64", S.dim()); _check(X, "X", "float64", X.dim())
+    if not S.is_contiguous() or not X.is_contiguous() or (1 if X.dim() == 1 else int(X.shape[1])) != dim:
+        raise ValueError("S and X must be contiguous and have the same number of coordinates")
+    out = torch.empty((int(X.shape[0]),), dtype=torch.int64, device=S.device)
+    s, dev = _stream_and_device(S, stream)
+    B.check(B.lib().wlsqm_hip_nearest_device(dim, int(S.shape[0]), _ptr(S), int(X.shape[0]), _ptr(X), dim, _ptr(out), dev, s))
+    return out

@@ -941,3 +941,23 @@ def test_expert_solver_copy_and_pickle(wlsqm):
     assert g2.ready and g2.host is not None and g2.host is not s and g2.host.ready
     fi3 = c["fi0"].copy(); g2.solve(fk=c["fk"], fi=fi3)
     assert np.array_equal(fi, fi3)
+
+
+@pytest.mark.parametrize("dim", [1, 2, 3])
+def test_gpu_nearest_equals_ckdtree(wlsqm, dim):
+    """wlsqm.hip.nearest (external queries, k = 1) against cKDTree.query — the model lookup of ExpertSolver.interpolate
+    (expert.pyx:830-895): same nearest distance for every query, including queries outside the cloud's bounding box."""
+    import torch
+    import wlsqm.hip as whip
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(dim)
+    S = rng.uniform(0, 1, (30_000, dim))
+    X = np.concatenate([rng.uniform(-0.3, 1.3, (20_000, dim)), S[:100] + 1e-9])
+    if dim == 1:
+        S, X = np.ascontiguousarray(S[:, 0]), np.ascontiguousarray(X[:, 0])
+    got = whip.nearest(torch.from_numpy(S).cuda(), torch.from_numpy(X).cuda()).cpu().numpy()
+    S2, X2 = (S[:, None], X[:, None]) if dim == 1 else (S, X)
+    dd, ii = cKDTree(S2).query(X2)
+    d_got = np.sqrt(((S2[got] - X2) ** 2).sum(-1))
+    assert np.allclose(d_got, dd, rtol=1e-13, atol=0)
+    assert (got == ii).mean() > 0.999
