@@ -1,23 +1,24 @@
 #!/usr/bin/env python3
-"""Everything on the GPU: geometry prepared once, one fused launch per time step, stacked fields in one launch."""
+"""Everything on the GPU: neighbour search, geometry prepared once, one fused launch per time step, stacked fields in one launch."""
 import os, sys, time
 import numpy as np
-import scipy.spatial
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "python-wlsqm_amd"))
 import wlsqm
+import wlsqm.hip
 
 n, nk, order = 200_000, 32, 2
 rng = np.random.default_rng(1)
 S = rng.uniform(0.0, 1.0, (n, 2))
-hoods = scipy.spatial.cKDTree(S).query(S, 1 + nk, workers=-1)[1][:, 1:]
+dev = torch.device("cuda", 0)
+S_d = torch.from_numpy(S).to(dev)
+h_d = wlsqm.hip.knn(S_d, nk).long()                                  # nk nearest neighbours of every point, on the GPU
+hoods = h_d.cpu().numpy()
 solver = wlsqm.ExpertSolver(dimension=2, nk=np.full(n, nk, np.int32), order=np.full(n, order, np.int32),
                             knowns=np.full(n, wlsqm.b2_F, np.int64),
                             weighting_method=np.full(n, wlsqm.WEIGHT_CENTER, np.int32))
 solver.prepare(xi=S, xk=S[hoods])
 
-dev = torch.device("cuda", 0)
-S_d = torch.from_numpy(S).to(dev); h_d = torch.from_numpy(hoods).to(dev)
 no = wlsqm.number_of_dofs(2, order)
 fi = torch.zeros((n, no), dtype=torch.float64, device=dev)
 
