@@ -375,21 +375,11 @@ static int launch_tile_impl(const KParams& p, hipStream_t stream) {
     using G = TileGeom<DIM, ORDER, K, KSPLIT, LPC, FKD, MOM>;
     constexpr size_t lds_bytes = G::LDS_BYTES;
     const long long ntiles = (p.ncases + G::TC - 1) / G::TC;
-    static int per_cu = 0, cus = 0;
+    static KernelSetup setup;
     auto kern = fit_tile_kernel<DIM, ORDER, K, KSPLIT, LPC, UNR, MINW, GATHER, FKD, MOM, SPLIT>;
-    if (!cus) {
-        int dev = 0;
-        WLSQM_HIP_CHECK(hipGetDevice(&dev));
-        hipDeviceProp_t prop;
-        WLSQM_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-        if (lds_bytes > 64 * 1024)
-            WLSQM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        int occ = 0;
-        WLSQM_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, G::NT, lds_bytes));
-        per_cu = occ > 0 ? occ : 1;
-        cus = prop.multiProcessorCount;
-    }
-    long long grid = (long long)per_cu * cus;
+    long long grid = 0;
+    int rc = persistent_grid(reinterpret_cast<const void*>(kern), G::NT, lds_bytes, lds_bytes, true, setup, &grid);
+    if (rc != WLSQM_OK) return rc;
     if (grid > ntiles) grid = ntiles;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G::NT), lds_bytes, stream, p, ntiles);
     WLSQM_HIP_CHECK(hipGetLastError());

@@ -488,19 +488,10 @@ static int launch_tilek(const KParams& p, long long K, hipStream_t stream, bool*
     *handled = true;
     const long long ntiles = (p.ncases + KW - 1) / KW;
     auto kern = fit_tilek_kernel<DIM, ORDER, MOM>;
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        WLSQM_HIP_CHECK(hipGetDevice(&dev));
-        hipDeviceProp_t prop;
-        WLSQM_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-        WLSQM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-        cus = prop.multiProcessorCount;
-    }
-    int per_cu = 0;
-    WLSQM_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, KNT, lds_bytes));
-    if (per_cu < 1) per_cu = 1;
-    long long grid = (long long)per_cu * cus;
+    static KernelSetup setup;
+    long long grid = 0;
+    int rc = persistent_grid(reinterpret_cast<const void*>(kern), KNT, lds_bytes, 80 * 1024, false, setup, &grid);
+    if (rc != WLSQM_OK) return rc;
     if (grid > ntiles) grid = ntiles;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(KNT), lds_bytes, stream, p, ntiles, G);
     WLSQM_HIP_CHECK(hipGetLastError());
@@ -518,18 +509,10 @@ static int launch_tile1(const KParams& p, long long K, hipStream_t stream, bool*
     *handled = true;
     const long long ntiles = (p.ncases + K1_TC - 1) / K1_TC;
     auto kern = fit_tile1_kernel<DIM, ORDER, MOM, FMAX, EXTRAS>;
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        WLSQM_HIP_CHECK(hipGetDevice(&dev));
-        hipDeviceProp_t prop;
-        WLSQM_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-        cus = prop.multiProcessorCount;
-    }
-    int per_cu = 0;
-    WLSQM_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, KW, lds_bytes));
-    if (per_cu < 1) per_cu = 1;
-    long long grid = (long long)per_cu * cus;
+    static KernelSetup setup;
+    long long grid = 0;
+    int rc = persistent_grid(reinterpret_cast<const void*>(kern), KW, lds_bytes, 0, false, setup, &grid);
+    if (rc != WLSQM_OK) return rc;
     if (grid > ntiles) grid = ntiles;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(KW), lds_bytes, stream, p, ntiles, G);
     WLSQM_HIP_CHECK(hipGetLastError());

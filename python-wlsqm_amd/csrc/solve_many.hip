@@ -166,18 +166,10 @@ static int launch_many(const KParams& p, long long K, const ManyRhs& R, hipStrea
     *handled = true;
     const long long ntiles = (p.ncases + K1_TC - 1) / K1_TC;
     auto kern = solve_many_kernel<DIM, ORDER, FMAX>;
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        WLSQM_HIP_CHECK(hipGetDevice(&dev));
-        hipDeviceProp_t prop;
-        WLSQM_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-        cus = prop.multiProcessorCount;
-    }
-    int per_cu = 0;
-    WLSQM_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, K1_WV, lds_bytes));
-    if (per_cu < 1) per_cu = 1;
-    long long grid = (long long)per_cu * cus;
+    static KernelSetup setup;
+    long long grid = 0;
+    int rc = persistent_grid(reinterpret_cast<const void*>(kern), K1_WV, lds_bytes, 0, false, setup, &grid);
+    if (rc != WLSQM_OK) return rc;
     if (grid > ntiles) grid = ntiles;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(K1_WV), lds_bytes, stream, p, ntiles, G, R);
     WLSQM_HIP_CHECK(hipGetLastError());

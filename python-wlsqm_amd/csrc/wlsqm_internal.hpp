@@ -6,6 +6,12 @@
 
 #include "wlsqm_hip.h"
 
+#define WLSQM_HIP_CHECK(expr)                                                   \
+    do {                                                                        \
+        hipError_t _e = (expr);                                                 \
+        if (_e != hipSuccess) return ::wlsqm::hip_fail(_e, #expr);              \
+    } while (0)
+
 namespace wlsqm {
 
 // Kernel parameter block (by value).  Strides in elements.
@@ -60,6 +66,33 @@ int launch_fit(int dimension, int order, const KParams& p, long long max_nk, hip
 const char* last_kernel_name();
 void note_kernel(const char* name);
 
+// Per-device launch facts of one persistent kernel (a process may drive several GPUs): CU count, the one-time opt-in to
+// more than 64 KB of dynamic LDS, and (when the LDS size never changes) the workgroups that fit one CU.
+struct KernelSetup { int cus[16] = {}; int per_cu[16] = {}; };
+
+// Grid of a persistent launch: resident workgroups per CU x CUs of the current device.
+inline int persistent_grid(const void* kern, int threads, size_t lds_bytes, size_t lds_optin, bool fixed_lds, KernelSetup& ks,
+                           long long* grid) {
+    int dev = 0;
+    WLSQM_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 16) { set_error("device ordinal out of range"); return WLSQM_EVALUE; }
+    if (!ks.cus[dev]) {
+        hipDeviceProp_t prop;
+        WLSQM_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+        if (lds_optin > 64 * 1024)
+            WLSQM_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_optin));
+        ks.cus[dev] = prop.multiProcessorCount;
+    }
+    int occ = fixed_lds ? ks.per_cu[dev] : 0;
+    if (!occ) {
+        WLSQM_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, threads, lds_bytes));
+        if (occ < 1) occ = 1;
+        if (fixed_lds) ks.per_cu[dev] = occ;
+    }
+    *grid = (long long)occ * ks.cus[dev];
+    return WLSQM_OK;
+}
+
 // RAII device buffer
 struct DevBuf {
     void* p = nullptr; size_t n = 0;
@@ -92,8 +125,3 @@ inline void effective_mask_host(int no, long long raw, unsigned long long& known
 
 }  // namespace wlsqm
 
-#define WLSQM_HIP_CHECK(expr)                                                   \
-    do {                                                                        \
-        hipError_t _e = (expr);                                                 \
-        if (_e != hipSuccess) return ::wlsqm::hip_fail(_e, #expr);              \
-    } while (0)
