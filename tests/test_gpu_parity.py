@@ -961,3 +961,41 @@ def test_gpu_nearest_equals_ckdtree(wlsqm, dim):
     d_got = np.sqrt(((S2[got] - X2) ** 2).sum(-1))
     assert np.allclose(d_got, dd, rtol=1e-13, atol=0)
     assert (got == ii).mean() > 0.999
+
+
+@pytest.mark.parametrize("dim,order,K", [(2, 2, 32), (3, 2, 40), (2, 4, 64), (2, 2, 20), (3, 4, 64), (1, 2, 8)])
+def test_degenerate_cases_do_not_disturb_their_neighbours(wlsqm, dim, order, K):
+    """Numerical failure is silent in the reference (singular systems give inf / NaN in fi, nothing raises).
+    Same here, and a degenerate case must not leak into the healthy cases of its tile: cases with no neighbours, with all
+    neighbours on top of the origin, with NaN data, or with fewer neighbours than unknowns sit between healthy ones; the
+    healthy ones come out bit-identical to a batch without the degenerate cases, and known DOFs stay untouched."""
+    rng = np.random.default_rng(dim * 100 + order)
+    n = 203
+    no = K_.NDOF[dim][order]
+    xi = rng.uniform(0, 1, (n, dim))
+    xk = xi[:, None, :] + 0.05 * rng.uniform(-1, 1, (n, K, dim))
+    fk = np.sin(3 * xk[..., 0]) * np.cos(2 * xk[..., -1])
+    nk = np.full(n, K, np.int32)
+    bad = np.zeros(n, bool)
+    nk[5] = 0; bad[5] = True                                   # no neighbours at all
+    xk[17] = xi[17]; bad[17] = True                            # all neighbours coincide with the origin (max_d2 = 0)
+    fk[40, 3] = np.nan; bad[40] = True                         # NaN in the data
+    nk[77] = max(1, no // 2); bad[77] = True                   # underdetermined
+    xk[120, :, 0] = xi[120, 0]; bad[120] = True                # all neighbours on the line x = const (singular for order >= 1)
+    orders = np.full(n, order, np.int32); knowns = np.zeros(n, np.int64); knowns[::7] = 1
+    wm = np.full(n, wlsqm.WEIGHT_CENTER, np.int32); wm[1::3] = wlsqm.WEIGHT_UNIFORM
+    fi0 = rng.uniform(-1, 1, (n, no)); fi0[:, 0] = np.sin(3 * xi[:, 0]) * np.cos(2 * xi[:, -1])
+    def run(sel):
+        a, b = xk[sel], xi[sel]
+        if dim == 1:
+            a, b = np.ascontiguousarray(a[..., 0]), np.ascontiguousarray(b[:, 0])
+        fi = fi0[sel].copy()
+        _many(wlsqm, dim)(a, fk[sel], nk[sel], b, fi, None, 0, orders[sel], knowns[sel], wm[sel])
+        return fi
+    everything = run(np.arange(n))
+    healthy = np.flatnonzero(~bad)
+    alone = run(healthy)
+    assert np.isfinite(alone).all()
+    assert np.array_equal(everything[healthy], alone)
+    kn = knowns == 1
+    assert np.array_equal(everything[kn, 0], fi0[kn, 0])      # knowns untouched, degenerate or not
