@@ -999,3 +999,32 @@ def test_degenerate_cases_do_not_disturb_their_neighbours(wlsqm, dim, order, K):
     assert np.array_equal(everything[healthy], alone)
     kn = knowns == 1
     assert np.array_equal(everything[kn, 0], fi0[kn, 0])      # knowns untouched, degenerate or not
+
+
+def test_concurrent_calls_from_python_threads(wlsqm):
+    """ctypes releases the GIL for the whole call (like the reference's `with nogil`, simple.pyx:396): several Python threads
+    fitting different batches at the same time (per-thread staging buffers and streams in the library) get the results of
+    the serial runs, bit for bit."""
+    from concurrent.futures import ThreadPoolExecutor
+    rng = np.random.default_rng(9)
+    jobs = []
+    for t in range(6):
+        dim, order, K, n = [(2, 2, 32, 4000), (3, 2, 40, 1500), (2, 4, 64, 900), (1, 2, 8, 5000), (2, 3, 20, 1200), (3, 3, 40, 300)][t]
+        no = K_.NDOF[dim][order]
+        xi = rng.uniform(0, 1, (n, dim)); xk = xi[:, None, :] + 0.05 * rng.uniform(-1, 1, (n, K, dim))
+        fk = np.sin(3 * xk[..., 0]) * np.cos(2 * xk[..., -1])
+        if dim == 1:
+            xi, xk = np.ascontiguousarray(xi[:, 0]), np.ascontiguousarray(xk[..., 0])
+        jobs.append((dim, xk, fk, np.full(n, K, np.int32), xi, np.zeros((n, no)), np.full(n, order, np.int32),
+                     np.zeros(n, np.int64), np.full(n, wlsqm.WEIGHT_CENTER, np.int32)))
+    def run(job):
+        dim, xk, fk, nk, xi, fi, order, knowns, wm = job
+        fi = fi.copy()
+        for _ in range(3):
+            _many(wlsqm, dim)(xk, fk, nk, xi, fi, None, 0, order, knowns, wm)
+        return fi
+    serial = [run(j) for j in jobs]
+    with ThreadPoolExecutor(max_workers=6) as pool:
+        threaded = list(pool.map(run, jobs * 2))
+    for i, fi in enumerate(threaded):
+        assert np.array_equal(fi, serial[i % len(jobs)])
