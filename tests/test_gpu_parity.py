@@ -1003,7 +1003,7 @@ def test_degenerate_cases_do_not_disturb_their_neighbours(wlsqm, dim, order, K):
 
 def test_concurrent_calls_from_python_threads(wlsqm):
     """ctypes releases the GIL for the whole call (like the reference's `with nogil`, simple.pyx:396): several Python threads
-    fitting different batches at the same time (per-thread staging buffers and streams in the library) get the results of
+    fitting different batches at the same time (per-thread staging and device buffers in the library) get the results of
     the serial runs, bit for bit."""
     from concurrent.futures import ThreadPoolExecutor
     rng = np.random.default_rng(9)
