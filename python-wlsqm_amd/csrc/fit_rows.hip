@@ -15,7 +15,11 @@
 //      no barrier; 1/d_c is computed once per column by all lanes;
 //   5. forward substitution the same way; for the backward one the factor is parked in LDS once (column access).
 // Per case ~5.5k wave-instructions for order 4 with 64 neighbours, against ~25k (and ~100 LDS round trips on the critical
-// path of its rolled loops) in fit_wave.hip.
+// path of its rolled loops) in fit_wave.hip.  Order 3 has only 20 rows, so three of its cases share a wave (template
+// parameters G = 3 cases x GS = 21 lanes); the pivot row then travels through a per-group LDS mailbox instead of v_readlane.
+// Measured (200k cases, 64 neighbours): order 4 7.9 -> 2.2 ms, order 3 2.3 -> 1.2 (one case per wave) -> 0.99 ms; the LDS
+// mailbox form with one case per wave is 10 % slower than v_readlane for both orders, the bpermute form with three cases
+// per wave 15 % slower than the mailbox.
 #include "wlsqm_internal.hpp"
 #include "wlsqm_kernels.hpp"
 #include "wlsqm_moments.hpp"
