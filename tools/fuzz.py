@@ -7,13 +7,16 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "python-wlsqm_amd"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
+import torch
 import wlsqm
+import wlsqm.hip as whip
 from oracle import oracle
 import _parity as P
 NDOF = {1: [1, 2, 3, 4, 5], 2: [1, 3, 6, 10, 15], 3: [1, 4, 10, 20, 35]}
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-t0 = time.time(); trials = 0; worst = 0.0; ratios = []; acc = []
+t0 = time.time(); trials = 0; worst = 0.0; ratios = []; acc = []; cloud_trials = 0
+dev = torch.device("cuda", 0)
 while time.time() - t0 < budget:
     dim = int(rng.integers(1, 4)); mixed = rng.random() < 0.25
     order = int(rng.integers(0, 5)); no_max = NDOF[dim][4 if mixed else order]
@@ -61,11 +64,31 @@ while time.time() - t0 < budget:
     if mode == "sens":
         assert np.array_equal(np.isnan(sens_g), np.isnan(sens_o)), desc
         assert np.array_equal(sens_g == 777.0, sens_o == 777.0), desc
+    if not mixed and mode != "iter" and n >= 15 and rng.random() < 0.5 and not (mode == "sens" and NDOF[dim][order] > 15):
+        # the same batch through the index-based entry point: S = all neighbour points followed by the origins
+        S = np.ascontiguousarray(np.concatenate([xk.reshape(n * K, dim), xi], axis=0)); Fv = np.concatenate([fk.reshape(n * K), fi0[:, 0]])
+        if dim == 1: S = np.ascontiguousarray(S[:, 0])
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        hoods = (np.arange(n)[:, None] * K + np.arange(K)[None, :]).astype(np.int32)
+        fi_c = t(fi0); sens_c = t(np.full((n, K, ncol), 777.0)) if mode == "sens" else None
+        whip.fit_cloud_device(dim, order, t(S), t(Fv), t(hoods), fi_c, t(nk), t(knowns), t(wm),
+                              point_index=t((n * K + np.arange(n)).astype(np.int32)), sens=sens_c)
+        torch.cuda.synchronize()
+        fi_c = fi_c.cpu().numpy(); no = NDOF[dim][order]
+        Ec = P.column_metric(fi_c[:, :no], truth[:, :no]); N = P.column_metric(fi_o[:, :no], truth[:, :no])
+        E = P.column_metric(fi_c[:, :no], fi_o[:, :no])
+        ratios.append((float(np.max(np.minimum(E, Ec) / (1e-10 + 8.0 * N))), n, desc + " INDEX-BASED: GPU vs oracle %.1e" % E.max()))
+        if n >= 16 and N.max() > 0: acc.append(float(Ec.max() / N.max()))
+        assert np.array_equal(fi_c[:, no:], fi0[:, no:]), desc + " index-based: columns beyond no touched"
+        if mode == "sens":
+            sc = sens_c.cpu().numpy()
+            assert np.array_equal(np.isnan(sc), np.isnan(sens_o)) and np.array_equal(sc == 777.0, sens_o == 777.0), desc + " index-based sens pattern"
+        cloud_trials += 1
     trials += 1
 ratios.sort(reverse=True)
 over = [r for r in ratios if r[0] > 1.0]
-print("fuzz: %d random batches (%d order buckets) in %.0f s; largest column metric vs oracle %.2e; buckets over the 1e-10 + 8 N criterion: %d"
-      % (trials, len(ratios), time.time() - t0, worst, len(over)))
+print("fuzz: %d random batches (%d of them also index-based; %d order buckets) in %.0f s; largest column metric vs oracle %.2e; buckets over the 1e-10 + 8 N criterion: %d"
+      % (trials, cloud_trials, len(ratios), time.time() - t0, worst, len(over)))
 for r, _, d in ratios[:8]:
     print("   ratio %.2f  %s" % (r, d))
 if acc:
