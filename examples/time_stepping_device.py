@@ -13,11 +13,10 @@ S = rng.uniform(0.0, 1.0, (n, 2))
 dev = torch.device("cuda", 0)
 S_d = torch.from_numpy(S).to(dev)
 h_d = wlsqm.hip.knn(S_d, nk).long()                                  # nk nearest neighbours of every point, on the GPU
-hoods = h_d.cpu().numpy()
 solver = wlsqm.ExpertSolver(dimension=2, nk=np.full(n, nk, np.int32), order=np.full(n, order, np.int32),
                             knowns=np.full(n, wlsqm.b2_F, np.int64),
                             weighting_method=np.full(n, wlsqm.WEIGHT_CENTER, np.int32))
-solver.prepare(xi=S, xk=S[hoods])
+solver.prepare_device(S_d, S_d[h_d].contiguous())                   # geometry device to device: nothing crosses PCIe
 
 no = wlsqm.number_of_dofs(2, order)
 fi = torch.zeros((n, no), dtype=torch.float64, device=dev)

@@ -122,6 +122,10 @@ int wlsqm_hip_expert_create_guest(wlsqm_expert** out, wlsqm_expert* host, int al
  * arrays are ignored (expert.pyx:350-352: the host's geometry is used) and only the host's ready state is checked. */
 int wlsqm_hip_expert_prepare(wlsqm_expert* h, const double* xi, int64_t xi_stride_case,
                              const double* xk, int64_t xk_stride_case, int64_t xk_stride_k, int64_t max_nk);
+/* Extension: prepare() from device-resident arrays (xi[ncases, xi_stride_case], xk[ncases, xk_stride_case / dimension,
+ * dimension] with xk_stride_k == dimension); the geometry is copied device-to-device on `stream` into the solver's own block. */
+int wlsqm_hip_expert_prepare_device(wlsqm_expert* h, void* stream, const double* xi, int64_t xi_stride_case,
+                                    const double* xk, int64_t xk_stride_case, int64_t xk_stride_k);
 /* expert.pyx:467-655 solve(fk, fi, sens): host arrays; returns max iterations via *iterations_out. */
 int wlsqm_hip_expert_solve(wlsqm_expert* h, const double* fk, int64_t fk_stride_case, int64_t fk_stride_k,
                            double* fi, int64_t fi_stride_case,

@@ -193,6 +193,35 @@ int wlsqm_hip_expert_prepare(wlsqm_expert* h, const double* xi, int64_t xi_strid
     return WLSQM_OK;
 }
 
+// prepare() from DEVICE-resident arrays (extension): xi[ncases, xi_stride_case], xk[ncases, >= max_nk, dimension] with the
+// coordinate axis contiguous and xk_stride_k == dimension; copied (device to device, on `stream`) into the solver's own
+// padded geometry block, so the caller's tensors may be freed afterwards.
+int wlsqm_hip_expert_prepare_device(wlsqm_expert* h, void* stream, const double* xi, int64_t xi_stride_case,
+                                    const double* xk, int64_t xk_stride_case, int64_t xk_stride_k) {
+    if (!h) { set_error("null argument"); return WLSQM_EVALUE; }
+    if (h->guest) {
+        if (!h->g->ready) { set_error("In guest mode, host must be in the ready state"); return WLSQM_ERUNTIME; }
+        return WLSQM_OK;
+    }
+    if (!xi || !xk) { set_error("null argument"); return WLSQM_EVALUE; }
+    wlsqm_expert_geometry& g = *h->g;
+    const int dim = g.dimension;
+    if (xk_stride_k != dim || xk_stride_case < g.max_nk * dim || xi_stride_case < dim) {
+        set_error("prepare_device needs xk[ncases, >= max_nk, dimension] with contiguous neighbour rows"); return WLSQM_EVALUE;
+    }
+    g.ready = false;
+    int rc = check_device(g.device);
+    if (rc != WLSQM_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    WLSQM_HIP_CHECK(hipMemcpy2DAsync(g.d_xk.p, (size_t)g.slots * dim * 8, xk, (size_t)xk_stride_case * 8, (size_t)g.max_nk * dim * 8,
+                                     (size_t)g.ncases, hipMemcpyDeviceToDevice, s));
+    WLSQM_HIP_CHECK(hipMemcpy2DAsync(g.d_xi.p, (size_t)dim * 8, xi, (size_t)xi_stride_case * 8, (size_t)dim * 8, (size_t)g.ncases,
+                                     hipMemcpyDeviceToDevice, s));
+    WLSQM_HIP_CHECK(hipStreamSynchronize(s));
+    g.ready = true;
+    return WLSQM_OK;
+}
+
 int wlsqm_hip_expert_solve(wlsqm_expert* h, const double* fk, int64_t fk_stride_case, int64_t fk_stride_k,
                            double* fi, int64_t fi_stride_case,
                            double* sens, int64_t sens_stride_case, int64_t sens_stride_k, int32_t* iterations_out) {

@@ -91,6 +91,7 @@ def lib():
                                                        C.c_void_p]
     L.wlsqm_hip_expert_create_guest.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int, C.c_int]
     L.wlsqm_hip_expert_prepare.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64]
+    L.wlsqm_hip_expert_prepare_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64]
     L.wlsqm_hip_expert_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,
                                          C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_int32)]
     L.wlsqm_hip_expert_solve_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
@@ -106,7 +107,7 @@ def lib():
     L.wlsqm_hip_interpolate_fit_host.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                                  C.c_int64, C.c_int, C.c_void_p, C.c_int]
     for name in ("wlsqm_hip_fit_many_host", "wlsqm_hip_fit_many_device", "wlsqm_hip_time_fit_device",
-                 "wlsqm_hip_expert_create", "wlsqm_hip_expert_create_guest", "wlsqm_hip_expert_prepare", "wlsqm_hip_expert_solve",
+                 "wlsqm_hip_expert_create", "wlsqm_hip_expert_create_guest", "wlsqm_hip_expert_prepare", "wlsqm_hip_expert_prepare_device", "wlsqm_hip_expert_solve",
                  "wlsqm_hip_expert_solve_device", "wlsqm_hip_expert_solve_many_device", "wlsqm_hip_expert_solve_many",
                  "wlsqm_hip_expert_memory_used", "wlsqm_hip_expert_destroy",
                  "wlsqm_hip_expert_conds", "wlsqm_hip_expert_interpolate", "wlsqm_hip_interpolate_fit_host",

@@ -20,6 +20,11 @@ def number_of_dofs(dimension, order):
     return B.lib().wlsqm_hip_number_of_dofs(int(dimension), int(order))
 
 
+def _to_numpy(a):
+    """host copy of a numpy array or of a (device) torch tensor"""
+    return a.detach().cpu().numpy() if hasattr(a, "detach") else np.asarray(a)
+
+
 class ExpertSolver:
     """Prepare once (geometry), solve many times (data).  See the reference's expert.pyx:66-90.
 
@@ -109,7 +114,7 @@ class ExpertSolver:
                     knowns=np.asarray(self.knowns), weighting_method=np.asarray(self.weighting_method),
                     algorithm=self.algorithm, do_sens=self.do_sens, max_iter=self.max_iter, ntasks=self.ntasks,
                     debug=self.debug, host=self.host, ready=self.ready,
-                    xi=None if self.xi is None else np.asarray(self.xi), xk=None if self.xk is None else np.asarray(self.xk))
+                    xi=None if self.xi is None else _to_numpy(self.xi), xk=None if self.xk is None else _to_numpy(self.xk))
 
     def __setstate__(self, st):
         ready, xi, xk = st.pop("ready"), st.pop("xi"), st.pop("xk")
@@ -164,6 +169,35 @@ class ExpertSolver:
             self.tree = None
         self.ready = True
 
+    def prepare_device(self, xi, xk, stream=None):
+        """prepare() from device-resident torch tensors (extension): xi (ncases, dim) [1D: (ncases,)], xk (ncases, >= max_nk,
+        dim) [1D: (ncases, >= max_nk)], float64, contiguous last axis.  The geometry is copied device-to-device into the
+        solver's own block (no PCIe traffic); together with wlsqm.hip.knn / ball and solve_device the whole workflow stays
+        on the GPU."""
+        self.ready = False
+        if self.host is not None:
+            return self.prepare(None, None)
+        import torch
+        want = (1, 2) if self.dimension == 1 else (2, 3)
+        if xi.dim() != want[0] or xk.dim() != want[1] or xi.dtype != torch.float64 or xk.dtype != torch.float64 \
+                or not xi.is_cuda or not xk.is_cuda:
+            raise ValueError("xi / xk must be float64 device tensors of %d / %d dimensions" % want)
+        if self.dimension > 1 and (xi.stride(1) != 1 or xk.stride(2) != 1 or xk.shape[2] != self.dimension
+                                   or xi.shape[1] != self.dimension or xk.stride(1) != self.dimension):
+            raise ValueError("xi (ncases, dim) and xk (ncases, K, dim) must have contiguous rows of exactly `dimension` coordinates")
+        if self.dimension == 1 and xk.stride(1) != 1:
+            raise ValueError("xk (ncases, K) must have a contiguous neighbour axis")
+        if xi.shape[0] < self.ncases or xk.shape[0] < self.ncases or xk.shape[1] < self._max_nk:
+            raise ValueError("xi / xk are too small")
+        if stream is None:
+            stream = torch.cuda.current_stream(xk.device).cuda_stream
+        B.check(B.lib().wlsqm_hip_expert_prepare_device(self._handle, C.c_void_p(int(stream) if stream else 0),
+                                                        C.c_void_p(xi.data_ptr()), xi.stride(0), C.c_void_p(xk.data_ptr()),
+                                                        xk.stride(0), self.dimension))
+        self.xk, self.xi = xk, xi
+        self.tree = None
+        self.ready = True
+
     def conds(self):
         """2-norm condition numbers of the (Ruiz-scaled) problem matrices, shape (ncases,) (expert.pyx:429-464).
         Only available in debug mode, like the reference (which fills them during prepare(), impl.pyx:662-682);
@@ -200,7 +234,7 @@ class ExpertSolver:
         if self.host is not None and self.host._tree_points is not None:
             self._tree, self._tree_points = self.host._tree, self.host._tree_points
         else:
-            xi = np.asarray(self.xi)
+            xi = _to_numpy(self.xi)
             self._tree, self._tree_points = None, (xi if self.dimension >= 2 else np.atleast_2d(xi).T)
 
     def interpolate(self, x, mode='nearest', r=None, diff=0, I=None):

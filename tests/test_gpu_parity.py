@@ -1028,3 +1028,29 @@ def test_concurrent_calls_from_python_threads(wlsqm):
         threaded = list(pool.map(run, jobs * 2))
     for i, fi in enumerate(threaded):
         assert np.array_equal(fi, serial[i % len(jobs)])
+
+
+def test_expert_prepare_device_keeps_the_workflow_on_the_gpu(wlsqm):
+    """Extension: neighbour search, geometry, data and fit all device-resident (wlsqm.hip.knn -> prepare_device ->
+    solve_device); bit-identical to the host-array ExpertSolver on the same neighbourhoods; interpolation still works."""
+    import torch
+    import synth
+    import wlsqm.hip as whip
+    n, k = 6000, 32
+    S = synth.halton(n, 2); F = synth.field(S)
+    dev = torch.device("cuda", 0)
+    S_d, F_d = torch.from_numpy(S).to(dev), torch.from_numpy(F).to(dev)
+    h_d = whip.knn(S_d, k).long()
+    mk = lambda: wlsqm.ExpertSolver(dimension=2, nk=np.full(n, k, np.int32), order=np.full(n, 2, np.int32),
+                                    knowns=np.full(n, wlsqm.b2_F, np.int64), weighting_method=np.full(n, 2, np.int32))
+    a, b = mk(), mk()
+    a.prepare_device(S_d, S_d[h_d].contiguous())
+    hoods = h_d.cpu().numpy()
+    b.prepare(xi=S, xk=S[hoods])
+    fi_a = torch.zeros((n, 6), dtype=torch.float64, device=dev); fi_a[:, 0] = F_d
+    a.solve_device(F_d[h_d].contiguous(), fi_a)
+    fi_b = np.zeros((n, 6)); fi_b[:, 0] = F
+    b.solve(fk=F[hoods], fi=fi_b)
+    torch.cuda.synchronize()
+    assert np.array_equal(fi_a.cpu().numpy(), fi_b)
+    assert a.memory_used() == b.memory_used()
