@@ -209,3 +209,12 @@ def test_c_abi_links_from_plain_c(tmp_path):
     exe = _build_c_example(tmp_path)
     rc = subprocess.call([exe])
     assert rc in (0, 2)
+
+
+def test_missing_library_is_an_import_error(monkeypatch):
+    """No silent fallback: if libwlsqm_hip.so is not there, the first call fails with build instructions."""
+    from wlsqm import _binding
+    monkeypatch.setattr(_binding, "_lib", None)
+    monkeypatch.setattr(_binding, "LIB_PATH", "/nonexistent/libwlsqm_hip.so")
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        _binding.lib()
