@@ -74,7 +74,8 @@ __device__ __forceinline__ void accumulate_moments(double (&mu)[mom_count<DIM>(2
 // 2D alternative: outer-product form.  With X[p] = dx^p and Yw[q] = w dy^q every moment is ONE fma,
 // mu(p,q) += X[p] * Yw[q], and nu(p,q) += X[p] * (f Yw[q]); the chain form above spends a multiply AND an add on every
 // monomial below the top degree.  Operations per neighbour, order 4: 45 + 15 fma + 21 multiplies = 81 against 96;
-// order 2: 31 against 30 (no gain: used from order 3 up, see accumulate_moments_best).
+// order 2: 31 against 30 (no gain: used from order 3 up, see accumulate_moments_best).  The 3D analogue (XY[p][q] * Zw[r])
+// has the chain form's operation count (64 for order 2) and measured the same on C5 (+-1 %): not kept.
 template <int ORDER>
 __device__ __forceinline__ void accumulate_moments_outer2d(double (&mu)[mom_count<2>(2 * ORDER)], double (&nu)[mom_count<2>(ORDER)],
                                                            const double (&d)[2], double w, double f) {
