@@ -19,7 +19,9 @@
 // parameters G = 3 cases x GS = 21 lanes); the pivot row then travels through a per-group LDS mailbox instead of v_readlane.
 // Measured (200k cases, 64 neighbours): order 4 7.9 -> 2.2 ms, order 3 2.3 -> 1.2 (one case per wave) -> 0.99 ms; the LDS
 // mailbox form with one case per wave is 10 % slower than v_readlane for both orders, the bpermute form with three cases
-// per wave 15 % slower than the mailbox.
+// per wave 15 % slower than the mailbox.  Sensitivities / refinement stay in fit_wave.hip: grafting its extras onto this kernel's
+// front end was measured (order 4 do_sens 8.6 vs 7.3 ms per 100k cases): their 64 LDS substitutions per case dominate and
+// the extra LDS state costs occupancy.
 #include "wlsqm_internal.hpp"
 #include "wlsqm_kernels.hpp"
 #include "wlsqm_moments.hpp"
