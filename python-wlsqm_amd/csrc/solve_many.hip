@@ -112,7 +112,8 @@ __global__ __launch_bounds__(K1_WV, 2) void solve_many_kernel(const KParams p, c
             double f[FMAX];
 #pragma unroll
             for (int kk = 0; kk < FMAX; ++kk) f[kk] = fnext[kk];
-            // prefetch the next field (two fields ahead measured slower: 0.093 vs 0.077 ms per field, register spills)
+            // prefetch the next field (two fields ahead measured slower: 0.093 vs 0.077 ms per field, register spills; also
+            // when the registers are freed by keeping only (offset, weight) per neighbour and recomputing the monomials: 0.081)
             if (r + 1 < R.nrhs) tile1_load_f<FMAX>(fnext, frow + (r + 1) * R.sfk_r, k0, G);
             double g[NO];
 #pragma unroll
