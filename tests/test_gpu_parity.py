@@ -1054,3 +1054,52 @@ def test_expert_prepare_device_keeps_the_workflow_on_the_gpu(wlsqm):
     torch.cuda.synchronize()
     assert np.array_equal(fi_a.cpu().numpy(), fi_b)
     assert a.memory_used() == b.memory_used()
+
+
+def test_reference_scenarios_order0_mean_and_exactly_determined_stencil(wlsqm):
+    """Scenarios of the reference's tests/test_edge_cases.py:14-31, 85-104: order 0 with uniform weights is the mean of
+    the data; order 2 in 1D on exactly three points reproduces the central differences."""
+    rng = np.random.default_rng(42)
+    xk = rng.uniform(-1.0, 1.0, size=(20, 2)); fk = rng.standard_normal(20)
+    fi = np.zeros(wlsqm.number_of_dofs(2, 0))
+    wlsqm.fit_2D(xk=xk, fk=fk, xi=np.array([0.0, 0.0]), fi=fi, sens=None, do_sens=False, order=0, knowns=0,
+                 weighting_method=wlsqm.WEIGHT_UNIFORM, debug=False)
+    assert fi.shape == (1,) and abs(fi[0] - fk.mean()) < 1e-12
+    h = 0.1
+    fi = np.zeros(wlsqm.number_of_dofs(1, 2))
+    wlsqm.fit_1D(xk=np.array([-h, 0.0, h]), fk=np.array([1.0, 0.5, 2.0]), xi=0.0, fi=fi, sens=None, do_sens=False, order=2,
+                 knowns=0, weighting_method=wlsqm.WEIGHT_UNIFORM, debug=False)
+    assert abs(fi[wlsqm.i1_F] - 0.5) < 1e-12 and abs(fi[wlsqm.i1_X] - (2.0 - 1.0) / (2 * h)) < 1e-12
+    assert abs(fi[wlsqm.i1_X2] - (1.0 + 2.0 - 2 * 0.5) / (h * h)) < 1e-10
+
+
+def test_reference_scenarios_expert_solver(wlsqm):
+    """Scenarios of the reference's tests/test_expert.py:35-170: a one-case ExpertSolver equals fit_2D; ALGO_ITERATIVE equals
+    ALGO_BASIC on data the model reproduces exactly; a 3D single case recovers the gradient."""
+    rng = np.random.default_rng(42)
+    xk = rng.uniform(-1, 1, (30, 2)); xi = np.array([0.1, -0.2])
+    f = lambda x, y: 1.0 + 2.0 * x - y + 0.5 * x * x + 0.25 * x * y - 0.75 * y * y
+    fk = f(xk[:, 0], xk[:, 1])
+    one = lambda v, dt: np.array([v], dtype=dt)
+    fi_ref = np.zeros(6)
+    wlsqm.fit_2D(xk=xk, fk=fk, xi=xi, fi=fi_ref, sens=None, do_sens=False, order=2, knowns=0,
+                 weighting_method=wlsqm.WEIGHT_UNIFORM, debug=False)
+    out = {}
+    for algo in (wlsqm.ALGO_BASIC, wlsqm.ALGO_ITERATIVE):
+        s = wlsqm.ExpertSolver(dimension=2, nk=one(30, np.int32), order=one(2, np.int32), knowns=one(0, np.int64),
+                               weighting_method=one(wlsqm.WEIGHT_UNIFORM, np.int32), algorithm=algo, do_sens=False,
+                               max_iter=10, ntasks=1, debug=False)
+        s.prepare(xi=xi[None, :], xk=xk[None, :, :])
+        fi = np.zeros((1, 6))
+        s.solve(fk=fk[None, :], fi=fi, sens=None)
+        out[algo] = fi[0]
+    assert np.array_equal(out[wlsqm.ALGO_BASIC], fi_ref)
+    dx, dy = xi
+    exact = np.array([f(dx, dy), 2.0 + dx + 0.25 * dy, -1.0 + 0.25 * dx - 1.5 * dy, 1.0, 0.25, -1.5])
+    assert np.allclose(out[wlsqm.ALGO_BASIC], exact, atol=1e-10) and np.allclose(out[wlsqm.ALGO_ITERATIVE], exact, atol=1e-10)
+    xk3 = rng.uniform(-1, 1, (40, 3)); fk3 = 3.0 + xk3[:, 0] - 2.0 * xk3[:, 1] + 0.5 * xk3[:, 2]
+    s3 = wlsqm.ExpertSolver(dimension=3, nk=one(40, np.int32), order=one(1, np.int32), knowns=one(0, np.int64),
+                            weighting_method=one(wlsqm.WEIGHT_UNIFORM, np.int32))
+    s3.prepare(xi=np.zeros((1, 3)), xk=xk3[None, :, :])
+    fi3 = np.zeros((1, 4)); s3.solve(fk=fk3[None, :], fi=fi3)
+    assert np.allclose(fi3[0], [3.0, 1.0, -2.0, 0.5], atol=1e-11)
