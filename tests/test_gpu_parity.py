@@ -1103,3 +1103,31 @@ def test_reference_scenarios_expert_solver(wlsqm):
     s3.prepare(xi=np.zeros((1, 3)), xk=xk3[None, :, :])
     fi3 = np.zeros((1, 4)); s3.solve(fk=fk3[None, :], fi=fi3)
     assert np.allclose(fi3[0], [3.0, 1.0, -2.0, 0.5], atol=1e-11)
+
+
+def test_no_device_memory_leak_over_solver_lifetimes(wlsqm):
+    """Creating, preparing, solving and closing many ExpertSolvers (and guests), and repeated moment-path / neighbour-search
+    calls with their temporaries, must give the device memory back."""
+    import torch
+    import wlsqm.hip as whip
+    c = K.config("C3")
+    def cycle():
+        s = wlsqm.ExpertSolver(dimension=c["dim"], nk=c["nk_a"], order=c["order_a"], knowns=c["knowns_a"],
+                               weighting_method=c["wm_a"], do_sens=True)
+        s.prepare(xi=c["xi"], xk=c["xk"])
+        g = wlsqm.ExpertSolver(dimension=c["dim"], nk=c["nk_a"], order=c["order_a"], knowns=c["knowns_a"],
+                               weighting_method=c["wm_a"], host=s)
+        g.prepare(None, None)
+        fi = c["fi0"].copy(); s.solve(fk=c["fk"], fi=fi, sens=np.zeros((c["n"], c["nkv"], c["no"])))
+        fi = c["fi0"].copy(); g.solve(fk=c["fk"], fi=fi)
+        whip.knn(torch.from_numpy(c["S"]).cuda(), 16)
+        g.close(); s.close()
+    for _ in range(3):
+        cycle()
+    torch.cuda.synchronize(); torch.cuda.empty_cache()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(40):
+        cycle()
+    torch.cuda.synchronize(); torch.cuda.empty_cache()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 64 * 2 ** 20, (free0 - free1) / 2 ** 20          # stream-ordered pool may keep a few blocks
