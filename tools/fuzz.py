@@ -15,7 +15,7 @@ import _parity as P
 NDOF = {1: [1, 2, 3, 4, 5], 2: [1, 3, 6, 10, 15], 3: [1, 4, 10, 20, 35]}
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-t0 = time.time(); trials = 0; worst = 0.0; ratios = []; acc = []; cloud_trials = 0
+t0 = time.time(); trials = 0; worst = 0.0; ratios = []; acc = []; cloud_trials = 0; expert_trials = 0
 dev = torch.device("cuda", 0)
 while time.time() - t0 < budget:
     dim = int(rng.integers(1, 4)); mixed = rng.random() < 0.25
@@ -84,11 +84,23 @@ while time.time() - t0 < budget:
             sc = sens_c.cpu().numpy()
             assert np.array_equal(np.isnan(sc), np.isnan(sens_o)) and np.array_equal(sc == 777.0, sens_o == 777.0), desc + " index-based sens pattern"
         cloud_trials += 1
+    if rng.random() < 0.3:
+        # the same batch through ExpertSolver (prepare once, solve): the same kernels on the same device layout -> same bits
+        es = wlsqm.ExpertSolver(dimension=dim, nk=nk, order=orders, knowns=knowns, weighting_method=wm,
+                                algorithm=wlsqm.ALGO_ITERATIVE if mode == "iter" else wlsqm.ALGO_BASIC,
+                                do_sens=(mode == "sens"), max_iter=6)
+        es.prepare(xi=xi_a, xk=xk_a)
+        fi_e = fi0.copy(); sens_e = np.full((n, K, ncol), 777.0) if mode == "sens" else None
+        es.solve(fk=fk, fi=fi_e, sens=sens_e)
+        assert np.array_equal(fi_e, fi_g, equal_nan=True), desc + ": ExpertSolver differs from the one-shot driver"
+        if mode == "sens":
+            assert np.array_equal(sens_e, sens_g, equal_nan=True), desc + ": ExpertSolver sens differs"
+        es.close(); expert_trials += 1
     trials += 1
 ratios.sort(reverse=True)
 over = [r for r in ratios if r[0] > 1.0]
-print("fuzz: %d random batches (%d of them also index-based; %d order buckets) in %.0f s; largest column metric vs oracle %.2e; buckets over the 1e-10 + 8 N criterion: %d"
-      % (trials, cloud_trials, len(ratios), time.time() - t0, worst, len(over)))
+print("fuzz: %d random batches (%d of them also index-based, %d also through ExpertSolver; %d order buckets) in %.0f s; largest column metric vs oracle %.2e; buckets over the 1e-10 + 8 N criterion: %d"
+      % (trials, cloud_trials, expert_trials, len(ratios), time.time() - t0, worst, len(over)))
 for r, _, d in ratios[:8]:
     print("   ratio %.2f  %s" % (r, d))
 if acc:
