@@ -36,7 +36,12 @@
 //     gfx950's v_permlane16_swap / v_permlane32_swap instead of the ds_bpermute butterflies (2 moves + 1 add per double
 //     and step, no LDS crossbar): correct, but C5 0.46 instead of 0.36 ms and do_sens 0.82 instead of 0.70 ms (both
 //     operands are overwritten, so every value needs two copies first); wave-shuffle instead of LDS for the per-case
-//     maximum of the one-wave shapes: no difference.
+//     maximum of the one-wave shapes: no difference;
+//     deferred solves (the wave parks the moments of 2, 3 or 4 consecutive tiles in LDS, the last tile's in its own dead
+//     staging rows, and then solves 32 / 48 / 64 cases at once, one per lane, instead of 16 cases on a quarter of the lanes
+//     after every tile — the solve is 26 % of C2's VALU instructions): bit-identical results, same registers and
+//     occupancy, but C2 0.183 / 0.229 / 0.189 ms instead of 0.175 and C5 0.381 (2 tiles) / 0.403 (4) instead of 0.352:
+//     the short solve after every tile is what the other waves' loads hide behind; VALU instruction count is not the limit.
 #include <cstdlib>
 
 #include "wlsqm_internal.hpp"
