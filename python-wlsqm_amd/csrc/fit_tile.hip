@@ -42,6 +42,10 @@
 //     after every tile — the solve is 26 % of C2's VALU instructions): bit-identical results, same registers and
 //     occupancy, but C2 0.183 / 0.229 / 0.189 ms instead of 0.175 and C5 0.381 (2 tiles) / 0.403 (4) instead of 0.352:
 //     the short solve after every tile is what the other waves' loads hide behind; VALU instruction count is not the limit.
+//     direct xk loads as well (every lane reads the 128 contiguous bytes of its own 8 neighbours with dwordx4 loads, the
+//     maximum met by shuffles: no LDS, no barrier at all): 0.189 vs 0.179 ms at three waves per SIMD, 0.241 at
+//     __launch_bounds__(64, 3), 0.397 with two lanes per case — 64 distinct lines per load instruction are fine for the
+//     fk third of the bytes but not for all of them.
 #include <cstdlib>
 
 #include "wlsqm_internal.hpp"
