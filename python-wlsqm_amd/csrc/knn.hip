@@ -38,20 +38,39 @@ static inline double value_of(unsigned long long k) {
     double v; memcpy(&v, &u, 8); return v;
 }
 
-__global__ void knn_bbox_kernel(const double* __restrict__ S, long long n, int dim, unsigned long long* mm /*[2][3]*/) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long ic = i < n ? i : n - 1;                       // tail lanes replay the last point
+// Grid-stride partial extrema per lane, met per wave by shuffles and per block through LDS: one pair of atomics per block
+// and axis (one per WAVE and axis serialises ~60k same-address atomics in L2 for 1M points: 0.71 ms instead of ~0.03).
+__global__ __launch_bounds__(256) void knn_bbox_kernel(const double* __restrict__ S, long long n, int dim,
+                                                       unsigned long long* mm /*[2][3]*/) {
+    __shared__ double s_lo[4][3], s_hi[4][3];
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int wave = threadIdx.x >> 6;
     for (int m = 0; m < dim; ++m) {
-        double lo = S[ic * dim + m], hi = lo;
-        for (int off = 32; off > 0; off >>= 1) {                  // one pair of atomics per wave, not per point
+        double lo = S[(i0 < n ? i0 : n - 1) * dim + m], hi = lo;   // tail lanes replay the last point
+        for (long long i = i0 + stride; i < n; i += stride) {
+            const double v = S[i * dim + m];
+            lo = (v < lo || v != v) ? v : lo;                       // NaN wins, so that it is reported
+            hi = (v > hi || v != v) ? v : hi;
+        }
+        for (int off = 32; off > 0; off >>= 1) {
             const double a = __shfl_xor(lo, off, 64), b = __shfl_xor(hi, off, 64);
-            lo = (a < lo || a != a) ? a : lo;                     // NaN wins, so that it is reported
+            lo = (a < lo || a != a) ? a : lo;
             hi = (b > hi || b != b) ? b : hi;
         }
-        if ((threadIdx.x & 63) == 0) {
-            atomicMin(&mm[m], key_of(lo));
-            atomicMax(&mm[3 + m], key_of(hi));
+        if ((threadIdx.x & 63) == 0) { s_lo[wave][m] = lo; s_hi[wave][m] = hi; }
+    }
+    __syncthreads();
+    if (threadIdx.x < dim) {
+        const int m = threadIdx.x;
+        double lo = s_lo[0][m], hi = s_hi[0][m];
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) {
+            const double a = s_lo[w][m], b = s_hi[w][m];
+            lo = (a < lo || a != a) ? a : lo;
+            hi = (b > hi || b != b) ? b : hi;
         }
+        atomicMin(&mm[m], key_of(lo));
+        atomicMax(&mm[3 + m], key_of(hi));
     }
 }
 
@@ -196,7 +215,8 @@ int GridIndex::build(int dimension, int64_t npoints, const double* S, hipStream_
     if ((rc = d_mm.alloc(6 * sizeof(unsigned long long)))) return rc;
     unsigned long long h_mm[6] = {~0ull, ~0ull, ~0ull, 0ull, 0ull, 0ull};
     WLSQM_HIP_CHECK(hipMemcpyAsync(d_mm.p, h_mm, sizeof(h_mm), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(knn_bbox_kernel, dim3(blocks), dim3(256), 0, s, S, n, dimension, d_mm.as<unsigned long long>());
+    hipLaunchKernelGGL(knn_bbox_kernel, dim3(blocks < 1024u ? blocks : 1024u), dim3(256), 0, s, S, n, dimension,
+                       d_mm.as<unsigned long long>());
     WLSQM_HIP_CHECK(hipMemcpyAsync(h_mm, d_mm.p, sizeof(h_mm), hipMemcpyDeviceToHost, s));
     WLSQM_HIP_CHECK(hipStreamSynchronize(s));
     G = KnnGrid{};
