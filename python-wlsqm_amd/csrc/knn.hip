@@ -120,8 +120,8 @@ __global__ __launch_bounds__(64) void knn_query_kernel(const double* __restrict_
 #pragma unroll
     for (int m = 0; m < DIM; ++m) { x[m] = Ss[q * DIM + m]; cq[m] = cell_coord(x[m], G, m); }
 
-    int count = 0, worst_slot = 0;
-    double worst = -1.0;
+    int count = 0;
+    double worst = -1.0;          // squared distance at the root of the full heap (k kept)
     int rmax = 0;
 #pragma unroll
     for (int m = 0; m < DIM; ++m) rmax = max(rmax, max(cq[m], G.g[m] - 1 - cq[m]));
@@ -152,13 +152,31 @@ __global__ __launch_bounds__(64) void knn_query_kernel(const double* __restrict_
                         for (int m = 0; m < DIM; ++m) { const double d = Ss[(long long)pos * DIM + m] - x[m]; d2 += d * d; }
                         if (d2 > r2max) continue;                                      // ball search: outside the radius
                         if (count < k) {
-                            bd[count * 64] = d2; bi[count * 64] = pos;
-                            if (d2 > worst) { worst = d2; worst_slot = count; }
-                            ++count;
+                            // append and sift up (max-heap on the squared distance: the root is the worst kept so far)
+                            int i = count++;
+                            while (i > 0) {
+                                const int up = (i - 1) >> 1;
+                                const double v = bd[up * 64];
+                                if (v >= d2) break;
+                                bd[i * 64] = v; bi[i * 64] = bi[up * 64];
+                                i = up;
+                            }
+                            bd[i * 64] = d2; bi[i * 64] = pos;
+                            if (count == k) worst = bd[0];
                         } else if (d2 < worst) {
-                            bd[worst_slot * 64] = d2; bi[worst_slot * 64] = pos;
-                            worst = -1.0;
-                            for (int s = 0; s < k; ++s) { const double v = bd[s * 64]; if (v > worst) { worst = v; worst_slot = s; } }
+                            // replace the root and sift down
+                            int i = 0;
+                            for (;;) {
+                                int ch = 2 * i + 1;
+                                if (ch >= k) break;
+                                double cv = bd[ch * 64];
+                                if (ch + 1 < k) { const double rv = bd[(ch + 1) * 64]; if (rv > cv) { cv = rv; ++ch; } }
+                                if (cv <= d2) break;
+                                bd[i * 64] = cv; bi[i * 64] = bi[ch * 64];
+                                i = ch;
+                            }
+                            bd[i * 64] = d2; bi[i * 64] = pos;
+                            worst = bd[0];
                         }
                     }
                 }
@@ -183,15 +201,29 @@ __global__ __launch_bounds__(64) void knn_query_kernel(const double* __restrict_
     if (counts) counts[self] = count;
     for (int i = count; i < row_stride; ++i) hoods[row + i] = self;       // unused slots: a valid index, masked by the count
     for (int i = 0; i < count; ++i) bi[i * 64] = perm[bi[i * 64]];
-    for (int i = 0; i < count; ++i) {
-        int best = i; double bdv = bd[i * 64]; int bidx = bi[i * 64];
-        for (int s = i + 1; s < count; ++s) {
-            const double v = bd[s * 64]; const int vi = bi[s * 64];
-            if (v < bdv || (v == bdv && vi < bidx)) { best = s; bdv = v; bidx = vi; }
+    // ascending (distance, original index): heap sort in place on the full key (the search ordered by distance only)
+    auto sift = [&](int i, int size, double v, int vi) {
+        for (;;) {
+            int ch = 2 * i + 1;
+            if (ch >= size) break;
+            double cv = bd[ch * 64]; int ci = bi[ch * 64];
+            if (ch + 1 < size) {
+                const double rv = bd[(ch + 1) * 64]; const int ri = bi[(ch + 1) * 64];
+                if (rv > cv || (rv == cv && ri > ci)) { cv = rv; ci = ri; ++ch; }
+            }
+            if (!(cv > v || (cv == v && ci > vi))) break;
+            bd[i * 64] = cv; bi[i * 64] = ci;
+            i = ch;
         }
-        if (best != i) { bd[best * 64] = bd[i * 64]; bi[best * 64] = bi[i * 64]; }
-        hoods[row + i] = bidx;
+        bd[i * 64] = v; bi[i * 64] = vi;
+    };
+    for (int i = count / 2 - 1; i >= 0; --i) sift(i, count, bd[i * 64], bi[i * 64]);
+    for (int size = count - 1; size > 0; --size) {
+        const double v = bd[size * 64]; const int vi = bi[size * 64];
+        bd[size * 64] = bd[0]; bi[size * 64] = bi[0];
+        sift(0, size, v, vi);
     }
+    for (int i = 0; i < count; ++i) hoods[row + i] = bi[i * 64];
 }
 
 }  // namespace wlsqm
