@@ -1131,3 +1131,50 @@ def test_no_device_memory_leak_over_solver_lifetimes(wlsqm):
     torch.cuda.synchronize(); torch.cuda.empty_cache()
     free1 = torch.cuda.mem_get_info()[0]
     assert free0 - free1 < 64 * 2 ** 20, (free0 - free1) / 2 ** 20          # stream-ordered pool may keep a few blocks
+
+
+@pytest.mark.gpu
+def test_device_api_captures_into_a_hip_graph(wlsqm):
+    """The device-resident entry points only enqueue work on the caller's stream (no host synchronisation, no host
+    reads), so a time-stepping loop can be captured once and replayed (hipGraph through torch.cuda.CUDAGraph): nothing
+    runs during capture, a replay follows the CURRENT contents of the captured buffers and is bit-identical to eager
+    calls — one-shot driver and ExpertSolver.solve_device alike."""
+    import torch
+    import synth
+    import wlsqm.hip as whip
+    n, k = 5000, 32
+    dev = torch.device("cuda", 0)
+    S = synth.halton(n, 2)
+    S_d = torch.from_numpy(S).to(dev)
+    h_d = whip.knn(S_d, k).long()
+    xk = S_d[h_d].contiguous()
+    fk = torch.zeros((n, k), dtype=torch.float64, device=dev)
+    fi = torch.zeros((n, 6), dtype=torch.float64, device=dev)
+    fi2 = torch.zeros((n, 6), dtype=torch.float64, device=dev)
+    nk = torch.full((n,), k, dtype=torch.int32, device=dev)
+    kn = torch.zeros(n, dtype=torch.int64, device=dev)
+    wm = torch.full((n,), 2, dtype=torch.int32, device=dev)
+    solver = wlsqm.ExpertSolver(dimension=2, nk=np.full(n, k, np.int32), order=np.full(n, 2, np.int32),
+                                knowns=np.zeros(n, np.int64), weighting_method=np.full(n, 2, np.int32))
+    solver.prepare_device(S_d, xk)
+    whip.fit_many_device(2, 2, xk, fk, nk, S_d, fi, kn, wm)       # warm up outside the capture (module load, setup)
+    solver.solve_device(fk, fi2)
+    torch.cuda.synchronize()
+    fi.fill_(-7.0); fi2.fill_(-7.0)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=torch.cuda.Stream()):
+        whip.fit_many_device(2, 2, xk, fk, nk, S_d, fi, kn, wm)
+        solver.solve_device(fk, fi2)
+    torch.cuda.synchronize()
+    assert float(fi.min()) == -7.0 and float(fi.max()) == -7.0 and float(fi2.max()) == -7.0     # captured, not run
+    for t in range(3):
+        Ft = torch.from_numpy(synth.field(S, t=float(t))).to(dev)
+        fk.copy_(Ft[h_d])
+        g.replay()
+        torch.cuda.synchronize()
+        got, got2 = fi.clone(), fi2.clone()
+        whip.fit_many_device(2, 2, xk, fk, nk, S_d, fi, kn, wm)
+        solver.solve_device(fk, fi2)
+        torch.cuda.synchronize()
+        assert torch.equal(got, fi) and torch.equal(got2, fi2)
+        assert float((got[:, 0] - Ft).abs().max()) < 1e-2            # follows the field of THIS step (truncation error only)
