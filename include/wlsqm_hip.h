@@ -178,6 +178,11 @@ int wlsqm_hip_expert_interpolate(wlsqm_expert* h, const double* x, int64_t x_str
  * expert.pyx:830-895): out[nx] the values, I_out[nx] (nullable) the model chosen for every point. */
 int wlsqm_hip_expert_interpolate_nearest(wlsqm_expert* h, const double* x, int64_t x_stride, int64_t nx, int diff,
                                          double* out, int64_t* I_out);
+/* mode='continuous' with the ball search on the device too (the reference builds the lists with
+ * cKDTree.query_ball_tree, expert.pyx:898-903): out[nx] = weighted average (weights (1 - d/r)^2, expert.pyx:45-46)
+ * of the models whose origin lies within r of the point; NaN where there is none. */
+int wlsqm_hip_expert_interpolate_continuous(wlsqm_expert* h, const double* x, int64_t x_stride, int64_t nx, double r,
+                                            int diff, double* out);
 /* expert.pyx:289-306 memory_used(): (bytes in use, bytes reserved) of the device-side state; a guest counts only
  * what it owns (the shared geometry is the host's). */
 int wlsqm_hip_expert_memory_used(const wlsqm_expert* h, int64_t* used, int64_t* total);

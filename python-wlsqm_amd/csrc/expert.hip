@@ -426,6 +426,34 @@ int wlsqm_hip_expert_interpolate_nearest(wlsqm_expert* h, const double* x, int64
     return WLSQM_OK;
 }
 
+// mode='continuous' without host-side lists (expert.pyx:898-985 builds them with cKDTree.query_ball_tree): the models within
+// r of every x are found on the device by a grid walk (knn.hip) and averaged in the same kernel.
+int wlsqm_hip_expert_interpolate_continuous(wlsqm_expert* h, const double* x, int64_t x_stride, int64_t nx, double r, int diff,
+                                            double* out) {
+    if (!h || !x || !out) { set_error("null argument"); return WLSQM_EVALUE; }
+    if (!h->g->ready || !h->solved) { set_error("interpolate() needs prepare() and solve() first"); return WLSQM_ERUNTIME; }
+    if (!(r > 0.0)) { set_error("r must be positive"); return WLSQM_EVALUE; }
+    int rc = check_device(h->g->device);
+    if (rc != WLSQM_OK) return rc;
+    if (nx <= 0) return WLSQM_OK;
+    const int dim = h->g->dimension;
+    std::vector<double> sx((size_t)nx * dim);
+    for (int64_t m = 0; m < nx; ++m)
+        for (int c = 0; c < dim; ++c) sx[(size_t)m * dim + c] = x[m * x_stride + c];
+    DevBuf d_x, d_out;
+    hipStream_t s = nullptr;
+    if ((rc = d_x.alloc(sx.size() * 8)) || (rc = d_out.alloc((size_t)nx * 8))) return rc;
+    WLSQM_HIP_CHECK(hipMemcpyAsync(d_x.p, sx.data(), d_x.n, hipMemcpyHostToDevice, s));
+    InterpParams q{};
+    q.xi = h->g->d_xi.as<double>(); q.sxi = dim; q.fi = h->d_fi.as<double>(); q.sfi = h->g->max_no;
+    q.order = h->g->d_order.as<int>(); q.sorder = 1; q.nmodels = h->g->ncases;
+    q.x = d_x.as<double>(); q.sx = dim; q.nx = nx; q.diff = diff; q.out = d_out.as<double>();
+    if ((rc = interp_continuous(dim, q, r, s))) return rc;
+    WLSQM_HIP_CHECK(hipMemcpyAsync(out, d_out.p, (size_t)nx * 8, hipMemcpyDeviceToHost, s));
+    WLSQM_HIP_CHECK(hipStreamSynchronize(s));
+    return WLSQM_OK;
+}
+
 int wlsqm_hip_expert_conds(wlsqm_expert* h, double* out) {
     if (!h || !out) { set_error("null argument"); return WLSQM_EVALUE; }
     if (!h->g->ready) { set_error("Solver is not in the ready state; prepare() must be called before conds()"); return WLSQM_ERUNTIME; }   // expert.pyx:438-439

@@ -17,35 +17,6 @@
 namespace wlsqm {
 
 template <int DIM>
-__device__ __forceinline__ double eval_model(const InterpParams& q, long long model, const double (&xp)[DIM], double* d2_out) {
-    const int order = q.order[model * q.sorder];
-    const int no = ndofs(DIM, order);
-    double pw[DIM][5];
-    double d2 = 0.0;
-#pragma unroll
-    for (int m = 0; m < DIM; ++m) {
-        const double d = xp[m] - q.xi[model * q.sxi + m];
-        d2 += d * d;
-        pw[m][0] = 1.0; pw[m][1] = d; pw[m][2] = 0.5 * d * d; pw[m][3] = (1.0 / 6.0) * d * d * d;
-        pw[m][4] = (1.0 / 24.0) * (d * d) * (d * d);
-    }
-    if (d2_out) *d2_out = d2;
-    if (q.diff >= no || q.diff < 0) return 0.0;
-    const int Qx = Mono<DIM>::P[q.diff], Qy = Mono<DIM>::Q[q.diff], Qz = Mono<DIM>::R[q.diff];
-    const double* f = q.fi + model * q.sfi;
-    double acc = 0.0;
-    for (int a = 0; a < no; ++a) {
-        const int ex = Mono<DIM>::P[a] - Qx, ey = Mono<DIM>::Q[a] - Qy, ez = Mono<DIM>::R[a] - Qz;
-        if (ex < 0 || ey < 0 || ez < 0) continue;
-        double term = f[a] * pw[0][ex];
-        if constexpr (DIM >= 2) term *= pw[1][ey];
-        if constexpr (DIM == 3) term *= pw[2][ez];
-        acc += term;
-    }
-    return acc;
-}
-
-template <int DIM>
 __global__ __launch_bounds__(256) void interp_kernel(const InterpParams q) {
     const long long m = (long long)blockIdx.x * 256 + threadIdx.x;
     if (m >= q.nx) return;

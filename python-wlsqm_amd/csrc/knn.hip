@@ -20,6 +20,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include "wlsqm_internal.hpp"
+#include "wlsqm_interp.hpp"
 
 namespace wlsqm {
 
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(64) void knn_query_kernel(const double* __restrict_
             if (reach > 0.0 && ((count == k && worst <= reach * reach) || reach * reach > r2max)) break;
         }
     }
-    // ascending (distance, original index): selection sort in place, then map sorted positions to point indices
+    // map sorted positions to point indices
     const int self = perm[q];
     const long long row = (long long)self * row_stride;
     if (counts) counts[self] = count;
@@ -401,6 +402,61 @@ int nearest_search(int dimension, int64_t ndata, const double* S, int64_t nquery
 #undef NEAREST_LAUNCH
     WLSQM_HIP_CHECK(hipGetLastError());
     WLSQM_HIP_CHECK(hipStreamSynchronize(s));
+    return WLSQM_OK;
+}
+
+// ExpertSolver.interpolate(mode='continuous') (expert.pyx:898-985: query_ball_tree of the origins, then the weighted average
+// of the models within r).  One lane per evaluation point; the ball's bounding block of cells is walked directly (cell_coord
+// is monotone, so every origin within r lies in a cell of [cell(x - r), cell(x + r)] on each axis), no lists are built.
+template <int DIM>
+__global__ __launch_bounds__(64) void interp_ball_kernel(const double* __restrict__ Ss, const int* __restrict__ perm,
+                                                         const int* __restrict__ start, KnnGrid G, const InterpParams q,
+                                                         double r) {
+    const long long m = (long long)blockIdx.x * 64 + threadIdx.x;
+    if (m >= q.nx) return;
+    double xp[DIM]; int c0[3] = {0, 0, 0}, c1[3] = {0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < DIM; ++c) {
+        xp[c] = q.x[m * q.sx + c];
+        c0[c] = cell_coord(xp[c] - r, G, c); c1[c] = cell_coord(xp[c] + r, G, c);
+    }
+    const double r2 = r * r;
+    double acc = 0.0, sum_w = 0.0;
+    for (int cz = c0[2]; cz <= c1[2]; ++cz)
+        for (int cy = c0[1]; cy <= c1[1]; ++cy) {
+            // the cells of one x-run are consecutive in the sorted order: one range of positions
+            const long long row = (long long)G.g[0] * (cy + (long long)G.g[1] * cz);
+            const int p0 = start[row + c0[0]], p1 = start[row + c1[0] + 1];
+            for (int pos = p0; pos < p1; ++pos) {
+                double d2 = 0.0;
+#pragma unroll
+                for (int c = 0; c < DIM; ++c) { const double d = Ss[(long long)pos * DIM + c] - xp[c]; d2 += d * d; }
+                if (d2 > r2) continue;
+                const double v = eval_model<DIM>(q, perm[pos], xp, nullptr);
+                const double t = 1.0 - sqrt(d2 / r2);     // expert.pyx:45-46: alpha = 0, beta = 1
+                const double w = t * t;
+                acc += w * v; sum_w += w;
+            }
+        }
+    q.out[m] = acc / sum_w;                               // no model in range: 0/0 = NaN, as the reference
+}
+
+int interp_continuous(int dimension, const InterpParams& q, double r, hipStream_t s) {
+    if (q.nmodels < 1 || q.nmodels > 0x7fffffffLL) { set_error("1 .. 2^31 - 1 models"); return WLSQM_EVALUE; }
+    if (!(r > 0.0)) { set_error("r must be positive"); return WLSQM_EVALUE; }
+    if (q.sxi != dimension) { set_error("origins must be contiguous"); return WLSQM_EVALUE; }
+    if (q.nx <= 0) return WLSQM_OK;
+    GridIndex grid;
+    int rc = grid.build(dimension, q.nmodels, q.xi, s);
+    if (rc != WLSQM_OK) return rc;
+    const unsigned blocks = (unsigned)((q.nx + 63) / 64);
+#define BALL_LAUNCH(D)                                                                                                    \
+    hipLaunchKernelGGL(interp_ball_kernel<D>, dim3(blocks), dim3(64), 0, s, grid.d_Ss.as<double>(), grid.d_perm.as<int>(), \
+                       grid.d_start.as<int>(), grid.G, q, r);
+    if (dimension == 1) BALL_LAUNCH(1) else if (dimension == 2) BALL_LAUNCH(2) else BALL_LAUNCH(3)
+#undef BALL_LAUNCH
+    WLSQM_HIP_CHECK(hipGetLastError());
+    WLSQM_HIP_CHECK(hipStreamSynchronize(s));      // the grid index dies with this scope
     return WLSQM_OK;
 }
 

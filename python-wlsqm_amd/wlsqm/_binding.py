@@ -89,6 +89,8 @@ def lib():
                                            C.c_void_p]
     L.wlsqm_hip_expert_interpolate_nearest.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p,
                                                        C.c_void_p]
+    L.wlsqm_hip_expert_interpolate_continuous.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_double, C.c_int,
+                                                          C.c_void_p]
     L.wlsqm_hip_expert_create_guest.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int, C.c_int]
     L.wlsqm_hip_expert_prepare.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64]
     L.wlsqm_hip_expert_prepare_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64]
@@ -112,7 +114,7 @@ def lib():
                  "wlsqm_hip_expert_memory_used", "wlsqm_hip_expert_destroy",
                  "wlsqm_hip_expert_conds", "wlsqm_hip_expert_interpolate", "wlsqm_hip_interpolate_fit_host",
                  "wlsqm_hip_fit_cloud_device", "wlsqm_hip_time_fit_cloud_device", "wlsqm_hip_knn_device", "wlsqm_hip_ball_device", "wlsqm_hip_nearest_device",
-                 "wlsqm_hip_expert_interpolate_nearest",
+                 "wlsqm_hip_expert_interpolate_nearest", "wlsqm_hip_expert_interpolate_continuous",
                  "wlsqm_hip_number_of_dofs", "wlsqm_hip_number_of_reduced_dofs", "wlsqm_hip_remap"):
         getattr(L, name).restype = C.c_int
     _lib = L

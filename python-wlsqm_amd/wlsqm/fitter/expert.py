@@ -227,8 +227,7 @@ class ExpertSolver:
 
     def prep_interpolate(self):
         """Prepare interpolate() (expert.pyx:658-681: index the origins xi for the nearest-model search).  The k-d tree of
-        the reference is only built when something asks for it (`self.tree`, mode='continuous'); mode='nearest' searches
-        on the GPU."""
+        the reference is only built when a caller asks for `self.tree`; both interpolation modes search on the GPU."""
         if not self.ready:
             raise RuntimeError("Solver is not in the ready state; prepare() must be called before prep_interpolate()")
         if self.host is not None and self.host._tree_points is not None:
@@ -254,10 +253,8 @@ class ExpertSolver:
             raise ValueError("When 'I' is specified, 'I' must have the same length as x; got len(I) = %d, len(x) = %d." % (len(I), len(x)))
         if self.dimension == 1:
             xv = B.view(x, np.float64, 1, "x")
-            xq = np.atleast_2d(xv).T
         else:
             xv = B.view(x, np.float64, 2, "x", contiguous_last=True)
-            xq = xv
         nx = xv.shape[0]
         out = np.empty((nx,), dtype=np.float64)
         lib = B.lib()
@@ -275,15 +272,9 @@ class ExpertSolver:
             B.check(lib.wlsqm_hip_expert_interpolate(self._handle, xv.ctypes.data, B.es(xv, 0), nx, Iv.ctypes.data,
                                                      None, None, 0.0, int(diff), out.ctypes.data))
             return out, np.asanyarray(I_out)
-        import scipy.spatial
-        lists = scipy.spatial.cKDTree(data=xq).query_ball_tree(other=self.tree, r=r)   # expert.pyx:901-903
-        off = np.zeros(nx + 1, dtype=np.int64)
-        off[1:] = np.cumsum([len(L) for L in lists])
-        idx = np.ascontiguousarray(np.fromiter((i for L in lists for i in L), dtype=np.int64, count=int(off[-1])))
-        if idx.size == 0:
-            idx = np.zeros(1, dtype=np.int64)
-        B.check(lib.wlsqm_hip_expert_interpolate(self._handle, xv.ctypes.data, B.es(xv, 0), nx, None, off.ctypes.data,
-                                                 idx.ctypes.data, float(r), int(diff), out.ctypes.data))
+        # the models within r are found and averaged on the device (expert.pyx:901-903 builds lists with query_ball_tree)
+        B.check(lib.wlsqm_hip_expert_interpolate_continuous(self._handle, xv.ctypes.data, B.es(xv, 0), nx, float(r), int(diff),
+                                                            out.ctypes.data))
         return out, np.asanyarray(None)
 
     def solve_device(self, fk, fi, stream=None):

@@ -1178,3 +1178,51 @@ def test_device_api_captures_into_a_hip_graph(wlsqm):
         torch.cuda.synchronize()
         assert torch.equal(got, fi) and torch.equal(got2, fi2)
         assert float((got[:, 0] - Ft).abs().max()) < 1e-2            # follows the field of THIS step (truncation error only)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim", [1, 2, 3])
+def test_continuous_interpolation_ball_search_on_the_device(wlsqm, dim):
+    """interpolate(mode='continuous') finds the models within r on the GPU (grid walk fused with the weighted average);
+    the reference builds lists with cKDTree.query_ball_tree (expert.pyx:898-985).  Against the list-taking entry point fed
+    with cKDTree's lists: same values up to the summation order, NaN exactly where no origin is in range (also for points
+    outside the cloud's bounding box)."""
+    import scipy.spatial
+    import synth
+    import wlsqm._binding as B
+    n, k, order = 4000, {1: 6, 2: 16, 3: 30}[dim], 2
+    no = wlsqm.number_of_dofs(dim, order)
+    rng = np.random.default_rng(5 + dim)
+    S = rng.uniform(0.0, 1.0, size=(n, dim))
+    F = np.sin(2.0 * S).prod(axis=1)
+    _, hoods = scipy.spatial.cKDTree(S).query(S, k + 1)
+    hoods = hoods[:, 1:]
+    xi = S[:, 0].copy() if dim == 1 else S
+    xk = S[hoods][:, :, 0].copy() if dim == 1 else S[hoods]
+    s = wlsqm.ExpertSolver(dimension=dim, nk=np.full(n, k, np.int32), order=np.full(n, order, np.int32),
+                           knowns=np.zeros(n, np.int64), weighting_method=np.full(n, 2, np.int32))
+    s.prepare(xi=xi, xk=xk)
+    fi = np.zeros((n, no))
+    s.solve(fk=F[hoods], fi=fi)
+    s.prep_interpolate()
+    X = rng.uniform(-0.2, 1.2, size=(3000, dim))                 # some points lie outside the cloud
+    r = {1: 0.004, 2: 0.03, 3: 0.08}[dim]
+    lists = scipy.spatial.cKDTree(X).query_ball_tree(scipy.spatial.cKDTree(S), r=r)
+    empty = np.array([len(L) == 0 for L in lists])
+    assert empty.any() and (~empty).sum() > 1000
+    off = np.zeros(len(X) + 1, np.int64); off[1:] = np.cumsum([len(L) for L in lists])
+    idx = np.array([i for L in lists for i in L], np.int64)
+    xq = X[:, 0].copy() if dim == 1 else X
+    xv = X if dim > 1 else np.ascontiguousarray(X)
+    for diff in (0, 1, no - 1):
+        got, _ = s.interpolate(xq, mode="continuous", r=r, diff=diff)
+        ref = np.empty(len(X))
+        B.check(B.lib().wlsqm_hip_expert_interpolate(s._handle, xv.ctypes.data, dim, len(X), None, off.ctypes.data,
+                                                     idx.ctypes.data, float(r), int(diff), ref.ctypes.data))
+        assert np.array_equal(np.isnan(got), empty) and np.array_equal(np.isnan(ref), empty)
+        scale = np.abs(ref[~empty]).max()
+        assert np.abs(got[~empty] - ref[~empty]).max() <= 1e-12 * max(scale, 1.0)
+    if dim == 2:                                                 # and it is the global model: close to the field itself
+        got, _ = s.interpolate(xq, mode="continuous", r=r, diff=0)
+        inside = ~empty & (X.min(axis=1) > 0.05) & (X.max(axis=1) < 0.95)
+        assert np.abs(got[inside] - np.sin(2.0 * X[inside]).prod(axis=1)).max() < 1e-3
