@@ -36,6 +36,10 @@ extern "C" {
 #define WLSQM_ENODEVICE    -4   /* -> RuntimeError: no HIP device; there is NO CPU fallback in this library */
 
 const char* wlsqm_hip_last_error(void);
+/* Diagnostics: name of the kernel family the last fit launch of this thread dispatched to ("tile", "tile-gather",
+ * "tile1", "tile1-extras", "tilek", "moment", "rows", "lane", "wave", "solve-many"; "" before the first launch).  The tests
+ * use it to make sure a fast path is what they exercise. */
+const char* wlsqm_hip_last_kernel(void);
 
 /* Number of usable HIP devices (0 if none).  Never initialises a context on failure. */
 int wlsqm_hip_device_count(void);

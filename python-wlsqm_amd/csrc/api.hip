@@ -105,6 +105,7 @@ using namespace wlsqm;
 extern "C" {
 
 const char* wlsqm_hip_last_error(void) { return g_err.c_str(); }
+const char* wlsqm_hip_last_kernel(void) { return last_kernel_name(); }
 
 int wlsqm_hip_device_count(void) {
     int n = 0;

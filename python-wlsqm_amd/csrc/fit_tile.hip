@@ -69,26 +69,29 @@ template <int DIM> __host__ __device__ constexpr int row_stride_x(int K) {
 }
 __host__ __device__ constexpr int row_stride_f(int K) { return round_up_mod(K, 2, 1); }
 
-template <int DIM, int ORDER, int K, int KSPLIT, int LPC, bool FKD = false, bool MOM = false>
+// K: neighbour slots per row in memory; KC >= K: slots the shares cover (K rounded up so that every share is even;
+// the slots beyond K are masked like the unused slots of a ragged case).
+template <int DIM, int ORDER, int K, int KSPLIT, int LPC, bool FKD = false, bool MOM = false, int KC = K>
 struct TileGeom {
     static constexpr int NO = ndofs(DIM, ORDER);
     static constexpr int NE = NO * (NO + 1) / 2;
     static constexpr int TC = WV / LPC;                      // cases per tile
     static constexpr int NT = WV * KSPLIT;                   // threads per workgroup
     static constexpr int SHARES = KSPLIT * LPC;              // neighbour shares per case
-    static constexpr int KPL = K / SHARES;                   // neighbours per lane
+    static constexpr int KPL = KC / SHARES;                  // neighbours per lane
     static constexpr int RS = row_stride_x<DIM>(K), FS = row_stride_f(K);
     static constexpr int XCH = TC * K * DIM / 2, FCH = TC * K / 2;      // 16-byte chunks per tile
     static constexpr int NX = (XCH + NT - 1) / NT, NF = (FCH + NT - 1) / NT;
     static constexpr int CPRX = K * DIM / 2, CPRF = K / 2;  // chunks per row
     static constexpr int NA = MOM ? mom_count<DIM>(2 * ORDER) : NE;   // matrix accumulators: distinct moments or unique entries
     static constexpr int NRED = NA + NO;                     // partial sums per case
-    static constexpr int LDS_TILE = TC * (RS + (FKD ? 0 : FS));   // FKD: fk is read straight from global by its owner lane
+    static constexpr int LDS_TILE = TC * (RS + (FKD ? 0 : FS)) + (KC - K) * DIM;   // FKD: fk is read straight from global by its owner lane; the last row's masked slots are read too
     static constexpr int LDS_RED = (KSPLIT - 1) * NRED * TC;
     static constexpr int LDS_MAIN = LDS_TILE > LDS_RED ? LDS_TILE : LDS_RED;
     static constexpr size_t LDS_BYTES = sizeof(double) * (LDS_MAIN + SHARES * TC);
     static_assert((K * DIM) % 2 == 0 && K % 2 == 0, "rows must be multiples of 16 bytes");
-    static_assert(K % SHARES == 0, "K must split evenly over the shares");
+    static_assert(KC % SHARES == 0 && KC >= K && KC - K < 8, "the covered slots must split evenly over the shares");
+    static_assert(KC == K || FKD, "padded shares: direct fk loads only");
     static_assert(LPC == 1 || LPC == 2 || LPC == 4, "1, 2 or 4 lanes per case");
     static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit LDS");
 };
@@ -101,9 +104,9 @@ struct TileGeom {
 // SPLIT: stop after the reduction and park the moments in the workspace p.ws (fit_moment.hip solves them in a second
 //        kernel): for systems whose expanded matrix does not fit the register file next to the accumulators.
 template <int DIM, int ORDER, int K, int KSPLIT, int LPC, int UNR, int MINW, bool GATHER, bool FKD = false, bool MOM = false,
-          bool SPLIT = false>
+          bool SPLIT = false, int KC = K>
 __global__ __launch_bounds__(WV * KSPLIT, MINW) void fit_tile_kernel(const KParams p, const long long ntiles) {
-    using G = TileGeom<DIM, ORDER, K, KSPLIT, LPC, FKD, MOM>;
+    using G = TileGeom<DIM, ORDER, K, KSPLIT, LPC, FKD, MOM, KC>;
     static_assert(!SPLIT || MOM, "the workspace holds moments");
     static_assert(!(FKD && GATHER), "direct fk loads are a dense-path option");
     static_assert(!FKD || G::KPL % 2 == 0, "direct fk loads need an even share");
@@ -157,9 +160,14 @@ __global__ __launch_bounds__(WV * KSPLIT, MINW) void fit_tile_kernel(const KPara
                     }
                 } else {
                     // this lane's KPL values of its own case: KPL*8 contiguous bytes of row jc
-                    const double2_* gr = reinterpret_cast<const double2_*>(p.fk + jc * (long long)K + k0);
+                    // (a padded share's slots beyond the row replay the row's last pair: masked below)
+                    const double* gr = p.fk + jc * (long long)K;
 #pragma unroll
-                    for (int i = 0; i < KPL / 2; ++i) { const double2_ v = gr[i]; fdir[2 * i] = v.x; fdir[2 * i + 1] = v.y; }
+                    for (int i = 0; i < KPL / 2; ++i) {
+                        const int kq = (KC == K || k0 + 2 * i < K) ? k0 + 2 * i : K - 2;
+                        const double2_ v = *reinterpret_cast<const double2_*>(gr + kq);
+                        fdir[2 * i] = v.x; fdir[2 * i + 1] = v.y;
+                    }
                 }
             }
 #pragma unroll
@@ -294,7 +302,7 @@ __global__ __launch_bounds__(WV * KSPLIT, MINW) void fit_tile_kernel(const KPara
                 accumulate<NO>(A, g, cc, w, f);
             }
         };
-        if (__all(nkc >= K)) {
+        if (KC == K && __all(nkc >= K)) {
 #pragma unroll UNR
             for (int kk = 0; kk < KPL; ++kk) neighbour(k0 + kk, true);
         } else {
@@ -379,13 +387,13 @@ template <int DIM, int ORDER, int K, int KSPLIT, int LPC = 1, int UNR = 2, int M
 static int launch_tile_any(const KParams& p, hipStream_t stream, bool gather);
 
 template <int DIM, int ORDER, int K, int KSPLIT, int LPC, int UNR, int MINW, bool GATHER, bool FKD = false, bool MOM = false,
-          bool SPLIT = false>
+          bool SPLIT = false, int KC = K>
 static int launch_tile_impl(const KParams& p, hipStream_t stream) {
-    using G = TileGeom<DIM, ORDER, K, KSPLIT, LPC, FKD, MOM>;
+    using G = TileGeom<DIM, ORDER, K, KSPLIT, LPC, FKD, MOM, KC>;
     constexpr size_t lds_bytes = G::LDS_BYTES;
     const long long ntiles = (p.ncases + G::TC - 1) / G::TC;
     static KernelSetup setup;
-    auto kern = fit_tile_kernel<DIM, ORDER, K, KSPLIT, LPC, UNR, MINW, GATHER, FKD, MOM, SPLIT>;
+    auto kern = fit_tile_kernel<DIM, ORDER, K, KSPLIT, LPC, UNR, MINW, GATHER, FKD, MOM, SPLIT, KC>;
     long long grid = 0;
     int rc = persistent_grid(reinterpret_cast<const void*>(kern), G::NT, lds_bytes, lds_bytes, true, setup, &grid);
     if (rc != WLSQM_OK) return rc;
@@ -509,6 +517,42 @@ int launch_fit_tile(int dimension, int order, const KParams& p, long long max_nk
     }
     // Curated shapes for other common (dim, order, K): best of {entry form, moment form} x {four waves per 64-case tile,
     // two waves per 32, one wave per 16 cases with direct fk}, tools/tune.py at 1M cases; anything else -> fit_tilek.hip.
+    // Every other even K up to 64 for order 2 (dense input): the same one-wave shape with the shares padded to the next
+    // multiple of 8 slots (KC; the extra slots are masked like those of a ragged case), or two waves x two lanes per case
+    // for the large 3D neighbourhoods, or two waves with one lane per case where K/2 is even and small.  tools/tune.py
+    // at 1M cases against the runtime-K kernels: 2D K = 20 / 28 / 30 / 36 / 44 / 50 / 52 / 60: 0.118 / 0.164 / 0.184 /
+    // 0.209 / 0.257 / 0.296 / 0.287 / 0.326 ms against 0.223 / 0.254 / 0.263 / 0.324 / 0.368 / 0.399 / 0.397 / 0.437;
+    // 3D K = 28 / 36 / 44 / 48 / 56 / 64: 0.261 / 0.371 / 0.456 / 0.403 / 0.508 / 0.560 against 0.449 / 0.609 / 0.695 /
+    // 0.692 / 0.823 / 0.977.  (Index-based input of these sizes stays on the runtime-K one-wave kernel.)
+#define PAD_CASE(D, O, KK, KS, LL, UU)                                                                                   \
+    if (!gather && dimension == D && order == O && max_nk == KK) {                                                      \
+        *handled = true;                                                                                                \
+        return launch_tile_impl<D, O, KK, KS, LL, UU, 2, false, true, true, false, (KK + 7) / 8 * 8>(p, stream);       \
+    }
+#define HALF_CASE(D, O, KK)                                                                                               \
+    if (!gather && dimension == D && order == O && max_nk == KK) {                                                      \
+        *handled = true;                                                                                                \
+        return launch_tile_impl<D, O, KK, 2, 1, 2, 2, false, true, true>(p, stream);                                    \
+    }
+    PAD_CASE(2, 2, 8, 1, 4, 2) PAD_CASE(2, 2, 10, 1, 4, 4) HALF_CASE(2, 2, 12)
+    PAD_CASE(2, 2, 14, 1, 4, 4) PAD_CASE(2, 2, 18, 1, 4, 6) HALF_CASE(2, 2, 20)
+    PAD_CASE(2, 2, 22, 1, 4, 6) PAD_CASE(2, 2, 26, 1, 4, 8) HALF_CASE(2, 2, 28)
+    PAD_CASE(2, 2, 30, 1, 4, 8) PAD_CASE(2, 2, 34, 1, 4, 10) PAD_CASE(2, 2, 36, 1, 4, 10)
+    PAD_CASE(2, 2, 38, 1, 4, 10) PAD_CASE(2, 2, 40, 1, 4, 10) PAD_CASE(2, 2, 42, 1, 4, 12)
+    PAD_CASE(2, 2, 44, 1, 4, 12) PAD_CASE(2, 2, 46, 1, 4, 12) PAD_CASE(2, 2, 50, 1, 4, 14)
+    PAD_CASE(2, 2, 52, 1, 4, 14) PAD_CASE(2, 2, 54, 1, 4, 14) PAD_CASE(2, 2, 56, 1, 4, 14)
+    PAD_CASE(2, 2, 58, 1, 4, 16) PAD_CASE(2, 2, 60, 1, 4, 16) PAD_CASE(2, 2, 62, 1, 4, 16)
+    HALF_CASE(3, 2, 12) PAD_CASE(3, 2, 14, 1, 4, 2) PAD_CASE(3, 2, 16, 1, 4, 2)
+    PAD_CASE(3, 2, 18, 1, 4, 2) HALF_CASE(3, 2, 20) PAD_CASE(3, 2, 22, 1, 4, 2)
+    PAD_CASE(3, 2, 24, 1, 4, 2) PAD_CASE(3, 2, 26, 1, 4, 2) HALF_CASE(3, 2, 28)
+    PAD_CASE(3, 2, 30, 1, 4, 2) PAD_CASE(3, 2, 34, 1, 4, 2) PAD_CASE(3, 2, 36, 1, 4, 2)
+    PAD_CASE(3, 2, 38, 1, 4, 2) PAD_CASE(3, 2, 42, 1, 4, 2) PAD_CASE(3, 2, 44, 1, 4, 2)
+    PAD_CASE(3, 2, 46, 1, 4, 2) PAD_CASE(3, 2, 48, 1, 4, 2) PAD_CASE(3, 2, 50, 2, 2, 2)
+    PAD_CASE(3, 2, 52, 2, 2, 2) PAD_CASE(3, 2, 54, 2, 2, 2) PAD_CASE(3, 2, 56, 2, 2, 2)
+    PAD_CASE(3, 2, 58, 2, 2, 2) PAD_CASE(3, 2, 60, 2, 2, 2) PAD_CASE(3, 2, 62, 2, 2, 2)
+    PAD_CASE(3, 2, 64, 2, 2, 2)
+#undef PAD_CASE
+#undef HALF_CASE
     TILE_CASE(2, 2, 16, 1, 4, 4, 2, true, true)
     TILE_CASE(2, 2, 24, 2, 1, 4, 2, false, true)
     TILE_CASE(2, 2, 48, 4, 1, 4, 2, false, true)

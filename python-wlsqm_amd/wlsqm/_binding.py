@@ -66,6 +66,7 @@ def lib():
     _init_torch_hip_first()
     L = C.CDLL(LIB_PATH)
     L.wlsqm_hip_last_error.restype = C.c_char_p
+    L.wlsqm_hip_last_kernel.restype = C.c_char_p
     L.wlsqm_hip_device_count.restype = C.c_int
     L.wlsqm_hip_number_of_dofs.argtypes = [C.c_int, C.c_int]
     L.wlsqm_hip_number_of_reduced_dofs.argtypes = [C.c_int, C.c_int64]

@@ -10,11 +10,17 @@ import ctypes as C
 
 from . import _binding as B
 
-__all__ = ["fit_many_device", "time_fit_device", "fit_cloud_device", "time_fit_cloud_device", "device_count", "knn", "ball", "nearest"]
+__all__ = ["fit_many_device", "time_fit_device", "fit_cloud_device", "time_fit_cloud_device", "device_count", "knn", "ball", "nearest",
+           "last_kernel"]
 
 
 def device_count():
     return B.lib().wlsqm_hip_device_count()
+
+
+def last_kernel():
+    """Diagnostics: name of the kernel family the last fit launch of this thread dispatched to (wlsqm_hip_last_kernel)."""
+    return B.lib().wlsqm_hip_last_kernel().decode()
 
 
 def _ptr(t):

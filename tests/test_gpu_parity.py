@@ -263,7 +263,23 @@ def test_tile_path_equals_lane_path(wlsqm, dim, order, K, ncases, monkeypatch):
     """The LDS-tiled fast path (contiguous, curated K) against the generic lane kernel on the same inputs:
     ragged nk <= K, mixed weightings and knowns, tail tiles.  Same arithmetic except for the split of the
     neighbour sum over lanes/waves, so agreement is to rounding."""
-    from wlsqm import _binding
+    _tile_vs_lane(wlsqm, dim, order, K, ncases, monkeypatch)
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+@pytest.mark.parametrize("K", list(range(8, 66, 2)))
+def test_every_even_neighbourhood_size_has_a_fixed_shape(wlsqm, dim, K, monkeypatch):
+    """Order 2 in 2D and 3D: every even K up to 64 runs an instantiation of the fixed-K tile kernel (shares padded to a
+    multiple of 8 slots where K is not one; csrc/fit_tile.hip), not the slower runtime-K kernels; parity as above, with a
+    tail tile, ragged nk, knowns and both weightings."""
+    if dim == 3 and K < 12:
+        pytest.skip("fewer neighbours than unknowns")
+    import wlsqm.hip as whip
+    _tile_vs_lane(wlsqm, dim, 2, K, 16 * 9 + 5 + K, monkeypatch, expect="tile")
+
+
+def _tile_vs_lane(wlsqm, dim, order, K, ncases, monkeypatch, expect=None):
+    import wlsqm.hip as whip
     rng = np.random.default_rng(ncases)
     no = K_.NDOF[dim][order]
     xi = rng.uniform(0, 1, (ncases, dim))
@@ -281,8 +297,11 @@ def test_tile_path_equals_lane_path(wlsqm, dim, order, K, ncases, monkeypatch):
     f = _many(wlsqm, dim)
     fi_t = fi0.copy(); fi_l = fi0.copy()
     f(xk, fk, nk, xi, fi_t, None, 0, orders, knowns, wm)
+    if expect is not None:
+        assert whip.last_kernel() == expect
     monkeypatch.setenv("WLSQM_HIP_DISABLE_TILE", "1")
     f(xk, fk, nk, xi, fi_l, None, 0, orders, knowns, wm)
+    assert whip.last_kernel() == "lane"
     monkeypatch.delenv("WLSQM_HIP_DISABLE_TILE")
     _check_untouched(fi_t, fi0, orders, knowns, dim)
     assert np.array_equal(fi_t == fi0, fi_l == fi0)
