@@ -551,6 +551,31 @@ int launch_fit_tile(int dimension, int order, const KParams& p, long long max_nk
     PAD_CASE(3, 2, 52, 2, 2, 2) PAD_CASE(3, 2, 54, 2, 2, 2) PAD_CASE(3, 2, 56, 2, 2, 2)
     PAD_CASE(3, 2, 58, 2, 2, 2) PAD_CASE(3, 2, 60, 2, 2, 2) PAD_CASE(3, 2, 62, 2, 2, 2)
     PAD_CASE(3, 2, 64, 2, 2, 2)
+    // The other families (dense input, every even K up to 64), shapes from the same A/B (1M cases, ms per launch, against the
+    // better runtime-K kernel): 1D, two waves per 64-case tile, moment form — order 2 at K = 6 / 10 / 20: 0.025 / 0.037 /
+    // 0.075 against 0.054 / 0.067 / 0.100, order 4 at K = 12 / 24: 0.050 / 0.102 against 0.096 / 0.144; 2D order 1 and 3D
+    // order 1, two waves x two lanes per case, padded shares — 2D K = 10 / 20 / 40: 0.062 / 0.110 / 0.197 against 0.082 /
+    // 0.129 / 0.284, 3D K = 16 / 24 / 32 / 40: 0.118 / 0.165 / 0.211 / 0.249 against 0.140 / 0.202 / 0.238 / 0.333; 2D order 3,
+    // one wave, padded shares — K = 24 / 32 / 48 / 64: 0.230 / 0.262 / 0.332 / 0.401 against 0.291 / 0.327 / 0.432 / 0.591.
+#define DENSE_CASE(D, O, KK, ...)                                                                                         \
+    if (!gather && dimension == D && order == O && max_nk == KK) {                                                      \
+        *handled = true;                                                                                                \
+        return launch_tile_impl<D, O, KK, __VA_ARGS__>(p, stream);                                                      \
+    }
+#define EVEN_K(X) X(2) X(4) X(6) X(8) X(10) X(12) X(14) X(16) X(18) X(20) X(22) X(24) X(26) X(28) X(30) X(32) X(34) X(36) X(38) \
+    X(40) X(42) X(44) X(46) X(48) X(50) X(52) X(54) X(56) X(58) X(60) X(62) X(64)
+#define LINE_CASES(KK) DENSE_CASE(1, 1, KK, 2, 1, 4, 2, false, false, true) DENSE_CASE(1, 2, KK, 2, 1, 4, 2, false, false, true) \
+    DENSE_CASE(1, 3, KK, 2, 1, 4, 2, false, false, true) DENSE_CASE(1, 4, KK, 2, 1, 4, 2, false, false, true)
+#define ORDER1_CASES(KK) PAD_CASE(2, 1, KK, 2, 2, 2) PAD_CASE(3, 1, KK, 2, 2, 2)
+#define CUBIC_CASES(KK) PAD_CASE(2, 3, KK, 1, 4, 2)
+    if (dimension == 1 && !(order == 2 && (max_nk == 8 || max_nk == 16))) { EVEN_K(LINE_CASES) }
+    if (order == 1 && !(dimension == 2 && (max_nk == 16 || max_nk == 32))) { EVEN_K(ORDER1_CASES) }
+    if (dimension == 2 && order == 3 && max_nk >= 10 && max_nk != 40) { EVEN_K(CUBIC_CASES) }
+#undef LINE_CASES
+#undef ORDER1_CASES
+#undef CUBIC_CASES
+#undef EVEN_K
+#undef DENSE_CASE
 #undef PAD_CASE
 #undef HALF_CASE
     TILE_CASE(2, 2, 16, 1, 4, 4, 2, true, true)

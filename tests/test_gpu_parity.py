@@ -266,26 +266,27 @@ def test_tile_path_equals_lane_path(wlsqm, dim, order, K, ncases, monkeypatch):
     _tile_vs_lane(wlsqm, dim, order, K, ncases, monkeypatch)
 
 
-@pytest.mark.parametrize("dim", [2, 3])
-@pytest.mark.parametrize("K", list(range(8, 66, 2)))
-def test_every_even_neighbourhood_size_has_a_fixed_shape(wlsqm, dim, K, monkeypatch):
-    """Order 2 in 2D and 3D: every even K up to 64 runs an instantiation of the fixed-K tile kernel (shares padded to a
-    multiple of 8 slots where K is not one; csrc/fit_tile.hip), not the slower runtime-K kernels; parity as above, with a
-    tail tile, ragged nk, knowns and both weightings."""
-    if dim == 3 and K < 12:
-        pytest.skip("fewer neighbours than unknowns")
-    import wlsqm.hip as whip
-    _tile_vs_lane(wlsqm, dim, 2, K, 16 * 9 + 5 + K, monkeypatch, expect="tile")
+@pytest.mark.parametrize("dim,order", [(1, 1), (1, 2), (1, 3), (1, 4), (2, 1), (2, 2), (2, 3), (3, 1), (3, 2)])
+@pytest.mark.parametrize("K", list(range(4, 66, 2)))
+def test_every_even_neighbourhood_size_has_a_fixed_shape(wlsqm, dim, order, K, monkeypatch):
+    """1D (all orders), 2D order 1-3 and 3D order 1-2: every even K up to 64 runs an instantiation of the fixed-K tile
+    kernel (shares padded to a multiple of 8 slots where the shape needs it; csrc/fit_tile.hip), not the slower runtime-K
+    kernels; parity as above, with a tail tile, ragged nk, knowns and both weightings."""
+    if K < K_.NDOF[dim][order] + 2:
+        pytest.skip("fewer neighbours than unknowns + 2")
+    # (ragged nk stays clear of the nearly determined systems, whose rounding noise differs between any two summation orders
+    # by more than the parity bar; those are the business of test_tile_path_equals_lane_path and tools/fuzz.py)
+    _tile_vs_lane(wlsqm, dim, order, K, 16 * 9 + 5 + K, monkeypatch, expect="tile", spare=6)
 
 
-def _tile_vs_lane(wlsqm, dim, order, K, ncases, monkeypatch, expect=None):
+def _tile_vs_lane(wlsqm, dim, order, K, ncases, monkeypatch, expect=None, spare=2):
     import wlsqm.hip as whip
     rng = np.random.default_rng(ncases)
     no = K_.NDOF[dim][order]
     xi = rng.uniform(0, 1, (ncases, dim))
     xk = xi[:, None, :] + 0.05 * rng.uniform(-1, 1, (ncases, K, dim))
     fk = np.sin(3 * xk[..., 0]) * np.cos(2 * xk[..., -1])
-    nk = rng.integers(min(K, max(no + 2, K // 3)), K + 1, ncases).astype(np.int32); nk[0] = K
+    nk = rng.integers(min(K, max(no + spare, K // 3)), K + 1, ncases).astype(np.int32); nk[0] = K
     nk[ncases // 2:] = K                                         # whole tiles at full K take the unpredicated loop
     orders = np.full(ncases, order, np.int32)
     masks = [0, 0, 1, (1 << no) - 1] + ([1 << (no - 1), 1 | (1 << (no // 2))] if no >= 3 else [])
@@ -409,15 +410,14 @@ def test_index_based_path_equals_dense_path(wlsqm, dim, order, K, n):
     whip.fit_many_device(dim, order, xk_d, fk_d, nk_d, xi_d, fi_a, kn_d, wm_d)
     whip.fit_cloud_device(dim, order, S_d, F_d, h_d, fi_b, nk_d, kn_d, wm_d, point_index=p_d)
     torch.cuda.synchronize()
-    if (dim, order, K) in ((2, 2, 32), (2, 4, 64), (2, 3, 20), (3, 2, 36), (1, 3, 12)):
-        # the two paths take differently shaped kernels here (one wave per 16-case tile with direct fk loads against
-        # four waves per 64-case tile; moment form against the generic kernel): equal to rounding
+    if not torch.equal(fi_a, fi_b):
+        # the two paths take differently shaped kernels for most sizes (dense: the fixed-K instantiation of (dim, order, K);
+        # index-based: four waves per 64-case tile or the runtime-K one-wave kernel; moment form against the generic
+        # kernel): equal to rounding
         xk_h, fk_h, xi_h = xk_d.cpu().numpy(), fk_d.cpu().numpy(), xi_d.cpu().numpy()
         truth = P.truth_fit(dim, xk_h, fk_h, nk_d.cpu().numpy(), xi_h, fi0, np.full(n, order, np.int32),
                             kn_d.cpu().numpy(), wm_d.cpu().numpy())
-        P.assert_parity(fi_b.cpu().numpy(), fi_a.cpu().numpy(), truth, "index-based vs dense (moment) path")
-    else:
-        assert torch.equal(fi_a, fi_b)
+        P.assert_parity(fi_b.cpu().numpy(), fi_a.cpu().numpy(), truth, "index-based vs dense path")
     if no > 15:
         return                                   # 3D order 3/4: index-based input is for the basic fit only
     # extras (sensitivities + iterative refinement): the index-based launch takes the generic kernel, the dense one the
