@@ -91,7 +91,6 @@ struct TileGeom {
     static constexpr size_t LDS_BYTES = sizeof(double) * (LDS_MAIN + SHARES * TC);
     static_assert((K * DIM) % 2 == 0 && K % 2 == 0, "rows must be multiples of 16 bytes");
     static_assert(KC % SHARES == 0 && KC >= K && KC - K < 8, "the covered slots must split evenly over the shares");
-    static_assert(KC == K || FKD, "padded shares: direct fk loads only");
     static_assert(LPC == 1 || LPC == 2 || LPC == 4, "1, 2 or 4 lanes per case");
     static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit LDS");
 };
@@ -197,9 +196,10 @@ __global__ __launch_bounds__(WV * KSPLIT, MINW) void fit_tile_kernel(const KPara
             }
         } else {
             // ---- stage 1: the tile's neighbour lists, TC*K int32 contiguous (coalesced 16 B per lane) ...
-            static_assert(!GATHER || K % 4 == 0, "index rows must be multiples of 16 bytes");
-            constexpr int HCH = TC * K / 4, NH = (HCH + NT - 1) / NT, CPRH = K / 4;
-            typedef int int4_ __attribute__((ext_vector_type(4)));
+            // (16 B per lane where K is a multiple of 4, 8 B otherwise)
+            constexpr int HW = (K % 4 == 0) ? 4 : 2;
+            constexpr int HCH = TC * K / HW, NH = (HCH + NT - 1) / NT, CPRH = K / HW;
+            typedef int int4_ __attribute__((ext_vector_type(HW)));
             int4_ hb[NH];
             {
                 const int4_* gh = reinterpret_cast<const int4_*>(p.hoods + j0 * (long long)K);
@@ -213,33 +213,33 @@ __global__ __launch_bounds__(WV * KSPLIT, MINW) void fit_tile_kernel(const KPara
             const long long pj = p.pidx ? (long long)p.pidx[jc] : jc;
 #pragma unroll
             for (int m = 0; m < DIM; ++m) xi[m] = p.S[pj * DIM + m];
-            // ... then the gathers of the point rows they name (4 per index chunk), all in flight together
-            double gx[NH * 4][DIM], gf[NH * 4];
+            // ... then the gathers of the point rows they name (HW per index chunk), all in flight together
+            double gx[NH * HW][DIM], gf[NH * HW];
 #pragma unroll
             for (int i = 0; i < NH; ++i)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
+                for (int e = 0; e < HW; ++e) {
                     const long long idx = hb[i][e];
                     if constexpr (DIM == 2) {
                         const double2_ v = *reinterpret_cast<const double2_*>(p.S + idx * 2);
-                        gx[i * 4 + e][0] = v.x; gx[i * 4 + e][1] = v.y;
+                        gx[i * HW + e][0] = v.x; gx[i * HW + e][1] = v.y;
                     } else {
 #pragma unroll
-                        for (int m = 0; m < DIM; ++m) gx[i * 4 + e][m] = p.S[idx * DIM + m];
+                        for (int m = 0; m < DIM; ++m) gx[i * HW + e][m] = p.S[idx * DIM + m];
                     }
-                    gf[i * 4 + e] = p.F[idx];
+                    gf[i * HW + e] = p.F[idx];
                 }
             // ---- stage 2: park them in the same padded LDS image the dense path builds
 #pragma unroll
             for (int i = 0; i < NH; ++i) {
                 const int q = tid + i * NT;
                 if (HCH % NT == 0 || q < HCH) {
-                    const int r = q / CPRH, kq = 4 * (q - r * CPRH);
+                    const int r = q / CPRH, kq = HW * (q - r * CPRH);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
+                    for (int e = 0; e < HW; ++e) {
 #pragma unroll
-                        for (int m = 0; m < DIM; ++m) sX[r * RS + (kq + e) * DIM + m] = gx[i * 4 + e][m];
-                        sF[r * FS + kq + e] = gf[i * 4 + e];
+                        for (int m = 0; m < DIM; ++m) sX[r * RS + (kq + e) * DIM + m] = gx[i * HW + e][m];
+                        sF[r * FS + kq + e] = gf[i * HW + e];
                     }
                 }
             }
@@ -407,11 +407,7 @@ static int launch_tile_impl(const KParams& p, hipStream_t stream) {
 // FKD (fk read straight from global memory) only exists for dense input; the index-based mode stages F[hoods].
 template <int DIM, int ORDER, int K, int KSPLIT, int LPC, int UNR, int MINW, bool FKD, bool MOM>
 static int launch_tile_any(const KParams& p, hipStream_t stream, bool gather) {
-    if constexpr (K % 4 == 0) {
-        if (gather) return launch_tile_impl<DIM, ORDER, K, KSPLIT, LPC, UNR, MINW, true, false, MOM>(p, stream);
-    } else {
-        if (gather) { set_error("index-based tile path needs K % 4 == 0"); return WLSQM_EVALUE; }
-    }
+    if (gather) return launch_tile_impl<DIM, ORDER, K, KSPLIT, LPC, UNR, MINW, true, false, MOM>(p, stream);
     return launch_tile_impl<DIM, ORDER, K, KSPLIT, LPC, UNR, MINW, false, FKD, MOM>(p, stream);
 }
 
@@ -420,7 +416,7 @@ static int launch_tile_any(const KParams& p, hipStream_t stream, bool gather) {
 static bool tile_eligible(int dim, const KParams& p, long long K) {
     if (p.do_sens || p.iterative || p.case_index) return false;
     if (p.hoods) {
-        if (p.shoods_j != K || (K % 4) != 0) return false;
+        if (p.shoods_j != K || (K % 2) != 0) return false;
         return ((reinterpret_cast<uintptr_t>(p.hoods) | reinterpret_cast<uintptr_t>(p.S)) & 15u) == 0;
     }
     if (p.sxk_k != dim || p.sxk_j != K * dim || p.sfk_k != 1 || p.sfk_j != K) return false;
@@ -576,6 +572,34 @@ int launch_fit_tile(int dimension, int order, const KParams& p, long long max_nk
 #undef CUBIC_CASES
 #undef EVEN_K
 #undef DENSE_CASE
+    // Index-based input (every even K up to 64, order 2): four waves per 64-case tile (two waves x two lanes per case for
+    // the large 2D and the middle 3D sizes), shares padded to a multiple of 4 slots.  tools/tune_cloud.py, 1M cases, ms per
+    // launch against the runtime-K one-wave kernel: 2D K = 20 / 36 / 40 / 52 / 60: 0.139 / 0.228 / 0.239 / 0.346 / 0.373
+    // against 0.207 / 0.310 / 0.337 / 0.411 / 0.457; 3D K = 28 / 36 / 48 / 56 / 64: 0.309 / 0.376 / 0.442 / 0.678 / 0.741
+    // against 0.382 / 0.602 / 0.768 / 0.934 / 1.120.
+#define GATHER_CASE(D, O, KK, KS, LL, UU)                                                                                \
+    if (gather && dimension == D && order == O && max_nk == KK) {                                                       \
+        *handled = true;                                                                                                \
+        return launch_tile_impl<D, O, KK, KS, LL, UU, 2, true, false, true, false, (KK + 3) / 4 * 4>(p, stream);       \
+    }
+    GATHER_CASE(2, 2, 8, 4, 1, 4) GATHER_CASE(2, 2, 10, 4, 1, 4) GATHER_CASE(2, 2, 12, 4, 1, 4)
+    GATHER_CASE(2, 2, 14, 4, 1, 4) GATHER_CASE(2, 2, 18, 4, 1, 4) GATHER_CASE(2, 2, 20, 4, 1, 4)
+    GATHER_CASE(2, 2, 22, 4, 1, 4) GATHER_CASE(2, 2, 26, 4, 1, 4) GATHER_CASE(2, 2, 28, 4, 1, 4)
+    GATHER_CASE(2, 2, 30, 4, 1, 4) GATHER_CASE(2, 2, 34, 4, 1, 4) GATHER_CASE(2, 2, 36, 4, 1, 4)
+    GATHER_CASE(2, 2, 38, 4, 1, 4) GATHER_CASE(2, 2, 40, 4, 1, 4) GATHER_CASE(2, 2, 42, 4, 1, 4)
+    GATHER_CASE(2, 2, 44, 4, 1, 4) GATHER_CASE(2, 2, 46, 4, 1, 4) GATHER_CASE(2, 2, 50, 2, 2, 4)
+    GATHER_CASE(2, 2, 52, 2, 2, 4) GATHER_CASE(2, 2, 54, 2, 2, 4) GATHER_CASE(2, 2, 56, 2, 2, 4)
+    GATHER_CASE(2, 2, 58, 2, 2, 4) GATHER_CASE(2, 2, 60, 2, 2, 4) GATHER_CASE(2, 2, 62, 2, 2, 4)
+    GATHER_CASE(3, 2, 12, 4, 1, 2) GATHER_CASE(3, 2, 14, 4, 1, 2) GATHER_CASE(3, 2, 16, 4, 1, 2)
+    GATHER_CASE(3, 2, 18, 4, 1, 2) GATHER_CASE(3, 2, 20, 4, 1, 2) GATHER_CASE(3, 2, 22, 4, 1, 2)
+    GATHER_CASE(3, 2, 24, 4, 1, 2) GATHER_CASE(3, 2, 26, 4, 1, 2) GATHER_CASE(3, 2, 28, 4, 1, 2)
+    GATHER_CASE(3, 2, 30, 4, 1, 2) GATHER_CASE(3, 2, 34, 4, 1, 2) GATHER_CASE(3, 2, 36, 4, 1, 2)
+    GATHER_CASE(3, 2, 38, 4, 1, 2) GATHER_CASE(3, 2, 42, 2, 2, 2) GATHER_CASE(3, 2, 44, 2, 2, 2)
+    GATHER_CASE(3, 2, 46, 2, 2, 2) GATHER_CASE(3, 2, 48, 2, 2, 2) GATHER_CASE(3, 2, 50, 4, 1, 2)
+    GATHER_CASE(3, 2, 52, 4, 1, 2) GATHER_CASE(3, 2, 54, 4, 1, 2) GATHER_CASE(3, 2, 56, 4, 1, 2)
+    GATHER_CASE(3, 2, 58, 4, 1, 2) GATHER_CASE(3, 2, 60, 4, 1, 2) GATHER_CASE(3, 2, 62, 4, 1, 2)
+    GATHER_CASE(3, 2, 64, 4, 1, 2)
+#undef GATHER_CASE
 #undef PAD_CASE
 #undef HALF_CASE
     TILE_CASE(2, 2, 16, 1, 4, 4, 2, true, true)

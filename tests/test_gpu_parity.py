@@ -1245,3 +1245,44 @@ def test_continuous_interpolation_ball_search_on_the_device(wlsqm, dim):
         got, _ = s.interpolate(xq, mode="continuous", r=r, diff=0)
         inside = ~empty & (X.min(axis=1) > 0.05) & (X.max(axis=1) < 0.95)
         assert np.abs(got[inside] - np.sin(2.0 * X[inside]).prod(axis=1)).max() < 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim", [2, 3])
+@pytest.mark.parametrize("K", list(range(8, 66, 2)))
+def test_index_based_input_has_a_fixed_shape_for_every_even_K(wlsqm, dim, K):
+    """Order 2, index-based ("cloud") input: every even K up to 64 runs a fixed-K instantiation of the gathering tile
+    kernel (8-byte index chunks where K is not a multiple of 4, shares padded to a multiple of 4 slots), and agrees with the
+    dense path on the same neighbourhoods to rounding: subset of the points as cases, ragged nk, knowns, both weightings."""
+    import torch
+    import synth
+    import wlsqm.hip as whip
+    no = K_.NDOF[dim][2]
+    if K < no + 2:
+        pytest.skip("fewer neighbours than unknowns + 2")
+    dev = torch.device("cuda", 0)
+    npts, n = 1500, 16 * 9 + 5 + K
+    S = synth.halton(npts, dim)
+    S = np.ascontiguousarray(S[synth.morton_order(S)])
+    F = synth.field(S)
+    hoods = synth.knn(S, K, workers=1)
+    rng = np.random.default_rng(K + dim)
+    pidx = rng.permutation(npts)[:n].astype(np.int32)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    S_d, F_d, h_d, p_d = t(S), t(F), t(hoods[pidx]), t(pidx)
+    nk = rng.integers(min(K, max(no + 6, K // 2)), K + 1, n).astype(np.int32); nk[n // 2:] = K
+    kn = rng.choice(np.array([0, 1, 1 << (no - 1)], np.int64), n); wm = rng.choice(np.array([1, 2], np.int32), n)
+    nk_d, kn_d, wm_d = t(nk), t(kn), t(wm)
+    fi0 = rng.uniform(-1, 1, (n, no)); fi0[:, 0] = F[pidx]
+    hl = h_d.long()
+    xk_d = S_d[hl].contiguous(); fk_d = F_d[hl].contiguous(); xi_d = S_d[p_d.long()].contiguous()
+    fi_a = t(fi0); fi_b = t(fi0)
+    whip.fit_cloud_device(dim, 2, S_d, F_d, h_d, fi_b, nk_d, kn_d, wm_d, point_index=p_d)
+    assert whip.last_kernel() == "tile-gather"
+    whip.fit_many_device(dim, 2, xk_d, fk_d, nk_d, xi_d, fi_a, kn_d, wm_d)
+    assert whip.last_kernel() == "tile"
+    torch.cuda.synchronize()
+    truth = P.truth_fit(dim, xk_d.cpu().numpy(), fk_d.cpu().numpy(), nk, xi_d.cpu().numpy(), fi0, np.full(n, 2, np.int32), kn, wm)
+    P.assert_parity(fi_b.cpu().numpy(), fi_a.cpu().numpy(), truth, "index-based vs dense path")
+    untouched = (kn[:, None] >> np.arange(no)[None, :]) & 1 == 1
+    assert np.array_equal(fi_b.cpu().numpy()[untouched], fi0[untouched])
