@@ -191,6 +191,9 @@ __global__ __launch_bounds__(KNT, 2) void fit_tilek_kernel(const KParams p, cons
 //   factors the matrix for itself at no extra cost (the instructions run for the whole wave anyway) and then handles
 //   ITS neighbours: one substitution per neighbour for the sensitivities, its share of the residual and of the
 //   correction's right-hand side per refinement sweep (met again through the butterfly).
+//   A K-specialised instantiation of this kernel (geometry as compile-time constants, predicates folded) does not help the
+//   extras: C2 at K = 32, iterative 1.08 instead of 1.10 ms, do_sens 1.80 instead of 0.73 ms (the unrolled substitutions
+//   spill) — unlike the basic fit, where fixed K is worth 20-70 % (fit_tile.hip).
 template <int DIM, int ORDER, bool MOM, int FMAX, bool EXTRAS = false>
 __global__ __launch_bounds__(KW, 2) void fit_tile1_kernel(const KParams p, const long long ntiles, const Tile1Geom G) {
     constexpr int NO = ndofs(DIM, ORDER), NE = NO * (NO + 1) / 2, NA = MOM ? mom_count<DIM>(2 * ORDER) : NE, TC = K1_TC;
