@@ -429,7 +429,7 @@ static bool tile_eligible(int dim, const KParams& p, long long K) {
 // Neighbour-slot counts with a two-kernel moment instantiation (2D order 4).  The host entry points round their device
 // rows up to the next of these (preferred_slots), so every host-array batch of 2D order-4 fits with <= 100 neighbours
 // takes this path (the reference's own example, examples/wlsqm_example.py:55-187, is order 4 with max_nk = 100).
-static bool moment_slots(long long K) { return K == 32 || K == 40 || K == 48 || K == 64 || K == 80 || K == 100; }
+static bool moment_slots(long long K) { return K >= 16 && K <= 100 && (K % 2) == 0; }      // every even size (shares padded to a multiple of 4)
 
 bool tile_moments_supported(int dimension, int order, const KParams& p, long long max_nk) {
     return dimension == 2 && order == 4 && moment_slots(max_nk) && tile_eligible(dimension, p, max_nk);
@@ -438,10 +438,8 @@ bool tile_moments_supported(int dimension, int order, const KParams& p, long lon
 // Device row length (neighbour slots) the host entry points should allocate for a batch whose largest neighbourhood has
 // max_nk members: even (16-byte rows for the tiled kernels), and for 2D order 4 the next size with a moment kernel.
 long long preferred_slots(int dimension, int order, long long max_nk) {
-    if (dimension == 2 && order == 4)
-        for (long long K : {32ll, 40ll, 48ll, 64ll, 80ll, 100ll})
-            if (max_nk <= K) return K;
-    const long long K = max_nk + (max_nk & 1);
+    long long K = max_nk + (max_nk & 1);
+    if (dimension == 2 && order == 4 && K < 16) K = 16;
     return K < 2 ? 2 : K;
 }
 
@@ -457,10 +455,15 @@ int launch_tile_moments(int dimension, int order, const KParams& p, long long ma
     // barrier) spills 408 B per lane and takes 1.34 instead of 0.70 ms.
 #define MOMENT_CASE(KK)                                                                                             \
     if (max_nk == KK) {                                                                                             \
-        if (gather) return launch_tile_impl<2, 4, KK, 2, 2, 4, 2, true, false, true, true>(p, stream);             \
-        return launch_tile_impl<2, 4, KK, 2, 2, 4, 2, false, false, true, true>(p, stream);                        \
+        if (gather) return launch_tile_impl<2, 4, KK, 2, 2, 4, 2, true, false, true, true, (KK + 3) / 4 * 4>(p, stream);   \
+        return launch_tile_impl<2, 4, KK, 2, 2, 4, 2, false, false, true, true, (KK + 3) / 4 * 4>(p, stream);      \
     }
-    MOMENT_CASE(32) MOMENT_CASE(40) MOMENT_CASE(48) MOMENT_CASE(64) MOMENT_CASE(80) MOMENT_CASE(100)
+    MOMENT_CASE(16) MOMENT_CASE(18) MOMENT_CASE(20) MOMENT_CASE(22) MOMENT_CASE(24) MOMENT_CASE(26) MOMENT_CASE(28) MOMENT_CASE(30)
+    MOMENT_CASE(32) MOMENT_CASE(34) MOMENT_CASE(36) MOMENT_CASE(38) MOMENT_CASE(40) MOMENT_CASE(42) MOMENT_CASE(44) MOMENT_CASE(46)
+    MOMENT_CASE(48) MOMENT_CASE(50) MOMENT_CASE(52) MOMENT_CASE(54) MOMENT_CASE(56) MOMENT_CASE(58) MOMENT_CASE(60) MOMENT_CASE(62)
+    MOMENT_CASE(64) MOMENT_CASE(66) MOMENT_CASE(68) MOMENT_CASE(70) MOMENT_CASE(72) MOMENT_CASE(74) MOMENT_CASE(76) MOMENT_CASE(78)
+    MOMENT_CASE(80) MOMENT_CASE(82) MOMENT_CASE(84) MOMENT_CASE(86) MOMENT_CASE(88) MOMENT_CASE(90) MOMENT_CASE(92) MOMENT_CASE(94)
+    MOMENT_CASE(96) MOMENT_CASE(98) MOMENT_CASE(100)
 #undef MOMENT_CASE
     *handled = false;
     return WLSQM_OK;

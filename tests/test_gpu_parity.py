@@ -279,6 +279,14 @@ def test_every_even_neighbourhood_size_has_a_fixed_shape(wlsqm, dim, order, K, m
     _tile_vs_lane(wlsqm, dim, order, K, 16 * 9 + 5 + K, monkeypatch, expect="tile", spare=6)
 
 
+@pytest.mark.parametrize("K", list(range(22, 102, 2)))
+def test_every_even_neighbourhood_size_2d_order4_takes_the_moment_kernels(wlsqm, K, monkeypatch):
+    """2D order 4: every even K from 16 to 100 has an instantiation of the two-kernel moment path (shares padded to a
+    multiple of 4 slots), so no host batch is padded by more than one slot and device batches of any even K avoid the generic
+    kernel."""
+    _tile_vs_lane(wlsqm, 2, 4, K, 32 * 5 + 7 + K, monkeypatch, expect="moment", spare=8)
+
+
 def _tile_vs_lane(wlsqm, dim, order, K, ncases, monkeypatch, expect=None, spare=2):
     import wlsqm.hip as whip
     rng = np.random.default_rng(ncases)
