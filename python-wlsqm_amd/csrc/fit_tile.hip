@@ -602,6 +602,26 @@ int launch_fit_tile(int dimension, int order, const KParams& p, long long max_nk
     GATHER_CASE(3, 2, 52, 4, 1, 2) GATHER_CASE(3, 2, 54, 4, 1, 2) GATHER_CASE(3, 2, 56, 4, 1, 2)
     GATHER_CASE(3, 2, 58, 4, 1, 2) GATHER_CASE(3, 2, 60, 4, 1, 2) GATHER_CASE(3, 2, 62, 4, 1, 2)
     GATHER_CASE(3, 2, 64, 4, 1, 2)
+#define EVEN_K4(X, ...) X(__VA_ARGS__, 4) X(__VA_ARGS__, 6) X(__VA_ARGS__, 8) X(__VA_ARGS__, 10) X(__VA_ARGS__, 12) X(__VA_ARGS__, 14) \
+    X(__VA_ARGS__, 16) X(__VA_ARGS__, 18) X(__VA_ARGS__, 20) X(__VA_ARGS__, 22) X(__VA_ARGS__, 24) X(__VA_ARGS__, 26) X(__VA_ARGS__, 28) \
+    X(__VA_ARGS__, 30) X(__VA_ARGS__, 32) X(__VA_ARGS__, 34) X(__VA_ARGS__, 36) X(__VA_ARGS__, 38) X(__VA_ARGS__, 40) X(__VA_ARGS__, 42) \
+    X(__VA_ARGS__, 44) X(__VA_ARGS__, 46) X(__VA_ARGS__, 48) X(__VA_ARGS__, 50) X(__VA_ARGS__, 52) X(__VA_ARGS__, 54) X(__VA_ARGS__, 56) \
+    X(__VA_ARGS__, 58) X(__VA_ARGS__, 60) X(__VA_ARGS__, 62) X(__VA_ARGS__, 64)
+    // (the other families, same rule: four waves per 64-case tile, two waves x two lanes per case for the large sizes;
+    // 2D order 1 at K = 10 / 20 / 40: 0.061 / 0.093 / 0.179 against 0.099 / 0.132 / 0.297 ms, 2D order 3 at K = 24 / 48: 0.242 /
+    // 0.333 against 0.309 / 0.484, 3D order 1 at K = 16 / 24: 0.094 / 0.145 against 0.143 / 0.191)
+#define GATHER_41(D, O, KK) GATHER_CASE(D, O, KK, 4, 1, 4)
+#define GATHER_22(D, O, KK) GATHER_CASE(D, O, KK, 2, 2, 4)
+    if (gather && var != 9) {
+        if (dimension == 2 && order == 1 && max_nk != 16 && max_nk != 32) { EVEN_K4(GATHER_41, 2, 1) }
+        if (dimension == 2 && order == 3 && max_nk >= 12 && max_nk <= 56 && max_nk != 40) { EVEN_K4(GATHER_41, 2, 3) }
+        if (dimension == 2 && order == 3 && max_nk > 56) { GATHER_22(2, 3, 58) GATHER_22(2, 3, 60) GATHER_22(2, 3, 62) GATHER_22(2, 3, 64) }
+        if (dimension == 3 && order == 1 && max_nk < 32) { EVEN_K4(GATHER_41, 3, 1) }
+        if (dimension == 3 && order == 1 && max_nk > 32) { EVEN_K4(GATHER_22, 3, 1) }
+    }
+#undef GATHER_41
+#undef GATHER_22
+#undef EVEN_K4
 #undef GATHER_CASE
 #undef PAD_CASE
 #undef HALF_CASE

@@ -1256,16 +1256,17 @@ def test_continuous_interpolation_ball_search_on_the_device(wlsqm, dim):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dim", [2, 3])
-@pytest.mark.parametrize("K", list(range(8, 66, 2)))
-def test_index_based_input_has_a_fixed_shape_for_every_even_K(wlsqm, dim, K):
-    """Order 2, index-based ("cloud") input: every even K up to 64 runs a fixed-K instantiation of the gathering tile
-    kernel (8-byte index chunks where K is not a multiple of 4, shares padded to a multiple of 4 slots), and agrees with the
-    dense path on the same neighbourhoods to rounding: subset of the points as cases, ragged nk, knowns, both weightings."""
+@pytest.mark.parametrize("dim,order", [(2, 1), (2, 2), (2, 3), (3, 1), (3, 2)])
+@pytest.mark.parametrize("K", list(range(6, 66, 2)))
+def test_index_based_input_has_a_fixed_shape_for_every_even_K(wlsqm, dim, order, K):
+    """Index-based ("cloud") input, 2D orders 1-3 and 3D orders 1-2: every even K up to 64 runs a fixed-K instantiation of
+    the gathering tile kernel (8-byte index chunks where K is not a multiple of 4, shares padded to a multiple of 4 slots),
+    and agrees with the dense path on the same neighbourhoods to rounding: subset of the points as cases, ragged nk, knowns,
+    both weightings."""
     import torch
     import synth
     import wlsqm.hip as whip
-    no = K_.NDOF[dim][2]
+    no = K_.NDOF[dim][order]
     if K < no + 2:
         pytest.skip("fewer neighbours than unknowns + 2")
     dev = torch.device("cuda", 0)
@@ -1285,12 +1286,12 @@ def test_index_based_input_has_a_fixed_shape_for_every_even_K(wlsqm, dim, K):
     hl = h_d.long()
     xk_d = S_d[hl].contiguous(); fk_d = F_d[hl].contiguous(); xi_d = S_d[p_d.long()].contiguous()
     fi_a = t(fi0); fi_b = t(fi0)
-    whip.fit_cloud_device(dim, 2, S_d, F_d, h_d, fi_b, nk_d, kn_d, wm_d, point_index=p_d)
+    whip.fit_cloud_device(dim, order, S_d, F_d, h_d, fi_b, nk_d, kn_d, wm_d, point_index=p_d)
     assert whip.last_kernel() == "tile-gather"
-    whip.fit_many_device(dim, 2, xk_d, fk_d, nk_d, xi_d, fi_a, kn_d, wm_d)
+    whip.fit_many_device(dim, order, xk_d, fk_d, nk_d, xi_d, fi_a, kn_d, wm_d)
     assert whip.last_kernel() == "tile"
     torch.cuda.synchronize()
-    truth = P.truth_fit(dim, xk_d.cpu().numpy(), fk_d.cpu().numpy(), nk, xi_d.cpu().numpy(), fi0, np.full(n, 2, np.int32), kn, wm)
+    truth = P.truth_fit(dim, xk_d.cpu().numpy(), fk_d.cpu().numpy(), nk, xi_d.cpu().numpy(), fi0, np.full(n, order, np.int32), kn, wm)
     P.assert_parity(fi_b.cpu().numpy(), fi_a.cpu().numpy(), truth, "index-based vs dense path")
     untouched = (kn[:, None] >> np.arange(no)[None, :]) & 1 == 1
     assert np.array_equal(fi_b.cpu().numpy()[untouched], fi0[untouched])
