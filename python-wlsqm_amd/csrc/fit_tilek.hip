@@ -359,7 +359,8 @@ __global__ __launch_bounds__(KW, 2) void fit_tile1_kernel(const KParams p, const
                 // neighbour 4*kk + h here) and leave as full-line stores of 8 B per lane.  Direct 8-byte stores from
                 // the owner lanes touch 64 lines per instruction and cost 0.73 ms per 1M C2 cases against 0.45 ms for
                 // everything else in this kernel.
-                const bool dense = p.ss_k == NO && p.ss_j == (long long)G.K * NO && !p.case_index && !__any(dropped != 0);
+                const bool dense = p.ss_k == NO && p.ss_j == (long long)G.K * NO && !p.case_index && !__any(dropped != 0) &&
+                                   (reinterpret_cast<uintptr_t>(p.sens) & 15u) == 0;
                 if (dense) {
                     constexpr int SL = 2, E = SL * K1_LPC * NO, CS = E + 1;      // elements per case and slab; padded stride
                     double* sS = lds + TC * G.RS;                                // [TC][CS]
@@ -378,6 +379,20 @@ __global__ __launch_bounds__(KW, 2) void fit_tile1_kernel(const KParams p, const
                         }
                         __syncthreads();
                         const int kbase = slab * SL * K1_LPC;
+                        if constexpr (NO % 2 == 0) {
+                            // 16 B per lane: a pair never straddles two neighbours (NO even) nor two cases (E even)
+#pragma unroll
+                            for (int q0 = 0; q0 < TC * E / 2; q0 += KW) {
+                                const int q = q0 + lane;
+                                if ((TC * E / 2) % KW == 0 || q < TC * E / 2) {
+                                    const int cs = q / (E / 2), e = 2 * (q - cs * (E / 2)), k = kbase + e / NO;
+                                    if (k < sNk[cs]) {
+                                        k1d2_ v; v.x = sS[cs * CS + e]; v.y = sS[cs * CS + e + 1];
+                                        *reinterpret_cast<k1d2_*>(out0 + (long long)cs * p.ss_j + (long long)kbase * NO + e) = v;
+                                    }
+                                }
+                            }
+                        } else {
 #pragma unroll
                         for (int q0 = 0; q0 < TC * E; q0 += KW) {
                             const int q = q0 + lane;
@@ -385,6 +400,7 @@ __global__ __launch_bounds__(KW, 2) void fit_tile1_kernel(const KParams p, const
                                 const int cs = q / E, e = q - cs * E, k = kbase + e / NO;       // compile-time divisors
                                 if (k < sNk[cs]) out0[(long long)cs * p.ss_j + (long long)kbase * NO + e] = sS[cs * CS + e];
                             }
+                        }
                         }
                         __syncthreads();
                     }
