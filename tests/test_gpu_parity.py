@@ -287,6 +287,14 @@ def test_every_even_neighbourhood_size_2d_order4_takes_the_moment_kernels(wlsqm,
     _tile_vs_lane(wlsqm, 2, 4, K, 32 * 5 + 7 + K, monkeypatch, expect="moment", spare=8)
 
 
+@pytest.mark.parametrize("dim,order", [(2, 1), (2, 2), (2, 3), (3, 1), (3, 2)])
+@pytest.mark.parametrize("K", list(range(66, 130, 2)))
+def test_large_neighbourhoods_have_fixed_shapes_too(wlsqm, dim, order, K, monkeypatch):
+    """64 < K <= 128 (e.g. the 124 neighbours of a 5 x 5 x 5 block): two waves x four lanes per case on a 16-case tile, shares
+    padded to a multiple of 16 slots, instead of the generic lane-per-case kernel these sizes used to take."""
+    _tile_vs_lane(wlsqm, dim, order, K, 16 * 5 + 3 + K % 7, monkeypatch, expect="tile", spare=6)
+
+
 def _tile_vs_lane(wlsqm, dim, order, K, ncases, monkeypatch, expect=None, spare=2):
     import wlsqm.hip as whip
     rng = np.random.default_rng(ncases)
@@ -1256,11 +1264,11 @@ def test_continuous_interpolation_ball_search_on_the_device(wlsqm, dim):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dim,order", [(2, 1), (2, 2), (2, 3), (3, 1), (3, 2)])
-@pytest.mark.parametrize("K", list(range(6, 66, 2)))
+@pytest.mark.parametrize("dim,order,K", [(d, o, k) for d, o in ((2, 1), (2, 2), (2, 3), (3, 1), (3, 2)) for k in range(6, 66, 2)] +
+                         [(d, 2, k) for d in (2, 3) for k in range(66, 130, 2)])
 def test_index_based_input_has_a_fixed_shape_for_every_even_K(wlsqm, dim, order, K):
-    """Index-based ("cloud") input, 2D orders 1-3 and 3D orders 1-2: every even K up to 64 runs a fixed-K instantiation of
-    the gathering tile kernel (8-byte index chunks where K is not a multiple of 4, shares padded to a multiple of 4 slots),
+    """Index-based ("cloud") input, 2D orders 1-3 and 3D orders 1-2: every even K up to 64 (order 2: up to 128) runs a fixed-K
+    instantiation of the gathering tile kernel (8-byte index chunks where K is not a multiple of 4, shares padded to a multiple of 4 slots),
     and agrees with the dense path on the same neighbourhoods to rounding: subset of the points as cases, ragged nk, knowns,
     both weightings."""
     import torch
