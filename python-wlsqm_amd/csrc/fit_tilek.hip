@@ -559,7 +559,17 @@ int launch_fit_tilek(int dimension, int order, const KParams& p, long long K, hi
     if (extras) {
         // sensitivities / iterative refinement: the one-wave kernel with EXTRAS (K <= 64), else the generic kernel
         const char* ex = getenv("WLSQM_HIP_DISABLE_TILE_EXTRAS");
-        if ((ex && ex[0] == '1') || K > K1_LPC * K1_FMAX) return WLSQM_OK;
+        if (ex && ex[0] == '1') return WLSQM_OK;
+        if (K > K1_LPC * K1_FMAX) {
+            // 64 < K <= 128 in 2D, orders 1-2: 32 neighbours per lane.  200k cases of 2D order 2 at K = 80 / 124: do_sens 0.93 /
+            // 1.29 ms, iterative 1.20 / 1.33 ms against 1.37 / 2.15 and 2.55 / 4.14 ms on the generic kernel.  (3D: the 32 fk
+            // values and 45 moments per lane spill 0.7-1.6 KB and lose to the generic kernel, 1.82 / 3.79 against 1.51 / 2.81 ms.)
+            if (K > K1_LPC * 32) return WLSQM_OK;
+#define XBIG(D, O) if (dimension == D && order == O) return launch_tile1<D, O, (O >= 2), 32, true>(p, K, stream, handled);
+            XBIG(2, 1) XBIG(2, 2)
+#undef XBIG
+            return WLSQM_OK;
+        }
 #define XCASE(D, O)                                                                                   \
     if (dimension == D && order == O)                                                                 \
         return K <= 32 ? launch_tile1<D, O, (O >= 2), 8, true>(p, K, stream, handled)                 \

@@ -8,7 +8,8 @@ import torch
 import bench, synth
 import wlsqm.hip as whip
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
-cfg = bench.CONFIGS["C2"]; dim, order, nk, no = 2, 2, 32, 6
+cfg = dict(bench.CONFIGS[os.environ.get("TUNE_CONFIG", "C2")]); cfg["nk"] = int(os.environ.get("TUNE_NK", cfg["nk"]))
+dim, order, nk = cfg["dim"], cfg["order"], cfg["nk"]; no = bench.NDOF[dim][order]
 dev = torch.device("cuda", 0)
 S, F, hoods = bench.build_problem(cfg, n, 0)
 t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -25,7 +26,7 @@ def timeit(f, reps=10):
 if len(sys.argv) > 2 and sys.argv[2] == "lane":
     os.environ["WLSQM_HIP_DISABLE_TILE_EXTRAS"] = "1"
 ms = timeit(lambda: whip.fit_many_device(dim, order, xk, fk, nk_d, S_d, fi, kn, wm, sens=sens))
-print("do_sens  : %.3f ms -> %.3e fits/s, %.0f GB/s (852 B in + 1536 B sens out per fit)" % (ms, n / ms * 1e3, 2388 * n / ms / 1e6))
+print("do_sens  : %.3f ms -> %.3e fits/s (%s, K = %d, kernel %s)" % (ms, n / ms * 1e3, os.environ.get("TUNE_CONFIG", "C2"), nk, whip.last_kernel()))
 ms = timeit(lambda: whip.fit_many_device(dim, order, xk, fk, nk_d, S_d, fi, kn, wm, iterative=True, max_iter=10))
 print("iterative: %.3f ms -> %.3e fits/s" % (ms, n / ms * 1e3))
 ms = timeit(lambda: whip.fit_many_device(dim, order, xk, fk, nk_d, S_d, fi, kn, wm))
