@@ -45,12 +45,21 @@ int launch_fit_tile_big(int dimension, int order, const KParams& p, long long ma
     }
 #define BIGG_2D2(KK) BIGG_CASE(2, 2, KK, 4)
 #define BIGG_3D2(KK) BIGG_CASE(3, 2, KK, 2)
+#define BIGG_2D1(KK) BIGG_CASE(2, 1, KK, 4)
+#define BIGG_3D1(KK) BIGG_CASE(3, 1, KK, 4)
+#define BIGG_2D3(KK) BIGG_CASE(2, 3, KK, 2)
     if (gather) {
         if (dimension == 2 && order == 2) { BIG_K(BIG_ONE, BIGG_2D2) }
         if (dimension == 3 && order == 2) { BIG_K(BIG_ONE, BIGG_3D2) }
+        if (dimension == 2 && order == 1) { BIG_K(BIG_ONE, BIGG_2D1) }
+        if (dimension == 3 && order == 1) { BIG_K(BIG_ONE, BIGG_3D1) }
+        if (dimension == 2 && order == 3) { BIG_K(BIG_ONE, BIGG_2D3) }
     }
 #undef BIGG_2D2
 #undef BIGG_3D2
+#undef BIGG_2D1
+#undef BIGG_3D1
+#undef BIGG_2D3
 #undef BIGG_CASE
 #undef BIG_ONE
 #undef BIG_2D2
