@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdlib>
 #include <string>
 
 #include "wlsqm_hip.h"
@@ -70,7 +71,19 @@ void note_kernel(const char* name);
 // more than 64 KB of dynamic LDS, and (when the LDS size never changes) the workgroups that fit one CU.
 struct KernelSetup { int cus[16] = {}; int per_cu[16] = {}; };
 
-// Grid of a persistent launch: resident workgroups per CU x CUs of the current device.
+// Workgroups launched per resident workgroup slot.  A grid of exactly the resident workgroups leaves the tail of the launch
+// unbalanced (1M C2 cases are 62 500 tiles over 3 072 waves: 20 or 21 tiles each, and the waves do not finish their tiles at
+// the same pace); launching several workgroups per slot lets the dispatcher hand the leftovers to whichever slot frees up first
+// (tools/tune.py g1 / g8 / g16 / g1000, interleaved: C2 0.1737 / 0.1665 / 0.1656 / 0.1655 ms, C5 0.3512 / 0.3426 / 0.3386 /
+// 0.3409, C3 0.672 / 0.650 / 0.639).  WLSQM_HIP_GRID_MULT overrides it (A/B).
+inline double grid_multiple() {
+    const char* e = getenv("WLSQM_HIP_GRID_MULT");
+    const double v = e ? atof(e) : 16.0;
+    return v > 0.0 ? v : 16.0;
+}
+
+// Grid of a persistent launch: resident workgroups per CU x CUs of the current device x grid_multiple()
+// (callers clamp it to the number of tiles).
 inline int persistent_grid(const void* kern, int threads, size_t lds_bytes, size_t lds_optin, bool fixed_lds, KernelSetup& ks,
                            long long* grid) {
     int dev = 0;
@@ -89,7 +102,8 @@ inline int persistent_grid(const void* kern, int threads, size_t lds_bytes, size
         if (occ < 1) occ = 1;
         if (fixed_lds) ks.per_cu[dev] = occ;
     }
-    *grid = (long long)occ * ks.cus[dev];
+    *grid = (long long)((double)occ * ks.cus[dev] * grid_multiple());
+    if (*grid < 1) *grid = 1;
     return WLSQM_OK;
 }
 

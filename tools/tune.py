@@ -36,8 +36,12 @@ for rnd in range(5):
             os.environ["WLSQM_TILEK_SHAPE"] = v[1]
         elif v == "fix":                   # curated fixed-K shape
             os.environ.pop("WLSQM_HIP_DISABLE_TILE", None); os.environ.pop("WLSQM_HIP_DISABLE_FIXEDK", None)
+        elif v.startswith("g"):            # grid size of the persistent launch as a multiple of the resident workgroups
+            os.environ.pop("WLSQM_HIP_DISABLE_TILE", None); os.environ.pop("WLSQM_HIP_DISABLE_FIXEDK", None)
+            os.environ["WLSQM_TILE_VARIANT"] = "0"; os.environ["WLSQM_HIP_GRID_MULT"] = v[1:]
         else:
             os.environ.pop("WLSQM_HIP_DISABLE_TILE", None); os.environ.pop("WLSQM_HIP_DISABLE_FIXEDK", None)
+            os.environ.pop("WLSQM_HIP_GRID_MULT", None)
             os.environ["WLSQM_TILE_VARIANT"] = v
         ms = whip.time_fit_device(*args, reps=20)
         res[v].append(ms)
