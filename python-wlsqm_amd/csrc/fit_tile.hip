@@ -91,15 +91,17 @@ int launch_fit_tile(int dimension, int order, const KParams& p, long long max_nk
             return var == 3 ? launch_tile_impl<2, 2, 32, 4, 1, 8, 2, true>(p, stream)
                             : launch_tile_impl<2, 2, 32, 4, 1, 8, 2, true, false, true>(p, stream);
         }
-        // A/B at 1M cases (tools/tune.py), ms per launch: one wave per 16-case tile + moments + direct fk 0.167;
+        // Since the grids launch 16 workgroups per resident slot (wlsqm_internal.hpp) one wave per 32-case tile with two
+        // lanes per case leads: 0.159 against 0.166 ms for four lanes per case (variant 4) at 1M cases, 0.314 against 0.348 at
+        // 2M.  Earlier A/B at 1M cases with resident-size grids (tools/tune.py), ms per launch: one wave per 16-case tile + moments + direct fk 0.167;
         // the same with two lanes per case 0.173; without direct fk 0.233; four waves per 64-case tile: moments
         // 0.181, entry form 0.186 (the round-1 kernel); eight waves 0.43; the default shape squeezed to 128 VGPRs (four
         // waves per SIMD, small spills) 0.182-0.199, with unroll 4 or 2 at three waves per SIMD 0.176-0.180.
         switch (var) {
-            case 1: return launch_tile_impl<2, 2, 32, 1, 2, 8, 2, false, true, true>(p, stream);
             case 2: return launch_tile_impl<2, 2, 32, 4, 1, 4, 3, false, false, true>(p, stream);
             case 3: return launch_tile_any<2, 2, 32, 4, 1, 8, 2>(p, stream, gather);
-            default: return launch_tile_any<2, 2, 32, 1, 4, 8, 2, true, true>(p, stream, gather);
+            case 4: return launch_tile_impl<2, 2, 32, 1, 4, 8, 2, false, true, true>(p, stream);
+            default: return launch_tile_impl<2, 2, 32, 1, 2, 8, 2, false, true, true>(p, stream);
         }
     }
     if (dimension == 3 && order == 2 && max_nk == 40) {      // C5
