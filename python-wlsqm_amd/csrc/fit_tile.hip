@@ -93,7 +93,8 @@ int launch_fit_tile(int dimension, int order, const KParams& p, long long max_nk
         }
         // Since the grids launch 16 workgroups per resident slot (wlsqm_internal.hpp) one wave per 32-case tile with two
         // lanes per case leads: 0.159 against 0.166 ms for four lanes per case (variant 4) at 1M cases, 0.314 against 0.348 at
-        // 2M.  Earlier A/B at 1M cases with resident-size grids (tools/tune.py), ms per launch: one wave per 16-case tile + moments + direct fk 0.167;
+        // 2M (228 VGPRs, two waves per SIMD; unroll 4 / 16: 0.159 / 0.158 against 0.157; squeezed to 168 VGPRs for three waves,
+        // by unroll 2 or __launch_bounds__(64, 3): 0.169 / 0.190).  Earlier A/B at 1M cases with resident-size grids (tools/tune.py), ms per launch: one wave per 16-case tile + moments + direct fk 0.167;
         // the same with two lanes per case 0.173; without direct fk 0.233; four waves per 64-case tile: moments
         // 0.181, entry form 0.186 (the round-1 kernel); eight waves 0.43; the default shape squeezed to 128 VGPRs (four
         // waves per SIMD, small spills) 0.182-0.199, with unroll 4 or 2 at three waves per SIMD 0.176-0.180.
