@@ -15,6 +15,7 @@ int launch_fit_tile_even(int dimension, int order, const KParams& p, long long m
     //    16 / 24 / 30: 0.054 / 0.097 / 0.123 / 0.175 against 0.092 / 0.121 / 0.145 / 0.200 with four lanes per case), 3D order
     //    2 up to 24 (K = 16 / 24: 0.162 / 0.206 against 0.246 / 0.286), order 1 up to 20 (2D K = 8 / 12: 0.038 / 0.062 against
     //    0.053 / 0.082), 2D order 3 up to 38 (K = 16 / 24 / 32: 0.132 / 0.169 / 0.201 against 0.215 / 0.243 / 0.276);
+    //    (one lane per case on a 64-case one-wave tile: within 10 % either way at K = 8-16, 2x slower at K = 24 — not instantiated);
     //  * PAD: one wave per 16-case tile, four lanes per case, or two waves x two lanes per case (3D order 2 from K = 50, order
     //    1), shares padded to a multiple of 8 slots — 2D order 2 at K = 36 / 44 / 52 / 60: 0.209 / 0.257 / 0.287 / 0.326 against
     //    0.324 / 0.368 / 0.397 / 0.437 on the runtime-K kernels, 3D order 2 at K = 36 / 48 / 56 / 64: 0.371 / 0.403 / 0.508 / 0.560
