@@ -194,9 +194,11 @@ __global__ __launch_bounds__(KNT, 2) void fit_tilek_kernel(const KParams p, cons
 //   A K-specialised instantiation of this kernel (geometry as compile-time constants, predicates folded) does not help the
 //   extras: C2 at K = 32, iterative 1.08 instead of 1.10 ms, do_sens 1.80 instead of 0.73 ms (the unrolled substitutions
 //   spill) — unlike the basic fit, where fixed K is worth 20-70 % (fit_tile.hip).
-template <int DIM, int ORDER, bool MOM, int FMAX, bool EXTRAS = false>
+// LPC: lanes per case (4 on 16-case tiles; 2 on 32-case tiles, which halves the butterflies and the redundant factorisations
+//   per case and wins for K <= 32 under the oversubscribed grids, like the fixed-K shapes of fit_tile_even.hip).
+template <int DIM, int ORDER, bool MOM, int FMAX, bool EXTRAS = false, int LPC = K1_LPC>
 __global__ __launch_bounds__(KW, 2) void fit_tile1_kernel(const KParams p, const long long ntiles, const Tile1Geom G) {
-    constexpr int NO = ndofs(DIM, ORDER), NE = NO * (NO + 1) / 2, NA = MOM ? mom_count<DIM>(2 * ORDER) : NE, TC = K1_TC;
+    constexpr int NO = ndofs(DIM, ORDER), NE = NO * (NO + 1) / 2, NA = MOM ? mom_count<DIM>(2 * ORDER) : NE, TC = KW / LPC;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* sX = lds;
     const int lane = threadIdx.x, c = lane % TC, h = lane / TC;
@@ -247,7 +249,7 @@ __global__ __launch_bounds__(KW, 2) void fit_tile1_kernel(const KParams p, const
         __syncthreads();
 
         const double* xr = sX + c * G.RS;
-        const double max_d2 = tile1_max_d2<DIM, FMAX>(xr, xi, k0, nkc, G);
+        const double max_d2 = tile1_max_d2<DIM, FMAX, LPC>(xr, xi, k0, nkc, G);
         const double inv_max = inverse_max(max_d2);
 
         double A[NA], g[NO];               // MOM: moments mu / nu; else the packed upper triangle of M / g
@@ -362,7 +364,7 @@ __global__ __launch_bounds__(KW, 2) void fit_tile1_kernel(const KParams p, const
                 const bool dense = p.ss_k == NO && p.ss_j == (long long)G.K * NO && !p.case_index && !__any(dropped != 0) &&
                                    (reinterpret_cast<uintptr_t>(p.sens) & 15u) == 0;
                 if (dense) {
-                    constexpr int SL = 2, E = SL * K1_LPC * NO, CS = E + 1;      // elements per case and slab; padded stride
+                    constexpr int SL = 2, E = SL * LPC * NO, CS = E + 1;      // elements per case and slab; padded stride
                     double* sS = lds + TC * G.RS;                                // [TC][CS]
                     int* sNk = reinterpret_cast<int*>(sS + TC * CS);             // rows each case stores (0: none)
                     if (h == 0) sNk[c] = store ? nkc : 0;
@@ -372,13 +374,13 @@ __global__ __launch_bounds__(KW, 2) void fit_tile1_kernel(const KParams p, const
 #pragma unroll
                         for (int i = 0; i < SL; ++i) {
                             double sv[NO];
-                            sens_row((slab * SL + i) * K1_LPC + h, sv);
-                            double* q = sS + c * CS + (i * K1_LPC + h) * NO;
+                            sens_row((slab * SL + i) * LPC + h, sv);
+                            double* q = sS + c * CS + (i * LPC + h) * NO;
 #pragma unroll
                             for (int a = 0; a < NO; ++a) q[a] = ((known >> a) & 1ull) ? __longlong_as_double(0x7ff8000000000000LL) : sv[a];
                         }
                         __syncthreads();
-                        const int kbase = slab * SL * K1_LPC;
+                        const int kbase = slab * SL * LPC;
                         if constexpr (NO % 2 == 0) {
                             // 16 B per lane: a pair never straddles two neighbours (NO even) nor two cases (E even)
 #pragma unroll
@@ -518,16 +520,17 @@ static int launch_tilek(const KParams& p, long long K, hipStream_t stream, bool*
     return WLSQM_OK;
 }
 
-template <int DIM, int ORDER, bool MOM, int FMAX, bool EXTRAS = false>
+template <int DIM, int ORDER, bool MOM, int FMAX, bool EXTRAS = false, int LPC = K1_LPC>
 static int launch_tile1(const KParams& p, long long K, hipStream_t stream, bool* handled) {
     Tile1Geom G;
-    if (!tile1_geometry<DIM>(K, FMAX, G)) return WLSQM_OK;
+    if (!tile1_geometry<DIM, LPC>(K, FMAX, G)) return WLSQM_OK;
+    constexpr int K1_TC = K1_WV / LPC;          // (shadows the default tile size below)
     constexpr int NO_ = ndofs(DIM, ORDER);
     // EXTRAS: + the sensitivities' staging slab [TC][2*4*no + 1] and 16 ints
-    const size_t lds_bytes = sizeof(double) * (size_t)(K1_TC * G.RS + (EXTRAS ? K1_TC * (2 * K1_LPC * NO_ + 1) + K1_TC / 2 : 0));
+    const size_t lds_bytes = sizeof(double) * (size_t)(K1_TC * G.RS + (EXTRAS ? K1_TC * (2 * LPC * NO_ + 1) + K1_TC / 2 : 0));
     *handled = true;
     const long long ntiles = (p.ncases + K1_TC - 1) / K1_TC;
-    auto kern = fit_tile1_kernel<DIM, ORDER, MOM, FMAX, EXTRAS>;
+    auto kern = fit_tile1_kernel<DIM, ORDER, MOM, FMAX, EXTRAS, LPC>;
     static KernelSetup setup;
     long long grid = 0;
     int rc = persistent_grid(reinterpret_cast<const void*>(kern), KW, lds_bytes, 0, false, setup, &grid);
@@ -569,6 +572,17 @@ int launch_fit_tilek(int dimension, int order, const KParams& p, long long K, hi
             XBIG(2, 1) XBIG(2, 2)
 #undef XBIG
             return WLSQM_OK;
+        }
+        if (K <= 2 * 8) {
+            // up to 16 neighbours: two lanes per case on 32-case tiles.  1M cases, 2D order 2 at K = 8 / 12 / 16: do_sens 0.225 /
+            // 0.276 / 0.336 ms and iterative 0.418 / 0.485 / 0.563 ms against 0.322 / 0.397 / 0.429 and 0.867 / 0.787 / 0.788 with
+            // four lanes; 3D order 2 at K = 12: 0.925 / 0.691 against 1.293 / 1.093.  (With 16 neighbours per lane, K <= 32, the
+            // two-lane shape loses: C2 0.73 / 1.10 against 0.66 / 1.00 ms.)
+#define XPAIR(D, O) if (dimension == D && order == O) return launch_tile1<D, O, (O >= 2), 8, true, 2>(p, K, stream, handled);
+            XPAIR(1, 0) XPAIR(1, 1) XPAIR(1, 2) XPAIR(1, 3) XPAIR(1, 4)
+            XPAIR(2, 0) XPAIR(2, 1) XPAIR(2, 2) XPAIR(2, 3)
+            XPAIR(3, 0) XPAIR(3, 1) XPAIR(3, 2)
+#undef XPAIR
         }
 #define XCASE(D, O)                                                                                   \
     if (dimension == D && order == O)                                                                 \

@@ -19,14 +19,15 @@ struct Tile1Geom {
 };
 
 // Host side: geometry for K neighbour slots; false when a lane would need more than fmax neighbours.
-template <int DIM>
+// (LPC lanes per case: 4 on 16-case tiles by default, 2 on 32-case tiles for the small neighbourhoods)
+template <int DIM, int LPC = K1_LPC>
 inline bool tile1_geometry(long long K, int fmax, Tile1Geom& G) {
     auto rup = [](int v, int m, int r) { return v + ((r - v % m) % m + m) % m; };
-    G.K = (int)K; G.KPL = (int)((K + K1_LPC - 1) / K1_LPC);
+    G.K = (int)K; G.KPL = (int)((K + LPC - 1) / LPC);
     if (G.KPL > fmax) return false;
     G.fvec = (K % 2 == 0 && G.KPL % 2 == 0) ? 1 : 0;
     G.RS = DIM == 2 ? rup((int)K * DIM, 4, 2) : rup((int)K * DIM, 2, 1);   // conflict-free ds_read_b128 / b64
-    G.XCH = K1_TC * (int)K * DIM / 2; G.CPRX = (int)K * DIM / 2; G.inv_cprx = 1.0f / (float)G.CPRX;
+    G.XCH = (K1_WV / LPC) * (int)K * DIM / 2; G.CPRX = (int)K * DIM / 2; G.inv_cprx = 1.0f / (float)G.CPRX;
     return true;
 }
 
@@ -101,7 +102,7 @@ __device__ __forceinline__ void tile1_stage_x_indexed(double* sX, const double* 
 }
 
 // Largest squared distance of the case (impl.pyx:389-391) over all four lanes; neighbours k >= nkc count as 0.
-template <int DIM, int FMAX>
+template <int DIM, int FMAX, int LPC = K1_LPC>
 __device__ __forceinline__ double tile1_max_d2(const double* xr, const double (&xi)[DIM], int k0, int nkc, const Tile1Geom& G) {
     double max_d2 = 0.0;
 #pragma unroll
@@ -117,7 +118,7 @@ __device__ __forceinline__ double tile1_max_d2(const double* xr, const double (&
         }
     }
 #pragma unroll
-    for (int off = K1_TC; off < K1_WV; off <<= 1) { const double o = __shfl_xor(max_d2, off, K1_WV); max_d2 = o > max_d2 ? o : max_d2; }
+    for (int off = K1_WV / LPC; off < K1_WV; off <<= 1) { const double o = __shfl_xor(max_d2, off, K1_WV); max_d2 = o > max_d2 ? o : max_d2; }
     return max_d2;
 }
 
