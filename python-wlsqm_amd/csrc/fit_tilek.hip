@@ -600,12 +600,15 @@ int launch_fit_tilek(int dimension, int order, const KParams& p, long long K, hi
     bool first1 = (dimension == 2 && order == 2) || (dimension == 3 && order == 1);
     if (sv && sv[0] == '1') first1 = true;
     if (sv && sv[0] == '4') first1 = false;
+    // up to 32 neighbours: two lanes per case on 32-case tiles (1M cases, 2D order 2 at K = 15 / 16 / 31 / 32: 0.133 / 0.133 / 0.223 /
+    // 0.219 ms against 0.196 / 0.192 / 0.249 / 0.247 with four lanes; 3D order 2 at K = 12: 0.176 against 0.289)
 #define KCASE(D, O)                                                                            \
     if (dimension == D && order == O) {                                                        \
         for (int attempt = 0; attempt < 2 && !*handled; ++attempt) {                           \
             const bool one = (attempt == 0) == first1;                                         \
             int rc = WLSQM_OK;                                                                 \
-            if (one && can1) rc = K <= 32 ? launch_tile1<D, O, (O >= 2), 8>(p, K, stream, handled)  \
+            if (one && can1) rc = K <= 16 ? launch_tile1<D, O, (O >= 2), 8, false, 2>(p, K, stream, handled)  \
+                                  : K <= 32 ? launch_tile1<D, O, (O >= 2), 16, false, 2>(p, K, stream, handled) \
                                           : launch_tile1<D, O, (O >= 2), 16>(p, K, stream, handled); \
             if (!one && can4) rc = launch_tilek<D, O, (O >= 2)>(p, K, stream, handled);        \
             if (rc != WLSQM_OK) return rc;                                                     \
