@@ -29,10 +29,10 @@ struct ManyRhs {
     double* fi;       long long sfi_r, sfi_j;      // fi[r * sfi_r + j * sfi_j + a]
 };
 
-template <int DIM, int ORDER, int FMAX>
+template <int DIM, int ORDER, int FMAX, int LPC = K1_LPC>
 __global__ __launch_bounds__(K1_WV, 2) void solve_many_kernel(const KParams p, const long long ntiles, const Tile1Geom G,
                                                               const ManyRhs R) {
-    constexpr int NO = ndofs(DIM, ORDER), NE = NO * (NO + 1) / 2, TC = K1_TC;
+    constexpr int NO = ndofs(DIM, ORDER), NE = NO * (NO + 1) / 2, TC = K1_WV / LPC;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* sX = lds;
     const int lane = threadIdx.x, c = lane % TC, h = lane / TC;
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(K1_WV, 2) void solve_many_kernel(const KParams p, c
         tile1_stage_x<DIM>(sX, p.xk + j0 * (long long)(G.K * DIM), nvalid, lane, G);
         __syncthreads();
         const double* xr = sX + c * G.RS;
-        const double inv_max = inverse_max(tile1_max_d2<DIM, FMAX>(xr, xi, k0, nkc, G));
+        const double inv_max = inverse_max(tile1_max_d2<DIM, FMAX, LPC>(xr, xi, k0, nkc, G));
 
         // ---- geometry, once per tile: this lane's rows of W C, the normal matrix, its factor
         double wc[FMAX][NO], M[NE];
@@ -157,16 +157,16 @@ __global__ __launch_bounds__(K1_WV, 2) void solve_many_kernel(const KParams p, c
     }
 }
 
-template <int DIM, int ORDER>
+template <int DIM, int ORDER, int FMAX = 8, int LPC = K1_LPC>
 static int launch_many(const KParams& p, long long K, const ManyRhs& R, hipStream_t stream, bool* handled) {
-    constexpr int FMAX = 8;
+    constexpr int K1_TC = K1_WV / LPC;          // (shadows the default tile size)
     Tile1Geom G;
-    if (!tile1_geometry<DIM>(K, FMAX, G)) return WLSQM_OK;
+    if (!tile1_geometry<DIM, LPC>(K, FMAX, G)) return WLSQM_OK;
     constexpr int NE_ = ndofs(DIM, ORDER) * (ndofs(DIM, ORDER) + 1) / 2;
     const size_t lds_bytes = sizeof(double) * (size_t)std::max(K1_TC * G.RS, K1_TC * NE_);   // tile rows, then the unfactored matrices
     *handled = true;
     const long long ntiles = (p.ncases + K1_TC - 1) / K1_TC;
-    auto kern = solve_many_kernel<DIM, ORDER, FMAX>;
+    auto kern = solve_many_kernel<DIM, ORDER, FMAX, LPC>;
     static KernelSetup setup;
     long long grid = 0;
     int rc = persistent_grid(reinterpret_cast<const void*>(kern), K1_WV, lds_bytes, 0, false, setup, &grid);
@@ -191,6 +191,7 @@ int launch_solve_many(int dimension, int order, const KParams& p, long long K, l
     if ((reinterpret_cast<uintptr_t>(p.xk) | reinterpret_cast<uintptr_t>(fk)) & 15u) return WLSQM_OK;
     if ((sfk_r % 2) != 0) return WLSQM_OK;                          // every field's rows stay 16-byte aligned
     const ManyRhs R{nrhs, fk, sfk_r, sfk_j, fi, sfi_r, sfi_j};
+    // (two lanes per case with 16 neighbours each — LPC 2, FMAX 16 — spills the 96-double operator slice: C4 16.5 instead of 4.8 ms)
 #define MCASE(D, O) if (dimension == D && order == O) return launch_many<D, O>(p, K, R, stream, handled);
     MCASE(1, 0) MCASE(1, 1) MCASE(1, 2) MCASE(1, 3) MCASE(1, 4)
     MCASE(2, 0) MCASE(2, 1) MCASE(2, 2)
