@@ -53,9 +53,15 @@ int launch_tile_moments(int dimension, int order, const KParams& p, long long ma
     // The tile kernel holds 256 VGPRs (two waves per SIMD by registers, 1.5 by its 50 KB of LDS; PMC at K = 64: VALU busy
     // 44 %, waves waiting 34 %): keeping the NEXT tile's loads in registers across the tile (issued after the staging
     // barrier) spills 408 B per lane and takes 1.34 instead of 0.70 ms.
+    // Shape sweep under the oversubscribed grids (1M cases, tile + solve kernel): K = 64: two waves x two lanes per case 0.640 ms
+    // (unroll 2 / 8: 0.660 / 0.640), two waves x four lanes 0.790, four waves x two 0.788, four waves x one 0.762, direct fk 0.775;
+    // K = 32: two waves x one lane per case on 64-case tiles 0.427 against 0.463 (one wave x two or four lanes: 0.615 / 0.665),
+    // so the multiples of 4 up to 32 take that shape (K = 16 / 20 / 24 / 28 / 32: 0.335 / 0.512 / 0.364 / 0.582 / 0.417 against 0.380 /
+    // 0.663 / 0.532 / 0.616 / 0.459; at K = 22 / 30 it loses, 0.509 / 0.615 against 0.426 / 0.462).
 #define MOMENT_CASE(KK)                                                                                             \
     if (max_nk == KK) {                                                                                             \
         if (gather) return launch_tile_impl<2, 4, KK, 2, 2, 4, 2, true, false, true, true, (KK + 3) / 4 * 4>(p, stream);   \
+        if (KK <= 32 && KK % 4 == 0) return launch_tile_impl<2, 4, KK, 2, 1, 4, 2, false, false, true, true>(p, stream); \
         return launch_tile_impl<2, 4, KK, 2, 2, 4, 2, false, false, true, true, (KK + 3) / 4 * 4>(p, stream);      \
     }
     MOMENT_CASE(16) MOMENT_CASE(18) MOMENT_CASE(20) MOMENT_CASE(22) MOMENT_CASE(24) MOMENT_CASE(26) MOMENT_CASE(28) MOMENT_CASE(30)
