@@ -194,6 +194,10 @@ __global__ __launch_bounds__(KNT, 2) void fit_tilek_kernel(const KParams p, cons
 //   A K-specialised instantiation of this kernel (geometry as compile-time constants, predicates folded) does not help the
 //   extras: C2 at K = 32, iterative 1.08 instead of 1.10 ms, do_sens 1.80 instead of 0.73 ms (the unrolled substitutions
 //   spill) — unlike the basic fit, where fixed K is worth 20-70 % (fit_tile.hip).
+//   The 3D order-2 / 2D order-3 instantiations (55-entry factor) spill 0.4-0.9 KB per lane; parking the factor in LDS (one
+//   copy per case, substitutions read it from there) made it worse — the compiler hoists the LDS reads of the unrolled
+//   substitutions back into registers: 0.75-1.2 KB of spills, C5 do_sens 4.68 instead of 3.72 ms, iterative 4.06 instead of
+//   3.18 ms.  (The generic kernel does C5's do_sens in 3.58 ms and its iterative fit in 4.62 ms.)
 // LPC: lanes per case (4 on 16-case tiles; 2 on 32-case tiles, which halves the butterflies and the redundant factorisations
 //   per case and wins for K <= 32 under the oversubscribed grids, like the fixed-K shapes of fit_tile_even.hip).
 template <int DIM, int ORDER, bool MOM, int FMAX, bool EXTRAS = false, int LPC = K1_LPC>
