@@ -200,8 +200,10 @@ __global__ __launch_bounds__(KNT, 2) void fit_tilek_kernel(const KParams p, cons
 //   3.18 ms.  (The generic kernel does C5's do_sens in 3.58 ms and its iterative fit in 4.62 ms.)
 // LPC: lanes per case (4 on 16-case tiles; 2 on 32-case tiles, which halves the butterflies and the redundant factorisations
 //   per case and wins for K <= 32 under the oversubscribed grids, like the fixed-K shapes of fit_tile_even.hip).
-template <int DIM, int ORDER, bool MOM, int FMAX, bool EXTRAS = false, int LPC = K1_LPC>
-__global__ __launch_bounds__(KW, 2) void fit_tile1_kernel(const KParams p, const long long ntiles, const Tile1Geom G) {
+// MINW: waves per SIMD the register allocator plans for.  1 lets the heavy extras instantiations keep everything in the
+//   512 registers of a lone wave (no scratch) instead of spilling at 2.
+template <int DIM, int ORDER, bool MOM, int FMAX, bool EXTRAS = false, int LPC = K1_LPC, int MINW = 2>
+__global__ __launch_bounds__(KW, MINW) void fit_tile1_kernel(const KParams p, const long long ntiles, const Tile1Geom G) {
     constexpr int NO = ndofs(DIM, ORDER), NE = NO * (NO + 1) / 2, NA = MOM ? mom_count<DIM>(2 * ORDER) : NE, TC = KW / LPC;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* sX = lds;
@@ -524,7 +526,7 @@ static int launch_tilek(const KParams& p, long long K, hipStream_t stream, bool*
     return WLSQM_OK;
 }
 
-template <int DIM, int ORDER, bool MOM, int FMAX, bool EXTRAS = false, int LPC = K1_LPC>
+template <int DIM, int ORDER, bool MOM, int FMAX, bool EXTRAS = false, int LPC = K1_LPC, int MINW = 2>
 static int launch_tile1(const KParams& p, long long K, hipStream_t stream, bool* handled) {
     Tile1Geom G;
     if (!tile1_geometry<DIM, LPC>(K, FMAX, G)) return WLSQM_OK;
@@ -534,7 +536,7 @@ static int launch_tile1(const KParams& p, long long K, hipStream_t stream, bool*
     const size_t lds_bytes = sizeof(double) * (size_t)(K1_TC * G.RS + (EXTRAS ? K1_TC * (2 * LPC * NO_ + 1) + K1_TC / 2 : 0));
     *handled = true;
     const long long ntiles = (p.ncases + K1_TC - 1) / K1_TC;
-    auto kern = fit_tile1_kernel<DIM, ORDER, MOM, FMAX, EXTRAS, LPC>;
+    auto kern = fit_tile1_kernel<DIM, ORDER, MOM, FMAX, EXTRAS, LPC, MINW>;
     static KernelSetup setup;
     long long grid = 0;
     int rc = persistent_grid(reinterpret_cast<const void*>(kern), KW, lds_bytes, 0, false, setup, &grid);
@@ -567,35 +569,46 @@ int launch_fit_tilek(int dimension, int order, const KParams& p, long long K, hi
         // sensitivities / iterative refinement: the one-wave kernel with EXTRAS (K <= 64), else the generic kernel
         const char* ex = getenv("WLSQM_HIP_DISABLE_TILE_EXTRAS");
         if (ex && ex[0] == '1') return WLSQM_OK;
+        // `lone`: instantiations whose registers are planned for ONE wave per SIMD (__launch_bounds__(64, 1): up to 512 registers,
+        // no scratch) instead of two.  The 10-unknown systems (2D order 3, 3D order 2) spill 0.4-1.2 KB per lane otherwise, and so
+        // do the 32-neighbours-per-lane shapes.  400k cases, lone / paired, ms: 3D order 2 do_sens at K = 12 / 24 / 40 / 64 / 124:
+        // 0.27 / 0.51 / 0.73 / 1.03 / 3.58 against 0.38 / 0.75 / 1.59 / 2.63 / 7.60 (generic kernel at K = 40 / 124: 1.43 / 5.6), its
+        // iterative fit 0.41 / 0.81 / 1.08 / 1.37 / 4.94 against 0.32 / 0.60 / 1.41 / 2.24 / 8.18; 2D order 3 do_sens at K = 16 / 32 /
+        // 48: 0.29 / 0.55 / 0.77 against 0.35 / 0.74 / 1.48, iterative 0.46 / 0.87 / 1.12 against 0.37 / 0.69 / 1.05; 2D order 2 at K =
+        // 48 / 64: 0.54 / 0.66 against 0.44 / 0.57 (paired stays), at K = 80 / 124: 0.84 / 1.18 against 1.48 / 2.65.
+        const bool heavy = wlsqm_hip_number_of_dofs(dimension, order) > 6;
+        const bool lone = heavy && (p.do_sens || K > 32);
+#define XP(D, O, FM, LL) if (dimension == D && order == O) return launch_tile1<D, O, (O >= 2), FM, true, LL, 2>(p, K, stream, handled);
+#define XL(D, O, FM, LL) if (dimension == D && order == O) return launch_tile1<D, O, (O >= 2), FM, true, LL, 1>(p, K, stream, handled);
+#define XB(D, O, FM, LL)                                                                                           \
+    if (dimension == D && order == O)                                                                              \
+        return lone ? launch_tile1<D, O, (O >= 2), FM, true, LL, 1>(p, K, stream, handled)                         \
+                    : launch_tile1<D, O, (O >= 2), FM, true, LL, 2>(p, K, stream, handled);
         if (K > K1_LPC * K1_FMAX) {
-            // 64 < K <= 128 in 2D, orders 1-2: 32 neighbours per lane.  200k cases of 2D order 2 at K = 80 / 124: do_sens 0.93 /
-            // 1.29 ms, iterative 1.20 / 1.33 ms against 1.37 / 2.15 and 2.55 / 4.14 ms on the generic kernel.  (3D: the 32 fk
-            // values and 45 moments per lane spill 0.7-1.6 KB and lose to the generic kernel, 1.82 / 3.79 against 1.51 / 2.81 ms.)
+            // 64 < K <= 128: 32 neighbours per lane, always a lone wave (2D orders 1-2, 3D orders 1-2)
             if (K > K1_LPC * 32) return WLSQM_OK;
-#define XBIG(D, O) if (dimension == D && order == O) return launch_tile1<D, O, (O >= 2), 32, true>(p, K, stream, handled);
-            XBIG(2, 1) XBIG(2, 2)
-#undef XBIG
+            XL(2, 1, 32, K1_LPC) XL(2, 2, 32, K1_LPC) XL(3, 1, 32, K1_LPC) XL(3, 2, 32, K1_LPC)
             return WLSQM_OK;
         }
         if (K <= 2 * 8) {
             // up to 16 neighbours: two lanes per case on 32-case tiles.  1M cases, 2D order 2 at K = 8 / 12 / 16: do_sens 0.225 /
             // 0.276 / 0.336 ms and iterative 0.418 / 0.485 / 0.563 ms against 0.322 / 0.397 / 0.429 and 0.867 / 0.787 / 0.788 with
-            // four lanes; 3D order 2 at K = 12: 0.925 / 0.691 against 1.293 / 1.093.  (With 16 neighbours per lane, K <= 32, the
-            // two-lane shape loses: C2 0.73 / 1.10 against 0.66 / 1.00 ms.)
-#define XPAIR(D, O) if (dimension == D && order == O) return launch_tile1<D, O, (O >= 2), 8, true, 2>(p, K, stream, handled);
-            XPAIR(1, 0) XPAIR(1, 1) XPAIR(1, 2) XPAIR(1, 3) XPAIR(1, 4)
-            XPAIR(2, 0) XPAIR(2, 1) XPAIR(2, 2) XPAIR(2, 3)
-            XPAIR(3, 0) XPAIR(3, 1) XPAIR(3, 2)
-#undef XPAIR
+            // four lanes.  (With 16 neighbours per lane, K <= 32, the two-lane shape loses: C2 0.73 / 1.10 against 0.66 / 1.00 ms.)
+            XP(1, 0, 8, 2) XP(1, 1, 8, 2) XP(1, 2, 8, 2) XP(1, 3, 8, 2) XP(1, 4, 8, 2)
+            XP(2, 0, 8, 2) XP(2, 1, 8, 2) XP(2, 2, 8, 2) XB(2, 3, 8, 2)
+            XP(3, 0, 8, 2) XP(3, 1, 8, 2) XB(3, 2, 8, 2)
         }
-#define XCASE(D, O)                                                                                   \
-    if (dimension == D && order == O)                                                                 \
-        return K <= 32 ? launch_tile1<D, O, (O >= 2), 8, true>(p, K, stream, handled)                 \
-                       : launch_tile1<D, O, (O >= 2), K1_FMAX, true>(p, K, stream, handled);
-        XCASE(1, 0) XCASE(1, 1) XCASE(1, 2) XCASE(1, 3) XCASE(1, 4)
-        XCASE(2, 0) XCASE(2, 1) XCASE(2, 2) XCASE(2, 3)
-        XCASE(3, 0) XCASE(3, 1) XCASE(3, 2)
-#undef XCASE
+        if (K <= 32) {
+            XP(1, 0, 8, K1_LPC) XP(1, 1, 8, K1_LPC) XP(1, 2, 8, K1_LPC) XP(1, 3, 8, K1_LPC) XP(1, 4, 8, K1_LPC)
+            XP(2, 0, 8, K1_LPC) XP(2, 1, 8, K1_LPC) XP(2, 2, 8, K1_LPC) XB(2, 3, 8, K1_LPC)
+            XP(3, 0, 8, K1_LPC) XP(3, 1, 8, K1_LPC) XB(3, 2, 8, K1_LPC)
+        }
+        XP(1, 0, K1_FMAX, K1_LPC) XP(1, 1, K1_FMAX, K1_LPC) XP(1, 2, K1_FMAX, K1_LPC) XP(1, 3, K1_FMAX, K1_LPC) XP(1, 4, K1_FMAX, K1_LPC)
+        XP(2, 0, K1_FMAX, K1_LPC) XP(2, 1, K1_FMAX, K1_LPC) XP(2, 2, K1_FMAX, K1_LPC) XL(2, 3, K1_FMAX, K1_LPC)
+        XP(3, 0, K1_FMAX, K1_LPC) XP(3, 1, K1_FMAX, K1_LPC) XL(3, 2, K1_FMAX, K1_LPC)
+#undef XP
+#undef XL
+#undef XB
         return WLSQM_OK;
     }
     const char* sv = getenv("WLSQM_TILEK_SHAPE");

@@ -331,7 +331,8 @@ def _tile_vs_lane(wlsqm, dim, order, K, ncases, monkeypatch, expect=None, spare=
                                                       (3, 1, 14, 129, True), (2, 2, 50, 200, False), (2, 1, 9, 100, False),
                                                       (2, 2, 80, 150, False), (2, 2, 124, 90, True), (2, 1, 100, 70, False),
                                                       (2, 2, 16, 333, False), (2, 2, 12, 200, True), (3, 2, 16, 150, False), (2, 3, 14, 100, False),
-                                                      (1, 4, 10, 90, False), (2, 2, 8, 77, False)])
+                                                      (1, 4, 10, 90, False), (2, 2, 8, 77, False), (3, 2, 80, 70, False), (3, 2, 124, 50, True),
+                                                      (3, 1, 100, 60, False), (3, 2, 56, 90, False), (2, 3, 48, 80, False), (2, 3, 24, 100, True)])
 def test_tile_extras_equal_lane_extras(wlsqm, dim, order, K, ncases, wide, monkeypatch):
     """Sensitivities and iterative refinement on the one-wave tile kernel (fit_tile1_kernel<..., EXTRAS>) against the
     generic lane kernel: ragged nk, mixed weightings and knowns (NaN rows), tail tiles; `wide`: sens/fi with spare

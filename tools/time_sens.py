@@ -9,6 +9,7 @@ import bench, synth
 import wlsqm.hip as whip
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 cfg = dict(bench.CONFIGS[os.environ.get("TUNE_CONFIG", "C2")]); cfg["nk"] = int(os.environ.get("TUNE_NK", cfg["nk"]))
+cfg["order"] = int(os.environ.get("TUNE_ORDER", cfg["order"]))
 dim, order, nk = cfg["dim"], cfg["order"], cfg["nk"]; no = bench.NDOF[dim][order]
 dev = torch.device("cuda", 0)
 S, F, hoods = bench.build_problem(cfg, n, 0)
