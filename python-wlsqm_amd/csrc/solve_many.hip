@@ -191,7 +191,8 @@ int launch_solve_many(int dimension, int order, const KParams& p, long long K, l
     if ((reinterpret_cast<uintptr_t>(p.xk) | reinterpret_cast<uintptr_t>(fk)) & 15u) return WLSQM_OK;
     if ((sfk_r % 2) != 0) return WLSQM_OK;                          // every field's rows stay 16-byte aligned
     const ManyRhs R{nrhs, fk, sfk_r, sfk_j, fi, sfi_r, sfi_j};
-    // (two lanes per case with 16 neighbours each — LPC 2, FMAX 16 — spills the 96-double operator slice: C4 16.5 instead of 4.8 ms)
+    // (two lanes per case with 16 neighbours each — LPC 2, FMAX 16 — spills the 96-double operator slice: C4 16.5 instead of 4.8 ms;
+    // compiled for a lone wave per SIMD it does not spill and comes to 5.15 against 4.91 ms in the same run: close, not better)
 #define MCASE(D, O) if (dimension == D && order == O) return launch_many<D, O>(p, K, R, stream, handled);
     MCASE(1, 0) MCASE(1, 1) MCASE(1, 2) MCASE(1, 3) MCASE(1, 4)
     MCASE(2, 0) MCASE(2, 1) MCASE(2, 2)
