@@ -58,11 +58,18 @@ int launch_tile_moments(int dimension, int order, const KParams& p, long long ma
     // K = 32: two waves x one lane per case on 64-case tiles 0.427 against 0.463 (one wave x two or four lanes: 0.615 / 0.665),
     // so the multiples of 4 up to 32 take that shape (K = 16 / 20 / 24 / 28 / 32: 0.335 / 0.512 / 0.364 / 0.582 / 0.417 against 0.380 /
     // 0.663 / 0.532 / 0.616 / 0.459; at K = 22 / 30 it loses, 0.509 / 0.615 against 0.426 / 0.462).
+    // All of them are compiled for a LONE wave per SIMD (__launch_bounds__(128, 1)): their 50-80 KB of LDS allow 1.5 waves per
+    // SIMD at best, and planned for two the 60 accumulators spill 50-580 B per lane at most sizes (K = 64 happens not to) — 400k
+    // cases at K = 20 / 28 / 36 / 40 / 56 / 80 / 100: 0.178 / 0.198 / 0.283 / 0.274 / 0.317 / 0.362 / 0.502 ms against 0.228 / 0.266 /
+    // 0.381 / 0.324 / 0.396 / 0.404 / 0.991; K = 24 / 48 / 64, which did not spill: unchanged.  Index-based input at K = 40 / 64 / 100:
+    // 0.275 / 0.270 / 0.453 against 0.278 / 0.267 / 0.699.
 #define MOMENT_CASE(KK)                                                                                             \
     if (max_nk == KK) {                                                                                             \
-        if (gather) return launch_tile_impl<2, 4, KK, 2, 2, 4, 2, true, false, true, true, (KK + 3) / 4 * 4>(p, stream);   \
-        if (KK <= 32 && KK % 4 == 0) return launch_tile_impl<2, 4, KK, 2, 1, 4, 2, false, false, true, true>(p, stream); \
-        return launch_tile_impl<2, 4, KK, 2, 2, 4, 2, false, false, true, true, (KK + 3) / 4 * 4>(p, stream);      \
+        if (gather) return launch_tile_impl<2, 4, KK, 2, 2, 4, 1, true, false, true, true, (KK + 3) / 4 * 4>(p, stream);   \
+        if constexpr (KK <= 32 && KK % 4 == 0)                                                                      \
+            return launch_tile_impl<2, 4, KK, 2, 1, 4, 1, false, false, true, true>(p, stream);                     \
+        else                                                                                                        \
+            return launch_tile_impl<2, 4, KK, 2, 2, 4, 1, false, false, true, true, (KK + 3) / 4 * 4>(p, stream);  \
     }
     MOMENT_CASE(16) MOMENT_CASE(18) MOMENT_CASE(20) MOMENT_CASE(22) MOMENT_CASE(24) MOMENT_CASE(26) MOMENT_CASE(28) MOMENT_CASE(30)
     MOMENT_CASE(32) MOMENT_CASE(34) MOMENT_CASE(36) MOMENT_CASE(38) MOMENT_CASE(40) MOMENT_CASE(42) MOMENT_CASE(44) MOMENT_CASE(46)
