@@ -198,6 +198,8 @@ __global__ __launch_bounds__(KNT, 2) void fit_tilek_kernel(const KParams p, cons
 //   copy per case, substitutions read it from there) made it worse — the compiler hoists the LDS reads of the unrolled
 //   substitutions back into registers: 0.75-1.2 KB of spills, C5 do_sens 4.68 instead of 3.72 ms, iterative 4.06 instead of
 //   3.18 ms.  (The generic kernel does C5's do_sens in 3.58 ms and its iterative fit in 4.62 ms.)
+//   A 15-unknown instantiation (2D order 4) fills all 512 registers of a lone wave and still spills 1.1 KB: 400k C3 cases,
+//   do_sens 3.96 and iterative 2.54 ms against 2.53 / 2.35 ms on the generic kernel, which keeps those.
 // LPC: lanes per case (4 on 16-case tiles; 2 on 32-case tiles, which halves the butterflies and the redundant factorisations
 //   per case and wins for K <= 32 under the oversubscribed grids, like the fixed-K shapes of fit_tile_even.hip).
 // MINW: waves per SIMD the register allocator plans for.  1 lets the heavy extras instantiations keep everything in the
