@@ -52,7 +52,8 @@ int launch_tile_moments(int dimension, int order, const KParams& p, long long ma
     // 16-case tile spills (60 accumulators + 16 fk values per lane) 0.85 ms; (2 or 4 waves) x 4 lanes per case 0.85 ms.
     // The tile kernel holds 256 VGPRs (two waves per SIMD by registers, 1.5 by its 50 KB of LDS; PMC at K = 64: VALU busy
     // 44 %, waves waiting 34 %): keeping the NEXT tile's loads in registers across the tile (issued after the staging
-    // barrier) spills 408 B per lane and takes 1.34 instead of 0.70 ms.
+    // barrier) spills 408 B per lane and takes 1.34 instead of 0.70 ms; in a lone-wave build (no spills) it still loses: 0.786
+    // against 0.652 ms at K = 64, 1.466 against 1.168 at K = 100, 0.611 against 0.621 at K = 40.
     // Shape sweep under the oversubscribed grids (1M cases, tile + solve kernel): K = 64: two waves x two lanes per case 0.640 ms
     // (unroll 2 / 8: 0.660 / 0.640), two waves x four lanes 0.790, four waves x two 0.788, four waves x one 0.762, direct fk 0.775;
     // K = 32: two waves x one lane per case on 64-case tiles 0.427 against 0.463 (one wave x two or four lanes: 0.615 / 0.665),
