@@ -1,6 +1,11 @@
 #!/usr/bin/env bash
 # Builds libwlsqm_hip.so for gfx950 (cross-compiles without a GPU).  In-tree output:
-#   python-wlsqm_amd/wlsqm/_lib/libwlsqm_hip.so
+#   python-wlsqm_amd/wlsqm/_lib/libwlsqm_hip.so   (+ libwlsqm_hip.manifest: sha256 of every source it was built from)
+#
+# Incremental by default: every object is compiled with -MMD, and a translation unit is rebuilt when its .hip or ANY header
+# its dependency file names (csrc/*.hpp, include/*.h) is newer than the object, when the dependency file is missing, or
+# when the compiler flags changed.  WLSQM_FORCE_REBUILD=1 recompiles everything regardless.  The last line of the output
+# says how many translation units were compiled ("compiled N of M").
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
@@ -8,14 +13,41 @@ OUT="$HERE/wlsqm/_lib"
 OBJ="$HERE/build"
 mkdir -p "$OUT" "$OBJ"
 FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fopenmp -I"$HERE/../include" -I"$HERE/csrc" -Wall -Wno-unused-function)
-pids=()
-for f in fit_tile_even fit_tile_gather fit_tile_big fit_tile api expert conds interp fit_lane fit_tilek fit_wave fit_moment solve_many knn fit_rows; do
-  src="$HERE/csrc/$f.hip"; obj="$OBJ/$f.o"
-  if [[ ! -f "$obj" || "$src" -nt "$obj" || "$HERE/csrc/wlsqm_kernels.hpp" -nt "$obj" || "$HERE/csrc/wlsqm_internal.hpp" -nt "$obj" || "$HERE/csrc/wlsqm_interp.hpp" -nt "$obj" || "$HERE/csrc/hostio.hpp" -nt "$obj" || "$HERE/csrc/wlsqm_moments.hpp" -nt "$obj" || "$HERE/csrc/wlsqm_tile1.hpp" -nt "$obj" || "$HERE/csrc/wlsqm_tile.hpp" -nt "$obj" || "$HERE/../include/wlsqm_hip.h" -nt "$obj" ]]; then
-    "$HIPCC" "${FLAGS[@]}" -c "$src" -o "$obj" &
-    pids+=($!)
+FORCE="${WLSQM_FORCE_REBUILD:-0}"
+JOBS="${WLSQM_BUILD_JOBS:-8}"
+
+# the flags are part of the build's identity
+flagsig="$(printf '%s\n' "$HIPCC" "${FLAGS[@]}" | sha256sum | cut -d' ' -f1)"
+if [[ ! -f "$OBJ/.flags" || "$(cat "$OBJ/.flags")" != "$flagsig" ]]; then FORCE=1; fi
+
+stale() {   # stale <obj> <dep> <src>
+  local obj="$1" dep="$2" src="$3" f
+  [[ "$FORCE" == "1" || ! -f "$obj" || ! -f "$dep" || "$src" -nt "$obj" ]] && return 0
+  # every prerequisite listed by the compiler (-MMD); a header that disappeared also forces a rebuild
+  for f in $(sed -e 's/^[^:]*://' -e 's/\\$//' "$dep"); do
+    [[ ! -e "$f" || "$f" -nt "$obj" ]] && return 0
+  done
+  return 1
+}
+
+units=()
+for src in "$HERE"/csrc/*.hip; do units+=("$(basename "${src%.hip}")"); done
+pids=(); compiled=0
+for f in "${units[@]}"; do
+  src="$HERE/csrc/$f.hip"; obj="$OBJ/$f.o"; dep="$OBJ/$f.d"
+  if stale "$obj" "$dep" "$src"; then
+    while (( $(jobs -rp | wc -l) >= JOBS )); do wait -n; done
+    "$HIPCC" "${FLAGS[@]}" -MMD -MF "$dep" -c "$src" -o "$obj" &
+    pids+=($!); compiled=$((compiled + 1))
   fi
 done
 for p in "${pids[@]:-}"; do [[ -n "$p" ]] && wait "$p"; done
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC -fopenmp -o "$OUT/libwlsqm_hip.so" "$OBJ"/api.o "$OBJ"/expert.o "$OBJ"/conds.o "$OBJ"/interp.o "$OBJ"/fit_lane.o "$OBJ"/fit_tile.o "$OBJ"/fit_tilek.o "$OBJ"/fit_wave.o "$OBJ"/fit_moment.o "$OBJ"/solve_many.o "$OBJ"/knn.o "$OBJ"/fit_rows.o "$OBJ"/fit_tile_even.o "$OBJ"/fit_tile_gather.o "$OBJ"/fit_tile_big.o
-echo "built $OUT/libwlsqm_hip.so"
+# objects of translation units that no longer exist must not be linked
+objs=(); for f in "${units[@]}"; do objs+=("$OBJ/$f.o"); done
+if (( compiled > 0 )) || [[ ! -f "$OUT/libwlsqm_hip.so" ]]; then
+  "$HIPCC" --offload-arch=gfx950 -shared -fPIC -fopenmp -o "$OUT/libwlsqm_hip.so" "${objs[@]}"
+fi
+echo "$flagsig" > "$OBJ/.flags"
+# manifest: what the library was built from (checked by wlsqm._binding.build_manifest_ok and tests/test_abi_and_host.py)
+( cd "$HERE" && sha256sum csrc/*.hip csrc/*.hpp ../include/*.h | sed 's#\.\./include#include#' ) > "$OUT/libwlsqm_hip.manifest"
+echo "built $OUT/libwlsqm_hip.so (compiled $compiled of ${#units[@]} translation units; force=$FORCE)"
