@@ -86,8 +86,12 @@ typedef struct wlsqm_batch {
 int wlsqm_hip_fit_many_host(const wlsqm_batch* b, int device, int32_t* iterations_out);
 
 /* Same computation on DEVICE-RESIDENT arrays (all pointers in `b` are device pointers of
- * `device`), enqueued on `stream` (a hipStream_t, NULL = default stream), no host sync
- * unless iterations_out != NULL (a host pointer; needs one D2H of 4 bytes) .
+ * `device`), enqueued on `stream` (a hipStream_t, NULL = default stream).  With iterations_out == NULL the
+ * call only enqueues kernels (no allocation, no host synchronisation: it can be captured into a hipGraph, refinement
+ * included); with iterations_out != NULL (a host pointer) and b->iterative it allocates a stream-ordered 4-byte counter,
+ * copies it back and synchronises `stream`.  The arrays must cover b->ncases rows (or every row `case_index` names),
+ * b->max_nk neighbour slots per row and number_of_dofs(dimension, order_uniform) columns of fi (and of sens); nk[j]
+ * is clamped to b->max_nk by every kernel.
  * `order_uniform` >= 0 states that every case has this order (required: the kernels are
  * specialised per (dimension, order); heterogeneous batches are bucketed by the caller,
  * one call per order with `case_index`).  `case_index` (device, nullable): the ncases_sel
@@ -102,6 +106,9 @@ int wlsqm_hip_fit_many_device(const wlsqm_batch* b, int device, void* stream, in
  * F[npoints] through hoods[ncases, max_nk] (int32), which cuts the algorithmic HBM bytes per fit from
  * 8 nk (dim+1) to 4 nk.  xi of case j is S[point_index ? point_index[j] : j].  All cases have polynomial order
  * `order`; nk / knowns / weighting_method are per-case device arrays (unit stride); fi is in/out as usual.
+ * Only the slots k < nk[j] of a hoods row are dereferenced: the padding of a ragged row may hold anything (-1, npoints,
+ * ...), as with the reference's dense arrays (simple.pyx:147).  Slots k < nk[j] must be valid point numbers.
+ * iterations_out as for wlsqm_hip_fit_many_device (NULL: nothing but kernel launches).
  * Every (dimension, order); with sensitivities or refinement only systems with no <= 15 DOFs (not 3D order 3/4). */
 int wlsqm_hip_fit_cloud_device(int dimension, int order, int64_t ncases, int64_t max_nk,
                                const double* S, const double* F, const int32_t* hoods, int64_t hoods_stride_case,
@@ -136,7 +143,10 @@ int wlsqm_hip_expert_solve(wlsqm_expert* h, const double* fk, int64_t fk_stride_
                            double* sens, int64_t sens_stride_case, int64_t sens_stride_k,
                            int32_t* iterations_out);
 /* Device-resident variant of solve(): fk [ncases,max_nk] and fi [ncases,fi_stride_case] are device
- * pointers (contiguous k axis); enqueued on `stream`; no host synchronisation. */
+ * pointers (contiguous k axis); enqueued on `stream`; no host synchronisation.  fi must be at least max_no doubles wide
+ * (every row is written at fi_stride_case pitch).  As in the reference, interpolate() afterwards evaluates the coefficients
+ * of the LATEST solve of any kind: after this call that is the caller's `fi` array itself (no copy is made), so it must
+ * stay allocated until the next solve or until interpolation is no longer used. */
 int wlsqm_hip_expert_solve_device(wlsqm_expert* h, void* stream, const double* fk, int64_t fk_stride_case,
                                   double* fi, int64_t fi_stride_case);
 /* Extension: the neighbour search the reference's examples run on the host before calling the fitter

@@ -35,7 +35,9 @@ int launch_fit_tilek(int dimension, int order, const KParams& p, long long max_n
 long long preferred_slots(int dimension, int order, long long max_nk);
 int launch_fit_rows(int dimension, int order, const KParams& p, hipStream_t stream, bool* handled);
 
-int launch_fit(int dimension, int order, const KParams& p, long long max_nk, hipStream_t stream) {
+int launch_fit(int dimension, int order, const KParams& p_in, long long max_nk, hipStream_t stream) {
+    KParams p = p_in;
+    p.max_nk = max_nk;
     const int no = wlsqm_hip_number_of_dofs(dimension, order);
     if (no < 0) { set_error("bad dimension/order"); return WLSQM_EVALUE; }
     if (p.ncases <= 0) return WLSQM_OK;
@@ -66,6 +68,34 @@ int check_device(int device) {
     }
     if (device < 0 || device >= n) { set_error("invalid device ordinal"); return WLSQM_ENODEVICE; }
     WLSQM_HIP_CHECK(hipSetDevice(device));
+    return WLSQM_OK;
+}
+
+int scratch_alloc_async(void** out, size_t bytes, hipStream_t stream) {
+    static hipMemPool_t pools[16] = {};
+    int dev = 0;
+    WLSQM_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 16) { set_error("device ordinal out of range"); return WLSQM_EVALUE; }
+    if (!pools[dev]) {
+        hipMemPoolProps props{};
+        props.allocType = hipMemAllocationTypePinned;
+        props.handleTypes = hipMemHandleTypeNone;
+        props.location.type = hipMemLocationTypeDevice;
+        props.location.id = dev;
+        hipMemPool_t pool;
+        WLSQM_HIP_CHECK(hipMemPoolCreate(&pool, &props));
+        uint64_t keep = ~0ull;                                   // keep freed blocks across synchronisations
+        WLSQM_HIP_CHECK(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep));
+        pools[dev] = pool;
+    }
+    *out = nullptr;
+    hipError_t e = hipMallocFromPoolAsync(out, bytes, pools[dev], stream);
+    if (e != hipSuccess) return hip_fail(e, "hipMallocFromPoolAsync");
+    return WLSQM_OK;
+}
+int scratch_free_async(void* p, hipStream_t stream) {
+    if (!p) return WLSQM_OK;
+    WLSQM_HIP_CHECK(hipFreeAsync(p, stream));
     return WLSQM_OK;
 }
 
@@ -140,30 +170,32 @@ int wlsqm_hip_fit_many_device(const wlsqm_batch* b, int device, void* stream, in
                               const int64_t* case_index, int64_t ncases_sel, int32_t* iterations_out) {
     int rc = validate_batch(b);
     if (rc != WLSQM_OK) return rc;
-    rc = check_device(device);
+    DeviceScope scope;
+    rc = scope.enter(device);
     if (rc != WLSQM_OK) return rc;
     if (order_uniform < 0 || order_uniform > 4) { set_error("order_uniform must be 0..4"); return WLSQM_EVALUE; }
     hipStream_t s = (hipStream_t)stream;
     KParams p = params_from(b);
     if (case_index) { p.case_index = (const long long*)case_index; p.ncases = ncases_sel; }
-    DevBuf it;
-    if (b->iterative) {
-        rc = it.alloc(sizeof(int)); if (rc != WLSQM_OK) return rc;
-        WLSQM_HIP_CHECK(hipMemsetAsync(it.p, 0, sizeof(int), s));
-        p.iters_out = it.as<int>();
+    // The iteration counter is only kept when the caller asks for it: without iterations_out the call enqueues kernels and
+    // nothing else (no allocation, no host synchronisation: legal inside a stream capture).
+    int* d_it = nullptr;
+    if (b->iterative && iterations_out) {
+        rc = scratch_alloc_async(reinterpret_cast<void**>(&d_it), sizeof(int), s); if (rc != WLSQM_OK) return rc;
+        WLSQM_HIP_CHECK(hipMemsetAsync(d_it, 0, sizeof(int), s));
+        p.iters_out = d_it;
     }
     rc = launch_fit(b->dimension, order_uniform, p, b->max_nk, s);
-    if (rc != WLSQM_OK) return rc;
+    if (rc != WLSQM_OK) { (void)scratch_free_async(d_it, s); return rc; }
     if (iterations_out) {
         *iterations_out = 0;
-        if (b->iterative) {
-            WLSQM_HIP_CHECK(hipMemcpyAsync(iterations_out, it.p, sizeof(int), hipMemcpyDeviceToHost, s));
+        if (d_it) {
+            WLSQM_HIP_CHECK(hipMemcpyAsync(iterations_out, d_it, sizeof(int), hipMemcpyDeviceToHost, s));
             WLSQM_HIP_CHECK(hipStreamSynchronize(s));
+            rc = scratch_free_async(d_it, s);
         }
-    } else if (b->iterative) {
-        WLSQM_HIP_CHECK(hipStreamSynchronize(s));   // `it` is freed on return
     }
-    return WLSQM_OK;
+    return rc;
 }
 
 // Per-thread, per-device transfer context of the host-array entry points (never freed: it must not outlive
@@ -220,7 +252,8 @@ int wlsqm_hip_fit_many_host(const wlsqm_batch* b, int device, int32_t* iteration
     if (bad_nk) { set_error("nk must be >= 0"); return WLSQM_EVALUE; }
     if (b->max_nk > 0 && max_nk > b->max_nk) { set_error("max(nk) exceeds the neighbour axis (max_nk)"); return WLSQM_EVALUE; }
     mark("metadata");
-    rc = check_device(device);
+    DeviceScope scope;
+    rc = scope.enter(device);
     if (rc != WLSQM_OK) return rc;
     HostCtx* cx = host_ctx(device);
     if (!cx) { set_error("device ordinal out of range"); return WLSQM_ENODEVICE; }
@@ -341,27 +374,27 @@ int wlsqm_hip_fit_cloud_device(int dimension, int order, int64_t ncases, int64_t
     int rc = cloud_params(p, dimension, order, ncases, max_nk, S, F, hoods, hoods_stride_case, point_index, nk, knowns,
                           weighting_method, fi, fi_stride_case);
     if (rc != WLSQM_OK) return rc;
-    rc = check_device(device);
+    DeviceScope scope;
+    rc = scope.enter(device);
     if (rc != WLSQM_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     p.sens = (do_sens ? sens : nullptr); p.ss_j = sens_stride_case; p.ss_k = sens_stride_k;
     p.do_sens = (do_sens && sens) ? 1 : 0; p.iterative = iterative ? 1 : 0; p.max_iter = max_iter;
-    DevBuf it;
-    if (iterative) {
-        rc = it.alloc(sizeof(int)); if (rc != WLSQM_OK) return rc;
-        WLSQM_HIP_CHECK(hipMemsetAsync(it.p, 0, sizeof(int), s));
-        p.iters_out = it.as<int>();
+    int* d_it = nullptr;               // as in wlsqm_hip_fit_many_device: only when the caller wants the count
+    if (iterative && iterations_out) {
+        rc = scratch_alloc_async(reinterpret_cast<void**>(&d_it), sizeof(int), s); if (rc != WLSQM_OK) return rc;
+        WLSQM_HIP_CHECK(hipMemsetAsync(d_it, 0, sizeof(int), s));
+        p.iters_out = d_it;
     }
     rc = launch_fit(dimension, order, p, max_nk, s);
-    if (rc != WLSQM_OK) return rc;
+    if (rc != WLSQM_OK) { (void)scratch_free_async(d_it, s); return rc; }
     if (iterations_out) *iterations_out = 0;
-    if (iterative) {
-        int h_it = 0;
-        WLSQM_HIP_CHECK(hipMemcpyAsync(&h_it, it.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    if (d_it) {
+        WLSQM_HIP_CHECK(hipMemcpyAsync(iterations_out, d_it, sizeof(int), hipMemcpyDeviceToHost, s));
         WLSQM_HIP_CHECK(hipStreamSynchronize(s));
-        if (iterations_out) *iterations_out = h_it;
+        rc = scratch_free_async(d_it, s);
     }
-    return WLSQM_OK;
+    return rc;
 }
 
 static int time_launches(int dimension, int order, const KParams& p, long long max_nk, hipStream_t s, int reps, float* ms_out) {
@@ -390,7 +423,8 @@ int wlsqm_hip_time_fit_cloud_device(int dimension, int order, int64_t ncases, in
     int rc = cloud_params(p, dimension, order, ncases, max_nk, S, F, hoods, hoods_stride_case, point_index, nk, knowns,
                           weighting_method, fi, fi_stride_case);
     if (rc != WLSQM_OK) return rc;
-    rc = check_device(device);
+    DeviceScope scope;
+    rc = scope.enter(device);
     if (rc != WLSQM_OK) return rc;
     if (reps < 1 || !ms_out) { set_error("reps must be >= 1"); return WLSQM_EVALUE; }
     return time_launches(dimension, order, p, max_nk, (hipStream_t)stream, reps, ms_out);
@@ -399,7 +433,8 @@ int wlsqm_hip_time_fit_cloud_device(int dimension, int order, int64_t ncases, in
 int wlsqm_hip_time_fit_device(const wlsqm_batch* b, int device, void* stream, int order_uniform, int reps, float* ms_out) {
     int rc = validate_batch(b);
     if (rc != WLSQM_OK) return rc;
-    rc = check_device(device);
+    DeviceScope scope;
+    rc = scope.enter(device);
     if (rc != WLSQM_OK) return rc;
     if (reps < 1 || !ms_out) { set_error("reps must be >= 1"); return WLSQM_EVALUE; }
     return time_launches(b->dimension, order_uniform, params_from(b), b->max_nk, (hipStream_t)stream, reps, ms_out);

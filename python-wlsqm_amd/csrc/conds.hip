@@ -26,7 +26,7 @@ __global__ __launch_bounds__(64) void cond_kernel(const KParams p, const int* __
     constexpr int oA = 0, oC = NO * NO, oR = oC + NO, oDR = oR + NO, oDC = oDR + NO, oDRp = oDC + NO, oDCp = oDRp + NO,
                   oRS = oDCp + NO, oCS = oRS + NO;
 
-    const int nk = p.nk[j * p.snk];
+    const int nk = min(p.nk[j * p.snk], (int)p.max_nk);      // never past the end of a row
     const bool uniform = (p.wm[j * p.swm] == WLSQM_WEIGHT_UNIFORM);
     unsigned long long known, dropped;
     effective_mask<NO>(p.knowns[j * p.sknowns], known, dropped);

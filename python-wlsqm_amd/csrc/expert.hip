@@ -37,6 +37,9 @@ struct wlsqm_expert {
     bool guest = false;
     int algorithm = 1, do_sens = 0, max_iter = 10;
     bool solved = false;
+    // the coefficients interpolate() evaluates = the result of the LATEST solve of any kind (case.fi in the reference): the
+    // handle's own d_fi after solve(), the caller's device array after solve_device() / solve_many_device() (last field)
+    const double* fi_view = nullptr; int64_t fi_view_stride = 0;
     wlsqm::DevBuf d_fk, d_fi, d_sens, d_it;
     wlsqm::GrowBuf d_fkm, d_fim;        // solve_many: a chunk of stacked right-hand sides / solutions
     wlsqm::Stager st;
@@ -70,7 +73,7 @@ static KParams expert_params(const wlsqm_expert* h, const double* d_fk, int64_t 
     const int dim = h->g->dimension;
     p.xk = h->g->d_xk.as<double>(); p.sxk_j = h->g->slots * dim; p.sxk_k = dim;
     p.fk = d_fk; p.sfk_j = sfk_j; p.sfk_k = 1;
-    p.nk = h->g->d_nk.as<int>(); p.snk = 1;
+    p.nk = h->g->d_nk.as<int>(); p.snk = 1; p.max_nk = h->g->slots;
     p.xi = h->g->d_xi.as<double>(); p.sxi_j = dim;
     p.fi = d_fi; p.sfi_j = sfi_j;
     p.sens = nullptr; p.ss_j = 0; p.ss_k = 0;
@@ -123,7 +126,7 @@ int wlsqm_hip_expert_create(wlsqm_expert** out, int device, int dimension, int64
     g.max_nk = std::max<int64_t>(mk, 1);
     g.uniform_order = std::all_of(g.order.begin(), g.order.end(), [&](int o) { return o == g.order[0]; });
     g.slots = preferred_slots(dimension, g.uniform_order ? g.order[0] : -1, g.max_nk);
-    int rc = check_device(device);
+    DeviceScope scope; int rc = scope.enter(device);
     if (rc != WLSQM_OK) { delete h; return rc; }
     if ((rc = g.d_nk.alloc(ncases * 4)) || (rc = g.d_wm.alloc(ncases * 4)) || (rc = g.d_kn.alloc(ncases * 8)) ||
         (rc = g.d_order.alloc(ncases * 4)) || (rc = g.d_xk.alloc((size_t)ncases * g.slots * dimension * 8)) ||
@@ -159,7 +162,7 @@ int wlsqm_hip_expert_create_guest(wlsqm_expert** out, wlsqm_expert* host, int al
         set_error("In guest mode, host must be in the ready state (host.prepare() must have been called first)");
         return WLSQM_ERUNTIME;
     }
-    int rc = check_device(host->g->device);
+    DeviceScope scope; int rc = scope.enter(host->g->device);
     if (rc != WLSQM_OK) return rc;
     wlsqm_expert* h = new (std::nothrow) wlsqm_expert();
     if (!h) { set_error("out of memory"); return WLSQM_EMEMORY; }
@@ -180,7 +183,7 @@ int wlsqm_hip_expert_prepare(wlsqm_expert* h, const double* xi, int64_t xi_strid
     if (!xi || !xk) { set_error("null argument"); return WLSQM_EVALUE; }
     h->g->ready = false;
     if (max_nk < h->g->max_nk && h->g->max_nk > 1) { set_error("xk has fewer neighbour slots than max(nk)"); return WLSQM_EVALUE; }
-    int rc = check_device(h->g->device);
+    DeviceScope scope; int rc = scope.enter(h->g->device);
     if (rc != WLSQM_OK) return rc;
     const int dim = h->g->dimension; const int64_t n = h->g->ncases, K = h->g->slots, mk = h->g->max_nk;
     if ((rc = h->st.ensure(h->g->device))) return rc;
@@ -210,7 +213,7 @@ int wlsqm_hip_expert_prepare_device(wlsqm_expert* h, void* stream, const double*
         set_error("prepare_device needs xk[ncases, >= max_nk, dimension] with contiguous neighbour rows"); return WLSQM_EVALUE;
     }
     g.ready = false;
-    int rc = check_device(g.device);
+    DeviceScope scope; int rc = scope.enter(g.device);
     if (rc != WLSQM_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     WLSQM_HIP_CHECK(hipMemcpy2DAsync(g.d_xk.p, (size_t)g.slots * dim * 8, xk, (size_t)xk_stride_case * 8, (size_t)g.max_nk * dim * 8,
@@ -227,7 +230,7 @@ int wlsqm_hip_expert_solve(wlsqm_expert* h, const double* fk, int64_t fk_stride_
                            double* sens, int64_t sens_stride_case, int64_t sens_stride_k, int32_t* iterations_out) {
     if (!h || !fk || !fi) { set_error("null argument"); return WLSQM_EVALUE; }
     if (!h->g->ready) { set_error("Solver is not in the ready state; prepare() must be called before solve()"); return WLSQM_ERUNTIME; }   // expert.pyx:493-494
-    int rc = check_device(h->g->device);
+    DeviceScope scope; int rc = scope.enter(h->g->device);
     if (rc != WLSQM_OK) return rc;
     const int64_t n = h->g->ncases, K = h->g->slots; const int NO = h->g->max_no;
     if ((rc = h->st.ensure(h->g->device))) return rc;
@@ -267,6 +270,7 @@ int wlsqm_hip_expert_solve(wlsqm_expert* h, const double* fk, int64_t fk_stride_
     WLSQM_HIP_CHECK(hipStreamSynchronize(s));
     if (iterations_out) *iterations_out = (h->algorithm == WLSQM_ALGO_ITERATIVE) ? h_it : 0;
     h->solved = true;                  // d_fi now holds the coefficients interpolate() evaluates (case.fi in the reference)
+    h->fi_view = h->d_fi.as<double>(); h->fi_view_stride = NO;
     return WLSQM_OK;
 }
 
@@ -274,12 +278,14 @@ int wlsqm_hip_expert_solve_device(wlsqm_expert* h, void* stream, const double* f
                                   double* fi, int64_t fi_stride_case) {
     if (!h || !fk || !fi) { set_error("null argument"); return WLSQM_EVALUE; }
     if (!h->g->ready) { set_error("Solver is not in the ready state; prepare() must be called before solve()"); return WLSQM_ERUNTIME; }
-    int rc = check_device(h->g->device);
+    DeviceScope scope; int rc = scope.enter(h->g->device);
     if (rc != WLSQM_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     KParams p = expert_params(h, fk, fk_stride_case, fi, fi_stride_case);
     p.iters_out = nullptr;
-    return expert_launch(h, p, s);
+    rc = expert_launch(h, p, s);
+    if (rc == WLSQM_OK) { h->solved = true; h->fi_view = fi; h->fi_view_stride = fi_stride_case; }
+    return rc;
 }
 
 // Many fields on the prepared geometry, device-resident (extension; BASELINE config 4).  Fast path: one launch that
@@ -310,9 +316,11 @@ int wlsqm_hip_expert_solve_many_device(wlsqm_expert* h, void* stream, int64_t nr
     if (nrhs < 1) { set_error("nrhs must be >= 1"); return WLSQM_EVALUE; }
     if (!h->g->ready) { set_error("Solver is not in the ready state; prepare() must be called before solve()"); return WLSQM_ERUNTIME; }
     if (h->do_sens) { set_error("solve_many does not compute sensitivities"); return WLSQM_EVALUE; }
-    int rc = check_device(h->g->device);
+    DeviceScope scope; int rc = scope.enter(h->g->device);
     if (rc != WLSQM_OK) return rc;
-    return solve_many_on_device(h, (hipStream_t)stream, nrhs, fk, fk_stride_rhs, fk_stride_case, fi, fi_stride_rhs, fi_stride_case);
+    rc = solve_many_on_device(h, (hipStream_t)stream, nrhs, fk, fk_stride_rhs, fk_stride_case, fi, fi_stride_rhs, fi_stride_case);
+    if (rc == WLSQM_OK) { h->solved = true; h->fi_view = fi + (nrhs - 1) * fi_stride_rhs; h->fi_view_stride = fi_stride_case; }
+    return rc;
 }
 
 int wlsqm_hip_expert_solve_many(wlsqm_expert* h, int64_t nrhs,
@@ -323,7 +331,7 @@ int wlsqm_hip_expert_solve_many(wlsqm_expert* h, int64_t nrhs,
     if (!h->g->ready) { set_error("Solver is not in the ready state; prepare() must be called before solve()"); return WLSQM_ERUNTIME; }
     if (h->do_sens) { set_error("solve_many does not compute sensitivities"); return WLSQM_EVALUE; }
     const wlsqm_expert_geometry& g = *h->g;
-    int rc = check_device(g.device);
+    DeviceScope scope; int rc = scope.enter(g.device);
     if (rc != WLSQM_OK) return rc;
     const int64_t n = g.ncases, K = g.slots; const int NO = g.max_no;
     if ((rc = h->st.ensure(g.device))) return rc;
@@ -349,6 +357,12 @@ int wlsqm_hip_expert_solve_many(wlsqm_expert* h, int64_t nrhs,
             if (rc != WLSQM_OK) return rc;
         }
     }
+    // the last field's coefficients are what interpolate() evaluates from now on
+    {
+        const int64_t last = (nrhs - 1) % chunk;
+        WLSQM_HIP_CHECK(hipMemcpyAsync(h->d_fi.p, d_fi + last * n * NO, (size_t)n * NO * 8, hipMemcpyDeviceToDevice, s));
+        h->solved = true; h->fi_view = h->d_fi.as<double>(); h->fi_view_stride = NO;
+    }
     WLSQM_HIP_CHECK(hipStreamSynchronize(s));
     return WLSQM_OK;
 }
@@ -361,9 +375,11 @@ int wlsqm_hip_expert_interpolate(wlsqm_expert* h, const double* x, int64_t x_str
     if (!h || !x || !out) { set_error("null argument"); return WLSQM_EVALUE; }
     if (!h->g->ready || !h->solved) { set_error("interpolate() needs prepare() and solve() first"); return WLSQM_ERUNTIME; }
     if (!I && !list_off) { set_error("either I or the neighbour lists must be given"); return WLSQM_EVALUE; }
-    int rc = check_device(h->g->device);
+    DeviceScope scope; int rc = scope.enter(h->g->device);
     if (rc != WLSQM_OK) return rc;
     if (nx <= 0) return WLSQM_OK;
+    // a solve_device() result may still be in flight on the caller's (possibly non-blocking) stream
+    if (h->fi_view != h->d_fi.as<double>()) WLSQM_HIP_CHECK(hipDeviceSynchronize());
     const int dim = h->g->dimension;
     std::vector<double> sx((size_t)nx * dim);
     for (int64_t m = 0; m < nx; ++m)
@@ -373,7 +389,7 @@ int wlsqm_hip_expert_interpolate(wlsqm_expert* h, const double* x, int64_t x_str
     if ((rc = d_x.alloc(sx.size() * 8)) || (rc = d_out.alloc((size_t)nx * 8))) return rc;
     WLSQM_HIP_CHECK(hipMemcpyAsync(d_x.p, sx.data(), d_x.n, hipMemcpyHostToDevice, s));
     InterpParams q{};
-    q.xi = h->g->d_xi.as<double>(); q.sxi = dim; q.fi = h->d_fi.as<double>(); q.sfi = h->g->max_no;
+    q.xi = h->g->d_xi.as<double>(); q.sxi = dim; q.fi = h->fi_view; q.sfi = h->fi_view_stride;
     q.order = h->g->d_order.as<int>(); q.sorder = 1; q.nmodels = h->g->ncases;
     q.x = d_x.as<double>(); q.sx = dim; q.nx = nx; q.diff = diff; q.out = d_out.as<double>();
     if (list_off) {
@@ -401,9 +417,11 @@ int wlsqm_hip_expert_interpolate_nearest(wlsqm_expert* h, const double* x, int64
                                          double* out, int64_t* I_out) {
     if (!h || !x || !out) { set_error("null argument"); return WLSQM_EVALUE; }
     if (!h->g->ready || !h->solved) { set_error("interpolate() needs prepare() and solve() first"); return WLSQM_ERUNTIME; }
-    int rc = check_device(h->g->device);
+    DeviceScope scope; int rc = scope.enter(h->g->device);
     if (rc != WLSQM_OK) return rc;
     if (nx <= 0) return WLSQM_OK;
+    // a solve_device() result may still be in flight on the caller's (possibly non-blocking) stream
+    if (h->fi_view != h->d_fi.as<double>()) WLSQM_HIP_CHECK(hipDeviceSynchronize());
     const int dim = h->g->dimension;
     std::vector<double> sx((size_t)nx * dim);
     for (int64_t m = 0; m < nx; ++m)
@@ -414,7 +432,7 @@ int wlsqm_hip_expert_interpolate_nearest(wlsqm_expert* h, const double* x, int64
     WLSQM_HIP_CHECK(hipMemcpyAsync(d_x.p, sx.data(), d_x.n, hipMemcpyHostToDevice, s));
     if ((rc = nearest_search(dim, h->g->ncases, h->g->d_xi.as<double>(), nx, d_x.as<double>(), dim, d_I.as<long long>(), s))) return rc;
     InterpParams q{};
-    q.xi = h->g->d_xi.as<double>(); q.sxi = dim; q.fi = h->d_fi.as<double>(); q.sfi = h->g->max_no;
+    q.xi = h->g->d_xi.as<double>(); q.sxi = dim; q.fi = h->fi_view; q.sfi = h->fi_view_stride;
     q.order = h->g->d_order.as<int>(); q.sorder = 1; q.nmodels = h->g->ncases;
     q.x = d_x.as<double>(); q.sx = dim; q.nx = nx; q.diff = diff; q.out = d_out.as<double>();
     q.I = d_I.as<long long>();
@@ -433,9 +451,11 @@ int wlsqm_hip_expert_interpolate_continuous(wlsqm_expert* h, const double* x, in
     if (!h || !x || !out) { set_error("null argument"); return WLSQM_EVALUE; }
     if (!h->g->ready || !h->solved) { set_error("interpolate() needs prepare() and solve() first"); return WLSQM_ERUNTIME; }
     if (!(r > 0.0)) { set_error("r must be positive"); return WLSQM_EVALUE; }
-    int rc = check_device(h->g->device);
+    DeviceScope scope; int rc = scope.enter(h->g->device);
     if (rc != WLSQM_OK) return rc;
     if (nx <= 0) return WLSQM_OK;
+    // a solve_device() result may still be in flight on the caller's (possibly non-blocking) stream
+    if (h->fi_view != h->d_fi.as<double>()) WLSQM_HIP_CHECK(hipDeviceSynchronize());
     const int dim = h->g->dimension;
     std::vector<double> sx((size_t)nx * dim);
     for (int64_t m = 0; m < nx; ++m)
@@ -445,7 +465,7 @@ int wlsqm_hip_expert_interpolate_continuous(wlsqm_expert* h, const double* x, in
     if ((rc = d_x.alloc(sx.size() * 8)) || (rc = d_out.alloc((size_t)nx * 8))) return rc;
     WLSQM_HIP_CHECK(hipMemcpyAsync(d_x.p, sx.data(), d_x.n, hipMemcpyHostToDevice, s));
     InterpParams q{};
-    q.xi = h->g->d_xi.as<double>(); q.sxi = dim; q.fi = h->d_fi.as<double>(); q.sfi = h->g->max_no;
+    q.xi = h->g->d_xi.as<double>(); q.sxi = dim; q.fi = h->fi_view; q.sfi = h->fi_view_stride;
     q.order = h->g->d_order.as<int>(); q.sorder = 1; q.nmodels = h->g->ncases;
     q.x = d_x.as<double>(); q.sx = dim; q.nx = nx; q.diff = diff; q.out = d_out.as<double>();
     if ((rc = interp_continuous(dim, q, r, s))) return rc;
@@ -457,7 +477,7 @@ int wlsqm_hip_expert_interpolate_continuous(wlsqm_expert* h, const double* x, in
 int wlsqm_hip_expert_conds(wlsqm_expert* h, double* out) {
     if (!h || !out) { set_error("null argument"); return WLSQM_EVALUE; }
     if (!h->g->ready) { set_error("Solver is not in the ready state; prepare() must be called before conds()"); return WLSQM_ERUNTIME; }   // expert.pyx:438-439
-    int rc = check_device(h->g->device);
+    DeviceScope scope; int rc = scope.enter(h->g->device);
     if (rc != WLSQM_OK) return rc;
     const int64_t n = h->g->ncases;
     const long long CH = std::min<int64_t>(n, 32768);
@@ -488,7 +508,8 @@ int wlsqm_hip_expert_memory_used(const wlsqm_expert* h, int64_t* used, int64_t* 
 
 int wlsqm_hip_expert_destroy(wlsqm_expert* h) {
     if (!h) return WLSQM_OK;
-    (void)hipSetDevice(h->g->device);
+    DeviceScope scope;
+    (void)scope.enter(h->g->device);
     delete h;
     return WLSQM_OK;
 }

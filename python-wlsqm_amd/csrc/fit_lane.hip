@@ -39,7 +39,7 @@ __global__ __launch_bounds__(LANE_BLOCK) void fit_lane_kernel(const KParams p) {
     if (t >= p.ncases) return;
     const long long j = p.case_index ? p.case_index[t] : t;
 
-    const int nk = p.nk[j * p.snk];
+    const int nk = min(p.nk[j * p.snk], (int)p.max_nk);      // never past the end of a row
     const bool uniform = (p.wm[j * p.swm] == WLSQM_WEIGHT_UNIFORM);
     unsigned long long known, dropped;
     effective_mask<NO>(p.knowns[j * p.sknowns], known, dropped);

@@ -65,32 +65,25 @@ static int launch_moment(const KParams& p0, long long max_nk, hipStream_t stream
     constexpr int NO = ndofs(DIM, ORDER), NACC = mom_count<DIM>(2 * ORDER) + NO;
     long long chunk = chunk_cases();
     if (chunk > p0.ncases) chunk = p0.ncases;
-    // stream-ordered workspace: concurrent launches on other streams get their own block, and the pool hands the same
-    // memory back to the next call on this stream without a device synchronisation
-    static bool pool_kept[16] = {};
-    int dev = 0;
-    WLSQM_HIP_CHECK(hipGetDevice(&dev));
-    if (dev >= 0 && dev < 16 && !pool_kept[dev]) {      // keep freed blocks in the pool across synchronisations
-        hipMemPool_t pool;
-        WLSQM_HIP_CHECK(hipDeviceGetDefaultMemPool(&pool, dev));
-        uint64_t keep = ~0ull;
-        WLSQM_HIP_CHECK(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep));
-        pool_kept[dev] = true;
-    }
+    // stream-ordered workspace from the library's private pool (wlsqm_internal.hpp): concurrent launches on other streams get
+    // their own block, and the pool hands the same memory back to the next call on this stream without a device synchronisation
     double* ws = nullptr;
-    WLSQM_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&ws), (size_t)NACC * (size_t)chunk * sizeof(double), stream));
+    {
+        const int rc = scratch_alloc_async(reinterpret_cast<void**>(&ws), (size_t)NACC * (size_t)chunk * sizeof(double), stream);
+        if (rc != WLSQM_OK) return rc;
+    }
     for (long long j0 = 0; j0 < p0.ncases; j0 += chunk) {
         const long long n = (p0.ncases - j0 < chunk) ? (p0.ncases - j0) : chunk;
         KParams p = slice_cases(p0, j0, n);
         p.ws = ws; p.ws_stride = chunk;
         int rc = launch_tile_moments(DIM, ORDER, p, max_nk, stream, handled);
-        if (rc != WLSQM_OK || !*handled) { (void)hipFreeAsync(ws, stream); return rc; }
+        if (rc != WLSQM_OK || !*handled) { (void)scratch_free_async(ws, stream); return rc; }
         const long long blocks = (n + 63) / 64;
         hipLaunchKernelGGL((moment_solve_kernel<DIM, ORDER>), dim3((unsigned)blocks), dim3(64), 0, stream, p);
         hipError_t e = hipGetLastError();
-        if (e != hipSuccess) { (void)hipFreeAsync(ws, stream); return hip_fail(e, "moment_solve_kernel"); }
+        if (e != hipSuccess) { (void)scratch_free_async(ws, stream); return hip_fail(e, "moment_solve_kernel"); }
     }
-    WLSQM_HIP_CHECK(hipFreeAsync(ws, stream));
+    { const int rc = scratch_free_async(ws, stream); if (rc != WLSQM_OK) return rc; }
     note_kernel(p0.hoods ? "moment-gather" : "moment");
     return WLSQM_OK;
 }

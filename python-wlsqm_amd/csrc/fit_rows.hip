@@ -64,7 +64,7 @@ __global__ __launch_bounds__(RW) void fit_rows_kernel(const KParams p) {
     const bool valid = t < p.ncases && !idle;
     const long long tc = t < p.ncases ? t : p.ncases - 1;
     const long long j = p.case_index ? p.case_index[tc] : tc;
-    const int nk = p.nk[j * p.snk];
+    const int nk = min(p.nk[j * p.snk], (int)p.max_nk);      // never past the end of a row
     const bool uniform = (p.wm[j * p.swm] == WLSQM_WEIGHT_UNIFORM);
     unsigned long long known, dropped;
     effective_mask<NO>(p.knowns[j * p.sknowns], known, dropped);

@@ -238,7 +238,8 @@ __global__ __launch_bounds__(KW, MINW) void fit_tile1_kernel(const KParams p, co
             for (int kk = 0; kk < FMAX; ++kk)
                 if (kk < G.KPL) {
                     const int k = k0 + kk;
-                    const long long idx = hr[k < G.K ? k : G.K - 1];
+                    // slots k >= nk[j] are padding and may hold anything (-1, npoints, ...): never dereferenced
+                    const long long idx = k < nkc ? (long long)hr[k] : pj;
                     fdir[kk] = p.F[idx];
                     if (k < G.K) {
 #pragma unroll

@@ -64,7 +64,7 @@ int wlsqm_hip_interpolate_fit_host(int dimension, int order, const double* xi, c
     const int no = wlsqm_hip_number_of_dofs(dimension, order);
     if (no < 0) { set_error("order must be 0, 1, 2, 3 or 4"); return WLSQM_EVALUE; }
     if (!xi || !fi || !x || !out || nx < 0) { set_error("null argument"); return WLSQM_EVALUE; }
-    int rc = check_device(device);
+    DeviceScope scope; int rc = scope.enter(device);
     if (rc != WLSQM_OK) return rc;
     if (nx == 0) return WLSQM_OK;
     std::vector<double> sx((size_t)nx * dimension);

@@ -306,7 +306,7 @@ static int neighbour_search(int dimension, int64_t npoints, const double* S, int
     if (npoints > 0x7fffffffLL) { set_error("at most 2^31 - 1 points"); return WLSQM_EVALUE; }
     const size_t lds = (size_t)k * 64 * (sizeof(double) + sizeof(int));
     if (lds > 160 * 1024) { set_error("k too large for the LDS-resident candidate lists (k <= 213)"); return WLSQM_EVALUE; }
-    int rc = check_device(device);
+    DeviceScope scope; int rc = scope.enter(device);
     if (rc != WLSQM_OK) return rc;
     hipStream_t s = (hipStream_t)stream_;
     const long long n = npoints;
@@ -479,7 +479,7 @@ extern "C" int wlsqm_hip_nearest_device(int dimension, int64_t ndata, const doub
                                         int64_t x_stride, int64_t* nearest, int device, void* stream) {
     if (dimension < 1 || dimension > 3) { set_error("dimension must be 1, 2 or 3"); return WLSQM_EVALUE; }
     if (!S || !X || !nearest) { set_error("null array"); return WLSQM_EVALUE; }
-    int rc = check_device(device);
+    DeviceScope scope; int rc = scope.enter(device);
     if (rc != WLSQM_OK) return rc;
     return nearest_search(dimension, ndata, S, nquery, X, x_stride, reinterpret_cast<long long*>(nearest), (hipStream_t)stream);
 }

@@ -20,6 +20,7 @@ struct KParams {
     const double* xk;  long long sxk_j, sxk_k;
     const double* fk;  long long sfk_j, sfk_k;
     const int* nk;     long long snk;
+    long long max_nk;              // extent of the neighbour axis: every kernel clamps nk[j] to it (set by launch_fit)
     const double* xi;  long long sxi_j;
     double* fi;        long long sfi_j;
     double* sens;      long long ss_j, ss_k;
@@ -126,6 +127,29 @@ struct DevBuf {
 };
 
 int check_device(int device);
+
+// Makes `device` current for the duration of one API call and puts the caller's device back on the way out (the library
+// must not leave a different current device behind in a C caller's thread).
+struct DeviceScope {
+    int prev = -1;
+    DeviceScope() = default;
+    DeviceScope(const DeviceScope&) = delete;
+    DeviceScope& operator=(const DeviceScope&) = delete;
+    ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+    int enter(int device) {
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); cur = -1; }
+        const int rc = check_device(device);
+        if (rc == WLSQM_OK && cur >= 0 && cur != device) prev = cur;
+        return rc;
+    }
+};
+
+// Stream-ordered scratch memory from a PRIVATE pool per device (the process-wide default pool and its release threshold are
+// left alone): freed blocks stay in the pool, so the next call on the stream gets the same memory back without a device
+// synchronisation.  Legal during stream capture (becomes an allocation node of the graph).
+int scratch_alloc_async(void** out, size_t bytes, hipStream_t stream);
+int scratch_free_async(void* p, hipStream_t stream);
 
 // Host mirror of effective_mask() in wlsqm_kernels.hpp (infra.pyx:119-121 quirk): returns the
 // mask of DOFs the reference never writes (true knowns | dropped) and the dropped subset.

@@ -203,25 +203,31 @@ __global__ __launch_bounds__(WV * KSPLIT, MINW) void fit_tile_kernel(const KPara
             constexpr int HCH = TC * K / HW, NH = (HCH + NT - 1) / NT, CPRH = K / HW;
             typedef int int4_ __attribute__((ext_vector_type(HW)));
             int4_ hb[NH];
+            int live_slots[NH];       // slots of chunk i's row that are real neighbours, counted from the chunk's first slot
             {
                 const int4_* gh = reinterpret_cast<const int4_*>(p.hoods + j0 * (long long)K);
                 const long long hlim = nvalid * CPRH;
 #pragma unroll
                 for (int i = 0; i < NH; ++i) {
                     const long long q = tid + (long long)i * NT;
-                    hb[i] = gh[q < hlim ? q : hlim - 1];
+                    const long long qq = q < hlim ? q : hlim - 1;
+                    hb[i] = gh[qq];
+                    const int rr = (int)(qq / CPRH);                          // compile-time divisor
+                    live_slots[i] = p.nk[(j0 + rr) * p.snk] - HW * (int)(qq - (long long)rr * CPRH);
                 }
             }
             const long long pj = p.pidx ? (long long)p.pidx[jc] : jc;
 #pragma unroll
             for (int m = 0; m < DIM; ++m) xi[m] = p.S[pj * DIM + m];
-            // ... then the gathers of the point rows they name (HW per index chunk), all in flight together
+            // ... then the gathers of the point rows they name (HW per index chunk), all in flight together.  Slots
+            // k >= nk[row] are padding and may hold anything (-1, npoints, ...; the reference never reads them either,
+            // simple.pyx:147): they are never dereferenced — the lane reads its own case's point instead, masked later.
             double gx[NH * HW][DIM], gf[NH * HW];
 #pragma unroll
             for (int i = 0; i < NH; ++i)
 #pragma unroll
                 for (int e = 0; e < HW; ++e) {
-                    const long long idx = hb[i][e];
+                    const long long idx = e < live_slots[i] ? (long long)hb[i][e] : pj;
                     if constexpr (DIM == 2) {
                         const double2_ v = *reinterpret_cast<const double2_*>(p.S + idx * 2);
                         gx[i * HW + e][0] = v.x; gx[i * HW + e][1] = v.y;

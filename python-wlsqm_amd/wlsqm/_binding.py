@@ -135,7 +135,20 @@ def check(rc):
 
 
 def default_device():
-    return int(os.environ.get("WLSQM_HIP_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    """Device of the host-array entry points: WLSQM_HIP_DEVICE if set; otherwise torch's current device when torch has
+    initialised the GPU in this process (so the library follows torch.cuda.set_device / torch.cuda.device), otherwise
+    LOCAL_RANK (one process per GPU under torch.distributed.run), otherwise 0."""
+    if "WLSQM_HIP_DEVICE" in os.environ:
+        return int(os.environ["WLSQM_HIP_DEVICE"])
+    import sys
+    torch = sys.modules.get("torch")
+    if torch is not None:
+        try:
+            if torch.cuda.is_initialized():
+                return int(torch.cuda.current_device())
+        except Exception:
+            pass
+    return int(os.environ.get("LOCAL_RANK", "0"))
 
 
 # ---- argument coercion with the reference's typed-memoryview rules (SURVEY §8b 'Array typing') ----

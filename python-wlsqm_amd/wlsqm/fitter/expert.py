@@ -76,6 +76,8 @@ class ExpertSolver:
         self.xk = self.xi = self.tree = None
         self.nk, self.order, self.knowns, self.weighting_method = nk, order, knowns, weighting_method
         self._max_nk = int(nk.max()) if ncases else 0
+        self._max_no = number_of_dofs(self.dimension, int(np.max(order))) if ncases else 0
+        self._fi_device = None
         h = C.c_void_p()
         if host is not None:
             # guest mode: share the host's device-resident geometry and metadata, own only the field buffers
@@ -290,8 +292,11 @@ class ExpertSolver:
                 raise ValueError("%s must be a 2-D float64 device tensor with a contiguous last axis" % name)
         if fk.shape[0] < self.ncases or fi.shape[0] < self.ncases or fk.shape[1] < self._max_nk:
             raise ValueError("fk/fi are too small")
+        if fi.shape[1] < self._max_no:
+            raise ValueError("fi has %d columns, need at least %d" % (fi.shape[1], self._max_no))
         if stream is None:
             stream = torch.cuda.current_stream(fi.device).cuda_stream
+        self._fi_device = fi            # interpolate() evaluates the latest solve: keep its coefficients alive
         B.check(B.lib().wlsqm_hip_expert_solve_device(self._handle, C.c_void_p(int(stream) if stream else 0),
                                                       C.c_void_p(fk.data_ptr()), fk.stride(0),
                                                       C.c_void_p(fi.data_ptr()), fi.stride(0)))
@@ -314,6 +319,9 @@ class ExpertSolver:
             raise ValueError("fk and fi must hold the same number (>= 1) of right-hand sides")
         if fk.shape[1] < self.ncases or fi.shape[1] < self.ncases or fk.shape[2] < self._max_nk:
             raise ValueError("fk/fi are too small")
+        if fi.shape[2] < self._max_no:
+            raise ValueError("fi has %d columns, need at least %d" % (fi.shape[2], self._max_no))
+        self._fi_device = fi            # interpolate() evaluates the latest solve (here: the last field)
         if stream is None:
             stream = torch.cuda.current_stream(fi.device).cuda_stream
         B.check(B.lib().wlsqm_hip_expert_solve_many_device(

@@ -36,8 +36,27 @@ def _check(t, name, dtype_name, ndim):
         raise ValueError("argument %s must be a device (HIP) tensor" % name)
 
 
-def _batch(dimension, xk, fk, nk, xi, fi, knowns, weighting_method, sens, iterative, max_iter, order_dummy):
+_NDOF = {1: (1, 2, 3, 4, 5), 2: (1, 3, 6, 10, 15), 3: (1, 4, 10, 20, 35)}
+
+
+def _ndofs(dimension, order):
+    if dimension not in _NDOF:
+        raise ValueError("Dimension must be 1, 2 or 3")
+    if not 0 <= int(order) <= 4:
+        raise ValueError("order must be 0, 1, 2, 3 or 4")
+    return _NDOF[dimension][int(order)]
+
+
+def _rows(n, **arrays):
+    """Every per-case array must cover the n cases of the launch (simple.py's _run_many makes the same checks on the host)."""
+    for name, t in arrays.items():
+        if t.shape[0] < n:
+            raise ValueError("%s has %d rows, fewer than the %d cases of the batch" % (name, t.shape[0], n))
+
+
+def _batch(dimension, order, xk, fk, nk, xi, fi, knowns, weighting_method, sens, iterative, max_iter, order_dummy):
     ncases = nk.shape[0]
+    no = _ndofs(dimension, order)
     _check(nk, "nk", "int32", 1); _check(knowns, "knowns", "int64", 1); _check(weighting_method, "weighting_method", "int32", 1)
     _check(fk, "fk", "float64", 2); _check(fi, "fi", "float64", 2)
     if dimension == 1:
@@ -48,6 +67,21 @@ def _batch(dimension, xk, fk, nk, xi, fi, knowns, weighting_method, sens, iterat
             raise ValueError("Buffer and memoryview are not contiguous in the same dimension.")
     if fi.stride(1) != 1:
         raise ValueError("Buffer and memoryview are not contiguous in the same dimension. (argument fi)")
+    # extents: the kernels write `no` doubles per fi row at the row pitch and read K neighbour slots per xk / fk row
+    _rows(ncases, xk=xk, fk=fk, xi=xi, fi=fi, knowns=knowns, weighting_method=weighting_method)
+    K = int(fk.shape[1])
+    if xk.shape[1] < K:
+        raise ValueError("xk has %d neighbour slots per case, fk has %d" % (xk.shape[1], K))
+    if dimension > 1 and (xk.shape[2] < dimension or xi.shape[1] < dimension):
+        raise ValueError("xk / xi must have %d coordinates on the last axis" % dimension)
+    if fi.shape[1] < no:
+        raise ValueError("fi has %d columns, need at least number_of_dofs(%d, %d) = %d" % (fi.shape[1], dimension, order, no))
+    if sens is not None:
+        _check(sens, "sens", "float64", 3)
+        if sens.stride(2) != 1:
+            raise ValueError("Buffer and memoryview are not contiguous in the same dimension. (argument sens)")
+        if sens.shape[0] < ncases or sens.shape[1] < K or sens.shape[2] < no:
+            raise ValueError("sens must be at least (ncases, %d, %d); got %s" % (K, no, tuple(sens.shape)))
     b = B.Batch()
     b.dimension, b.ncases = dimension, ncases
     b.xk, b.xk_stride_case, b.xk_stride_k = xk.data_ptr(), xk.stride(0), xk.stride(1)
@@ -56,7 +90,6 @@ def _batch(dimension, xk, fk, nk, xi, fi, knowns, weighting_method, sens, iterat
     b.xi, b.xi_stride_case = xi.data_ptr(), xi.stride(0)
     b.fi, b.fi_stride_case = fi.data_ptr(), fi.stride(0)
     if sens is not None:
-        _check(sens, "sens", "float64", 3)
         b.do_sens = 1
         b.sens, b.sens_stride_case, b.sens_stride_k = sens.data_ptr(), sens.stride(0), sens.stride(1)
     # the per-case order array is not read on this path (order_uniform is); point it somewhere valid
@@ -84,7 +117,7 @@ def fit_many_device(dimension, order, xk, fk, nk, xi, fi, knowns, weighting_meth
     tensor) restricts the launch to those cases (used to bucket heterogeneous orders).  Asynchronous on
     `stream` (default: torch's current stream) unless want_iterations=True.  The caller guarantees that
     fk/xk do not alias fi (outputs are written in place)."""
-    b = _batch(dimension, xk, fk, nk, xi, fi, knowns, weighting_method, sens, iterative, max_iter, nk)
+    b = _batch(dimension, order, xk, fk, nk, xi, fi, knowns, weighting_method, sens, iterative, max_iter, nk)
     s, dev = _stream_and_device(fi, stream)
     its = C.c_int32(0)
     nsel = 0
@@ -99,7 +132,7 @@ def fit_many_device(dimension, order, xk, fk, nk, xi, fi, knowns, weighting_meth
 
 def time_fit_device(dimension, order, xk, fk, nk, xi, fi, knowns, weighting_method, reps=10, stream=None):
     """Mean duration in milliseconds of one fit launch (HIP events on `stream`, `reps` back-to-back launches)."""
-    b = _batch(dimension, xk, fk, nk, xi, fi, knowns, weighting_method, None, False, 0, nk)
+    b = _batch(dimension, order, xk, fk, nk, xi, fi, knowns, weighting_method, None, False, 0, nk)
     s, dev = _stream_and_device(fi, stream)
     ms = C.c_float(0.0)
     B.check(B.lib().wlsqm_hip_time_fit_device(C.byref(b), dev, s, int(order), int(reps), C.byref(ms)))
@@ -118,6 +151,18 @@ def _cloud_args(dimension, order, S, F, hoods, fi, nk, knowns, weighting_method,
     if point_index is not None:
         _check(point_index, "point_index", "int32", 1)
     ncases, K = int(hoods.shape[0]), int(hoods.shape[1])
+    no = _ndofs(dimension, order)
+    _rows(ncases, fi=fi, nk=nk, knowns=knowns, weighting_method=weighting_method)
+    if point_index is not None:
+        _rows(ncases, point_index=point_index)
+    elif S.shape[0] < ncases:
+        raise ValueError("S has %d points but there are %d cases (xi of case j is S[j] without point_index)" % (S.shape[0], ncases))
+    if dimension > 1 and S.shape[1] != dimension:
+        raise ValueError("S must be (npoints, %d)" % dimension)
+    if F.shape[0] < S.shape[0]:
+        raise ValueError("F has fewer entries than S has points")
+    if fi.shape[1] < no:
+        raise ValueError("fi has %d columns, need at least number_of_dofs(%d, %d) = %d" % (fi.shape[1], dimension, order, no))
     return [int(dimension), int(order), ncases, K, _ptr(S), _ptr(F), _ptr(hoods), int(hoods.stride(0)), _ptr(point_index),
             _ptr(nk), _ptr(knowns), _ptr(weighting_method), _ptr(fi), int(fi.stride(0))]
 
@@ -128,17 +173,22 @@ def fit_cloud_device(dimension, order, S, F, hoods, fi, nk, knowns, weighting_me
 
     S (npoints, dim) [1D: (npoints,)] and F (npoints,) are the device-resident point tables, hoods (ncases, K)
     int32 the neighbour lists, xi of case j is S[point_index[j]] (default: S[j]); nk/knowns/weighting_method
-    per case; fi (ncases, >= no) in/out.  4 nk bytes of indices per fit instead of 8 nk (dim+1) bytes of gathered
+    per case; fi (ncases, >= no) in/out.  Only the slots k < nk[j] of a hoods row are dereferenced (the padding of a ragged
+    row may hold anything, e.g. -1 or npoints as scipy pads); those must be valid point numbers.  Asynchronous on `stream`
+    unless want_iterations=True (returns the maximum refinement count; otherwise 0).  4 nk bytes of indices per fit instead of 8 nk (dim+1) bytes of gathered
     coordinates; order the points along a space-filling curve (synth.morton_order) so that the gathers hit L2."""
     a = _cloud_args(dimension, order, S, F, hoods, fi, nk, knowns, weighting_method, point_index)
     s, dev = _stream_and_device(fi, stream)
     ss = (int(sens.stride(0)), int(sens.stride(1))) if sens is not None else (0, 0)
     if sens is not None:
         _check(sens, "sens", "float64", 3)
+        if sens.stride(2) != 1 or sens.shape[0] < hoods.shape[0] or sens.shape[1] < hoods.shape[1] \
+                or sens.shape[2] < _ndofs(dimension, order):
+            raise ValueError("sens must be at least (ncases, max_nk, no) with a contiguous last axis; got %s" % (tuple(sens.shape),))
     its = C.c_int32(0)
     B.check(B.lib().wlsqm_hip_fit_cloud_device(*a, _ptr(sens), ss[0], ss[1], 1 if sens is not None else 0,
                                                1 if iterative else 0, int(max_iter), dev, s,
-                                               C.byref(its) if (want_iterations or iterative) else None))
+                                               C.byref(its) if want_iterations else None))
     return int(its.value)
 
 
