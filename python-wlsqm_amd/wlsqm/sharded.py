@@ -26,12 +26,14 @@ class ShardedCloudSolver:
     passes the same arrays; only its own rows of `hoods` are kept).  order/knowns/weighting are uniform.
     """
 
-    def __init__(self, dimension, S, hoods, order, knowns, weighting_method, device, group=None, fit_fn=None):
+    def __init__(self, dimension, S, hoods, order, knowns, weighting_method, device, group=None, fit_fn=None, single=False):
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.group = torch, dist, group
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # single=True: own the whole cloud even inside an initialised process group (the one-process answer a sharded run
+        # is compared with)
+        self.rank = dist.get_rank(group) if dist.is_initialized() and not single else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() and not single else 1
         self.dimension, self.order = int(dimension), int(order)
         self.N, self.nk = int(hoods.shape[0]), int(hoods.shape[1])
         self.lo, self.hi = case_range(self.N, self.rank, self.world)

@@ -31,6 +31,25 @@ def halton(n, dim, skip=1):
     return out
 
 
+def halton_at(index, dim, skip=1):
+    """Rows `index` (any integer array) of halton(n, dim, skip) without building the whole cloud: bit-identical to
+    halton(n, dim, skip)[index] (same operations in the same order per point)."""
+    index = np.asarray(index, dtype=np.int64)
+    idx = index.ravel() + skip
+    out = np.empty((idx.size, dim), dtype=np.float64)
+    for d in range(dim):
+        b = _PRIMES[d]
+        i = idx.copy()
+        f = 1.0
+        r = np.zeros(idx.size, dtype=np.float64)
+        while np.any(i > 0):
+            f = f / b
+            r += f * (i % b)
+            i //= b
+        out[:, d] = r
+    return out.reshape(index.shape + (dim,))
+
+
 def field(S, t=0.0):
     """sin(pi x + 0.01 t) cos(pi y) [exp(z)] on points S (n, dim); 1D: sin(2 pi x)."""
     S = np.asarray(S)

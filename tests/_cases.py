@@ -14,6 +14,7 @@ import synth  # noqa: E402
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 NDOF = {1: [1, 2, 3, 4, 5], 2: [1, 3, 6, 10, 15], 3: [1, 4, 10, 20, 35]}
 CONFIGS = ("C1", "C2", "C3", "C5", "X2", "X3")
+DENSE = ("C2_1M", "C3_1M", "C5_1M", "C5_16M")     # every 977th case of the FULL-density clouds the metric is quoted on
 
 
 def golden(name):
@@ -58,3 +59,25 @@ def scaled_cond(g, j, no, knowns):
     A = g["A"][j, :nr * nr].reshape(nr, nr, order="F")
     As = A * g["row_scale"][j, :nr, None] * g["col_scale"][j, None, :nr]
     return float(np.linalg.cond(As))
+
+
+def config_dense(name):
+    """Dense inputs of a full-density fixture (tests/golden/make_golden.py gen_config_dense): 1024 cases picked from the 1M /
+    16M-point Halton cloud, rebuilt point by point (synth.halton_at) and checked bit-for-bit against the digest of what the
+    reference was given."""
+    import hashlib
+    g = golden("config_%s.npz" % name)
+    dim, order, nk, n = int(g["dim"]), int(g["order"]), int(g["nk"]), int(g["ncases"])
+    hoods, cases = g["hoods"].astype(np.int64), g["cases"]
+    xk = synth.halton_at(hoods, dim); xi = synth.halton_at(cases, dim)
+    fk = synth.field(xk.reshape(-1, dim)).reshape(n, nk)
+    no = NDOF[dim][order]
+    fi0 = np.zeros((n, no)); fi0[:, 0] = synth.field(xi)
+    h = hashlib.sha256()
+    for a in (xk, fk, xi, fi0):
+        h.update(np.ascontiguousarray(a).tobytes())
+    assert np.array_equal(np.frombuffer(h.digest(), dtype=np.uint8), g["digest"]), \
+        "rebuilt inputs of %s differ from what the reference was given (numpy / libm difference on this host?)" % name
+    return dict(g=g, dim=dim, order=order, nkv=nk, n=n, no=no, xk=xk, fk=fk, xi=xi, fi0=fi0, conds=g["conds"],
+                order_a=np.full(n, order, np.int32), knowns_a=np.full(n, int(g["knowns"]), np.int64),
+                wm_a=np.full(n, int(g["wm"]), np.int32), nk_a=np.full(n, nk, np.int32))

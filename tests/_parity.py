@@ -130,3 +130,48 @@ def assert_parity(cand, ref, truth=None, what="", tol=TOL, noise_mult=NOISE_MULT
             % (what, Ec, N))
     assert np.all(E <= bound), "%s: column metric %s exceeds bound %s" % (what, E, bound)
     return E
+
+
+COND_EDGES = (1.0, 1e1, 1e2, 1e3, 1e4, 1e5)     # six bins: [1, 10), [10, 1e2), ..., [1e5, inf)
+
+
+def accounting(cand, ref, truth=None, oracle=None, conds=None, known_cols=()):
+    """Strict-tolerance accounting of one batch against the REFERENCE's output (SURVEY.md section 8d "Parity metric").
+
+    Returns a JSON-able dict: per DOF column m the metric E_m of the candidate against the reference, the reference's own
+    fp64 noise floor N_m (its distance to the 80-bit solution `truth`), the distance `ref_vs_oracle` between the reference
+    and the bit-faithful CPU restatement of its algorithm on the same inputs (what two correct fp64 implementations of the
+    SAME algorithm differ by when only the LAPACK summation order changes), how many of the unknown columns meet the strict
+    north-star bound E_m <= 1e-10, and the per-case relative error binned by the reference's own condition numbers
+    (ExpertSolver(debug=True).conds(), expert.pyx:429-464).  `known_cols` are excluded from the counts (they must be
+    bit-identical and are asserted separately)."""
+    cand = np.asarray(cand, np.float64); ref = np.asarray(ref, np.float64)
+    cols = [m for m in range(ref.shape[1]) if m not in set(known_cols)]
+    E = column_metric(cand, ref)
+    out = {"cases": int(ref.shape[0]), "columns": len(cols), "E": [float(E[m]) for m in cols], "E_max": float(max(E[m] for m in cols)),
+           "strict_1e-10_columns": int(sum(E[m] <= TOL for m in cols))}
+    if truth is not None:
+        N = column_metric(ref, truth); T = column_metric(cand, truth)
+        out["ref_noise_floor_N"] = [float(N[m]) for m in cols]
+        out["cand_vs_truth"] = [float(T[m]) for m in cols]
+        out["N_max"] = float(max(N[m] for m in cols))
+        out["within_1e-10_plus_8N"] = bool(all(E[m] <= TOL + NOISE_MULT * N[m] for m in cols))
+        # a column the reference itself resolves to 1e-11 must meet the strict bound: anything else is a bug
+        out["resolved_columns_missing_strict"] = [int(m) for m in cols if N[m] < 1e-11 and E[m] > TOL]
+    if oracle is not None:
+        R = column_metric(np.asarray(oracle, np.float64), ref)
+        out["ref_vs_oracle"] = [float(R[m]) for m in cols]
+        out["ref_vs_oracle_max"] = float(max(R[m] for m in cols))
+    if conds is not None:
+        scale = np.nanmax(np.abs(ref), axis=0); scale = np.where(scale > 0, scale, 1.0)
+        e_case = np.nanmax(np.abs(cand - ref)[:, cols] / scale[cols], axis=1)
+        conds = np.asarray(conds, np.float64)
+        edges = list(COND_EDGES) + [np.inf]
+        hist = []
+        for lo, hi in zip(edges[:-1], edges[1:]):
+            sel = (conds >= lo) & (conds < hi)
+            hist.append({"cond_lo": lo, "cond_hi": (hi if np.isfinite(hi) else None), "cases": int(sel.sum()),
+                         "err_median": (float(np.median(e_case[sel])) if sel.any() else None),
+                         "err_max": (float(e_case[sel].max()) if sel.any() else None)})
+        out["err_vs_cond"] = hist
+    return out

@@ -292,6 +292,64 @@ def gen_config(name, dim, order, nk, wm, knowns, npoints, ncases, outdir, extra_
           (name, ncases, iters, np.median(conds), np.max(conds)))
 
 
+def input_digest(*arrays):
+    """sha256 over the bytes of the rebuilt inputs: lets a test assert that the arrays it rebuilds from synth.py are
+    bit-identical to what the reference was given here."""
+    import hashlib
+    h = hashlib.sha256()
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return np.frombuffer(h.digest(), dtype=np.uint8).copy()
+
+
+def gen_config_dense(name, dim, order, nk, wm, knowns, npoints, outdir, every=977, ncases=1024):
+    """BASELINE.json configs AT THE DENSITY THE METRIC IS QUOTED ON: the full `npoints`-point Halton cloud (1M for C2 / C3 /
+    C5, 16M for configs[4]), every `every`-th point as a case (1024 cases: well under the reference's per-call limit,
+    SURVEY.md section 6), neighbourhoods from a cKDTree over the WHOLE cloud.  Reference outputs: fit_*_many_parallel
+    (simple.pyx:379-421), the iterative variant, ExpertSolver(debug=True).conds() (expert.pyx:429-464)."""
+    import wlsqm
+    S = synth.halton(npoints, dim)
+    F = synth.field(S)
+    cases = np.arange(ncases, dtype=np.int64) * every
+    assert cases[-1] < npoints
+    hoods = synth.knn(S, nk, query=cases).astype(np.int64)
+    xk = S[hoods]; fk = F[hoods]; xi = S[cases].copy()
+    # what a test rebuilds without the whole cloud must be the same bits
+    xk2 = synth.halton_at(hoods, dim); xi2 = synth.halton_at(cases, dim)
+    fk2 = synth.field(xk2.reshape(-1, dim)).reshape(ncases, nk); F2 = synth.field(xi2)
+    assert np.array_equal(xk, xk2) and np.array_equal(xi, xi2) and np.array_equal(fk, fk2) and np.array_equal(F[cases], F2)
+    no = wlsqm.number_of_dofs(dim, order)
+    o = np.full(ncases, order, np.int32); kn = np.full(ncases, knowns, np.int64)
+    w = np.full(ncases, wm, np.int32); nka = np.full(ncases, nk, np.int32)
+    fi0 = np.zeros((ncases, no)); fi0[:, 0] = F[cases]
+    fi = fi0.copy()
+    call_many(wlsqm, dim, "_many_parallel", xk, fk, nka, xi, fi, None, 0, o, kn, w, ntasks=8)
+    fi_it = fi0.copy()
+    iters = call_many(wlsqm, dim, "_iterative_many_parallel", xk, fk, nka, xi, fi_it, None, 0, o, kn, w,
+                      max_iter=10, ntasks=8)
+    solver = wlsqm.ExpertSolver(dimension=dim, nk=nka, order=o, knowns=kn, weighting_method=w,
+                                algorithm=wlsqm.ALGO_BASIC, do_sens=False, ntasks=8, debug=True)
+    solver.prepare(xi=xi, xk=xk)
+    conds = solver.conds()
+    fi_e = fi0.copy()
+    solver.solve(fk=fk, fi=fi_e)
+    assert np.allclose(fi_e, fi, rtol=1e-13, atol=1e-13)
+    np.savez_compressed(os.path.join(outdir, "config_%s.npz" % name),
+                        dim=dim, order=order, nk=nk, wm=wm, knowns=knowns, npoints=npoints, ncases=ncases, every=every,
+                        cases=cases, hoods=hoods.astype(np.int32), fi=fi, fi_iter=fi_it, iters=np.int32(iters), conds=conds,
+                        digest=input_digest(xk, fk, xi, fi0))
+    print("config_%s: %d cases of a %d-point cloud, iters=%d, cond_scaled median=%.3g max=%.3g" %
+          (name, ncases, npoints, iters, np.median(conds), np.max(conds)))
+
+
+DENSE = {   # name -> (dim, order, nk, wm, knowns, npoints)
+    "C2_1M": (2, 2, 32, 2, 0, 1_000_000),
+    "C3_1M": (2, 4, 64, 2, 1, 1_000_000),
+    "C5_1M": (3, 2, 40, 2, 0, 1_000_000),
+    "C5_16M": (3, 2, 40, 2, 0, 16_000_000),
+}
+
+
 def gen_edge(outdir):
     """Edge cases the reference's own tests pin (tests/test_edge_cases.py, test_stencil.py) + a few it does not."""
     import wlsqm
@@ -416,6 +474,10 @@ def main():
     if a.only == "testmany2d":
         gen_testmany2d(a.out)
         return
+    if a.only == "dense":
+        for name, (dim, order, nk, wm, kn, npts) in DENSE.items():
+            gen_config_dense(name, dim, order, nk, wm, kn, npts, a.out)
+        return
     gen_remap(a.out)
     for dim in (1, 2, 3):
         gen_sweep(dim, a.out)
@@ -428,6 +490,8 @@ def main():
     gen_config("X2", 2, 3, 40, wlsqm.WEIGHT_CENTER, wlsqm.b2_F, 16384, 256, a.out)
     gen_interp(a.out)
     gen_testmany2d(a.out)
+    for name, (dim, order, nk, wm, kn, npts) in DENSE.items():
+        gen_config_dense(name, dim, order, nk, wm, kn, npts, a.out)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,348 @@
+"""GPU tests added in round 2: parity at the density the metric is quoted on (reference-generated goldens of the 1M / 16M-point
+clouds), strict-1e-10 accounting, the reference contracts that had no test (fk aliasing fi, the 3D 7-point stencil), the
+ADVICE items (pad slots of index-based rows, extent validation, interpolate() after solve_device, refinement inside a graph
+capture), and the HIP kernels under world_size 2."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import _cases as K
+import _parity as P
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def wlsqm():
+    import wlsqm as W
+    from wlsqm import _binding
+    assert _binding.lib().wlsqm_hip_device_count() >= 1, "no HIP device: the GPU tests need a real MI355X"
+    return W
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import oracle as O
+    return O
+
+
+def _t(a, dev="cuda:0"):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# parity at the headline density, against the REFERENCE (simple.pyx:379-421 output captured in tests/golden/config_*_1M.npz)
+
+FAST_KERNELS = {"C2_1M": ("tile",), "C3_1M": ("tile-solve", "moment"), "C5_1M": ("tile",), "C5_16M": ("tile",)}
+
+
+@pytest.mark.parametrize("name", K.DENSE)
+def test_dense_density_vs_reference_golden(wlsqm, oracle, name):
+    """Every 977th case of the full 1M-point (16M for configs[4]) Halton cloud, fitted by the device-resident FAST kernel
+    (asserted through last_kernel) and compared with what the reference's fit_*_many_parallel returned for exactly these
+    inputs.  Prints the strict-tolerance accounting (per column: E_m against the reference, the reference's own noise floor
+    N_m, reference-vs-oracle on the same inputs, columns meeting strict 1e-10, error vs the reference's conds())."""
+    import torch
+    import wlsqm.hip as whip
+    c = K.config_dense(name)
+    dim, order, n, no = c["dim"], c["order"], c["n"], c["no"]
+    xk = c["xk"] if dim > 1 else c["xk"][..., 0]
+    fi_d = _t(c["fi0"])
+    whip.fit_many_device(dim, order, _t(xk), _t(c["fk"]), _t(c["nk_a"]), _t(c["xi"]), fi_d, _t(c["knowns_a"]), _t(c["wm_a"]))
+    torch.cuda.synchronize()
+    assert whip.last_kernel() in FAST_KERNELS[name], whip.last_kernel()
+    fi = fi_d.cpu().numpy()
+    kn = int(c["knowns_a"][0])
+    known_cols = [a for a in range(no) if (kn >> a) & 1]
+    for a in known_cols:
+        assert np.array_equal(fi[:, a], c["fi0"][:, a]), "known DOF modified"
+    fi_o = c["fi0"].copy()
+    oracle.fit_many(dim, c["xk"], c["fk"], c["nk_a"], c["xi"], fi_o, None, 0, c["order_a"], c["knowns_a"], c["wm_a"])
+    truth = P.truth_fit(dim, c["xk"], c["fk"], c["nk_a"], c["xi"], c["fi0"], c["order_a"], c["knowns_a"], c["wm_a"])
+    acc = P.accounting(fi, c["g"]["fi"], truth=truth, oracle=fi_o, conds=c["conds"], known_cols=known_cols)
+    print("\n%s vs reference golden: %s" % (name, json.dumps(acc)))
+    assert acc["within_1e-10_plus_8N"], acc
+    assert not acc["resolved_columns_missing_strict"], acc
+    # the GPU result must be as close to the 80-bit solution as the reference is (same multiplier as everywhere)
+    assert all(t <= P.TOL + P.NOISE_MULT * nn for t, nn in zip(acc["cand_vs_truth"], acc["ref_noise_floor_N"])), acc
+    # the host-array entry point (the reference's own signature) lands on the same kernel family and the same numbers
+    fi_h = c["fi0"].copy()
+    getattr(wlsqm, "fit_%dD_many_parallel" % dim)(xk=xk, fk=c["fk"], nk=c["nk_a"], xi=c["xi"] if dim > 1 else c["xi"][:, 0],
+                                                  fi=fi_h, sens=None, do_sens=0, order=c["order_a"], knowns=c["knowns_a"],
+                                                  weighting_method=c["wm_a"])
+    assert whip.last_kernel() in FAST_KERNELS[name]
+    assert np.array_equal(fi_h, fi)
+
+
+@pytest.mark.parametrize("name", ["C2_1M", "C5_1M"])
+def test_dense_density_iterative_vs_reference_golden(wlsqm, name):
+    """fit_*_iterative_many_parallel of the reference at the headline density (fi_iter in the same fixture)."""
+    c = K.config_dense(name)
+    dim = c["dim"]
+    truth = P.truth_fit(dim, c["xk"], c["fk"], c["nk_a"], c["xi"], c["fi0"], c["order_a"], c["knowns_a"], c["wm_a"])
+    fi = c["fi0"].copy()
+    it = getattr(wlsqm, "fit_%dD_iterative_many_parallel" % dim)(
+        xk=c["xk"], fk=c["fk"], nk=c["nk_a"], xi=c["xi"], fi=fi, sens=None, do_sens=0, order=c["order_a"],
+        knowns=c["knowns_a"], weighting_method=c["wm_a"], max_iter=10)
+    assert 1 <= it <= 10
+    P.assert_parity(fi, c["g"]["fi_iter"], truth, name + " iterative")
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# reference contracts that had no test
+
+def test_fk_may_alias_fi_column(wlsqm):
+    """simple.pyx:1010-1019: fk may be a VIEW into the user's fi array (here a sliding window over fi[:, 0] built with stride
+    tricks — no copy); the reference commits results only after every case has read its inputs, so the answer must be the one
+    obtained from an independent copy of fk."""
+    from numpy.lib.stride_tricks import as_strided
+    n, Kn = 400, 9
+    x = np.sort(np.random.default_rng(3).uniform(0.0, 1.0, n + Kn))
+    f = np.sin(2.0 * np.pi * x)
+    fi = np.zeros((n + Kn, 3)); fi[:, 0] = f
+    s0 = fi.strides[0]
+    fk_view = as_strided(fi[:, 0], shape=(n, Kn), strides=(s0, s0))           # fk[j, k] IS fi[j + k, 0]
+    assert np.shares_memory(fk_view, fi)
+    xk = as_strided(x, shape=(n, Kn), strides=(x.strides[0], x.strides[0])).copy()
+    xi = x[Kn // 2: Kn // 2 + n].copy()                                        # fit at the window's middle point
+    fi_cases = fi[Kn // 2: Kn // 2 + n]                                        # ... whose fi row is written: another case's input
+    nk = np.full(n, Kn, np.int32); o = np.full(n, 2, np.int32); kn = np.zeros(n, np.int64); w = np.full(n, 2, np.int32)
+    fk_copy = fk_view.copy()
+    ref = np.zeros((n, 3)); ref[:, 0] = f[Kn // 2: Kn // 2 + n]
+    wlsqm.fit_1D_many_parallel(xk=xk, fk=fk_copy, nk=nk, xi=xi, fi=ref, sens=None, do_sens=0, order=o, knowns=kn,
+                               weighting_method=w)
+    wlsqm.fit_1D_many_parallel(xk=xk, fk=fk_view, nk=nk, xi=xi, fi=fi_cases, sens=None, do_sens=0, order=o, knowns=kn,
+                               weighting_method=w)
+    assert np.array_equal(fi_cases, ref)
+    assert not np.array_equal(fi_cases[:, 0], f[Kn // 2: Kn // 2 + n])        # the aliased column really was overwritten
+    # ExpertSolver.solve has the same contract (expert.pyx:573-580)
+    fi2 = np.zeros((n + Kn, 3)); fi2[:, 0] = f
+    fk_view2 = as_strided(fi2[:, 0], shape=(n, Kn), strides=(s0, s0))
+    s = wlsqm.ExpertSolver(dimension=1, nk=nk, order=o, knowns=kn, weighting_method=w)
+    s.prepare(xi=xi, xk=xk)
+    s.solve(fk=fk_view2, fi=fi2[Kn // 2: Kn // 2 + n])
+    assert np.array_equal(fi2[Kn // 2: Kn // 2 + n], ref)
+
+
+H = 1e-2            # /root/reference/tests/test_stencil.py:34
+
+
+@pytest.mark.parametrize("f,x0,y0,z0", [
+    (lambda x, y, z: np.sin(x) * np.cos(y) * np.exp(z), 0.2, 0.3, -0.1),
+    (lambda x, y, z: np.exp(-0.5 * (x * x + y * y + z * z)), 0.1, -0.2, 0.3),
+])
+def test_stencil_3d_plus_shape(wlsqm, oracle, f, x0, y0, z0):
+    """The reference's tests/test_stencil.py:150-212: a 7-point plus stencil determines F, the three first and the three
+    pure second derivatives exactly as central differences do when the mixed derivatives are pinned (knowns = XY | YZ | XZ);
+    the knowns must come back == 0.0."""
+    xk = np.array([[x0, y0, z0], [x0 + H, y0, z0], [x0 - H, y0, z0], [x0, y0 + H, z0], [x0, y0 - H, z0],
+                   [x0, y0, z0 + H], [x0, y0, z0 - H]])
+    fk = np.array([f(*p) for p in xk])
+    fc, fxp, fxm, fyp, fym, fzp, fzm = fk
+    fi = np.zeros(wlsqm.number_of_dofs(3, 2))
+    knowns = wlsqm.b3_XY | wlsqm.b3_YZ | wlsqm.b3_XZ
+    wlsqm.fit_3D(xk=xk, fk=fk, xi=np.array([x0, y0, z0]), fi=fi, sens=None, do_sens=False, order=2, knowns=knowns,
+                 weighting_method=wlsqm.WEIGHT_UNIFORM, debug=False)
+    assert abs(fi[wlsqm.i3_F] - fc) < 1e-10
+    assert abs(fi[wlsqm.i3_X] - (fxp - fxm) / (2 * H)) < 1e-10
+    assert abs(fi[wlsqm.i3_Y] - (fyp - fym) / (2 * H)) < 1e-10
+    assert abs(fi[wlsqm.i3_Z] - (fzp - fzm) / (2 * H)) < 1e-10
+    assert abs(fi[wlsqm.i3_X2] - (fxp - 2 * fc + fxm) / (H * H)) < 1e-6
+    assert abs(fi[wlsqm.i3_Y2] - (fyp - 2 * fc + fym) / (H * H)) < 1e-6
+    assert abs(fi[wlsqm.i3_Z2] - (fzp - 2 * fc + fzm) / (H * H)) < 1e-6
+    for i in (wlsqm.i3_XY, wlsqm.i3_YZ, wlsqm.i3_XZ):
+        assert fi[i] == 0.0
+    # and the oracle (the reference's algorithm) agrees on the same stencil
+    fo = np.zeros((1, 10))
+    oracle.fit_many(3, xk[None], fk[None], np.array([7], np.int32), np.array([[x0, y0, z0]]), fo, None, 0,
+                    np.array([2], np.int32), np.array([knowns], np.int64), np.array([wlsqm.WEIGHT_UNIFORM], np.int32))
+    assert np.abs(fi - fo[0])[:4].max() < 1e-10 and np.abs(fi - fo[0]).max() < 1e-6      # second derivatives carry 1/h^2
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# ADVICE round 1
+
+@pytest.mark.parametrize("dim,order,Kn", [(2, 2, 32), (2, 2, 30), (3, 2, 40), (2, 4, 64), (2, 3, 22), (1, 2, 8), (3, 3, 60)])
+@pytest.mark.parametrize("pad", [-1, "npoints", 2 ** 31 - 1])
+def test_ragged_hoods_padding_is_never_dereferenced(wlsqm, oracle, dim, order, Kn, pad):
+    """Index-based rows padded the way scipy pads (npoints) or with -1 / garbage: only the slots k < nk[j] may be read,
+    whichever kernel the shape dispatches to."""
+    import torch
+    import synth
+    import wlsqm.hip as whip
+    rng = np.random.default_rng(5)
+    npts, n = 3000, 1500
+    S = synth.halton(npts, dim) if dim > 1 else np.sort(rng.uniform(0, 1, npts))
+    F = synth.field(S)
+    hoods = synth.knn(S if dim > 1 else S[:, None], Kn, query=np.arange(n)).astype(np.int32)
+    no = K.NDOF[dim][order]
+    nk = rng.integers(no + 2, Kn + 1, n).astype(np.int32)
+    nk[::7] = Kn
+    padv = npts if pad == "npoints" else pad
+    hp = hoods.copy()
+    hp[np.arange(Kn)[None, :] >= nk[:, None]] = padv
+    kn = np.zeros(n, np.int64); w = np.full(n, 2, np.int32)
+    fi0 = np.zeros((n, no)); fi0[:, 0] = F[:n]
+    fi_d = _t(fi0)
+    whip.fit_cloud_device(dim, order, _t(S), _t(F), _t(hp), fi_d, _t(nk), _t(kn), _t(w))
+    torch.cuda.synchronize()
+    kernel = whip.last_kernel()
+    got = fi_d.cpu().numpy()
+    # oracle on the dense form with clean padding
+    hc = np.where(np.arange(Kn)[None, :] < nk[:, None], hoods, 0).astype(np.int64)
+    xk = S[hc] if dim > 1 else S[hc][..., None]
+    xi = S[:n] if dim > 1 else S[:n, None]
+    ref = fi0.copy()
+    oracle.fit_many(dim, xk, F[hc], nk, xi, ref, None, 0, np.full(n, order, np.int32), kn, w)
+    truth = P.truth_fit(dim, xk if dim > 1 else xk[..., 0], F[hc], nk, xi if dim > 1 else xi[:, 0], fi0,
+                        np.full(n, order, np.int32), kn, w)
+    P.assert_parity(got, ref, truth, "ragged index-based rows (%s, pad %s)" % (kernel, pad))
+
+
+def test_device_api_validates_extents(wlsqm):
+    """A too-narrow fi (or any array shorter than the batch) must raise instead of letting the kernels write past the rows."""
+    import torch
+    import wlsqm.hip as whip
+    n, Kn = 64, 12
+    dev = "cuda:0"
+    xk = torch.rand((n, Kn, 2), dtype=torch.float64, device=dev); fk = torch.rand((n, Kn), dtype=torch.float64, device=dev)
+    xi = torch.rand((n, 2), dtype=torch.float64, device=dev)
+    nk = torch.full((n,), Kn, dtype=torch.int32, device=dev); kn = torch.zeros(n, dtype=torch.int64, device=dev)
+    wm = torch.full((n,), 2, dtype=torch.int32, device=dev)
+    ok = torch.zeros((n, 6), dtype=torch.float64, device=dev)
+    whip.fit_many_device(2, 2, xk, fk, nk, xi, ok, kn, wm)
+    with pytest.raises(ValueError):
+        whip.fit_many_device(2, 2, xk, fk, nk, xi, torch.zeros((n, 1), dtype=torch.float64, device=dev), kn, wm)
+    with pytest.raises(ValueError):
+        whip.fit_many_device(2, 3, xk, fk, nk, xi, ok, kn, wm)                  # order 3 needs 10 columns
+    with pytest.raises(ValueError):
+        whip.fit_many_device(2, 2, xk[: n - 1], fk, nk, xi, ok, kn, wm)
+    with pytest.raises(ValueError):
+        whip.fit_many_device(2, 2, xk, fk, nk, xi[: n - 1], ok, kn, wm)
+    with pytest.raises(ValueError):
+        whip.fit_many_device(2, 2, xk[:, : Kn - 1], fk, nk, xi, ok, kn, wm)
+    with pytest.raises(ValueError):
+        whip.fit_many_device(2, 2, xk, fk, nk, xi, ok, kn, wm, sens=torch.zeros((n, Kn, 5), dtype=torch.float64, device=dev))
+    with pytest.raises(ValueError):
+        whip.fit_many_device(2, 2, xk, fk, nk, xi, ok, kn[: n - 1], wm)
+    S = torch.rand((n, 2), dtype=torch.float64, device=dev); F = torch.rand(n, dtype=torch.float64, device=dev)
+    hoods = torch.randint(0, n, (n, Kn), dtype=torch.int32, device=dev)
+    whip.fit_cloud_device(2, 2, S, F, hoods, ok, nk, kn, wm)
+    with pytest.raises(ValueError):
+        whip.fit_cloud_device(2, 2, S, F, hoods, torch.zeros((n, 3), dtype=torch.float64, device=dev), nk, kn, wm)
+    with pytest.raises(ValueError):
+        whip.fit_cloud_device(2, 2, S, F, hoods, ok, nk[: n - 1], kn, wm)
+    with pytest.raises(ValueError):
+        whip.fit_cloud_device(2, 2, S[: n - 1], F, hoods, ok, nk, kn, wm)
+    s = wlsqm.ExpertSolver(dimension=2, nk=np.full(n, Kn, np.int32), order=np.full(n, 2, np.int32),
+                           knowns=np.zeros(n, np.int64), weighting_method=np.full(n, 2, np.int32))
+    s.prepare_device(xi, xk)
+    with pytest.raises(ValueError):
+        s.solve_device(fk, torch.zeros((n, 1), dtype=torch.float64, device=dev))
+    with pytest.raises(ValueError):
+        s.solve_many_device(fk[None], torch.zeros((1, n, 5), dtype=torch.float64, device=dev))
+    torch.cuda.synchronize()
+    # nk beyond the neighbour axis is clamped by every kernel (strided input -> generic kernel)
+    big = torch.full((n,), Kn + 50, dtype=torch.int32, device=dev)
+    a = torch.zeros((n, 6), dtype=torch.float64, device=dev); b = torch.zeros((n, 8), dtype=torch.float64, device=dev)[:, :6]
+    whip.fit_many_device(2, 2, xk, fk, nk, xi, a, kn, wm)
+    whip.fit_many_device(2, 2, xk, fk, big, xi, b, kn, wm)
+    assert whip.last_kernel() == "lane"
+    torch.cuda.synchronize()
+    assert float((a - b).abs().max()) <= 1e-9 * float(a.abs().max())
+
+
+def test_interpolate_follows_the_latest_solve_of_any_kind(wlsqm):
+    """expert.pyx:687-781: interpolate() evaluates the coefficients of the last solve — also when that solve was
+    solve_device() / solve_many_device() / solve_many()."""
+    import torch
+    import synth
+    n, Kn = 600, 16
+    p = synth.cloud_problem(2, 4096, Kn, n)
+    mk = lambda: wlsqm.ExpertSolver(dimension=2, nk=np.full(n, Kn, np.int32), order=np.full(n, 2, np.int32),
+                                    knowns=np.zeros(n, np.int64), weighting_method=np.full(n, 2, np.int32))
+    xq = p["xi"][::7] + 1e-3
+    hoods = p["hoods"].astype(np.int64)
+    F1 = synth.field(p["S"], t=0.0); F2 = synth.field(p["S"], t=40.0)
+    a = mk(); a.prepare(xi=p["xi"], xk=p["xk"]); a.prep_interpolate()
+    fi = np.zeros((n, 6)); a.solve(fk=F2[hoods], fi=fi)
+    want, I = a.interpolate(xq, mode="nearest")
+    b = mk(); b.prepare(xi=p["xi"], xk=p["xk"]); b.prep_interpolate()
+    with pytest.raises(RuntimeError):
+        b.interpolate(xq, mode="nearest")                                      # nothing solved yet
+    fi_b = np.zeros((n, 6)); b.solve(fk=F1[hoods], fi=fi_b)                    # an OLDER host solve ...
+    fi_d = torch.zeros((n, 6), dtype=torch.float64, device="cuda:0")
+    b.solve_device(_t(F2[hoods]), fi_d)                                        # ... then a device solve of another field
+    got, I2 = b.interpolate(xq, mode="nearest")
+    assert np.array_equal(I, I2) and np.array_equal(got, want)
+    c = mk(); c.prepare(xi=p["xi"], xk=p["xk"]); c.prep_interpolate()
+    fim = torch.zeros((2, n, 6), dtype=torch.float64, device="cuda:0")
+    c.solve_many_device(_t(np.stack([F1[hoods], F2[hoods]])), fim)             # last field = F2
+    got3, _ = c.interpolate(xq, mode="nearest")
+    assert np.abs(got3 - want).max() <= 1e-12 * np.abs(want).max()
+    d = mk(); d.prepare(xi=p["xi"], xk=p["xk"]); d.prep_interpolate()
+    fih = np.zeros((2, n, 6)); d.solve_many(np.stack([F1[hoods], F2[hoods]]), fih)
+    got4, _ = d.interpolate(xq, mode="continuous", r=0.05)
+    want4, _ = a.interpolate(xq, mode="continuous", r=0.05)
+    assert np.allclose(got4, want4, rtol=1e-12, atol=0, equal_nan=True)
+
+
+def test_refinement_captures_into_a_hip_graph(wlsqm):
+    """Without an iteration count to return, the iterative entry points only enqueue kernels: no allocation, no host
+    synchronisation — they capture into a hipGraph like the basic fit (include/wlsqm_hip.h)."""
+    import torch
+    import synth
+    import wlsqm.hip as whip
+    n, k = 4000, 32
+    dev = torch.device("cuda", 0)
+    S = synth.halton(n, 2)
+    S_d = _t(S)
+    h32 = whip.knn(S_d, k)
+    h_d = h32.long()
+    xk = S_d[h_d].contiguous()
+    F = _t(synth.field(S))
+    fk = F[h_d].contiguous()
+    nk = torch.full((n,), k, dtype=torch.int32, device=dev); kn = torch.zeros(n, dtype=torch.int64, device=dev)
+    wm = torch.full((n,), 2, dtype=torch.int32, device=dev)
+    fi = torch.zeros((n, 6), dtype=torch.float64, device=dev); fi2 = torch.zeros_like(fi)
+    its = whip.fit_many_device(2, 2, xk, fk, nk, S_d, fi, kn, wm, iterative=True, max_iter=10, want_iterations=True)
+    assert 1 <= its <= 10
+    whip.fit_cloud_device(2, 2, S_d, F, h32, fi2, nk, kn, wm, iterative=True, max_iter=10)
+    torch.cuda.synchronize()
+    want, want2 = fi.clone(), fi2.clone()
+    fi.fill_(-7.0); fi2.fill_(-7.0)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=torch.cuda.Stream()):
+        assert whip.fit_many_device(2, 2, xk, fk, nk, S_d, fi, kn, wm, iterative=True, max_iter=10) == 0
+        assert whip.fit_cloud_device(2, 2, S_d, F, h32, fi2, nk, kn, wm, iterative=True, max_iter=10) == 0
+    torch.cuda.synchronize()
+    assert float(fi.max()) == -7.0 and float(fi2.max()) == -7.0               # captured, not run
+    fi.zero_(); fi2.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(fi, want) and torch.equal(fi2, want2)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the HIP kernels under world_size 2 (two processes sharing this box's GPU; gloo carries the collective)
+
+def test_hip_kernels_under_world_size_2(wlsqm, tmp_path):
+    """tests/test_sharded_gloo.py checks the sharding logic with the CPU oracle as the fit; this one runs the REAL kernels in
+    two ranks (process group over gloo, both ranks on the one GPU of the box): case-axis shards of one batch and the
+    time-stepped partitioned cloud must reproduce the single-process run bit for bit."""
+    script = os.path.join(ROOT, "tests", "_two_rank_hip.py")
+    out = tmp_path / "res"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29517", script, str(out)],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.load(open(str(out) + ".json"))
+    assert res["dense_bit_identical"] and res["cloud_bit_identical"], res
+    assert res["kernel_dense"] == "tile" and res["world"] == 2

@@ -170,3 +170,23 @@ def test_example_harness_ragged_radius_neighbourhoods():
     oracle.fit_many(2, xk, fk, nk, S, fi, None, 0, o, kn, w, ntasks=4)
     truth = P.truth_fit(2, xk, fk, nk, S, fi0, o, kn, w)
     P.assert_parity(fi, g["fi"], truth, "testmany2d")
+
+
+@pytest.mark.parametrize("name", K.DENSE)
+def test_dense_density_oracle_vs_reference(name):
+    """The oracle against the reference at the density the metric is quoted on (1M / 16M-point clouds, every 977th case):
+    this is the floor two correct fp64 implementations of the SAME algorithm differ by (only LAPACK's summation order
+    changes) — the number the GPU tests and bench.py print beside gpu-vs-reference."""
+    c = K.config_dense(name)
+    fi = c["fi0"].copy()
+    oracle.fit_many(c["dim"], c["xk"], c["fk"], c["nk_a"], c["xi"], fi, None, 0, c["order_a"], c["knowns_a"], c["wm_a"])
+    truth = P.truth_fit(c["dim"], c["xk"], c["fk"], c["nk_a"], c["xi"], c["fi0"], c["order_a"], c["knowns_a"], c["wm_a"])
+    kn = int(c["knowns_a"][0])
+    known_cols = [a for a in range(c["no"]) if (kn >> a) & 1]
+    for a in known_cols:
+        assert np.array_equal(fi[:, a], c["fi0"][:, a])
+    acc = P.accounting(fi, c["g"]["fi"], truth=truth, conds=c["conds"], known_cols=known_cols)
+    print("%s oracle-vs-reference: E_max %.2e, N_max %.2e, strict columns %d/%d" %
+          (name, acc["E_max"], acc["N_max"], acc["strict_1e-10_columns"], acc["columns"]))
+    assert acc["within_1e-10_plus_8N"], acc
+    assert not acc["resolved_columns_missing_strict"], acc
