@@ -196,12 +196,11 @@ def test_ragged_hoods_padding_is_never_dereferenced(wlsqm, oracle, dim, order, K
     got = fi_d.cpu().numpy()
     # oracle on the dense form with clean padding
     hc = np.where(np.arange(Kn)[None, :] < nk[:, None], hoods, 0).astype(np.int64)
-    xk = S[hc] if dim > 1 else S[hc][..., None]
-    xi = S[:n] if dim > 1 else S[:n, None]
+    xk = S[hc]                                   # 1D: (n, K) and xi (n,), the reference's 1D layout
+    xi = S[:n].copy()
     ref = fi0.copy()
     oracle.fit_many(dim, xk, F[hc], nk, xi, ref, None, 0, np.full(n, order, np.int32), kn, w)
-    truth = P.truth_fit(dim, xk if dim > 1 else xk[..., 0], F[hc], nk, xi if dim > 1 else xi[:, 0], fi0,
-                        np.full(n, order, np.int32), kn, w)
+    truth = P.truth_fit(dim, xk, F[hc], nk, xi, fi0, np.full(n, order, np.int32), kn, w)
     P.assert_parity(got, ref, truth, "ragged index-based rows (%s, pad %s)" % (kernel, pad))
 
 
