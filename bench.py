@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
     ap.add_argument("--ncases", type=int, default=1_000_000, help="local fits per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the spot parity check (profiling passes)")
     ap.add_argument("--nrhs", type=int, default=64, help="C4: right-hand sides stacked per step (256 = 4 steps)")
     a = ap.parse_args()
 
@@ -168,6 +169,11 @@ def main():
         }
         # spot parity check of this very run against the CPU oracle (checker only), judged like the tests:
         # per-column metric, widened only by the oracle's own fp64 noise floor vs an 80-bit solve (tests/_parity.py)
+        if a.no_parity:
+            print(json.dumps(out), flush=True)
+            if dist is not None:
+                dist.barrier(); dist.destroy_process_group()
+            return
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from oracle import oracle
         import _parity
@@ -266,6 +272,11 @@ def run_c4(a, cfg, S, F, hoods, dev, dist, rank, world):
             "time_stepping": {"ms_per_field": ms_step_field, "fits_per_s": n / (ms_step_field * 1e-3),
                               "bytes_per_fit": bytes_per_fit(dim, order, nk, cfg["knowns"])},
         }
+        if a.no_parity:
+            print(json.dumps(out), flush=True)
+            if dist is not None:
+                dist.barrier(); dist.destroy_process_group()
+            return
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from oracle import oracle
         import _parity

@@ -1,0 +1,264 @@
+// fit_ring.hip — ONE-kernel fit of the 15-unknown systems (2D order 4; BASELINE configs[2], "C3"): LDS-DMA ring + moments +
+// register-parked lane-per-case solve.  Replaces the two-kernel moment path (tile pass -> 480 B/case workspace ->
+// moment_solve_kernel: 960 B/case of extra HBM traffic, profiles/traffic_C3.json) for dense contiguous input.
+//
+// Reference arithmetic (file:line in /root/reference): make_c_2D impl.pyx:286-432, weights infra.pyx:668-702, make_A
+// impl.pyx:566-602, RHS + knowns elimination impl.pyx:768-823, factor/solve lapackdrivers.pyx:1628-1665 (here: moments +
+// unpivoted LDL^T, wlsqm_kernels.hpp / wlsqm_moments.hpp).
+//
+// Shape: one wave per workgroup, __launch_bounds__(64, 1) (the 120-entry matrix of the solve needs > 256 registers, so the
+// kernel owns its SIMD and must hide its own memory latency):
+//   * a tile = 16 consecutive cases, 4 lanes per case (lane = h * 16 + c), each lane sums KC / 4 neighbours into the 45 + 15
+//     distinct moments (outer-product form), the 4 partial sums meet in a two-step xor butterfly;
+//   * the NEXT tile's xk block is already on its way while the current one is computed: `global_load_lds_dwordx4` into the
+//     other half of a two-tile LDS ring (no VGPR destination, no ds_write).  The DMA writes LDS lane-linearly, so rows cannot be
+//     padded; bank conflicts are removed on the SOURCE side: row r is stored rotated by rot(r) = r (1 - K) mod 16 chunks, so
+//     that lane (c, h) finds neighbour k of its case at chunk (k + rot(c)) mod K and 16 consecutive lanes hit 16 different
+//     4-bank groups (ds_read_b128).  The next tile's fk values (16-byte loads of the lane's own share) and per-case scalars
+//     travel through a second register set;
+//   * after the butterfly all 4 lanes of a case hold the same sums; lane h keeps those of the tile with (iteration mod 4) == h
+//     in a parked register set.  After 4 tiles the 64 lanes hold 64 DIFFERENT cases and the whole wave expands the matrix,
+//     eliminates knowns, factors and substitutes — the solve runs once per 64 cases on all lanes instead of after every tile
+//     on a quarter of them, and nothing but xk, fk, xi, the scalars and fi crosses HBM.
+// A workgroup owns a CONTIGUOUS run of tiles (so a solve stores 64 consecutive fi rows).
+#include <cstdlib>
+
+#include "wlsqm_internal.hpp"
+#include "wlsqm_kernels.hpp"
+#include "wlsqm_moments.hpp"
+
+namespace wlsqm {
+
+typedef double rd2_ __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void* ring_lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* ring_glb_ptr_t;
+
+template <int K> struct RingGeom {
+    static constexpr int DIM = 2, WV = 64, TC = 16, LPC = 4;
+    static constexpr int KC = (K + 7) / 8 * 8;              // slots the four shares cover (even share each); slots >= K are masked
+    static constexpr int KPL = KC / LPC;
+    static constexpr int PARTS = (K + WV - 1) / WV;          // DMA instructions per row (64 neighbours = 1 KiB each)
+    static constexpr int NI = TC * PARTS;                    // DMA instructions per tile
+    // padded row stride in doubles: == 2 (mod 4), so that 16 consecutive lanes reading one neighbour of 16 consecutive rows
+    // with ds_read_b128 hit 16 different 4-bank groups; rows cover KC slots (a padded share reads up to KC - K slots past K)
+    static constexpr int RS = ((2 * KC + 1) / 4) * 4 + 2;
+    static constexpr int SLOT = TC * RS + 2 * WV;            // doubles per ring slot (+ slack: the last row's DMA writes whole 16-B lanes only)
+    static constexpr size_t LDS_BYTES = sizeof(double) * 2 * SLOT;
+    static_assert(K % 2 == 0 && K >= 8, "rows must be multiples of 16 bytes");
+    static_assert(RS >= 2 * KC && RS % 4 == 2, "row stride");
+};
+
+template <int ORDER, int K, int UNR>
+__global__ __launch_bounds__(64, 1) void fit_ring_kernel(const KParams p, const long long ntiles, const int tiles_per_wg) {
+    using G = RingGeom<K>;
+    constexpr int DIM = 2, WV = 64, TC = G::TC, KPL = G::KPL, RS = G::RS;
+    constexpr int NO = ndofs(DIM, ORDER), NE = NO * (NO + 1) / 2, NM = mom_count<DIM>(2 * ORDER), NN = mom_count<DIM>(ORDER);
+    static_assert(NN == NO, "one right-hand-side moment per DOF");
+    extern __shared__ __attribute__((aligned(16))) double lds[];          // [2][SLOT]
+
+    const int lane = threadIdx.x, c = lane % TC, h = lane / TC, k0 = h * KPL;
+
+    struct Meta { int nk, wm; long long kn; double xi0, xi1; };
+    Meta nxt;
+    double fnext[KPL];
+
+    // Everything of tile `tile` that can be requested ahead of time.  One DMA instruction moves (at most) 64 neighbours = 1 KiB
+    // of ONE row: its LDS base is the row's padded position (wave-uniform, M0), its global address a wave-uniform base plus
+    // lane * 16 — no per-lane address arithmetic at all.  (A first version filled the ring lane-linearly with source-side
+    // rotated rows; its sixteen hoisted 64-bit per-lane addresses were spilled next to the 120-entry solve, and the scratch
+    // reloads BETWEEN the DMAs waited — vmcnt is in order — for the DMA issued just before: 0.73 ms instead of 0.56.)
+    auto prefetch = [&](long long tile, int slot) {
+        const long long j0 = tile * TC;
+        const int nvalid = (p.ncases - j0 < TC) ? (int)(p.ncases - j0) : TC;      // wave-uniform
+        double* dst = lds + slot * G::SLOT;
+        const char* xbase = reinterpret_cast<const char*>(p.xk + j0 * (long long)(K * DIM));
+        const unsigned lane16 = (unsigned)lane * 16u;
+#pragma unroll
+        for (int r = 0; r < TC; ++r) {
+            const int rs = r < nvalid ? r : nvalid - 1;                            // tail tile: replay the last valid row
+#pragma unroll
+            for (int pp = 0; pp < G::PARTS; ++pp) {
+                if ((pp + 1) * WV <= K || pp * WV + lane < K) {
+                    const char* src = xbase + (size_t)(rs * K + pp * WV) * 16u;   // uniform
+                    __builtin_amdgcn_global_load_lds((ring_glb_ptr_t)(src + lane16), (ring_lds_ptr_t)(dst + r * RS + pp * WV * DIM),
+                                                     16, 0, 0);
+                }
+            }
+        }
+        const int cc = c < nvalid ? c : nvalid - 1;                                // tail tile: replay the last valid case
+        const long long jc = j0 + cc;
+        nxt.nk = p.nk[jc * p.snk]; nxt.wm = p.wm[jc * p.swm]; nxt.kn = p.knowns[jc * p.sknowns];
+        nxt.xi0 = p.xi[jc * p.sxi_j]; nxt.xi1 = p.xi[jc * p.sxi_j + 1];
+        const char* fbase = reinterpret_cast<const char*>(p.fk + j0 * (long long)K);
+#pragma unroll
+        for (int i = 0; i < KPL / 2; ++i) {
+            // a padded share's slots beyond the row replay the row's last pair (masked in the loop)
+            const int kq = (G::KC == K) ? k0 + 2 * i : ((k0 + 2 * i < K) ? k0 + 2 * i : K - 2);
+            const unsigned foff = (unsigned)(cc * K + kq) * 8u;
+            const rd2_ v = *reinterpret_cast<const rd2_*>(fbase + foff);
+            fnext[2 * i] = v.x; fnext[2 * i + 1] = v.y;
+        }
+    };
+
+    // parked sums: lane (c, h) keeps the reduced moments of case c of the tile of iteration it with it % 4 == h
+    double Pm[NM], Pn[NO];
+    long long jp = 0;
+    unsigned long long knownp = 0, droppedp = 0;
+    bool havep = false;
+    constexpr unsigned long long FULL = (1ull << NO) - 1ull;
+
+    auto solve_parked = [&]() {
+        if (havep && knownp != FULL) {
+            double* fio = p.fi + jp * p.sfi_j;
+            double M[NE], rhs[NO];
+            expand_moments_from<DIM, ORDER>([&](int i) { return Pm[i]; }, [&](int i) { return Pn[i]; }, M, rhs);
+            if (knownp) {
+                double val[NO];
+#pragma unroll
+                for (int a = 0; a < NO; ++a) val[a] = (((knownp & ~droppedp) >> a) & 1ull) ? fio[a] : 0.0;
+                eliminate_knowns<NO>(M, rhs, knownp, val);
+            }
+            ldlt_factor<NO>(M);
+            ldlt_solve<NO>(M, rhs);
+#pragma unroll
+            for (int a = 0; a < NO; ++a)
+                if (!((knownp >> a) & 1ull)) fio[a] = rhs[a];
+        }
+        havep = false;
+    };
+
+    const long long tile0 = (long long)blockIdx.x * tiles_per_wg;
+    long long tend = tile0 + tiles_per_wg;
+    if (tend > ntiles) tend = ntiles;
+    if (tile0 < tend) prefetch(tile0, 0);
+    int it = 0;
+    for (long long tile = tile0; tile < tend; ++tile, ++it) {
+        __syncthreads();                               // with a DMA in flight: s_waitcnt vmcnt(0) + s_barrier (one wave)
+        const long long j = tile * TC + c;
+        const bool valid = j < p.ncases;
+        const int nkc = min(nxt.nk, K);
+        const bool uniform = (nxt.wm == WLSQM_WEIGHT_UNIFORM);
+        unsigned long long known, dropped;
+        effective_mask<NO>(nxt.kn, known, dropped);
+        const double xi[DIM] = {nxt.xi0, nxt.xi1};
+        double f[KPL];
+#pragma unroll
+        for (int i = 0; i < KPL; ++i) f[i] = fnext[i];
+        const double* row = lds + (it & 1) * G::SLOT + c * RS + k0 * DIM;       // this lane's share of its case's row
+        if (tile + 1 < tend) prefetch(tile + 1, (it + 1) & 1);
+
+        auto offset = [&](int kk, double (&d)[DIM]) {  // neighbour k0 + kk of this lane's case (ds_read_b128, immediate offset)
+            const rd2_ xy = *reinterpret_cast<const rd2_*>(row + kk * DIM);
+            d[0] = xy.x - xi[0]; d[1] = xy.y - xi[1];
+        };
+        const bool full = (G::KC == K) && __all(nkc >= K);     // wave-uniform: no ragged case in this tile
+        double max_d2 = 0.0;
+        if (full) {
+#pragma unroll
+            for (int kk = 0; kk < KPL; ++kk) {
+                double d[DIM];
+                offset(kk, d);
+                const double d2 = d[0] * d[0] + d[1] * d[1];
+                max_d2 = d2 > max_d2 ? d2 : max_d2;
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < KPL; ++kk) {
+                double d[DIM];
+                offset(kk, d);
+                double d2 = d[0] * d[0] + d[1] * d[1];
+                d2 = (k0 + kk < nkc) ? d2 : 0.0;
+                max_d2 = d2 > max_d2 ? d2 : max_d2;
+            }
+        }
+#pragma unroll
+        for (int off = TC; off < WV; off <<= 1) { const double o = __shfl_xor(max_d2, off, WV); max_d2 = o > max_d2 ? o : max_d2; }
+        const double inv_max = inverse_max(max_d2);
+
+        double mu[NM], nu[NO];
+#pragma unroll
+        for (int e = 0; e < NM; ++e) mu[e] = 0.0;
+#pragma unroll
+        for (int a = 0; a < NO; ++a) nu[a] = 0.0;
+        auto neighbour = [&](int kk, bool live) {
+            double d[DIM];
+            offset(kk, d);
+            d[0] = live ? d[0] : 0.0; d[1] = live ? d[1] : 0.0;
+            const double d2 = d[0] * d[0] + d[1] * d[1];
+            const double w = live ? weight(d2, inv_max, uniform) : 0.0;
+            accumulate_moments_best<DIM, ORDER>(mu, nu, d, w, live ? f[kk] : 0.0);
+        };
+        if (full) {
+#pragma unroll UNR
+            for (int kk = 0; kk < KPL; ++kk) neighbour(kk, true);
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < KPL; ++kk) neighbour(kk, k0 + kk < nkc);
+        }
+#pragma unroll
+        for (int off = TC; off < WV; off <<= 1) {
+#pragma unroll
+            for (int e = 0; e < NM; ++e) mu[e] += __shfl_xor(mu[e], off, WV);
+#pragma unroll
+            for (int a = 0; a < NO; ++a) nu[a] += __shfl_xor(nu[a], off, WV);
+        }
+        if (h == (it & 3)) {
+#pragma unroll
+            for (int e = 0; e < NM; ++e) Pm[e] = mu[e];
+#pragma unroll
+            for (int a = 0; a < NO; ++a) Pn[a] = nu[a];
+            jp = j; knownp = known; droppedp = dropped; havep = valid;
+        }
+        if ((it & 3) == 3) solve_parked();             // the 64 lanes hold 64 different cases
+    }
+    if (it & 3) solve_parked();                        // leftovers of a run that is not a multiple of 4 tiles
+}
+
+// tiles per workgroup: a multiple of 4 (one solve per 4 tiles); WLSQM_HIP_RING_TILES overrides (A/B)
+static int ring_tiles_per_wg() {
+    const char* e = getenv("WLSQM_HIP_RING_TILES");
+    const int v = e ? atoi(e) : 8;
+    return v >= 1 ? v : 8;
+}
+
+template <int ORDER, int K, int UNR>
+static int launch_ring_impl(const KParams& p, hipStream_t stream) {
+    using G = RingGeom<K>;
+    const long long ntiles = (p.ncases + G::TC - 1) / G::TC;
+    const int T = ring_tiles_per_wg();
+    const long long grid = (ntiles + T - 1) / T;
+    if (grid > 0x7fffffffll) { set_error("fit_ring: batch too large for one launch"); return WLSQM_EVALUE; }
+    auto kern = fit_ring_kernel<ORDER, K, UNR>;
+    static bool optin[16] = {};
+    int dev = 0;
+    WLSQM_HIP_CHECK(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 16 && !optin[dev]) {
+        if (G::LDS_BYTES > 64 * 1024)
+            WLSQM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                (int)G::LDS_BYTES));
+        optin[dev] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), G::LDS_BYTES, stream, p, ntiles, T);
+    WLSQM_HIP_CHECK(hipGetLastError());
+    note_kernel("tile-solve");
+    return WLSQM_OK;
+}
+
+// Dense contiguous 2D order-4 batches (the tile path's eligibility: fit_tile.hip tile_eligible).
+bool tile_dense_eligible(int dimension, const KParams& p, long long max_nk);
+
+int launch_fit_ring(int dimension, int order, const KParams& p, long long max_nk, hipStream_t stream, bool* handled) {
+    *handled = false;
+    const char* off = getenv("WLSQM_HIP_DISABLE_TILE");
+    if (off && off[0] == '1') return WLSQM_OK;
+    const char* noring = getenv("WLSQM_HIP_DISABLE_RING");       // A/B against the two-kernel moment path
+    if (noring && noring[0] == '1') return WLSQM_OK;
+    if (dimension != 2 || order != 4 || p.hoods) return WLSQM_OK;
+    if (!tile_dense_eligible(dimension, p, max_nk)) return WLSQM_OK;
+#define RING_CASE(KK) if (max_nk == KK) { *handled = true; return launch_ring_impl<4, KK, 16>(p, stream); }
+    RING_CASE(64)
+#undef RING_CASE
+    return WLSQM_OK;
+}
+
+}  // namespace wlsqm

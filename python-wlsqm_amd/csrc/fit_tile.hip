@@ -24,6 +24,9 @@ static bool tile_eligible(int dim, const KParams& p, long long K) {
     return true;
 }
 
+// exported for fit_ring.hip: dense contiguous input the tile kernels can take
+bool tile_dense_eligible(int dimension, const KParams& p, long long max_nk) { return !p.hoods && tile_eligible(dimension, p, max_nk); }
+
 // First kernel of the two-kernel moment path (fit_moment.hip): tile pass that leaves the moments in p.ws.
 // `handled` stays false when no instantiation covers (dimension, order, max_nk) or the input is not tile-eligible.
 // Neighbour-slot counts with a two-kernel moment instantiation (2D order 4).  The host entry points round their device

@@ -250,8 +250,10 @@ def test_device_api_validates_extents(wlsqm):
     # nk beyond the neighbour axis is clamped by every kernel (strided input -> generic kernel)
     big = torch.full((n,), Kn + 50, dtype=torch.int32, device=dev)
     a = torch.zeros((n, 6), dtype=torch.float64, device=dev); b = torch.zeros((n, 8), dtype=torch.float64, device=dev)[:, :6]
+    xk_s = torch.zeros((n, Kn, 3), dtype=torch.float64, device=dev)[:, :, :2]      # neighbour stride 3: not tile-eligible
+    xk_s.copy_(xk)
     whip.fit_many_device(2, 2, xk, fk, nk, xi, a, kn, wm)
-    whip.fit_many_device(2, 2, xk, fk, big, xi, b, kn, wm)
+    whip.fit_many_device(2, 2, xk_s, fk, big, xi, b, kn, wm)
     assert whip.last_kernel() == "lane"
     torch.cuda.synchronize()
     assert float((a - b).abs().max()) <= 1e-9 * float(a.abs().max())

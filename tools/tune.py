@@ -29,7 +29,14 @@ res = {v: [] for v in variants}
 ref = None
 for rnd in range(5):
     for v in variants:
-        if v == "lane":
+        os.environ.pop("WLSQM_HIP_DISABLE_RING", None); os.environ.pop("WLSQM_HIP_RING_TILES", None)
+        if v == "noring":                  # 2D order 4: the two-kernel moment path instead of the one-kernel ring fit
+            os.environ.pop("WLSQM_HIP_DISABLE_TILE", None); os.environ.pop("WLSQM_HIP_DISABLE_FIXEDK", None)
+            os.environ["WLSQM_HIP_DISABLE_RING"] = "1"
+        elif v.startswith("ring"):         # ring fit with N tiles per workgroup (ring8, ring16, ...)
+            os.environ.pop("WLSQM_HIP_DISABLE_TILE", None); os.environ.pop("WLSQM_HIP_DISABLE_FIXEDK", None)
+            if v[4:]: os.environ["WLSQM_HIP_RING_TILES"] = v[4:]
+        elif v == "lane":
             os.environ["WLSQM_HIP_DISABLE_TILE"] = "1"
         elif v in ("w1", "w4"):            # runtime-K kernels (curated fixed-K shapes off): one wave / four waves per tile
             os.environ.pop("WLSQM_HIP_DISABLE_TILE", None); os.environ["WLSQM_HIP_DISABLE_FIXEDK"] = "1"
