@@ -4,9 +4,18 @@
 A "step" is one pass of the fused assemble+factor+solve kernel over one batch of synthetic local
 fits (inputs resident in HBM before the timed region starts).  Default workload = BASELINE.json
 configs[1] ("C2"): 2D order-2, 1M Halton points, 32 nearest neighbours, WEIGHT_CENTER, all DOFs
-unknown.  One process per GPU; for N > 1 the driver launches this file under torch.distributed.run
-and every rank fits its own 1M-case shard (independent local problems: no data-path collective,
-"weak" scaling).
+unknown — that is `value`.  One process per GPU; for N > 1 the driver launches this file under
+torch.distributed.run and every rank fits its own 1M-case shard (independent local problems: no
+data-path collective, "weak" scaling).
+
+The default single-GPU run also measures every other BASELINE config with the same --steps / --warmup and
+reports them under "configs" (each with ms_per_step, kernel_ms, roofline fraction, traffic and parity against the
+reference-generated golden of that config): C1 at its specified 10k points and at a working set beyond the
+Infinity Cache, C3, C4 (ExpertSolver, 256 stacked right-hand sides), C5 at 1M and at the full 16M points of
+configs[4] on one GPU, and the literal form of configs[4] (`--config C5 --sharded`: ONE Morton-ordered cloud
+partitioned over the ranks, own-points-only neighbour search against a halo band, index-based fit, halo values
+exchanged per step on a side stream under the interior fits; wlsqm/sharded.py HaloCloudSolver).
+`--config Cx` measures one config as `value` instead.
 
 Prints ONE JSON line on rank 0 (see DESIGN.md §Measurement for every field).
 """
@@ -21,6 +30,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "python-wlsqm_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import synth  # noqa: E402
 
@@ -30,11 +40,13 @@ CONFIGS = {
     "C2": dict(dim=2, order=2, nk=32, wm=2, knowns=0, desc="2D order-2, Halton, 32 neighbours, WEIGHT_CENTER, all DOFs unknown"),
     "C3": dict(dim=2, order=4, nk=64, wm=2, knowns=1, desc="2D order-4, Halton, 64 neighbours, WEIGHT_CENTER, F known"),
     "C5": dict(dim=3, order=2, nk=40, wm=2, knowns=0, desc="3D order-2, Halton, 40 neighbours, WEIGHT_CENTER, all DOFs unknown"),
-    # BASELINE configs[3]: the C2 geometry prepared once in an ExpertSolver, then many right-hand sides (run_c4 below)
+    # BASELINE configs[3]: the C2 geometry prepared once in an ExpertSolver, then many right-hand sides (measure_c4 below)
     "C4": dict(dim=2, order=2, nk=32, wm=2, knowns=0, desc="ExpertSolver, 2D order-2, Halton, 32 neighbours: prepare once + stacked right-hand sides"),
 }
 NDOF = {1: [1, 2, 3, 4, 5], 2: [1, 3, 6, 10, 15], 3: [1, 4, 10, 20, 35]}
 HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+FP64_PEAK_TFLOPS = 78.6    # vector fp64 peak; measured: a lone wave per SIMD issues 62, four waves 74 (tools/ubench/fp64_issue.hip)
+GOLDEN_OF = {"C2": "C2_1M", "C3": "C3_1M", "C5": "C5_1M"}      # reference outputs at the density the metric is quoted on
 
 
 def bytes_per_fit(dim, order, nk, knowns):
@@ -44,15 +56,52 @@ def bytes_per_fit(dim, order, nk, knowns):
     return 8 * nk * (dim + 1) + 8 * dim + 8 * no + 8 * bin(knowns).count("1") + 20
 
 
+def bytes_per_fit_indexed(dim, order, nk):
+    """Index-based input (reported separately): 4 nk [hoods] + 8 (dim+1) [the point's own row of S and F]
+    + 8 no [fi] + 20."""
+    return 4 * nk + 8 * (dim + 1) + 8 * NDOF[dim][order] + 20
+
+
+def flops_per_fit(dim, order, nk, knowns):
+    """fp64 operations per fit of the moment-form kernels (FMA = 2): per neighbour the offsets and squared distance
+    (3 dim - 1), the weight (23: a reciprocal-square-root seeded root, two Newton steps, the quadratic), the monomial
+    powers and the distinct moments of the matrix and of the right-hand side (one FMA each); per case the expansion of
+    the no(no+1)/2 entries, the LDL^T factorisation (no^3 / 3) and the two substitutions (2 no^2)."""
+    no = NDOF[dim][order]
+    D = 2 * order
+    nmom = {1: D + 1, 2: (D + 1) * (D + 2) // 2, 3: (D + 1) * (D + 2) * (D + 3) // 6}[dim]
+    per_nb = (3 * dim - 1) + 23 + dim * D + 2 * (nmom + no)
+    return nk * per_nb + no * (no + 1) // 2 + no ** 3 // 3 + 2 * no * no
+
+
 def load_traffic(config, units_per_launch):
-    """HBM bytes per launch from the committed PMC summary (profiles/traffic_<config>.json, tools/make_traffic.py), or None
-    when there is none for this config / launch size."""
-    tfile = os.path.join(ROOT, "profiles", "traffic_%s.json" % config)
+    """HBM bytes per launch from the committed PMC summary (profiles/traffic_<config>.json, tools/make_traffic.py) and the
+    file it came from, or (None, None) when there is none for this config / launch size.  This is a RECORDED measurement
+    of the same kernel at the same launch size (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes), not something this run
+    measures: PMC collection needs the profiler."""
+    name = "traffic_%s.json" % config
     try:
-        t = json.load(open(tfile))
-        return t.get("hbm_bytes_per_launch") if int(t.get("cases_per_launch", -1)) == int(units_per_launch) else None
+        t = json.load(open(os.path.join(ROOT, "profiles", name)))
+        if int(t.get("cases_per_launch", -1)) == int(units_per_launch):
+            return t.get("hbm_bytes_per_launch"), "profiles/" + name
     except Exception:
-        return None
+        pass
+    return None, None
+
+
+def load_valu_busy(config):
+    """VALU-busy fraction of the dominant kernel from the committed SQ counter pass (profiles/*_<config>_pmc_summary.json)."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_pmc_summary.json" % config))):
+        try:
+            ks = json.load(open(f))["kernels"]
+            v = max((k["derived"].get("valu_busy", 0.0) for k in ks.values()), default=None)
+            if v:
+                best = (v, "profiles/" + os.path.basename(f))
+        except Exception:
+            pass
+    return best or (None, None)
 
 
 def build_problem(cfg, ncases, rank, device=None):
@@ -75,45 +124,98 @@ def build_problem(cfg, ncases, rank, device=None):
     return S, F, hoods
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
-    ap.add_argument("--ncases", type=int, default=1_000_000, help="local fits per GPU per step")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-parity", action="store_true", help="skip the spot parity check (profiling passes)")
-    ap.add_argument("--nrhs", type=int, default=64, help="C4: right-hand sides stacked per step (256 = 4 steps)")
-    a = ap.parse_args()
+class Timer:
+    """The timed region of the contract: W untimed steps, then exactly K steps bracketed by barrier + synchronize, MAX over ranks."""
 
+    def __init__(self, dist, dev):
+        self.dist, self.dev = dist, dev
+
+    def barrier(self):
+        import torch
+        torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+            torch.cuda.synchronize()
+
+    def run(self, step, steps, warmup, wake_s=0.3):
+        import torch
+        # The GPU sat idle through the setup and has dropped to its low power state; the first ~50 ms of kernels run at
+        # reduced clocks (measured: 0.214 ms vs 0.183 ms per step).  Bring it back to the clocks of a long-running job before
+        # the untimed warm-up, so a short --warmup does not measure the ramp.  (Collective steps: a fixed count, the same on
+        # every rank.)
+        if self.dist is None:
+            t_wake = time.perf_counter()
+            while time.perf_counter() - t_wake < wake_s:
+                for _ in range(8):
+                    step()
+                torch.cuda.synchronize()
+        else:
+            for _ in range(8):
+                step()
+        for _ in range(warmup):
+            step()
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        self.barrier()
+        dt = time.perf_counter() - t0
+        if self.dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=self.dev)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+
+def golden_parity(name, dev):
+    """Parity of the device-resident fast kernel against the REFERENCE at the density the metric is quoted on: the 1 024
+    cases of tests/golden/config_<name>.npz (every 977th case of the full cloud; inputs rebuilt bit-for-bit, outputs
+    captured from the reference's fit_*_many_parallel and ExpertSolver(debug=True).conds() by tests/golden/make_golden.py).
+    Strict-1e-10 accounting as in tests/_parity.accounting."""
     import torch
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if a.gpus > 1 and world != a.gpus:
-        raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    if "RANK" in os.environ:        # launched by torch.distributed.run: one rank per GPU, RCCL ("nccl") process group
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
-
+    import _cases
+    import _parity
     import wlsqm.hip as whip
-    cfg = CONFIGS[a.config]
-    dim, order, nk, n = cfg["dim"], cfg["order"], cfg["nk"], a.ncases
+    from oracle import oracle
+    c = _cases.config_dense(name)
+    dim, order, no = c["dim"], c["order"], c["no"]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    xk = c["xk"] if dim > 1 else c["xk"][..., 0]
+    fi_d = t(c["fi0"])
+    whip.fit_many_device(dim, order, t(xk), t(c["fk"]), t(c["nk_a"]), t(c["xi"]), fi_d, t(c["knowns_a"]), t(c["wm_a"]))
+    torch.cuda.synchronize()
+    kernel = whip.last_kernel()
+    fi = fi_d.cpu().numpy()
+    kn = int(c["knowns_a"][0])
+    known_cols = [a for a in range(no) if (kn >> a) & 1]
+    fi_o = c["fi0"].copy()
+    oracle.fit_many(dim, c["xk"], c["fk"], c["nk_a"], c["xi"], fi_o, None, 0, c["order_a"], c["knowns_a"], c["wm_a"], ntasks=8)
+    truth = _parity.truth_fit(dim, c["xk"], c["fk"], c["nk_a"], c["xi"], c["fi0"], c["order_a"], c["knowns_a"], c["wm_a"])
+    acc = _parity.accounting(fi, c["g"]["fi"], truth=truth, oracle=fi_o, conds=c["conds"], known_cols=known_cols)
+    acc["golden"] = "tests/golden/config_%s.npz" % name
+    acc["kernel"] = kernel
+    acc["knowns_bit_identical"] = bool(all(np.array_equal(fi[:, a], c["fi0"][:, a]) for a in known_cols))
+    return acc
+
+
+def measure_fit(name, cfg, n, dev, timer, steps, warmup, rank, parity=True, keep=False):
+    """One BASELINE config through the device-resident dense API: build, time, roofline, parity."""
+    import torch
+    import wlsqm.hip as whip
+    dim, order, nk = cfg["dim"], cfg["order"], cfg["nk"]
     no = NDOF[dim][order]
     S, F, hoods = build_problem(cfg, n, rank, device=dev)
-    if a.config == "C4":
-        return run_c4(a, cfg, S, F, hoods, dev, dist, rank, world)
-
     # device-resident inputs in the reference's dense layout: xk = S[hoods], fk = F[hoods]  (gathered on the GPU)
     S_d = torch.from_numpy(np.ascontiguousarray(S)).to(dev)
     F_d = torch.from_numpy(F).to(dev)
-    h_d = torch.from_numpy(hoods.astype(np.int64)).to(dev)
-    xk_d = S_d[h_d].contiguous()
-    fk_d = F_d[h_d].contiguous()
+    h_d = torch.from_numpy(hoods).to(dev)
+    chunk = 2_000_000
+    xk_d = torch.empty((n, nk) + ((dim,) if dim > 1 else ()), dtype=torch.float64, device=dev)
+    fk_d = torch.empty((n, nk), dtype=torch.float64, device=dev)
+    for j0 in range(0, n, chunk):                      # chunked: the int64 index tensor of 16M x 40 would be 5 GB
+        hh = h_d[j0:j0 + chunk].long()
+        xk_d[j0:j0 + chunk] = S_d[hh]; fk_d[j0:j0 + chunk] = F_d[hh]
+        del hh
     xi_d = S_d.clone()
     fi_d = torch.zeros((n, no), dtype=torch.float64, device=dev)
     fi_d[:, 0] = F_d
@@ -122,128 +224,64 @@ def main():
     wm_d = torch.full((n,), cfg["wm"], dtype=torch.int32, device=dev)
     del h_d
     args = (dim, order, xk_d, fk_d, nk_d, xi_d, fi_d, kn_d, wm_d)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    # The GPU sat idle through the host-side neighbour search above and has dropped to its low power state; the
-    # first ~50 ms of kernels run at reduced clocks (measured: 0.214 ms vs 0.183 ms per step).  Bring it back to the
-    # clocks of a long-running job before the untimed warm-up, so a short --warmup does not measure the ramp.
-    t_wake = time.perf_counter()
-    while time.perf_counter() - t_wake < 0.3:
-        for _ in range(50):
-            whip.fit_many_device(*args)
-        torch.cuda.synchronize()
-    for _ in range(a.warmup):
-        whip.fit_many_device(*args)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        whip.fit_many_device(*args)
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
+    dt = timer.run(lambda: whip.fit_many_device(*args), steps, warmup)
+    kernel = whip.last_kernel()
     # dominant kernel, timed live with HIP events on the stream it is launched on
-    ms_kernel = whip.time_fit_device(*args, reps=min(max(a.steps, 20), 500))
+    ms_kernel = whip.time_fit_device(*args, reps=min(max(steps, 20), 500))
     B_fit = bytes_per_fit(dim, order, nk, cfg["knowns"])
     achieved = B_fit * n / (ms_kernel * 1e-3) / 1e9
-
-    out = None
-    if rank == 0:
-        traffic = load_traffic(a.config, n)
-        out = {
-            "metric": "local fits/s (whole node)", "value": world * n * a.steps / dt, "unit": "fits/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s: %s; %d local fits per GPU per step, device-resident dense xk/fk"
-                       % (a.config, cfg["desc"], n), "fits_per_gpu": n, "bytes_per_fit": B_fit},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "kernel_ms": ms_kernel},
-        }
-        # spot parity check of this very run against the CPU oracle (checker only), judged like the tests:
-        # per-column metric, widened only by the oracle's own fp64 noise floor vs an 80-bit solve (tests/_parity.py)
-        if a.no_parity:
-            print(json.dumps(out), flush=True)
-            if dist is not None:
-                dist.barrier(); dist.destroy_process_group()
-            return
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        from oracle import oracle
-        import _parity
-        ns = min(n, 1024)
-        fi_g = fi_d[:ns].cpu().numpy()
-        xk_h = xk_d[:ns].cpu().numpy(); fk_h = fk_d[:ns].cpu().numpy(); xi_h = xi_d[:ns].cpu().numpy()
-        fi_o = np.zeros((ns, no)); fi_o[:, 0] = F[:ns]
-        fi_in = fi_o.copy()
-        meta = (np.full(ns, nk, np.int32), np.full(ns, order, np.int32), np.full(ns, cfg["knowns"], np.int64),
-                np.full(ns, cfg["wm"], np.int32))
-        oracle.fit_many(dim, xk_h, fk_h, meta[0], xi_h, fi_o, None, 0, meta[1], meta[2], meta[3], ntasks=8)
-        truth = _parity.truth_fit(dim, xk_h, fk_h, meta[0], xi_h, fi_in, meta[1], meta[2], meta[3])
-        E = _parity.column_metric(fi_g, fi_o); N = _parity.column_metric(fi_o, truth)
-        out["parity"] = {"cases": ns, "colmax_vs_oracle": float(E.max()), "oracle_fp64_noise_floor": float(N.max()),
-                         "within_1e-10_plus_8x_noise": bool(np.all(E <= 1e-10 + 8.0 * N))}
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(oracle, cfg, xk_d, fk_d, xi_d, F, n, no)
-        print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    working_set = B_fit * n
+    traffic, tsrc = load_traffic(name, n)
+    roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": traffic, "traffic_source": tsrc, "kernel_ms": ms_kernel, "kernel": kernel,
+            "algorithmic_bytes_per_launch": working_set}
+    if working_set < 256 * 2 ** 20:
+        roof["note"] = ("working set %.0f MB fits the 256 MB Infinity Cache: back-to-back launches re-read it on-die, so this is a "
+                        "cache-resident rate, not an HBM fraction" % (working_set / 1e6))
+    if name == "C3":
+        fl = flops_per_fit(dim, order, nk, cfg["knowns"])
+        tf = fl * n / (ms_kernel * 1e-3) / 1e12
+        vb, vsrc = load_valu_busy("C3")
+        roof.update({"valu_flop_per_fit": fl, "valu_achieved_tflops": tf, "valu_peak_tflops": FP64_PEAK_TFLOPS,
+                     "valu_frac": tf / FP64_PEAK_TFLOPS, "valu_busy_pmc": vb, "valu_busy_source": vsrc})
+    res = {"workload": "%s: %s; %d local fits per GPU per step, device-resident dense xk/fk" % (name, cfg["desc"], n),
+           "fits_per_gpu": n, "bytes_per_fit": B_fit, "ms_per_step": dt / steps * 1e3, "fits_per_s": n * steps / dt,
+           "roofline": roof}
+    if parity and rank == 0 and name in GOLDEN_OF:
+        res["parity"] = {"vs_reference_golden": golden_parity(GOLDEN_OF[name], dev)}
+    if keep:
+        res["_tensors"] = dict(xk=xk_d, fk=fk_d, xi=xi_d, fi=fi_d, F=F)
+    return res, dt
 
 
-def run_c4(a, cfg, S, F, hoods, dev, dist, rank, world):
+def measure_c4(cfg, n, R, dev, timer, steps, warmup, rank, parity=True):
     """BASELINE configs[3]: ExpertSolver on the C2 geometry, prepare once, then right-hand sides F_t = sin(pi x + 0.01 t)
-    cos(pi y).  A step = ONE solve_many_device call over --nrhs stacked fields (256 right-hand
-    sides = 4 steps at the default 64); a fit = one (case, field) pair.  Algorithmic bytes per fit: fk 8 nk + fi 8 no
-    + the geometry (8 nk dim + 8 dim + 20) shared by the nrhs fields of a step.  The time-stepping rate (one fused
-    solve_device launch per field, 852 B per fit) is reported beside it."""
+    cos(pi y).  A step = ONE solve_many_device call over R stacked fields; a fit = one (case, field)
+    pair.  Algorithmic bytes per fit: fk 8 nk + fi 8 no + the geometry (8 nk dim + 8 dim + 20) shared by the R fields of a
+    step.  The time-stepping rate (one fused solve_device launch per field, 852 B per fit) is reported beside it."""
     import torch
     import wlsqm
-    dim, order, nk, n, R = cfg["dim"], cfg["order"], cfg["nk"], a.ncases, a.nrhs
+    import wlsqm.hip as whip
+    dim, order, nk = cfg["dim"], cfg["order"], cfg["nk"]
     no = NDOF[dim][order]
+    S, F, hoods = build_problem(cfg, n, rank, device=dev)
     solver = wlsqm.ExpertSolver(dimension=dim, nk=np.full(n, nk, np.int32), order=np.full(n, order, np.int32),
                                 knowns=np.full(n, cfg["knowns"], np.int64),
                                 weighting_method=np.full(n, cfg["wm"], np.int32))
-    t0 = time.perf_counter()
-    solver.prepare(xi=S, xk=S[hoods])
-    t_prepare = time.perf_counter() - t0
     S_d = torch.from_numpy(S).to(dev)
     h_d = torch.from_numpy(hoods.astype(np.int64)).to(dev)
+    t0 = time.perf_counter()
+    solver.prepare_device(S_d, S_d[h_d].contiguous())
+    torch.cuda.synchronize()
+    t_prepare = time.perf_counter() - t0
     fk = torch.empty((R, n, nk), dtype=torch.float64, device=dev)
     for r in range(R):
         fk[r] = (torch.sin(np.pi * S_d[:, 0] + 0.01 * r) * torch.cos(np.pi * S_d[:, 1]))[h_d]
     fi = torch.zeros((R, n, no), dtype=torch.float64, device=dev)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    t_wake = time.perf_counter()
-    while time.perf_counter() - t_wake < 0.3:
-        solver.solve_many_device(fk, fi)
-        torch.cuda.synchronize()
-    for _ in range(a.warmup):
-        solver.solve_many_device(fk, fi)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        solver.solve_many_device(fk, fi)
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = timer.run(lambda: solver.solve_many_device(fk, fi), steps, warmup)
+    kernel = whip.last_kernel()
     # the kernel alone, events on the stream it is launched on (torch's current stream is passed to the launch)
-    reps = min(max(a.steps, 5), 50)
+    reps = min(max(steps, 5), 50)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
@@ -253,31 +291,25 @@ def run_c4(a, cfg, S, F, hoods, dev, dist, rank, world):
     # time stepping: one fused launch per field
     fi_seq = torch.zeros_like(fi[0])
     e0.record()
-    for r in range(R):
+    for r in range(min(R, 64)):
         solver.solve_device(fk[r], fi_seq)
     e1.record(); torch.cuda.synchronize()
-    ms_step_field = e0.elapsed_time(e1) / R
+    ms_step_field = e0.elapsed_time(e1) / min(R, 64)
     B_fit = 8 * nk + 8 * no + (8 * nk * dim + 8 * dim + 20) / R
     achieved = B_fit * n * R / (ms_kernel * 1e-3) / 1e9
-    if rank == 0:
-        out = {
-            "metric": "local fits/s (whole node)", "value": world * n * R * a.steps / dt, "unit": "fits/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "C4: %s; %d cases x %d stacked fields per GPU per step (a fit = one case of one field), "
-                                   "geometry and fields device-resident" % (cfg["desc"], n, R),
-                       "fits_per_gpu": n * R, "bytes_per_fit": B_fit, "prepare_ms_host_arrays": t_prepare * 1e3},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": load_traffic("C4", n * R), "kernel_ms": ms_kernel},
-            "time_stepping": {"ms_per_field": ms_step_field, "fits_per_s": n / (ms_step_field * 1e-3),
-                              "bytes_per_fit": bytes_per_fit(dim, order, nk, cfg["knowns"])},
-        }
-        if a.no_parity:
-            print(json.dumps(out), flush=True)
-            if dist is not None:
-                dist.barrier(); dist.destroy_process_group()
-            return
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
+    traffic, tsrc = load_traffic("C4", n * R)
+    res = {"workload": "C4: %s; %d cases x %d stacked fields per GPU per step (a fit = one case of one field), "
+                       "geometry and fields device-resident" % (cfg["desc"], n, R),
+           "fits_per_gpu": n * R, "nrhs": R, "bytes_per_fit": B_fit, "prepare_ms_device_arrays": t_prepare * 1e3,
+           "ms_per_step": dt / steps * 1e3, "fits_per_s": n * R * steps / dt,
+           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": tsrc, "kernel_ms": ms_kernel,
+                        "kernel": kernel, "algorithmic_bytes_per_launch": B_fit * n * R},
+           "time_stepping": {"ms_per_field": ms_step_field, "fits_per_s": n / (ms_step_field * 1e-3),
+                             "bytes_per_fit": bytes_per_fit(dim, order, nk, cfg["knowns"])}}
+    if parity and rank == 0:
+        # the last field of the stack against the oracle and the 80-bit solution (the reference has no stacked solve: its
+        # ExpertSolver.solve is called once per field, expert.pyx:537-571; the golden of this geometry is C2's)
         from oracle import oracle
         import _parity
         ns = min(n, 1024)
@@ -288,13 +320,135 @@ def run_c4(a, cfg, S, F, hoods, dev, dist, rank, world):
                 np.full(ns, cfg["wm"], np.int32))
         oracle.fit_many(dim, xk_h, fk_h, meta[0], xi_h, fi_o, None, 0, meta[1], meta[2], meta[3], ntasks=8)
         truth = _parity.truth_fit(dim, xk_h, fk_h, meta[0], xi_h, fi_in, meta[1], meta[2], meta[3])
-        E = _parity.column_metric(fi[r, :ns].cpu().numpy(), fi_o); N = _parity.column_metric(fi_o, truth)
-        out["parity"] = {"cases": ns, "field": r, "colmax_vs_oracle": float(E.max()), "oracle_fp64_noise_floor": float(N.max()),
-                         "within_1e-10_plus_8x_noise": bool(np.all(E <= 1e-10 + 8.0 * N))}
-        print(json.dumps(out), flush=True)
+        fi_seq2 = torch.zeros_like(fi[0])
+        solver.solve_device(fk[r], fi_seq2)
+        torch.cuda.synchronize()
+        acc = _parity.accounting(fi[r, :ns].cpu().numpy(), fi_o, truth=truth)
+        acc["reference"] = "CPU oracle on the first %d cases of field %d (the reference has no stacked solve)" % (ns, r)
+        acc["max_rel_diff_to_sequential_solve_device"] = float(((fi[r] - fi_seq2).abs().amax(0) / fi_seq2.abs().amax(0)).max())
+        res["parity"] = {"vs_oracle": acc}
+    del fk, fi
+    return res, dt
+
+
+def halton_device(n, dim, dev, skip=1):
+    """synth.halton on the GPU (same operations in the same order per point: bit-identical), for the 16M-point cloud."""
+    import torch
+    idx = torch.arange(skip, skip + n, dtype=torch.int64, device=dev)
+    out = torch.empty((n, dim), dtype=torch.float64, device=dev)
+    for d in range(dim):
+        b = (2, 3, 5)[d]
+        i = idx.clone(); f = 1.0
+        r = torch.zeros(n, dtype=torch.float64, device=dev)
+        while bool((i > 0).any()):
+            f = f / b
+            r += f * (i % b).to(torch.float64)
+            i //= b
+        out[:, d] = r
+    return out
+
+
+def morton_order_device(S, bits=16):
+    """synth.morton_order on the GPU."""
+    import torch
+    q = (S * (1 << bits)).to(torch.int64).clamp_(0, (1 << bits) - 1)
+    dim = S.shape[1]
+    key = torch.zeros(S.shape[0], dtype=torch.int64, device=S.device)
+    for b in range(bits):
+        for d in range(dim):
+            key |= ((q[:, d] >> b) & 1) << (b * dim + d)
+    return torch.argsort(key, stable=True)
+
+
+def run_sharded(a, dev, dist, rank, world, timer, parity=True):
+    """BASELINE configs[4] in its literal form: ONE 3D cloud of world x --ncases Morton-ordered Halton points, partitioned over
+    the ranks in contiguous blocks; every rank searches only its own points (against a verified halo band), fits them with the
+    index-based kernel from its local tables and, per step, receives only the halo values it names (all_to_all_single on a side
+    stream, overlapped with the interior fits).  A step = exchange + fit of every point + an explicit update of the field
+    (F <- fitted value + 1e-7 x fitted Laplacian).  value = points of the whole cloud x steps / time."""
+    import torch
+    import wlsqm.hip as whip
+    from wlsqm.sharded import HaloCloudSolver
+    cfg = CONFIGS["C5"]
+    dim, order, nk = cfg["dim"], cfg["order"], cfg["nk"]
+    no = NDOF[dim][order]
+    n_local = a.ncases
+    N = n_local * world
+    t0 = time.perf_counter()
+    S = halton_device(N, dim, dev)
+    S = S[morton_order_device(S)].contiguous()
+    solver = HaloCloudSolver(dim, S, nk, order=order, knowns=cfg["knowns"], weighting_method=cfg["wm"], device=dev)
+    F0 = torch.sin(np.pi * S[:, 0]) * torch.cos(np.pi * S[:, 1]) * torch.exp(S[:, 2])
+    solver.set_own_values_from_global(F0)
+    del F0
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter() - t0
+
+    def step():
+        fi = solver.step()
+        solver.values[: solver.n_own] = fi[:, 0] + 1e-7 * (fi[:, 4] + fi[:, 6] + fi[:, 8])      # i3_X2, i3_Y2, i3_Z2
+    dt = timer.run(step, a.steps, a.warmup)
+    kernel = whip.last_kernel()
+    # the two parts alone (events on the launch stream): fits without the exchange, exchange without the fits
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    reps = max(3, min(a.steps, 20))
+    timer.barrier()
+    ev[0].record()
+    for _ in range(reps):
+        solver.fit_interior(); solver.fit_boundary()
+    ev[1].record(); torch.cuda.synchronize()
+    timer.barrier()
+    ev[2].record()
+    for _ in range(reps):
+        solver.exchange_begin(); solver.exchange_end()
+    ev[3].record(); torch.cuda.synchronize()
+    ms_fit = ev[0].elapsed_time(ev[1]) / reps
+    ms_comm = ev[2].elapsed_time(ev[3]) / reps
+    stats = torch.tensor([ms_fit, ms_comm, float(solver.n_halo), float(solver.n_own - solver.n_int), float(solver.send_idx.numel())],
+                         dtype=torch.float64, device=dev)
     if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        dist.all_reduce(stats, op=dist.ReduceOp.MAX)
+    ms_fit, ms_comm, halo_max, bnd_max, send_max = stats.tolist()
+    B_fit = bytes_per_fit_indexed(dim, order, nk)
+    achieved = B_fit * solver.n_own / (ms_fit * 1e-3) / 1e9
+    out = {"metric": "local fits/s (whole node)", "value": N * a.steps / dt, "unit": "fits/s",
+           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "C5 sharded (BASELINE configs[4] literal): one Morton-ordered 3D Halton cloud of %d points, %d per "
+                                  "rank, 40 neighbours, order 2, WEIGHT_CENTER; own-points-only neighbour search + halo band, "
+                                  "index-based fit from local tables, halo values exchanged per step (all_to_all_single) under the "
+                                  "interior fits, explicit field update" % (N, n_local),
+                      "fits_per_gpu": n_local, "bytes_per_fit": B_fit},
+           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                        "traffic": None, "traffic_source": None, "kernel_ms": ms_fit, "kernel": kernel,
+                        "note": "index-based bytes (4 nk + 8 (dim+1) + 8 no + 20 per fit): never mixed with the dense-layout metric; "
+                                "kernel_ms = interior + boundary launch of a step"},
+           "sharded": {"points": N, "ms_fit": ms_fit, "ms_comm_alone": ms_comm, "ms_step": dt / a.steps * 1e3,
+                       "halo_points_max_over_ranks": int(halo_max), "boundary_cases_max_over_ranks": int(bnd_max),
+                       "sent_values_max_over_ranks": int(send_max), "halo_bytes_received_per_step": int(halo_max) * 8,
+                       "full_allgather_bytes_per_step": 8 * (N - n_local), "halo_radius": solver.halo_radius,
+                       "setup_s": t_setup}}
+    if parity and rank == 0:
+        # first 1 024 local cases against the oracle on the same (dense-gathered) inputs of the CURRENT field
+        from oracle import oracle
+        import _parity
+        ns = min(solver.n_own, 1024)
+        solver.exchange_begin(); solver.exchange_end()
+        h = solver.hoods32[:ns].long()
+        xk_h = solver.S_tab[h].cpu().numpy(); fk_h = solver.values[h].cpu().numpy(); xi_h = solver.S_tab[:ns].cpu().numpy()
+        fi_d = torch.zeros((ns, no), dtype=torch.float64, device=dev); fi_d[:, 0] = solver.values[:ns]
+        fi_in = fi_d.cpu().numpy()
+        whip.fit_cloud_device(dim, order, solver.S_tab, solver.values, solver.hoods32[:ns], fi_d, solver.nk_t[:ns], solver.kn_t[:ns],
+                              solver.wm_t[:ns], point_index=solver.pidx[:ns])
+        torch.cuda.synchronize()
+        meta = (np.full(ns, nk, np.int32), np.full(ns, order, np.int32), np.full(ns, cfg["knowns"], np.int64), np.full(ns, cfg["wm"], np.int32))
+        fi_o = fi_in.copy()
+        oracle.fit_many(dim, xk_h, fk_h, meta[0], xi_h, fi_o, None, 0, meta[1], meta[2], meta[3], ntasks=8)
+        truth = _parity.truth_fit(dim, xk_h, fk_h, meta[0], xi_h, fi_in, meta[1], meta[2], meta[3])
+        acc = _parity.accounting(fi_d.cpu().numpy(), fi_o, truth=truth)
+        acc["reference"] = "CPU oracle on the first %d local cases, current field" % ns
+        out["parity"] = {"vs_oracle": acc}
+    return out
 
 
 def cpu_baseline(oracle, cfg, xk_d, fk_d, xi_d, F, n, no):
@@ -306,6 +460,7 @@ def cpu_baseline(oracle, cfg, xk_d, fk_d, xi_d, F, n, no):
     xk_h = xk_d[:ns].cpu().numpy(); fk_h = fk_d[:ns].cpu().numpy(); xi_h = xi_d[:ns].cpu().numpy()
     meta = (np.full(ns, nk, np.int32), np.full(ns, order, np.int32), np.full(ns, cfg["knowns"], np.int64),
             np.full(ns, cfg["wm"], np.int32))
+
     def rate(threads, budget_s):
         best, reps, t_all = 0.0, 0, time.perf_counter()
         while True:
@@ -327,6 +482,114 @@ def cpu_baseline(oracle, cfg, xk_d, fk_d, xi_d, F, n, no):
             "sample": "%d cases of the same workload, best pass per team size, OpenMP static schedule; team sizes tried: %s "
                       "(host has %d hardware threads)" % (ns, ", ".join("%d: %.3g" % (t, rates[t]) for t in ladder), cores),
             "value_8_threads": rates.get(8, rates[ladder[0]]), "value_all_threads": rates[cores]}
+
+
+def headline_line(res, world, a, dt, units):
+    out = {"metric": "local fits/s (whole node)", "value": world * units * a.steps / dt, "unit": "fits/s",
+           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {k: res[k] for k in ("workload", "fits_per_gpu", "bytes_per_fit") if k in res},
+           "roofline": res["roofline"]}
+    for k in ("nrhs", "prepare_ms_device_arrays", "time_stepping", "parity"):
+        if k in res:
+            out[k] = res[k]
+    return out
+
+
+def side_configs(a, dev, timer, rank, parity):
+    """Every other BASELINE config with the same --steps / --warmup (single GPU).  Each entry carries its own roofline block."""
+    import copy
+    import torch
+    side = {}
+    short = dict(steps=max(1, min(a.steps, 20)), warmup=min(a.warmup, 3))
+
+    def add(key, fn):
+        t0 = time.perf_counter()
+        try:
+            res = fn()
+            res = res[0] if isinstance(res, tuple) else res
+            res["wall_s_including_setup"] = time.perf_counter() - t0
+            side[key] = res
+        except Exception as e:      # a side config must never take the headline down with it
+            side[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+        torch.cuda.empty_cache()
+
+    add("C1@10k", lambda: measure_fit("C1", CONFIGS["C1"], 10_000, dev, timer, a.steps, a.warmup, rank, False))
+    add("C1@4M", lambda: measure_fit("C1", CONFIGS["C1"], 4_000_000, dev, timer, a.steps, a.warmup, rank, False))
+    add("C3@1M", lambda: measure_fit("C3", CONFIGS["C3"], 1_000_000, dev, timer, a.steps, a.warmup, rank, parity))
+    add("C4@1M,R=%d" % (a.nrhs or 256), lambda: measure_c4(CONFIGS["C4"], 1_000_000, a.nrhs or 256, dev, timer, short["steps"],
+                                                           short["warmup"], rank, parity))
+    add("C5@1M", lambda: measure_fit("C5", CONFIGS["C5"], 1_000_000, dev, timer, a.steps, a.warmup, rank, parity))
+    add("C5@16M", lambda: measure_fit("C5", CONFIGS["C5"], 16_000_000, dev, timer, short["steps"], short["warmup"], rank, False))
+
+    def sharded():
+        b = copy.copy(a)
+        b.ncases, b.steps, b.warmup = 2_000_000, short["steps"], short["warmup"]
+        line = run_sharded(b, dev, None, rank, 1, timer, parity)
+        return {k: line[k] for k in ("config", "steps", "ms_per_step", "value", "roofline", "sharded", "parity") if k in line}
+    add("C5-sharded@2M-per-rank", sharded)
+    return side
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default=None, choices=sorted(CONFIGS),
+                    help="measure this config as `value` (default: C2 as `value` plus every other config under `configs`)")
+    ap.add_argument("--ncases", type=int, default=None, help="local fits per GPU per step (default 1M; --sharded: 2M points per rank)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the parity checks (profiling passes)")
+    ap.add_argument("--no-side-configs", action="store_true", help="default run: C2 only")
+    ap.add_argument("--nrhs", type=int, default=None, help="C4: right-hand sides stacked per step (default 256 = BASELINE configs[3])")
+    ap.add_argument("--sharded", action="store_true",
+                    help="C5 in the literal form of BASELINE configs[4]: one Morton-ordered cloud of --ncases points PER RANK, "
+                         "index-based fit, time-stepped with a halo exchange between ranks (wlsqm/sharded.py)")
+    a = ap.parse_args()
+    if a.ncases is None:
+        a.ncases = 2_000_000 if a.sharded else 1_000_000
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if "RANK" in os.environ:        # launched by torch.distributed.run: one rank per GPU, RCCL ("nccl") process group
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    timer = Timer(dist, dev)
+    headline = a.config or "C2"
+    cfg = CONFIGS[headline]
+    parity = not a.no_parity
+
+    if a.sharded:
+        out = run_sharded(a, dev, dist, rank, world, timer, parity)
+    elif headline == "C4":
+        R = a.nrhs or 256
+        res, dt = measure_c4(cfg, a.ncases, R, dev, timer, a.steps, a.warmup, rank, parity)
+        out = headline_line(res, world, a, dt, a.ncases * R)
+    else:
+        res, dt = measure_fit(headline, cfg, a.ncases, dev, timer, a.steps, a.warmup, rank, parity, keep=True)
+        tensors = res.pop("_tensors")
+        out = headline_line(res, world, a, dt, a.ncases)
+        if rank == 0 and world == 1 and not a.no_cpu_baseline:
+            from oracle import oracle
+            out["cpu_baseline"] = cpu_baseline(oracle, cfg, tensors["xk"], tensors["fk"], tensors["xi"], tensors["F"], a.ncases,
+                                               NDOF[cfg["dim"]][cfg["order"]])
+        del tensors
+        torch.cuda.empty_cache()
+        if a.config is None and world == 1 and not a.no_side_configs:
+            out["configs"] = side_configs(a, dev, timer, rank, parity)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

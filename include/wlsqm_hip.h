@@ -156,6 +156,11 @@ int wlsqm_hip_expert_solve_device(wlsqm_expert* h, void* stream, const double* f
  * wlsqm_hip_fit_cloud_device.  Exact (uniform-grid search with a provable stop test).  1 <= k <= min(npoints - 1, 213).
  * Synchronises `stream` before returning. */
 int wlsqm_hip_knn_device(int dimension, int64_t npoints, const double* S, int k, int32_t* hoods, int device, void* stream);
+/* Extension: the same search asked only by the FIRST nquery points of the cloud; the remaining npoints - nquery points are
+ * candidates only (hoods[nquery, k], indices into S).  The rank of a partitioned cloud searches its own points against its
+ * own points plus a halo band of its neighbours' (wlsqm/sharded.py) instead of the global cloud. */
+int wlsqm_hip_knn_subset_device(int dimension, int64_t npoints, const double* S, int k, int64_t nquery, int32_t* hoods,
+                                int device, void* stream);
 /* Extension: the radius form of the same search (examples/wlsqm_example.py:103-133: query_ball_point(x, r), at most
  * max_nk neighbours kept).  For every point the other points within `radius`, nearest first, at most max_nk of them:
  * hoods[npoints, max_nk] (int32; unused slots hold the point's own index) and nk[npoints] (int32, the counts). */

@@ -73,12 +73,15 @@ __global__ __launch_bounds__(64, 1) void fit_ring_kernel(const KParams p, const 
         double* dst = lds + slot * G::SLOT;
         const char* xbase = reinterpret_cast<const char*>(p.xk + j0 * (long long)(K * DIM));
         const unsigned lane16 = (unsigned)lane * 16u;
+        // one region per 64-neighbour part, so that the active lanes of every DMA are a PREFIX of the wave (with the parts
+        // interleaved per row the compiler threads the repeated lane condition into two paths and issues the full-row DMAs
+        // once for the low and once for the high lanes: wrong rows for K > 64, measured)
 #pragma unroll
-        for (int r = 0; r < TC; ++r) {
-            const int rs = r < nvalid ? r : nvalid - 1;                            // tail tile: replay the last valid row
+        for (int pp = 0; pp < G::PARTS; ++pp) {
+            if ((pp + 1) * WV <= K || pp * WV + lane < K) {
 #pragma unroll
-            for (int pp = 0; pp < G::PARTS; ++pp) {
-                if ((pp + 1) * WV <= K || pp * WV + lane < K) {
+                for (int r = 0; r < TC; ++r) {
+                    const int rs = r < nvalid ? r : nvalid - 1;                    // tail tile: replay the last valid row
                     const char* src = xbase + (size_t)(rs * K + pp * WV) * 16u;   // uniform
                     __builtin_amdgcn_global_load_lds((ring_glb_ptr_t)(src + lane16), (ring_lds_ptr_t)(dst + r * RS + pp * WV * DIM),
                                                      16, 0, 0);
@@ -147,6 +150,8 @@ __global__ __launch_bounds__(64, 1) void fit_ring_kernel(const KParams p, const 
         const double* row = lds + (it & 1) * G::SLOT + c * RS + k0 * DIM;       // this lane's share of its case's row
         if (tile + 1 < tend) prefetch(tile + 1, (it + 1) & 1);
 
+        // (squared distances are written as explicit fma(dy, dy, dx * dx) everywhere: the ragged and the full-tile code paths
+        // must round identically, or a case's result would depend on which other cases share its tile)
         auto offset = [&](int kk, double (&d)[DIM]) {  // neighbour k0 + kk of this lane's case (ds_read_b128, immediate offset)
             const rd2_ xy = *reinterpret_cast<const rd2_*>(row + kk * DIM);
             d[0] = xy.x - xi[0]; d[1] = xy.y - xi[1];
@@ -158,7 +163,7 @@ __global__ __launch_bounds__(64, 1) void fit_ring_kernel(const KParams p, const 
             for (int kk = 0; kk < KPL; ++kk) {
                 double d[DIM];
                 offset(kk, d);
-                const double d2 = d[0] * d[0] + d[1] * d[1];
+                const double d2 = fma(d[1], d[1], d[0] * d[0]);
                 max_d2 = d2 > max_d2 ? d2 : max_d2;
             }
         } else {
@@ -166,7 +171,7 @@ __global__ __launch_bounds__(64, 1) void fit_ring_kernel(const KParams p, const 
             for (int kk = 0; kk < KPL; ++kk) {
                 double d[DIM];
                 offset(kk, d);
-                double d2 = d[0] * d[0] + d[1] * d[1];
+                double d2 = fma(d[1], d[1], d[0] * d[0]);
                 d2 = (k0 + kk < nkc) ? d2 : 0.0;
                 max_d2 = d2 > max_d2 ? d2 : max_d2;
             }
@@ -184,7 +189,7 @@ __global__ __launch_bounds__(64, 1) void fit_ring_kernel(const KParams p, const 
             double d[DIM];
             offset(kk, d);
             d[0] = live ? d[0] : 0.0; d[1] = live ? d[1] : 0.0;
-            const double d2 = d[0] * d[0] + d[1] * d[1];
+            const double d2 = fma(d[1], d[1], d[0] * d[0]);
             const double w = live ? weight(d2, inv_max, uniform) : 0.0;
             accumulate_moments_best<DIM, ORDER>(mu, nu, d, w, live ? f[kk] : 0.0);
         };
@@ -214,11 +219,12 @@ __global__ __launch_bounds__(64, 1) void fit_ring_kernel(const KParams p, const 
     if (it & 3) solve_parked();                        // leftovers of a run that is not a multiple of 4 tiles
 }
 
-// tiles per workgroup: a multiple of 4 (one solve per 4 tiles); WLSQM_HIP_RING_TILES overrides (A/B)
+// tiles per workgroup: a multiple of 4 (one solve per 4 tiles); WLSQM_HIP_RING_TILES overrides (A/B: 1M C3 cases at
+// 4 / 8 / 16 / 64 tiles per workgroup 0.532 / 0.539 / 0.536 / 0.539 ms — the dispatcher balances short workgroups best)
 static int ring_tiles_per_wg() {
     const char* e = getenv("WLSQM_HIP_RING_TILES");
-    const int v = e ? atoi(e) : 8;
-    return v >= 1 ? v : 8;
+    const int v = e ? atoi(e) : 4;
+    return v >= 1 ? v : 4;
 }
 
 template <int ORDER, int K, int UNR>
@@ -254,9 +260,15 @@ int launch_fit_ring(int dimension, int order, const KParams& p, long long max_nk
     const char* noring = getenv("WLSQM_HIP_DISABLE_RING");       // A/B against the two-kernel moment path
     if (noring && noring[0] == '1') return WLSQM_OK;
     if (dimension != 2 || order != 4 || p.hoods) return WLSQM_OK;
+    if (p.do_sens || p.iterative || p.case_index) return WLSQM_OK;
     if (!tile_dense_eligible(dimension, p, max_nk)) return WLSQM_OK;
+    // Every even K from 26 to 64 (400k cases, ms per launch, two-kernel moment path -> this kernel): K = 26 / 32 / 40 / 48 / 56 / 64:
+    // 0.220 / 0.192 / 0.281 / 0.238 / 0.323 / 0.260 -> 0.179 / 0.184 / 0.189 / 0.212 / 0.228 / 0.213.  Below 26 the two paths tie
+    // (K = 16 / 24: 0.147 / 0.167 against 0.151 / 0.170); beyond 64 a row needs two DMA instructions and the ring 43-56 KB of
+    // LDS (three waves per CU): K = 80 / 100: 0.424 / 0.644 against 0.361 / 0.504 — those stay on the two-kernel path.
 #define RING_CASE(KK) if (max_nk == KK) { *handled = true; return launch_ring_impl<4, KK, 16>(p, stream); }
-    RING_CASE(64)
+    RING_CASE(26) RING_CASE(28) RING_CASE(30) RING_CASE(32) RING_CASE(34) RING_CASE(36) RING_CASE(38) RING_CASE(40) RING_CASE(42) RING_CASE(44)
+    RING_CASE(46) RING_CASE(48) RING_CASE(50) RING_CASE(52) RING_CASE(54) RING_CASE(56) RING_CASE(58) RING_CASE(60) RING_CASE(62) RING_CASE(64)
 #undef RING_CASE
     return WLSQM_OK;
 }

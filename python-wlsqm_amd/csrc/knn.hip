@@ -111,12 +111,15 @@ template <int DIM>
 __global__ __launch_bounds__(64) void knn_query_kernel(const double* __restrict__ Ss, const int* __restrict__ perm,
                                                       const int* __restrict__ start, long long n, int k, KnnGrid G,
                                                       double r2max, int row_stride, int* __restrict__ hoods,
-                                                      int* __restrict__ counts) {
+                                                      int* __restrict__ counts, long long nquery) {
     extern __shared__ __attribute__((aligned(8))) unsigned char smem[];
     double* bd = reinterpret_cast<double*>(smem) + threadIdx.x;                       // [k][64] best squared distances
     int* bi = reinterpret_cast<int*>(smem + (size_t)k * 64 * sizeof(double)) + threadIdx.x;   // [k][64] their sorted positions
     const long long q = (long long)blockIdx.x * 64 + threadIdx.x;
     if (q >= n) return;
+    // subset search: only the first `nquery` points of the cloud ask (the others are candidates only — the halo band of a
+    // partitioned cloud, wlsqm/sharded.py); their lanes retire here
+    if (perm[q] >= nquery) return;
     double x[DIM]; int cq[DIM];
 #pragma unroll
     for (int m = 0; m < DIM; ++m) { x[m] = Ss[q * DIM + m]; cq[m] = cell_coord(x[m], G, m); }
@@ -299,7 +302,9 @@ int GridIndex::build(int dimension, int64_t npoints, const double* S, hipStream_
 
 // k nearest other points within squared distance r2max of every point; row_stride slots per row of hoods
 static int neighbour_search(int dimension, int64_t npoints, const double* S, int k, double r2max, int row_stride,
-                            int32_t* hoods, int32_t* counts, int device, void* stream_) {
+                            int32_t* hoods, int32_t* counts, int device, void* stream_, int64_t nquery = -1) {
+    if (nquery < 0) nquery = npoints;
+    if (nquery > npoints) { set_error("nquery must be <= npoints"); return WLSQM_EVALUE; }
     if (dimension < 1 || dimension > 3) { set_error("dimension must be 1, 2 or 3"); return WLSQM_EVALUE; }
     if (!S || !hoods) { set_error("null array"); return WLSQM_EVALUE; }
     if (k < 1 || npoints < 2 || (int64_t)k > npoints - 1) { set_error("k must be in 1 .. npoints - 1"); return WLSQM_EVALUE; }
@@ -320,7 +325,7 @@ static int neighbour_search(int dimension, int64_t npoints, const double* S, int
         if (lds > 64 * 1024)                                                                                            \
             WLSQM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL(kern, dim3(qblocks), dim3(64), lds, s, grid.d_Ss.as<double>(), grid.d_perm.as<int>(),        \
-                           grid.d_start.as<int>(), n, k, G, r2max, row_stride, hoods, counts);                         \
+                           grid.d_start.as<int>(), n, k, G, r2max, row_stride, hoods, counts, (long long)nquery);     \
     }
     if (dimension == 1) KNN_LAUNCH(1) else if (dimension == 2) KNN_LAUNCH(2) else KNN_LAUNCH(3)
 #undef KNN_LAUNCH
@@ -467,6 +472,10 @@ extern "C" int wlsqm_hip_knn_device(int dimension, int64_t npoints, const double
     return neighbour_search(dimension, npoints, S, k, DBL_MAX, k, hoods, nullptr, device, stream);
 }
 
+extern "C" int wlsqm_hip_knn_subset_device(int dimension, int64_t npoints, const double* S, int k, int64_t nquery, int32_t* hoods,
+                                           int device, void* stream) {
+    return neighbour_search(dimension, npoints, S, k, DBL_MAX, k, hoods, nullptr, device, stream, nquery);
+}
 extern "C" int wlsqm_hip_ball_device(int dimension, int64_t npoints, const double* S, double radius, int max_nk,
                                      int32_t* hoods, int32_t* nk, int device, void* stream) {
     if (!(radius > 0.0)) { set_error("radius must be positive"); return WLSQM_EVALUE; }

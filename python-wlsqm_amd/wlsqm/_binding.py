@@ -84,6 +84,7 @@ def lib():
     L.wlsqm_hip_expert_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
     L.wlsqm_hip_knn_device.argtypes = [C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    L.wlsqm_hip_knn_subset_device.argtypes = [C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]
     L.wlsqm_hip_ball_device.argtypes = [C.c_int, C.c_int64, C.c_void_p, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                         C.c_void_p]
     L.wlsqm_hip_nearest_device.argtypes = [C.c_int, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int,
@@ -114,7 +115,7 @@ def lib():
                  "wlsqm_hip_expert_solve_device", "wlsqm_hip_expert_solve_many_device", "wlsqm_hip_expert_solve_many",
                  "wlsqm_hip_expert_memory_used", "wlsqm_hip_expert_destroy",
                  "wlsqm_hip_expert_conds", "wlsqm_hip_expert_interpolate", "wlsqm_hip_interpolate_fit_host",
-                 "wlsqm_hip_fit_cloud_device", "wlsqm_hip_time_fit_cloud_device", "wlsqm_hip_knn_device", "wlsqm_hip_ball_device", "wlsqm_hip_nearest_device",
+                 "wlsqm_hip_fit_cloud_device", "wlsqm_hip_time_fit_cloud_device", "wlsqm_hip_knn_device", "wlsqm_hip_knn_subset_device", "wlsqm_hip_ball_device", "wlsqm_hip_nearest_device",
                  "wlsqm_hip_expert_interpolate_nearest", "wlsqm_hip_expert_interpolate_continuous",
                  "wlsqm_hip_number_of_dofs", "wlsqm_hip_number_of_reduced_dofs", "wlsqm_hip_remap"):
         getattr(L, name).restype = C.c_int

@@ -202,12 +202,13 @@ def time_fit_cloud_device(dimension, order, S, F, hoods, fi, nk, knowns, weighti
     return float(ms.value)
 
 
-def knn(S, k, stream=None):
+def knn(S, k, stream=None, nquery=None):
     """The k nearest OTHER points of every point of the device-resident cloud S (npoints, dim) [1D: (npoints,)], as an
     int32 device tensor (npoints, k), ascending by (distance, index) — what the reference's examples get on the host from
     ``cKDTree(S).query(S, 1 + k)[1][:, 1:]`` (examples/expertsolver_example.py:48-66).  Exact uniform-grid search on the
     GPU; the result is the ``hoods`` argument of fit_cloud_device / ShardedCloudSolver, or of ``S[hoods]`` for the dense
-    API.  1 <= k <= min(npoints - 1, 213).  Synchronises the stream."""
+    API.  1 <= k <= min(npoints - 1, 213).  Synchronises the stream.
+    With `nquery`, only the first nquery points ask and the rest are candidates only: returns (nquery, k)."""
     import torch
     if S.dim() == 1:
         dim = 1
@@ -219,9 +220,15 @@ def knn(S, k, stream=None):
     if not S.is_contiguous():
         raise ValueError("S must be contiguous")
     n = int(S.shape[0])
-    hoods = torch.empty((n, int(k)), dtype=torch.int32, device=S.device)
+    nq = n if nquery is None else int(nquery)
+    if not 0 < nq <= n:
+        raise ValueError("nquery must be in 1 .. npoints")
+    hoods = torch.empty((nq, int(k)), dtype=torch.int32, device=S.device)
     s, dev = _stream_and_device(S, stream)
-    B.check(B.lib().wlsqm_hip_knn_device(dim, n, _ptr(S), int(k), _ptr(hoods), dev, s))
+    if nquery is None:
+        B.check(B.lib().wlsqm_hip_knn_device(dim, n, _ptr(S), int(k), _ptr(hoods), dev, s))
+    else:
+        B.check(B.lib().wlsqm_hip_knn_subset_device(dim, n, _ptr(S), int(k), nq, _ptr(hoods), dev, s))
     return hoods
 
 

@@ -8,7 +8,7 @@ torch.distributed backend "nccl", gloo on CPU for the tests) — SURVEY.md §8(e
 
 torch is plumbing here: device memory, index gathers and the process group.
 """
-__all__ = ["case_range", "ShardedCloudSolver"]
+__all__ = ["case_range", "ShardedCloudSolver", "HaloCloudSolver"]
 
 
 def case_range(ncases, rank, world):
@@ -88,3 +88,184 @@ class ShardedCloudSolver:
             lo, hi = case_range(self.N, r, self.world)
             parts.append(out[r * self._pad: r * self._pad + (hi - lo)])
         return torch.cat(parts)
+
+
+def _default_knn(cand, k, nquery):
+    from . import hip
+    return hip.knn(cand, k, nquery=nquery).long()
+
+
+class HaloCloudSolver:
+    """ONE global cloud partitioned over the ranks, halo exchange only (the literal form of BASELINE configs[4]).
+
+    Points are owned in contiguous index blocks (`case_range`; order the cloud along a space-filling curve first —
+    synth.morton_order — so that a block is a compact region).  Every rank
+      * searches the neighbours of ITS OWN points only, against its own points plus a halo band of candidates (all points inside
+        its bounding box inflated by a radius that is verified afterwards: the largest k-th neighbour distance must not exceed
+        it, otherwise the band is widened and the search repeated) — `wlsqm.hip.knn(..., nquery=n_own)`;
+      * keeps a LOCAL point table [interior own | boundary own | halo] (coordinates and values) and local neighbour lists, so the
+        index-based fit kernel gathers from a table of its shard's size;
+      * per step exchanges only halo values: the owned values other ranks' neighbour lists name, sent with one
+        `all_to_all_single` (uneven splits; RCCL over xGMI, gloo in the CPU tests) on a side stream while the INTERIOR cases
+        (all neighbours owned) are fitted; the boundary cases follow when the halo has arrived.
+    The coordinates of the global cloud are needed once, at construction (every rank passes the same S)."""
+
+    def __init__(self, dimension, S, nk, order, knowns, weighting_method, device, group=None, fit_fn=None, knn_fn=None,
+                 single=False):
+        import numpy as np
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group = torch, dist, group
+        self.rank = dist.get_rank(group) if dist.is_initialized() and not single else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() and not single else 1
+        self.dimension, self.order, self.nk = int(dimension), int(order), int(nk)
+        self.fit_fn = fit_fn
+        knn_fn = knn_fn or _default_knn
+        dev = torch.device(device)
+        self.device = dev
+        S = torch.as_tensor(S, dtype=torch.float64)
+        if S.dim() == 1:
+            S = S[:, None]
+        S = S.to(dev)
+        N, dim = int(S.shape[0]), int(S.shape[1])
+        self.N = N
+        self.lo, self.hi = case_range(N, self.rank, self.world)
+        lo, hi = self.lo, self.hi
+        n_own = hi - lo
+        own = S[lo:hi]
+        # ---- 1. candidates: own points + halo band, verified
+        if self.world == 1:
+            cand_g = torch.arange(N, device=dev)
+            hl = knn_fn(own.contiguous() if dim > 1 else own[:, 0].contiguous(), self.nk, n_own)
+            self.halo_radius = 0.0
+        else:
+            ext = (S.max(0).values - S.min(0).values).clamp_min(1e-300)
+            ball = {1: 2.0, 2: np.pi, 3: 4.0 * np.pi / 3.0}[dim]
+            r = 1.5 * float((self.nk * float(ext.prod()) / (N * ball)) ** (1.0 / dim))
+            blo, bhi = own.min(0).values, own.max(0).values
+            for attempt in range(8):
+                inside = ((S >= blo - r) & (S <= bhi + r)).all(1)
+                inside[lo:hi] = False
+                halo_g = torch.nonzero(inside)[:, 0]
+                cand_g = torch.cat([torch.arange(lo, hi, device=dev), halo_g])
+                cand = S[cand_g].contiguous()
+                hl = knn_fn(cand if dim > 1 else cand[:, 0].contiguous(), self.nk, n_own)
+                dk = (cand[hl[:, -1]] - own).pow(2).sum(1).max().sqrt().item()
+                if dk <= r:
+                    break
+                r = 1.25 * dk
+            else:
+                raise RuntimeError("halo band did not converge")
+            self.halo_radius = r
+        # ---- 2. canonical neighbour order: ascending (distance, GLOBAL index) — independent of the candidate numbering, so a
+        # partitioned run reproduces the one-rank run bit for bit
+        hg = cand_g[hl]                                           # (n_own, nk) global indices
+        d2 = (S[hg] - own[:, None, :]).pow(2).sum(2)
+        o1 = torch.argsort(hg, dim=1, stable=True)
+        hg = torch.gather(hg, 1, o1); d2 = torch.gather(d2, 1, o1)
+        o2 = torch.argsort(d2, dim=1, stable=True)
+        hg = torch.gather(hg, 1, o2)
+        del d2, o1, o2, hl
+        # ---- 3. local numbering [interior own | boundary own | halo]
+        foreign = (hg < lo) | (hg >= hi)
+        is_bnd = foreign.any(1)
+        order_own = torch.cat([torch.nonzero(~is_bnd)[:, 0], torch.nonzero(is_bnd)[:, 0]])       # local -> own offset
+        self.n_own, self.n_int = n_own, int((~is_bnd).sum().item())
+        need_g = torch.unique(hg[foreign])                        # sorted global indices of the halo points actually named
+        self.n_halo = int(need_g.numel())
+        self.gidx_own = (order_own + lo)                          # global index of local own point i
+        loc_of_own = torch.empty(n_own, dtype=torch.int64, device=dev)
+        loc_of_own[order_own] = torch.arange(n_own, device=dev)
+        hl = torch.where(foreign, torch.zeros_like(hg), loc_of_own[(hg - lo).clamp(0, n_own - 1)])
+        if self.n_halo:
+            hl = torch.where(foreign, n_own + torch.searchsorted(need_g, hg.clamp(0, N - 1)), hl)
+        hl = hl[order_own]                                        # rows in local case order
+        tab_g = torch.cat([self.gidx_own, need_g])
+        S_tab = S[tab_g]
+        self.S_tab = (S_tab[:, 0] if self.dimension == 1 else S_tab).contiguous()
+        self.hoods32 = hl.to(torch.int32).contiguous()
+        self.values = torch.zeros(n_own + self.n_halo, dtype=torch.float64, device=dev)     # field on the local table
+        no = {1: [1, 2, 3, 4, 5], 2: [1, 3, 6, 10, 15], 3: [1, 4, 10, 20, 35]}[self.dimension][self.order]
+        self.fi = torch.zeros((n_own, no), dtype=torch.float64, device=dev)
+        self.nk_t = torch.full((n_own,), self.nk, dtype=torch.int32, device=dev)
+        self.kn_t = torch.full((n_own,), int(knowns), dtype=torch.int64, device=dev)
+        self.wm_t = torch.full((n_own,), int(weighting_method), dtype=torch.int32, device=dev)
+        self.pidx = torch.arange(n_own, dtype=torch.int32, device=dev)
+        # ---- 4. exchange plan (set-up only: object all-gather of the need lists)
+        self.send_idx = torch.zeros(0, dtype=torch.int64, device=dev)
+        self.send_splits, self.recv_splits = [0] * self.world, [0] * self.world
+        if self.world > 1:
+            needs = [None] * self.world
+            dist.all_gather_object(needs, need_g.cpu().numpy(), group=group)
+            bounds = np.array([case_range(N, q, self.world)[0] for q in range(self.world)] + [N])
+            mine = need_g.cpu().numpy()
+            self.recv_splits = [int(np.searchsorted(mine, bounds[q + 1]) - np.searchsorted(mine, bounds[q])) for q in range(self.world)]
+            parts = []
+            loc_cpu = loc_of_own.cpu().numpy()
+            for q in range(self.world):
+                want = needs[q][(needs[q] >= lo) & (needs[q] < hi)] if q != self.rank else np.zeros(0, np.int64)
+                parts.append(loc_cpu[want - lo])
+                self.send_splits[q] = int(len(want))
+            self.send_idx = torch.from_numpy(np.concatenate(parts).astype(np.int64)).to(dev)
+        self._send = torch.empty(int(self.send_idx.numel()), dtype=torch.float64, device=dev)
+        self._recv = torch.empty(self.n_halo, dtype=torch.float64, device=dev)
+        self._comm_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        self._work = None
+
+    # -- values ------------------------------------------------------------------------------------------------------------
+    def set_own_values_from_global(self, F_global):
+        """Own part of the local value table from a global (N,) vector."""
+        self.values[: self.n_own] = F_global.to(self.device)[self.gidx_own]
+
+    def own_values_global(self):
+        """(global indices, values) of the owned points."""
+        return self.gidx_own, self.values[: self.n_own]
+
+    # -- one step ----------------------------------------------------------------------------------------------------------
+    def exchange_begin(self):
+        """Pack the owned values the other ranks name and start the halo exchange (side stream on a GPU)."""
+        torch, dist = self.torch, self.dist
+        if self.world == 1:
+            return
+        torch.index_select(self.values, 0, self.send_idx, out=self._send)
+        if self._comm_stream is not None:
+            ev = torch.cuda.Event(); ev.record()
+            with torch.cuda.stream(self._comm_stream):
+                self._comm_stream.wait_event(ev)
+                dist.all_to_all_single(self._recv, self._send, self.recv_splits, self.send_splits, group=self.group)
+                self.values[self.n_own:] = self._recv
+                self._halo_ready = torch.cuda.Event(); self._halo_ready.record()
+        else:
+            dist.all_to_all_single(self._recv, self._send, self.recv_splits, self.send_splits, group=self.group)
+            self.values[self.n_own:] = self._recv
+
+    def exchange_end(self):
+        if self.world > 1 and self._comm_stream is not None:
+            self.torch.cuda.current_stream().wait_event(self._halo_ready)
+
+    def _fit_rows(self, a, b):
+        if b <= a:
+            return
+        self.fi[a:b, 0] = self.values[a:b]
+        if self.fit_fn is None:
+            from . import hip
+            hip.fit_cloud_device(self.dimension, self.order, self.S_tab, self.values, self.hoods32[a:b], self.fi[a:b],
+                                 self.nk_t[a:b], self.kn_t[a:b], self.wm_t[a:b], point_index=self.pidx[a:b])
+        else:
+            self.fit_fn(self.dimension, self.order, self.S_tab, self.values, self.hoods32[a:b], self.fi[a:b], self.nk_t[a:b],
+                        self.kn_t[a:b], self.wm_t[a:b], self.pidx[a:b])
+
+    def fit_interior(self):
+        self._fit_rows(0, self.n_int)
+
+    def fit_boundary(self):
+        self._fit_rows(self.n_int, self.n_own)
+
+    def step(self):
+        """Exchange the halo and fit every owned point; the interior fits overlap the exchange.  Returns fi (n_own, no) in
+        LOCAL order (gidx_own names the global point of each row)."""
+        self.exchange_begin()
+        self.fit_interior()
+        self.exchange_end()
+        self.fit_boundary()
+        return self.fi

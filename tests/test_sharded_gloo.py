@@ -66,3 +66,67 @@ def test_two_rank_time_stepping_equals_single_process(tmp_path):
     for r in range(2):
         got = np.load(tmp_path / ("F_%d_of_2.npy" % r))
         assert np.array_equal(got, ref)                           # same arithmetic per case -> bit-identical
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# halo-only exchange (HaloCloudSolver): own-points-only neighbour search against a verified halo band, local tables,
+# all_to_all_single of the halo values, interior / boundary split
+
+def _cpu_knn(cand, k, nquery):
+    import torch
+    from scipy.spatial import cKDTree
+    c = cand.numpy()
+    if c.ndim == 1:
+        c = c[:, None]
+    _, idx = cKDTree(c).query(c[:nquery], k + 1)
+    return torch.from_numpy(np.ascontiguousarray(idx[:, 1:]).astype(np.int64))
+
+
+def _oracle_cloud_fit(dimension, order, S_tab, values, hoods, fi, nk, knowns, wm, pidx):
+    from oracle import oracle
+    n = nk.shape[0]
+    S = S_tab.numpy(); V = values.numpy(); h = hoods.numpy().astype(np.int64); p = pidx.numpy().astype(np.int64)
+    xk = S[h]; fk = V[h]; xi = S[p]
+    fi_np = fi.numpy()                                           # a view: the oracle writes the solver's rows in place
+    oracle.fit_many(dimension, xk, fk, nk.numpy(), xi, fi_np, None, 0, np.full(n, order, np.int32), knowns.numpy(), wm.numpy())
+
+
+def _run_halo(rank, world, port, S, nk, F0, steps, out_dir):
+    import torch
+    import torch.distributed as dist
+    from wlsqm.sharded import HaloCloudSolver, case_range
+    if world > 1:
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    s = HaloCloudSolver(2, S, nk, order=2, knowns=1, weighting_method=2, device="cpu", fit_fn=_oracle_cloud_fit, knn_fn=_cpu_knn)
+    assert (s.lo, s.hi) == case_range(len(S), rank, world)
+    if world > 1:
+        assert 0 < s.n_halo < len(S) - s.n_own               # a band, not the rest of the cloud
+        assert 0 < s.n_int < s.n_own                         # interior and boundary cases both exist
+        assert sum(s.recv_splits) == s.n_halo and s.recv_splits[rank] == 0
+    s.set_own_values_from_global(torch.from_numpy(F0))
+    for _ in range(steps):
+        fi = s.step()
+        s.values[: s.n_own] = fi[:, 0] + 1e-4 * (fi[:, 3] + fi[:, 5])     # toy explicit step on the owned points
+    g, v = s.own_values_global()
+    np.save(os.path.join(out_dir, "halo_g_%d_of_%d.npy" % (rank, world)), g.numpy())
+    np.save(os.path.join(out_dir, "halo_v_%d_of_%d.npy" % (rank, world)), v.numpy())
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_halo_exchange_time_stepping_equals_single_process(tmp_path, world):
+    import torch.multiprocessing as mp
+    N, nk, steps = 1501, 12, 3                                    # 1501 points: uneven shards
+    S = synth.halton(N, 2)
+    S = np.ascontiguousarray(S[synth.morton_order(S)])            # contiguous blocks = compact regions
+    F0 = synth.field(S)
+    _run_halo(0, 1, 0, S, nk, F0, steps, str(tmp_path))
+    port = _free_port()
+    mp.spawn(_run_halo, args=(world, port, S, nk, F0, steps, str(tmp_path)), nprocs=world, join=True)
+    ref = np.empty(N); ref[np.load(tmp_path / "halo_g_0_of_1.npy")] = np.load(tmp_path / "halo_v_0_of_1.npy")
+    got = np.full(N, np.nan)
+    for r in range(world):
+        got[np.load(tmp_path / ("halo_g_%d_of_%d.npy" % (r, world)))] = np.load(tmp_path / ("halo_v_%d_of_%d.npy" % (r, world)))
+    assert np.array_equal(got, ref)                               # same neighbours in the same order, same arithmetic per case

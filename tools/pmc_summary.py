@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Summaries of the rocprofv3 passes tools/profile_config.sh makes.
-usage: python tools/pmc_summary.py TAG CONFIG RAW_DIR
-Writes profiles/TAG_CONFIG_kernel_stats.csv (this package's kernels of the --stats pass) and
-profiles/TAG_CONFIG_pmc_summary.json: for every kernel of the package (the neighbour search of the setup excluded) the
+usage: python tools/pmc_summary.py TAG CONFIG RAW_DIR [CASES_PER_LAUNCH ALGORITHMIC_BYTES_PER_LAUNCH]
+Writes gpurun_out/profiles/TAG_CONFIG_kernel_stats.csv (this package's kernels of the --stats pass) and
+gpurun_out/profiles/TAG_CONFIG_pmc_summary.json (gpurun brings back only gpurun_out/; copy them into profiles/ afterwards): for every kernel of the package (the neighbour search of the setup excluded) the
 per-dispatch median of each counter, the register / LDS footprint the dispatch reports, and derived ratios:
   hbm_read_bytes = FETCH_SIZE x 1024 x 2 (gfx950 tallies the 128-B requests of wide coalesced reads at 64 B;
   MI355X_MICROARCH.md, HBM section), hbm_write_bytes = WRITE_SIZE x 1024;
@@ -18,6 +18,8 @@ import sys
 
 tag, cfg, raw = sys.argv[1], sys.argv[2], sys.argv[3]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEST = os.path.join(ROOT, "gpurun_out", "profiles")
+os.makedirs(DEST, exist_ok=True)
 CUS = 256
 
 
@@ -38,7 +40,7 @@ if stats:
         r = csv.DictReader(f)
         fields = r.fieldnames
         rows = [x for x in r if ours(x["Name"])]
-    with open(os.path.join(ROOT, "profiles", "%s_%s_kernel_stats.csv" % (tag, cfg)), "w", newline="") as f:
+    with open(os.path.join(DEST, "%s_%s_kernel_stats.csv" % (tag, cfg)), "w", newline="") as f:
         w = csv.DictWriter(f, fieldnames=fields)
         w.writeheader()
         w.writerows(rows)
@@ -96,7 +98,20 @@ for k, d in out["kernels"].items():
         der["lds_conflict_frac_of_lds_active"] = med["SQ_LDS_BANK_CONFLICT"] / med["SQ_LDS_IDX_ACTIVE"]
     if "SQ_LDS_IDX_ACTIVE" in med and "kernel_cycles" in der:
         der["lds_busy"] = med["SQ_LDS_IDX_ACTIVE"] / (der["kernel_cycles"] * CUS)
-json.dump(out, open(os.path.join(ROOT, "profiles", "%s_%s_pmc_summary.json" % (tag, cfg)), "w"), indent=1)
+json.dump(out, open(os.path.join(DEST, "%s_%s_pmc_summary.json" % (tag, cfg)), "w"), indent=1)
+# traffic_<config>.json in the format bench.py reads (sum over the kernels one fit launch consists of)
+only = os.environ.get("PMC_TRAFFIC_KERNEL", "")          # substring: the kernels a launch of the config consists of (C4: solve_many)
+sel = [d for k, d in out["kernels"].items() if only in k]
+rd = sum(d["derived"].get("hbm_read_bytes", 0.0) for d in sel)
+wr = sum(d["derived"].get("hbm_write_bytes", 0.0) for d in sel)
+if rd and wr and len(sys.argv) > 5:
+    cases, alg = int(sys.argv[4]), float(sys.argv[5])
+    json.dump(dict(config=cfg, tag=tag, kernels=sorted(out["kernels"]), cases_per_launch=cases,
+                   correction="FETCH_SIZE x2 (gfx950, 16-B/lane coalesced streams; MI355X_MICROARCH.md HBM section); WRITE_SIZE as read",
+                   hbm_read_bytes_per_launch=rd, hbm_write_bytes_per_launch=wr, hbm_bytes_per_launch=rd + wr,
+                   algorithmic_bytes_per_launch=alg, source="%s_%s_pmc_summary.json" % (tag, cfg)),
+              open(os.path.join(DEST, "traffic_%s.json" % cfg), "w"), indent=1)
+    print("traffic %s: read %.1f MB + written %.1f MB = %.1f MB per launch; algorithmic %.1f MB" % (cfg, rd / 1e6, wr / 1e6, (rd + wr) / 1e6, alg / 1e6))
 for r in rows:
     print("%s: %s calls, avg %.1f us" % (r["Name"][:110], r["Calls"], float(r["AverageNs"]) / 1e3))
 for k, d in out["kernels"].items():
