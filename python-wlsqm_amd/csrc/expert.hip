@@ -29,7 +29,11 @@ struct wlsqm_expert_geometry {
     std::vector<int64_t> kn;
     std::vector<long long> idx; int64_t off[6] = {0, 0, 0, 0, 0, 0};
     wlsqm::DevBuf d_nk, d_wm, d_kn, d_order, d_idx, d_xk, d_xi;
-    int64_t bytes() const { return (int64_t)(d_nk.n + d_wm.n + d_kn.n + d_order.n + d_idx.n + d_xk.n + d_xi.n); }
+    // solution operator of every case (solve_op.hip): built on the first stacked solve of a supported shape, shared with guests
+    wlsqm::DevBuf d_op, d_T;
+    int op_state = 0;                  // 0 not built, 1 ready, -1 shape not supported
+    int op_any_known = 0;
+    int64_t bytes() const { return (int64_t)(d_nk.n + d_wm.n + d_kn.n + d_order.n + d_idx.n + d_xk.n + d_xi.n + d_op.n + d_T.n); }
 };
 
 struct wlsqm_expert {
@@ -63,6 +67,11 @@ long long preferred_slots(int dimension, int order, long long max_nk);
 int launch_solve_many(int dimension, int order, const KParams& p, long long K, long long nrhs,
                       const double* fk, long long sfk_r, long long sfk_j, double* fi, long long sfi_r, long long sfi_j,
                       hipStream_t stream, bool* handled);
+int solve_op_build(int dimension, int order, const KParams& geom, long long K, const long long* h_knowns, long long ncases,
+                   DevBuf& d_op, DevBuf& d_T, int* any_known, hipStream_t s, bool* ok);
+int launch_solve_op(int dimension, int order, const KParams& geom, long long K, const double* op, const double* T, int any_known,
+                    long long nrhs, const double* fk, long long sfk_r, long long sfk_j, double* fi, long long sfi_r, long long sfi_j,
+                    hipStream_t stream, bool* handled);
 long long cond_workspace_doubles(int no);
 int launch_conds(int dimension, int order, const KParams& p, const int* order_arr, double* ws, long long CH,
                  long long case0, double* out, hipStream_t stream);
@@ -182,6 +191,7 @@ int wlsqm_hip_expert_prepare(wlsqm_expert* h, const double* xi, int64_t xi_strid
     }
     if (!xi || !xk) { set_error("null argument"); return WLSQM_EVALUE; }
     h->g->ready = false;
+    h->g->op_state = 0;                // a new geometry: the stored solution operator is stale
     if (max_nk < h->g->max_nk && h->g->max_nk > 1) { set_error("xk has fewer neighbour slots than max(nk)"); return WLSQM_EVALUE; }
     DeviceScope scope; int rc = scope.enter(h->g->device);
     if (rc != WLSQM_OK) return rc;
@@ -213,6 +223,7 @@ int wlsqm_hip_expert_prepare_device(wlsqm_expert* h, void* stream, const double*
         set_error("prepare_device needs xk[ncases, >= max_nk, dimension] with contiguous neighbour rows"); return WLSQM_EVALUE;
     }
     g.ready = false;
+    g.op_state = 0;                    // a new geometry: the stored solution operator is stale
     DeviceScope scope; int rc = scope.enter(g.device);
     if (rc != WLSQM_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
@@ -290,14 +301,57 @@ int wlsqm_hip_expert_solve_device(wlsqm_expert* h, void* stream, const double* f
 
 // Many fields on the prepared geometry, device-resident (extension; BASELINE config 4).  Fast path: one launch that
 // shares the geometry work between the fields (solve_many.hip); otherwise nrhs launches of the fused kernel.
+// Which stacked-solve kernel: WLSQM_HIP_SOLVE_MANY = "fma" (solve_many.hip: geometry work shared inside the launch, FMA loop,
+// no <= 6 and K <= 32 only), "op" (solve_op.hip: stored solution operator, batched GEMM on the matrix cores) or unset = the
+// default rule below.
+static int solve_many_choice() {
+    const char* e = getenv("WLSQM_HIP_SOLVE_MANY");
+    if (e && e[0] == 'f') return 1;
+    if (e && e[0] == 'o') return 2;
+    return 0;
+}
+
+static int ensure_operator(wlsqm_expert* h, hipStream_t s) {
+    wlsqm_expert_geometry& g = *h->g;
+    if (g.op_state != 0) return WLSQM_OK;
+    bool ok = false;
+    KParams p = expert_params(h, nullptr, 0, nullptr, 0);
+    int rc = solve_op_build(g.dimension, g.order[0], p, g.slots, reinterpret_cast<const long long*>(g.kn.data()), g.ncases,
+                            g.d_op, g.d_T, &g.op_any_known, s, &ok);
+    if (rc != WLSQM_OK) { g.d_op.alloc(0); g.d_T.alloc(0); return rc; }
+    g.op_state = ok ? 1 : -1;
+    if (!ok) { g.d_op.alloc(0); g.d_T.alloc(0); }
+    return WLSQM_OK;
+}
+
+// Many fields on the prepared geometry, device-resident (extension; BASELINE config 4).  Fast paths: the stored solution
+// operator applied as one batched GEMM (solve_op.hip; built on the first call: that call synchronises the stream), or one launch
+// that shares the geometry work between the fields (solve_many.hip); otherwise nrhs launches of the fused kernel.
 static int solve_many_on_device(wlsqm_expert* h, hipStream_t s, int64_t nrhs, const double* fk, int64_t sfk_r, int64_t sfk_j,
                                 double* fi, int64_t sfi_r, int64_t sfi_j) {
-    const wlsqm_expert_geometry& g = *h->g;
+    wlsqm_expert_geometry& g = *h->g;
     bool handled = false;
     if (g.uniform_order && h->algorithm == WLSQM_ALGO_BASIC) {
         KParams p = expert_params(h, nullptr, 0, nullptr, 0);
-        int rc = launch_solve_many(g.dimension, g.order[0], p, g.slots, nrhs, fk, sfk_r, sfk_j, fi, sfi_r, sfi_j, s, &handled);
-        if (rc != WLSQM_OK) return rc;
+        const int choice = solve_many_choice();
+        const int no = wlsqm_hip_number_of_dofs(g.dimension, g.order[0]);
+        // default: the FMA kernel where it exists and the stack is short (it needs no stored operator: 8 * 16 * K bytes per case);
+        // the operator from 64 fields on, and wherever the FMA kernel has no instantiation (no > 6 or K > 32)
+        const bool fma_shape = no <= 6 && g.slots <= 32;
+        const bool want_op = choice == 2 || (choice == 0 && (!fma_shape || nrhs >= 64));
+        if (want_op && nrhs >= 2) {
+            int rc = ensure_operator(h, s);
+            if (rc != WLSQM_OK) return rc;
+            if (g.op_state == 1) {
+                rc = launch_solve_op(g.dimension, g.order[0], p, g.slots, g.d_op.as<double>(), g.d_T.as<double>(), g.op_any_known, nrhs,
+                                     fk, sfk_r, sfk_j, fi, sfi_r, sfi_j, s, &handled);
+                if (rc != WLSQM_OK) return rc;
+            }
+        }
+        if (!handled && choice != 2) {
+            int rc = launch_solve_many(g.dimension, g.order[0], p, g.slots, nrhs, fk, sfk_r, sfk_j, fi, sfi_r, sfi_j, s, &handled);
+            if (rc != WLSQM_OK) return rc;
+        }
     }
     if (handled) return WLSQM_OK;
     for (int64_t r = 0; r < nrhs; ++r) {

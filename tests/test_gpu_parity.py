@@ -636,8 +636,8 @@ def test_expert_guest_mode_shares_geometry(wlsqm):
 @pytest.mark.parametrize("name,knowns", [("C2", 0), ("C2", 0b010001), ("C1", 0), ("C5", 0)])
 def test_expert_solve_many_matches_sequential_solves(wlsqm, name, knowns):
     """solve_many (extension, BASELINE config 4): R fields in one call == R solve() calls, to rounding (the shared-geometry
-    kernel sums in a different order); known DOFs are read per field and stay bit-identical.  C5 (no = 10) has no
-    shared-geometry instantiation and takes R fused launches: bit-identical there."""
+    kernel sums in a different order); known DOFs are read per field and stay bit-identical.  C5 (no = 10, 40 neighbour slots) has
+    no shared-geometry instantiation and takes the stored solution operator (solve_op.hip) even for a short stack."""
     import torch
     import synth
     c = K.config(name)
@@ -669,8 +669,8 @@ def test_expert_solve_many_matches_sequential_solves(wlsqm, name, knowns):
         for a in range(no):
             if (knowns >> a) & 1:
                 assert np.array_equal(got[r, :, a], fi0[r, :, a]) and np.array_equal(got_d[r, :, a], fi0[r, :, a])
-        if name == "C5":
-            assert np.array_equal(got[r], ref[r]) and np.array_equal(got_d[r], ref[r])
+        if False:
+            pass
         else:
             truth = P.truth_fit(dim, c["xk"], fks[r], nk_a, c["xi"], fi0[r], c["order_a"], kn, c["wm_a"])
             P.assert_parity(got[r], ref[r], truth, "%s solve_many host, field %d" % (name, r))

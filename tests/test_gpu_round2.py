@@ -397,3 +397,76 @@ def test_ring_fit_vs_oracle_and_two_kernel_path(wlsqm, oracle, Kn, n, ragged, kn
     e_ref = max(P.column_metric(fo, truth).max(), P.column_metric(out["two"][0], truth).max())
     assert e_ring <= P.TOL + P.NOISE_MULT * e_ref, (e_ring, e_ref)
     assert np.array_equal(np.isnan(out["ring"][0]), np.isnan(fo))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# stacked right-hand sides through the stored solution operator (csrc/solve_op.hip, v_mfma_f64_16x16x4_f64)
+
+@pytest.mark.parametrize("dim,order,Kn,knowns", [(2, 2, 32, 0), (2, 2, 32, 0b1), (3, 2, 40, 0), (3, 2, 40, 0b10001), (2, 4, 64, 1),
+                                                 (2, 3, 24, 0b1011), (1, 3, 16, 0), (2, 1, 16, 0b100)])
+@pytest.mark.parametrize("R", [1, 5, 16, 37])
+def test_solve_many_operator_path(wlsqm, oracle, dim, order, Kn, knowns, R, monkeypatch):
+    """R stacked fields through the operator kernel (forced with WLSQM_HIP_SOLVE_MANY=op) against one fused solve per field and
+    the oracle: ragged nk, known DOFs (their values differ per field and must stay bit-identical), field counts that are not
+    multiples of the 16-field block, case counts that are not multiples of the workgroup's cases, a fully known case."""
+    import torch
+    import synth
+    import wlsqm.hip as whip
+    rng = np.random.default_rng(1000 * dim + 100 * order + R)
+    n = 333
+    no = K.NDOF[dim][order]
+    if dim == 1:
+        S = np.sort(rng.uniform(0, 1, 3000))
+        hoods = synth.knn(S[:, None], Kn, workers=2)[:n]
+        xk = S[hoods]; xi = S[:n].copy()
+    else:
+        S = synth.halton(3000, dim, skip=1)
+        hoods = synth.knn(S, Kn, workers=2)[:n]
+        xk = S[hoods]; xi = S[:n].copy()
+    nk = rng.integers(max(no + 2, Kn - 7), Kn + 1, n).astype(np.int32); nk[0] = Kn
+    kn = np.full(n, knowns, np.int64); kn[7] = (1 << no) - 1                       # one case with nothing to solve
+    wm = np.full(n, 2, np.int32); wm[::4] = 1
+    orders = np.full(n, order, np.int32)
+    s = wlsqm.ExpertSolver(dimension=dim, nk=nk, order=orders, knowns=kn, weighting_method=wm)
+    s.prepare(xi=xi, xk=xk)
+    Sx = S if dim == 1 else S[:, 0]
+    fks = np.stack([np.sin((2.0 + 0.3 * r) * Sx + 0.1 * r)[hoods] * (1.0 if dim == 1 else np.cos(1.5 * S[:, 1])[hoods]) for r in range(R)])
+    fi0 = rng.uniform(-1, 1, (R, n, no))
+    ref = fi0.copy()
+    for r in range(R):
+        s.solve(fk=fks[r], fi=ref[r])
+    monkeypatch.setenv("WLSQM_HIP_SOLVE_MANY", "op")
+    fk_d = _t(fks); got_d = _t(fi0)
+    s.solve_many_device(fk_d, got_d)
+    torch.cuda.synchronize()
+    if R >= 2:
+        assert whip.last_kernel() == "solve-op-mfma", whip.last_kernel()
+    got = got_d.cpu().numpy()
+    assert np.array_equal(got[:, 7], fi0[:, 7])                                     # the fully known case is untouched
+    for r in range(R):
+        for a in range(no):
+            if (knowns >> a) & 1:
+                assert np.array_equal(got[r, :, a], fi0[r, :, a])
+        fo = fi0[r].copy()
+        oracle.fit_many(dim, xk, fks[r], nk, xi, fo, None, 0, orders, kn, wm)
+        truth = P.truth_fit(dim, xk, fks[r], nk, xi, fi0[r], orders, kn, wm)
+        P.assert_parity(got[r], fo, truth, "operator path vs oracle, field %d" % r)
+        P.assert_parity(got[r], ref[r], truth, "operator path vs fused solve, field %d" % r)
+    # a guest shares the host's operator; re-preparing the geometry rebuilds it
+    g = wlsqm.ExpertSolver(dimension=dim, nk=nk, order=orders, knowns=kn, weighting_method=wm, host=s)
+    g.prepare(xi=xi, xk=xk)
+    got_g = _t(fi0)
+    g.solve_many_device(fk_d, got_g)
+    torch.cuda.synchronize()
+    assert torch.equal(got_g, got_d)
+    if dim > 1:
+        xk2 = xk + 0.0; xk2[:, 0, :] += 1e-3                                         # a different geometry
+        s.prepare(xi=xi, xk=xk2)
+        got2 = _t(fi0)
+        s.solve_many_device(fk_d, got2)
+        torch.cuda.synchronize()
+        ref2 = fi0[R - 1].copy()
+        monkeypatch.delenv("WLSQM_HIP_SOLVE_MANY")
+        s.solve(fk=fks[R - 1], fi=ref2)
+        truth2 = P.truth_fit(dim, xk2, fks[R - 1], nk, xi, fi0[R - 1], orders, kn, wm)
+        P.assert_parity(got2[R - 1].cpu().numpy(), ref2, truth2, "operator rebuilt after prepare()")
