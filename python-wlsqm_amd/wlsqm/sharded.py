@@ -210,7 +210,8 @@ class HaloCloudSolver:
         self._send = torch.empty(int(self.send_idx.numel()), dtype=torch.float64, device=dev)
         self._recv = torch.empty(self.n_halo, dtype=torch.float64, device=dev)
         self._comm_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
-        self._work = None
+        # gloo has no device-memory all_to_all: stage through the host (tests with several ranks on one GPU; RCCL takes the device tensors)
+        self._host_stage = bool(self.world > 1 and dev.type == "cuda" and dist.get_backend(group) == "gloo")
 
     # -- values ------------------------------------------------------------------------------------------------------------
     def set_own_values_from_global(self, F_global):
@@ -228,6 +229,12 @@ class HaloCloudSolver:
         if self.world == 1:
             return
         torch.index_select(self.values, 0, self.send_idx, out=self._send)
+        if self._host_stage:
+            send = self._send.cpu(); recv = torch.empty(self.n_halo, dtype=torch.float64)
+            dist.all_to_all_single(recv, send, self.recv_splits, self.send_splits, group=self.group)
+            self.values[self.n_own:] = recv.to(self.device)
+            self._halo_ready = torch.cuda.Event(); self._halo_ready.record()
+            return
         if self._comm_stream is not None:
             ev = torch.cuda.Event(); ev.record()
             with torch.cuda.stream(self._comm_stream):

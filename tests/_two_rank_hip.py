@@ -19,7 +19,7 @@ import torch.distributed as dist
 
 import synth
 import wlsqm.hip as whip
-from wlsqm.sharded import ShardedCloudSolver, case_range
+from wlsqm.sharded import HaloCloudSolver, ShardedCloudSolver, case_range
 
 
 def main():
@@ -63,12 +63,38 @@ def main():
         torch.cuda.synchronize()
         return F.cpu().numpy()
     got = run(False)
+
+    # (3) the same with the halo-only exchange: own-points-only GPU neighbour search against a halo band, local tables,
+    # all_to_all of the halo values, interior / boundary launches (wlsqm.sharded.HaloCloudSolver) -- 3D, 40 neighbours
+    N3, k3 = 30011, 40
+    S3 = synth.halton(N3, 3)
+    S3 = np.ascontiguousarray(S3[synth.morton_order(S3)])
+    F3 = synth.field(S3)
+
+    def run_halo(single):
+        s = HaloCloudSolver(3, t(S3), k3, order=2, knowns=0, weighting_method=2, device=dev, single=single)
+        s.set_own_values_from_global(t(F3))
+        for _ in range(steps):
+            fi = s.step()
+            s.values[: s.n_own] = fi[:, 0] + 1e-7 * (fi[:, 4] + fi[:, 6] + fi[:, 8])
+        torch.cuda.synchronize()
+        g, v = s.own_values_global()
+        return g.cpu().numpy(), v.cpu().numpy(), whip.last_kernel(), (s.n_halo, s.n_int, s.n_own)
+    g_mine, v_mine, k_halo, shape = run_halo(False)
+    sizes = [None] * world
+    dist.all_gather_object(sizes, (g_mine, v_mine))
     res = None
     if rank == 0:
         single, k1 = fit(0, n)
         ref = run(True)
+        g1, v1, _, _ = run_halo(True)
+        ref3 = np.empty(N3); ref3[g1] = v1
+        got3 = np.full(N3, np.nan)
+        for g_r, v_r in sizes:
+            got3[g_r] = v_r
         res = {"world": world, "kernel_dense": kernel, "dense_bit_identical": bool(torch.equal(whole, single)),
-               "cloud_bit_identical": bool(np.array_equal(got, ref))}
+               "cloud_bit_identical": bool(np.array_equal(got, ref)), "halo_bit_identical": bool(np.array_equal(got3, ref3)),
+               "halo_kernel": k_halo, "halo_shape_rank0": list(shape)}
         json.dump(res, open(out + ".json", "w"))
     dist.barrier()
     dist.destroy_process_group()

@@ -345,8 +345,9 @@ def test_hip_kernels_under_world_size_2(wlsqm, tmp_path):
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     res = json.load(open(str(out) + ".json"))
-    assert res["dense_bit_identical"] and res["cloud_bit_identical"], res
+    assert res["dense_bit_identical"] and res["cloud_bit_identical"] and res["halo_bit_identical"], res
     assert res["kernel_dense"] == "tile" and res["world"] == 2
+    assert res["halo_kernel"] == "tile-gather" and 0 < res["halo_shape_rank0"][0] < 30011 // 2, res
 
 
 # ----------------------------------------------------------------------------------------------------------------------
