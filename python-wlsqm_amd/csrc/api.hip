@@ -36,6 +36,26 @@ int launch_fit_tilek(int dimension, int order, const KParams& p, long long max_n
 long long preferred_slots(int dimension, int order, long long max_nk);
 int launch_fit_rows(int dimension, int order, const KParams& p, hipStream_t stream, bool* handled);
 
+// Dense rows the tiled kernels cannot take as they are — a strided neighbour or case axis, rows that are not multiples of 16
+// bytes (odd K), misaligned bases — are repacked on the device into contiguous [ncases, K', dim] / [ncases, K'] scratch
+// (K' = preferred_slots: even, and a moment size for 2D order 4) in front of the same kernels: two extra passes over xk and fk
+// instead of the lane-per-case kernel (8.5 % of the HBM peak on C2).  Only slots k < K are read; the pad slot replays slot 0 and
+// is masked by nk like every unused slot.
+__global__ void repack_rows_kernel(const KParams p, int dim, long long K, long long Kp, double* __restrict__ xk, double* __restrict__ fk) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= p.ncases * Kp) return;
+    const long long j = t / Kp; const long long k = t - j * Kp;
+    const long long ks = k < K ? k : 0;
+    const double* src = p.xk + j * p.sxk_j + ks * p.sxk_k;
+    for (int m = 0; m < dim; ++m) xk[t * dim + m] = src[m];
+    fk[t] = p.fk[j * p.sfk_j + ks * p.sfk_k];
+}
+
+static bool dense_layout_ok(int dim, const KParams& p, long long K) {
+    if (p.sxk_k != dim || p.sxk_j != K * dim || p.sfk_k != 1 || p.sfk_j != K || (K % 2) != 0) return false;
+    return ((reinterpret_cast<uintptr_t>(p.xk) | reinterpret_cast<uintptr_t>(p.fk)) & 15u) == 0;
+}
+
 int launch_fit(int dimension, int order, const KParams& p_in, long long max_nk, hipStream_t stream) {
     KParams p = p_in;
     p.max_nk = max_nk;
@@ -45,6 +65,30 @@ int launch_fit(int dimension, int order, const KParams& p_in, long long max_nk, 
     if (p.hoods && no > 15 && (p.do_sens || p.iterative)) {
         set_error("index-based input with sensitivities or refinement supports systems with at most 15 DOFs");
         return WLSQM_EVALUE;
+    }
+    {
+        const char* off = getenv("WLSQM_HIP_DISABLE_TILE");
+        const char* norp = getenv("WLSQM_HIP_DISABLE_REPACK");
+        const bool tiles_on = !(off && off[0] == '1') && !(norp && norp[0] == '1');
+        if (tiles_on && !p.hoods && !p.case_index && p.xk && p.fk && no <= 15 && max_nk >= 2 && max_nk <= 128 && p.ncases >= 256 &&
+            !dense_layout_ok(dimension, p, max_nk)) {
+            const long long Kp = preferred_slots(dimension, order, max_nk);
+            double* ws = nullptr;
+            const size_t nx = (size_t)p.ncases * Kp * dimension, nf = (size_t)p.ncases * Kp;
+            int rc = scratch_alloc_async(reinterpret_cast<void**>(&ws), (nx + nf) * sizeof(double), stream);
+            if (rc != WLSQM_OK) return rc;
+            const long long threads = p.ncases * Kp;
+            hipLaunchKernelGGL(repack_rows_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, p, dimension, max_nk, Kp,
+                               ws, ws + nx);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) { (void)scratch_free_async(ws, stream); return hip_fail(e, "repack_rows_kernel"); }
+            KParams q = p;
+            q.xk = ws; q.sxk_j = Kp * dimension; q.sxk_k = dimension;
+            q.fk = ws + nx; q.sfk_j = Kp; q.sfk_k = 1;
+            rc = launch_fit(dimension, order, q, Kp, stream);          // contiguous now: takes the tiled kernels
+            const int rc2 = scratch_free_async(ws, stream);
+            return rc != WLSQM_OK ? rc : rc2;
+        }
     }
     bool handled = false;
     int rc = launch_fit_ring(dimension, order, p, max_nk, stream, &handled);      // one-kernel fit of the 15-unknown systems

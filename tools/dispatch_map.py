@@ -9,8 +9,8 @@ import torch
 import wlsqm.hip as whip
 NDOF = {1: [1, 2, 3, 4, 5], 2: [1, 3, 6, 10, 15], 3: [1, 4, 10, 20, 35]}
 dev = torch.device("cuda", 0)
-n = 200
-Ks = [4, 7, 8, 12, 16, 21, 30, 32, 40, 50, 64, 66, 80, 100, 124, 128, 130, 160]
+n = 512          # >= 256: batches this size are repacked on the device when their layout needs it
+Ks = [4, 7, 8, 12, 16, 21, 30, 32, 40, 50, 64, 66, 80, 100, 124, 128, 130, 160, 256]
 rng = np.random.default_rng(0)
 for dim in (1, 2, 3):
     for order in range(5):
@@ -30,12 +30,21 @@ for dim in (1, 2, 3):
             whip.fit_many_device(dim, order, xk_a, fk, nk, xi_a, fi, kn, wm); names.append(whip.last_kernel())
             sens = torch.zeros((n, K, no), dtype=torch.float64, device=dev)
             whip.fit_many_device(dim, order, xk_a, fk, nk, xi_a, fi, kn, wm, sens=sens); names.append(whip.last_kernel())
+            # simply-strided dense input: the neighbour axis of xk and fk has a stride (views into wider arrays)
+            if dim == 1:
+                xk_s = torch.zeros((n, K, 2), dtype=torch.float64, device=dev)[:, :, 0]; xk_s.copy_(xk_a)
+            else:
+                xk_s = torch.zeros((n, K + 3, dim), dtype=torch.float64, device=dev)[:, :K]; xk_s.copy_(xk_a)
+            fk_s = torch.zeros((n, K, 2), dtype=torch.float64, device=dev)[:, :, 0]; fk_s.copy_(fk)
+            whip.fit_many_device(dim, order, xk_s, fk_s, nk, xi_a, fi, kn, wm); names.append(whip.last_kernel())
             S = torch.cat([xk.reshape(n * K, dim), xi]).contiguous(); F = torch.cat([fk.reshape(n * K), torch.sin(xi[:, 0])]).contiguous()
             S_a = S[:, 0].contiguous() if dim == 1 else S
             hoods = torch.arange(n * K, dtype=torch.int32, device=dev).reshape(n, K).contiguous()
             pidx = (n * K + torch.arange(n, device=dev)).to(torch.int32)
             whip.fit_cloud_device(dim, order, S_a, F, hoods, fi, nk, kn, wm, point_index=pidx); names.append(whip.last_kernel())
             row.append("/".join(names))
-        print("dim %d order %d: " % (dim, order) + "  ".join("K=%d %s" % (k, r) for k, r in zip(Ks, row)))
+        print("dim %d order %d:" % (dim, order))
+        for k, r in zip(Ks, row):
+            print("    K=%d %s" % (k, r))
 torch.cuda.synchronize()
-print("(dense basic / dense with sensitivities / index-based basic)")
+print("(dense basic / dense with sensitivities / strided dense basic / index-based basic)")
