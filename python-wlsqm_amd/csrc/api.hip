@@ -35,6 +35,7 @@ int launch_fit_ring(int dimension, int order, const KParams& p, long long max_nk
 int launch_fit_tilek(int dimension, int order, const KParams& p, long long max_nk, hipStream_t stream, bool* handled);
 long long preferred_slots(int dimension, int order, long long max_nk);
 int launch_fit_rows(int dimension, int order, const KParams& p, hipStream_t stream, bool* handled);
+int launch_fit_chunk(int dimension, int order, const KParams& p, long long K, hipStream_t stream, bool* handled);
 
 // Dense rows the tiled kernels cannot take as they are — a strided neighbour or case axis, rows that are not multiples of 16
 // bytes (odd K), misaligned bases — are repacked on the device into contiguous [ncases, K', dim] / [ncases, K'] scratch
@@ -49,6 +50,21 @@ __global__ void repack_rows_kernel(const KParams p, int dim, long long K, long l
     const double* src = p.xk + j * p.sxk_j + ks * p.sxk_k;
     for (int m = 0; m < dim; ++m) xk[t * dim + m] = src[m];
     fk[t] = p.fk[j * p.sfk_j + ks * p.sfk_k];
+}
+
+// Index-based rows (S / F / hoods) of a shape without an index-based tile kernel: gathered once into dense scratch rows
+// (slots k >= nk[j] are never dereferenced: they replay the case's own point and stay masked).
+__global__ void gather_rows_kernel(const KParams p, int dim, long long K, long long Kp, double* __restrict__ xk, double* __restrict__ fk,
+                                   double* __restrict__ xi) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= p.ncases * Kp) return;
+    const long long j = t / Kp; const long long k = t - j * Kp;
+    const long long pj = p.pidx ? (long long)p.pidx[j] : j;
+    const long long idx = (k < K && k < p.nk[j * p.snk]) ? (long long)p.hoods[j * p.shoods_j + k] : pj;
+    for (int m = 0; m < dim; ++m) xk[t * dim + m] = p.S[idx * dim + m];
+    fk[t] = p.F[idx];
+    if (k == 0)
+        for (int m = 0; m < dim; ++m) xi[j * dim + m] = p.S[pj * dim + m];
 }
 
 static bool dense_layout_ok(int dim, const KParams& p, long long K) {
@@ -70,7 +86,7 @@ int launch_fit(int dimension, int order, const KParams& p_in, long long max_nk, 
         const char* off = getenv("WLSQM_HIP_DISABLE_TILE");
         const char* norp = getenv("WLSQM_HIP_DISABLE_REPACK");
         const bool tiles_on = !(off && off[0] == '1') && !(norp && norp[0] == '1');
-        if (tiles_on && !p.hoods && !p.case_index && p.xk && p.fk && no <= 15 && max_nk >= 2 && max_nk <= 128 && p.ncases >= 256 &&
+        if (tiles_on && !p.hoods && !p.case_index && p.xk && p.fk && no <= 15 && max_nk >= 2 && p.ncases >= 256 && !(p.do_sens || p.iterative ? max_nk > 128 : false) &&
             !dense_layout_ok(dimension, p, max_nk)) {
             const long long Kp = preferred_slots(dimension, order, max_nk);
             double* ws = nullptr;
@@ -99,7 +115,38 @@ int launch_fit(int dimension, int order, const KParams& p_in, long long max_nk, 
     if (rc != WLSQM_OK || handled) return rc;
     rc = launch_fit_tilek(dimension, order, p, max_nk, stream, &handled);
     if (rc != WLSQM_OK || handled) return rc;
-    if (no <= 15) return launch_fit_lane(dimension, order, p, stream);
+    {
+        // index-based input no tiled kernel took: gather it into dense rows and dispatch again (the dense tables are complete)
+        const char* off = getenv("WLSQM_HIP_DISABLE_TILE");
+        const char* norp = getenv("WLSQM_HIP_DISABLE_REPACK");
+        const bool tiles_on = !(off && off[0] == '1') && !(norp && norp[0] == '1');
+        if (tiles_on && p.hoods && !p.case_index && no <= 15 && max_nk >= 2 && p.ncases >= 256 &&
+            !((p.do_sens || p.iterative) && max_nk > 128)) {
+            const long long Kp = preferred_slots(dimension, order, max_nk);
+            double* ws = nullptr;
+            const size_t nx = (size_t)p.ncases * Kp * dimension, nf = (size_t)p.ncases * Kp, ni = (size_t)p.ncases * dimension;
+            rc = scratch_alloc_async(reinterpret_cast<void**>(&ws), (nx + nf + ni) * sizeof(double), stream);
+            if (rc != WLSQM_OK) return rc;
+            const long long threads = p.ncases * Kp;
+            hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, p, dimension, max_nk, Kp,
+                               ws, ws + nx, ws + nx + nf);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) { (void)scratch_free_async(ws, stream); return hip_fail(e, "gather_rows_kernel"); }
+            KParams q = p;
+            q.hoods = nullptr; q.S = nullptr; q.F = nullptr; q.pidx = nullptr; q.shoods_j = 0;
+            q.xk = ws; q.sxk_j = Kp * dimension; q.sxk_k = dimension;
+            q.fk = ws + nx; q.sfk_j = Kp; q.sfk_k = 1;
+            q.xi = ws + nx + nf; q.sxi_j = dimension;
+            rc = launch_fit(dimension, order, q, Kp, stream);
+            const int rc2 = scratch_free_async(ws, stream);
+            return rc != WLSQM_OK ? rc : rc2;
+        }
+    }
+    if (no <= 15) {
+        rc = launch_fit_chunk(dimension, order, p, max_nk, stream, &handled);   // any K: neighbours through LDS in chunks, two passes
+        if (rc != WLSQM_OK || handled) return rc;
+        return launch_fit_lane(dimension, order, p, stream);
+    }
     rc = launch_fit_rows(dimension, order, p, stream, &handled);        // basic fit of the 3D order-3/4 systems
     if (rc != WLSQM_OK || handled) return rc;
     return launch_fit_wave(dimension, order, p, stream);

@@ -1,0 +1,179 @@
+// fit_chunk.hip — basic fit for ANY number of neighbour slots (K > 128, and the (dimension, order, K) combinations without a
+// fixed-K or runtime-K tile kernel): the neighbours of a 16-case tile travel through LDS in chunks of 32 slots, twice — once for
+// the largest squared distance of every case (the weights need it, infra.pyx:668-702), once for the moments.  1.6x the
+// algorithmic traffic on xk, against the lane-per-case kernel's uncoalesced row reads (8.5 % of the HBM peak on C2).
+//
+// Same arithmetic as the tile kernels (wlsqm_tile.hpp): one wave per tile, four lanes per case (lane = h * 16 + c), every lane
+// takes 8 of a chunk's 32 slots, moments (wlsqm_moments.hpp), xor butterfly, lane h == 0 expands, eliminates knowns
+// (impl.pyx:792-823), factors and substitutes.  Dense contiguous rows with an even K (api.hip repacks anything else).
+#include "wlsqm_internal.hpp"
+#include "wlsqm_kernels.hpp"
+#include "wlsqm_moments.hpp"
+
+namespace wlsqm {
+
+typedef double cd2_ __attribute__((ext_vector_type(2)));
+
+template <int DIM, int ORDER, int MINW>
+__global__ __launch_bounds__(64, MINW) void fit_chunk_kernel(const KParams p, const long long ntiles, const int K) {
+    constexpr int WV = 64, TC = 16, LPC = 4, CH = 32, SPL = CH / LPC;          // slots per lane and chunk
+    constexpr int NO = ndofs(DIM, ORDER), NE = NO * (NO + 1) / 2, NM = mom_count<DIM>(2 * ORDER);
+    constexpr int CPR = CH * DIM / 2;                                           // 16-byte pieces per row of a chunk
+    constexpr int RS = (DIM == 2) ? CH * DIM + 2 : CH * DIM + 1;                // padded row (conflict-free ds_read_b128 / b64)
+    constexpr int NX = (TC * CPR + WV - 1) / WV;
+    __shared__ __attribute__((aligned(16))) double sX[TC * RS + 2];
+    const int lane = threadIdx.x, c = lane % TC, h = lane / TC;
+    const int nchunks = (K + CH - 1) / CH;
+
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long j0 = tile * TC, j = j0 + c;
+        const bool valid = j < p.ncases;
+        const long long jc = valid ? j : p.ncases - 1;
+        const long long nvalid = (p.ncases - j0 < TC) ? (p.ncases - j0) : TC;
+        const int nkc = min(p.nk[jc * p.snk], K);
+        const bool uniform = (p.wm[jc * p.swm] == WLSQM_WEIGHT_UNIFORM);
+        unsigned long long known, dropped;
+        effective_mask<NO>(p.knowns[jc * p.sknowns], known, dropped);
+        double xi[DIM];
+#pragma unroll
+        for (int m = 0; m < DIM; ++m) xi[m] = p.xi[jc * p.sxi_j + m];
+
+        // one chunk of the tile's rows into LDS: rows j0 .. j0 + nvalid - 1, slots [k0c, k0c + CH) clipped to the row
+        auto stage = [&](int k0c) {
+            const int live_pieces = (min(CH, K - k0c) * DIM) / 2;             // (K * DIM even, k0c * DIM even)
+            cd2_ b[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                const int q = lane + i * WV;
+                int r = q / CPR, c2 = q - r * CPR;
+                r = r < (int)nvalid ? r : (int)nvalid - 1;
+                c2 = c2 < live_pieces ? c2 : live_pieces - 1;
+                b[i] = *reinterpret_cast<const cd2_*>(p.xk + ((j0 + r) * (long long)K + k0c) * DIM + 2 * c2);
+            }
+            __syncthreads();                                                   // the previous chunk has been consumed
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                const int q = lane + i * WV;
+                if (TC * CPR % WV == 0 || q < TC * CPR) {
+                    const int r = q / CPR, c2 = q - r * CPR;
+                    double* d = sX + r * RS + 2 * c2;
+                    if constexpr (RS % 2 == 0) *reinterpret_cast<cd2_*>(d) = b[i];
+                    else { d[0] = b[i].x; d[1] = b[i].y; }
+                }
+            }
+            __syncthreads();
+        };
+        const double* xr = sX + c * RS + h * SPL * DIM;                        // this lane's 8 slots of its case's row
+
+        // ---- pass 1: largest squared distance
+        double max_d2 = 0.0;
+        for (int ch = 0; ch < nchunks; ++ch) {
+            stage(ch * CH);
+#pragma unroll
+            for (int s = 0; s < SPL; ++s) {
+                const int k = ch * CH + h * SPL + s;
+                double d2 = 0.0;
+#pragma unroll
+                for (int m = 0; m < DIM; ++m) { const double dd = xr[s * DIM + m] - xi[m]; d2 = fma(dd, dd, d2); }
+                d2 = (k < nkc) ? d2 : 0.0;
+                max_d2 = d2 > max_d2 ? d2 : max_d2;
+            }
+        }
+#pragma unroll
+        for (int off = TC; off < WV; off <<= 1) { const double o = __shfl_xor(max_d2, off, WV); max_d2 = o > max_d2 ? o : max_d2; }
+        const double inv_max = inverse_max(max_d2);
+
+        // ---- pass 2: moments
+        double mu[NM], nu[NO];
+#pragma unroll
+        for (int e = 0; e < NM; ++e) mu[e] = 0.0;
+#pragma unroll
+        for (int a = 0; a < NO; ++a) nu[a] = 0.0;
+        for (int ch = 0; ch < nchunks; ++ch) {
+            // this lane's fk values of the chunk, straight from global memory (8 contiguous doubles; slots beyond the row are masked)
+            double f[SPL];
+            {
+                const int kb = ch * CH + h * SPL;
+                const double* gr = p.fk + jc * (long long)K;
+#pragma unroll
+                for (int s = 0; s < SPL; s += 2) {
+                    const int kq = (kb + s < K) ? kb + s : K - 2;
+                    const cd2_ v = *reinterpret_cast<const cd2_*>(gr + kq);
+                    f[s] = v.x; f[s + 1] = v.y;
+                }
+            }
+            stage(ch * CH);
+#pragma unroll 2
+            for (int s = 0; s < SPL; ++s) {
+                const int k = ch * CH + h * SPL + s;
+                const bool live = k < nkc;
+                double d[DIM];
+#pragma unroll
+                for (int m = 0; m < DIM; ++m) { const double dd = xr[s * DIM + m] - xi[m]; d[m] = live ? dd : 0.0; }
+                double d2 = 0.0;
+#pragma unroll
+                for (int m = 0; m < DIM; ++m) d2 = fma(d[m], d[m], d2);
+                const double w = live ? weight(d2, inv_max, uniform) : 0.0;
+                accumulate_moments_best<DIM, ORDER>(mu, nu, d, w, live ? f[s] : 0.0);
+            }
+        }
+#pragma unroll
+        for (int off = TC; off < WV; off <<= 1) {
+#pragma unroll
+            for (int e = 0; e < NM; ++e) mu[e] += __shfl_xor(mu[e], off, WV);
+#pragma unroll
+            for (int a = 0; a < NO; ++a) nu[a] += __shfl_xor(nu[a], off, WV);
+        }
+        constexpr unsigned long long FULL = (1ull << NO) - 1ull;
+        if (valid && h == 0 && known != FULL) {
+            double* fio = p.fi + j * p.sfi_j;
+            double M[NE], rhs[NO];
+            expand_moments<DIM, ORDER>(mu, nu, M, rhs);
+            if (known) {
+                double val[NO];
+#pragma unroll
+                for (int a = 0; a < NO; ++a) val[a] = (((known & ~dropped) >> a) & 1ull) ? fio[a] : 0.0;
+                eliminate_knowns<NO>(M, rhs, known, val);
+            }
+            ldlt_factor<NO>(M);
+            ldlt_solve<NO>(M, rhs);
+#pragma unroll
+            for (int a = 0; a < NO; ++a)
+                if (!((known >> a) & 1ull)) fio[a] = rhs[a];
+        }
+    }
+}
+
+template <int DIM, int ORDER>
+static int launch_chunk(const KParams& p, long long K, hipStream_t stream) {
+    constexpr int MINW = (ndofs(DIM, ORDER) > 10) ? 1 : 2;
+    const long long ntiles = (p.ncases + 15) / 16;
+    static KernelSetup setup;
+    auto kern = fit_chunk_kernel<DIM, ORDER, MINW>;
+    long long grid = 0;
+    int rc = persistent_grid(reinterpret_cast<const void*>(kern), 64, 0, 0, true, setup, &grid);
+    if (rc != WLSQM_OK) return rc;
+    if (grid > ntiles) grid = ntiles;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), 0, stream, p, ntiles, (int)K);
+    WLSQM_HIP_CHECK(hipGetLastError());
+    note_kernel("chunk");
+    return WLSQM_OK;
+}
+
+// Dense contiguous basic fits of any K (even, 16-byte aligned rows) with at most 15 unknowns.
+int launch_fit_chunk(int dimension, int order, const KParams& p, long long K, hipStream_t stream, bool* handled) {
+    *handled = false;
+    const char* off = getenv("WLSQM_HIP_DISABLE_TILE");
+    if (off && off[0] == '1') return WLSQM_OK;
+    if (p.hoods || p.case_index || p.do_sens || p.iterative || K < 2 || (K % 2) != 0 || K > 0x3fffffff) return WLSQM_OK;
+    if (p.sxk_k != dimension || p.sxk_j != K * dimension || p.sfk_k != 1 || p.sfk_j != K) return WLSQM_OK;
+    if ((reinterpret_cast<uintptr_t>(p.xk) | reinterpret_cast<uintptr_t>(p.fk)) & 15u) return WLSQM_OK;
+#define CCASE(D, O) if (dimension == D && order == O) { *handled = true; return launch_chunk<D, O>(p, K, stream); }
+    CCASE(1, 0) CCASE(1, 1) CCASE(1, 2) CCASE(1, 3) CCASE(1, 4)
+    CCASE(2, 0) CCASE(2, 1) CCASE(2, 2) CCASE(2, 3) CCASE(2, 4)
+    CCASE(3, 0) CCASE(3, 1) CCASE(3, 2)
+#undef CCASE
+    return WLSQM_OK;
+}
+
+}  // namespace wlsqm

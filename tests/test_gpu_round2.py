@@ -471,3 +471,85 @@ def test_solve_many_operator_path(wlsqm, oracle, dim, order, Kn, knowns, R, monk
         s.solve(fk=fks[R - 1], fi=ref2)
         truth2 = P.truth_fit(dim, xk2, fks[R - 1], nk, xi, fi0[R - 1], orders, kn, wm)
         P.assert_parity(got2[R - 1].cpu().numpy(), ref2, truth2, "operator rebuilt after prepare()")
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# any number of neighbour slots (csrc/fit_chunk.hip) and layouts the tiled kernels cannot take (device-side repack, api.hip)
+
+@pytest.mark.parametrize("dim,order,Kn", [(2, 2, 130), (2, 2, 256), (3, 2, 160), (3, 1, 300), (1, 2, 130), (1, 4, 200), (2, 4, 150),
+                                          (2, 0, 80), (3, 0, 66), (2, 3, 131)])
+def test_any_neighbourhood_size_runs_a_tiled_kernel(wlsqm, oracle, dim, order, Kn):
+    """K > 128 (and the shapes without a fixed-K kernel) take the chunked kernel instead of the lane-per-case one; ragged nk,
+    knowns, both weightings; odd K is repacked to an even row first."""
+    import torch
+    import wlsqm.hip as whip
+    rng = np.random.default_rng(Kn + 7 * order)
+    n = 300
+    no = K.NDOF[dim][order]
+    xi = rng.uniform(0, 1, (n, dim))
+    xk = xi[:, None, :] + 0.1 * rng.uniform(-1, 1, (n, Kn, dim))
+    fk = np.sin(3 * xk[..., 0]) * np.cos(2 * xk[..., -1])
+    nk = rng.integers(Kn - 40, Kn + 1, n).astype(np.int32); nk[0] = Kn
+    orders = np.full(n, order, np.int32)
+    kn = rng.choice(np.array([0, 0, 1], np.int64), n)
+    wm = rng.choice(np.array([1, 2], np.int32), n)
+    fi0 = rng.uniform(-1, 1, (n, no)); fi0[:, 0] = np.sin(3 * xi[:, 0]) * np.cos(2 * xi[:, -1])
+    xk_a, xi_a = (np.ascontiguousarray(xk[..., 0]), np.ascontiguousarray(xi[:, 0])) if dim == 1 else (xk, xi)
+    fi_d = _t(fi0)
+    whip.fit_many_device(dim, order, _t(xk_a), _t(fk), _t(nk), _t(xi_a), fi_d, _t(kn), _t(wm))
+    torch.cuda.synchronize()
+    assert whip.last_kernel() in ("chunk", "tile", "tilek", "moment"), whip.last_kernel()
+    if Kn > 128:
+        assert whip.last_kernel() == "chunk"
+    fo = fi0.copy()
+    oracle.fit_many(dim, xk_a, fk, nk, xi_a, fo, None, 0, orders, kn, wm)
+    truth = P.truth_fit(dim, xk_a, fk, nk, xi_a, fi0, orders, kn, wm)
+    got = fi_d.cpu().numpy()
+    assert np.array_equal(got[kn == 1, 0], fi0[kn == 1, 0])
+    P.assert_parity(got, fo, truth, "chunked kernel dim %d order %d K %d" % (dim, order, Kn))
+
+
+@pytest.mark.parametrize("dim,order,Kn", [(2, 2, 32), (3, 2, 40), (2, 2, 31), (1, 2, 9), (3, 1, 25), (2, 4, 64)])
+def test_strided_and_odd_rows_are_repacked_for_the_tiled_kernels(wlsqm, dim, order, Kn, monkeypatch):
+    """Views into wider arrays (strided neighbour and case axes) and odd K: same numbers as the contiguous call, from a tiled
+    kernel (the repack is exact: a copy), and the caller's arrays are not modified."""
+    import torch
+    import wlsqm.hip as whip
+    rng = np.random.default_rng(Kn)
+    n = 700
+    no = K.NDOF[dim][order]
+    xi = rng.uniform(0, 1, (n, dim))
+    xk = xi[:, None, :] + 0.08 * rng.uniform(-1, 1, (n, Kn, dim))
+    fk = np.sin(3 * xk[..., 0]) * np.cos(2 * xk[..., -1])
+    nk = rng.integers(max(no + 2, Kn - 6), Kn + 1, n).astype(np.int32); nk[0] = Kn
+    kn = np.zeros(n, np.int64); wm = np.full(n, 2, np.int32)
+    fi0 = np.zeros((n, no)); fi0[:, 0] = np.sin(3 * xi[:, 0]) * np.cos(2 * xi[:, -1])
+    dev = "cuda:0"
+    wide = torch.full((n, Kn + 5, dim + (0 if dim > 1 else 1)), 7.0, dtype=torch.float64, device=dev)
+    if dim == 1:
+        xk_s = wide[:, :Kn, 0]; xk_s.copy_(_t(xk[..., 0])); xi_t = _t(xi[:, 0])
+    else:
+        xk_s = wide[:, :Kn]; xk_s.copy_(_t(xk)); xi_t = _t(xi)
+    fwide = torch.full((n, 2 * Kn), 7.0, dtype=torch.float64, device=dev)
+    fk_s = fwide[:, ::2]; fk_s.copy_(_t(fk))
+    before = (wide.clone(), fwide.clone())
+    a = _t(fi0)
+    whip.fit_many_device(dim, order, xk_s, fk_s, _t(nk), xi_t, a, _t(kn), _t(wm))
+    torch.cuda.synchronize()
+    k_strided = whip.last_kernel()
+    assert k_strided != "lane", k_strided
+    assert torch.equal(wide, before[0]) and torch.equal(fwide, before[1])
+    b = _t(fi0)
+    xk_c = _t(xk[..., 0]) if dim == 1 else _t(xk)
+    monkeypatch.setenv("WLSQM_HIP_DISABLE_REPACK", "1")
+    whip.fit_many_device(dim, order, xk_s, fk_s, _t(nk), xi_t, b, _t(kn), _t(wm))
+    torch.cuda.synchronize()
+    assert whip.last_kernel() == "lane"                                  # what these layouts took before
+    monkeypatch.delenv("WLSQM_HIP_DISABLE_REPACK")
+    truth = P.truth_fit(dim, xk[..., 0] if dim == 1 else xk, fk, nk, xi[:, 0] if dim == 1 else xi, fi0, np.full(n, order, np.int32), kn, wm)
+    P.assert_parity(a.cpu().numpy(), b.cpu().numpy(), truth, "repacked vs lane kernel")
+    if Kn % 2 == 0:
+        c = _t(fi0)
+        whip.fit_many_device(dim, order, xk_c, _t(fk), _t(nk), xi_t, c, _t(kn), _t(wm))
+        torch.cuda.synchronize()
+        assert torch.equal(a, c), "repacked rows must give the contiguous call's numbers"
