@@ -33,6 +33,22 @@ typedef double rd2_ __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void* ring_lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* ring_glb_ptr_t;
 
+typedef unsigned ru2_ __attribute__((ext_vector_type(2)));
+// v_permlane16_swap / v_permlane32_swap on a double (both halves): afterwards, in the lanes of the EVEN 16-lane rows (lower 32
+// lanes) x is unchanged and y holds the partner lane's x; in the ODD rows (upper 32 lanes) y is unchanged and x holds the
+// partner's y (tools/ubench/permlane_swap.hip) — so x + y is "x summed over the pair" in one half of the lanes and "y summed
+// over the pair" in the other: one step of a reduce-SCATTER without selects, LDS traffic or copies.
+__device__ __forceinline__ void swap16(double& x, double& y) {
+    const ru2_ lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+    const ru2_ hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+    x = __hiloint2double((int)hi.x, (int)lo.x); y = __hiloint2double((int)hi.y, (int)lo.y);
+}
+__device__ __forceinline__ void swap32(double& x, double& y) {
+    const ru2_ lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+    const ru2_ hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+    x = __hiloint2double((int)hi.x, (int)lo.x); y = __hiloint2double((int)hi.y, (int)lo.y);
+}
+
 template <int K> struct RingGeom {
     static constexpr int DIM = 2, WV = 64, TC = 16, LPC = 4;
     static constexpr int KC = (K + 7) / 8 * 8;              // slots the four shares cover (even share each); slots >= K are masked
@@ -103,18 +119,35 @@ __global__ __launch_bounds__(64, 1) void fit_ring_kernel(const KParams p, const 
         }
     };
 
-    // parked sums: lane (c, h) keeps the reduced moments of case c of the tile of iteration it with it % 4 == h
-    double Pm[NM], Pn[NO];
+    // Parked sums.  The four partial sums of a case meet in a reduce-scatter (two swap steps, below): afterwards lane (c, h)
+    // holds the COMPLETE sums of one quarter of the 60 moments of case c (quarter QB[h] of the list mu[0..44], nu[0..14]) and
+    // keeps them in PQ[it % 4].  After four tiles a 4 x 4 transpose between the four lanes of a case (two more swap steps, no
+    // arithmetic) leaves lane (c, h) with all 60 moments of case c of the tile of iteration it % 4 == h: the 64 lanes hold 64
+    // different cases and the whole wave solves.
+    constexpr int NV = NM + NO, NQ = NV / 4;
+    static_assert(NV % 4 == 0, "the moments split into four equal quarters");
+    double PQ[4][NQ];
     long long jp = 0;
     unsigned long long knownp = 0, droppedp = 0;
     bool havep = false;
     constexpr unsigned long long FULL = (1ull << NO) - 1ull;
 
     auto solve_parked = [&]() {
+        // 4 x 4 transpose of the quarters: rows of 16 lanes first, then the halves of the wave.  Afterwards PQ[r] holds
+        // quarter QR[r] = {0, 2, 1, 3}[r] of this lane's own case (see the derivation in DESIGN.md section 4).
+#pragma unroll
+        for (int e = 0; e < NQ; ++e) { swap16(PQ[0][e], PQ[1][e]); swap16(PQ[2][e], PQ[3][e]); }
+#pragma unroll
+        for (int e = 0; e < NQ; ++e) { swap32(PQ[0][e], PQ[2][e]); swap32(PQ[1][e], PQ[3][e]); }
         if (havep && knownp != FULL) {
             double* fio = p.fi + jp * p.sfi_j;
             double M[NE], rhs[NO];
-            expand_moments_from<DIM, ORDER>([&](int i) { return Pm[i]; }, [&](int i) { return Pn[i]; }, M, rhs);
+            auto entry = [&](int i) -> double {                  // moment i of the list (mu, nu): quarter i / NQ sits in PQ[QRinv]
+                const int qtr = i / NQ, e = i - qtr * NQ;
+                const int r = (qtr == 0) ? 0 : (qtr == 1) ? 2 : (qtr == 2) ? 1 : 3;
+                return PQ[r][e];
+            };
+            expand_moments_from<DIM, ORDER>([&](int i) { return entry(i); }, [&](int i) { return entry(NM + i); }, M, rhs);
             if (knownp) {
                 double val[NO];
 #pragma unroll
@@ -200,20 +233,34 @@ __global__ __launch_bounds__(64, 1) void fit_ring_kernel(const KParams p, const 
 #pragma unroll
             for (int kk = 0; kk < KPL; ++kk) neighbour(kk, k0 + kk < nkc);
         }
+        // reduce-scatter over the four lanes of a case.  V = (mu, nu), 60 entries.  Step 1 (rows of 16 lanes: h <-> h ^ 1) on the
+        // pairs (e, e + 30): even rows keep the sums of the first half, odd rows of the second; step 2 (halves of the wave:
+        // h <-> h ^ 2) on the pairs (e, e + 15) of what a lane kept.  Same association as the xor butterfly it replaces
+        // ((h, h^1) first), so the sums are bit-identical to it; 135 instead of 360 instructions and nothing through LDS.
+        {
+            double Rr[NV / 2], Qq[NQ];
+            auto V = [&](int i) -> double& { return i < NM ? mu[i] : nu[i - NM]; };
 #pragma unroll
-        for (int off = TC; off < WV; off <<= 1) {
+            for (int e = 0; e < NV / 2; ++e) { swap16(V(e), V(e + NV / 2)); Rr[e] = V(e) + V(e + NV / 2); }
 #pragma unroll
-            for (int e = 0; e < NM; ++e) mu[e] += __shfl_xor(mu[e], off, WV);
+            for (int e = 0; e < NQ; ++e) { swap32(Rr[e], Rr[e + NQ]); Qq[e] = Rr[e] + Rr[e + NQ]; }
+            // lane h now holds quarter {0, 2, 1, 3}[h] (h = 0: entries 0..14, h = 1: 30..44, h = 2: 15..29, h = 3: 45..59)
+            const int slot = it & 3;                   // wave-uniform
+            if (slot == 0) {
 #pragma unroll
-            for (int a = 0; a < NO; ++a) nu[a] += __shfl_xor(nu[a], off, WV);
+                for (int e = 0; e < NQ; ++e) PQ[0][e] = Qq[e];
+            } else if (slot == 1) {
+#pragma unroll
+                for (int e = 0; e < NQ; ++e) PQ[1][e] = Qq[e];
+            } else if (slot == 2) {
+#pragma unroll
+                for (int e = 0; e < NQ; ++e) PQ[2][e] = Qq[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < NQ; ++e) PQ[3][e] = Qq[e];
+            }
         }
-        if (h == (it & 3)) {
-#pragma unroll
-            for (int e = 0; e < NM; ++e) Pm[e] = mu[e];
-#pragma unroll
-            for (int a = 0; a < NO; ++a) Pn[a] = nu[a];
-            jp = j; knownp = known; droppedp = dropped; havep = valid;
-        }
+        if (h == (it & 3)) { jp = j; knownp = known; droppedp = dropped; havep = valid; }
         if ((it & 3) == 3) solve_parked();             // the 64 lanes hold 64 different cases
     }
     if (it & 3) solve_parked();                        // leftovers of a run that is not a multiple of 4 tiles
