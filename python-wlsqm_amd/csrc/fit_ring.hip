@@ -49,32 +49,35 @@ __device__ __forceinline__ void swap32(double& x, double& y) {
     x = __hiloint2double((int)hi.x, (int)lo.x); y = __hiloint2double((int)hi.y, (int)lo.y);
 }
 
-template <int K> struct RingGeom {
-    static constexpr int DIM = 2, WV = 64, TC = 16, LPC = 4;
+template <int DIM, int K> struct RingGeom {
+    static constexpr int WV = 64, TC = 16, LPC = 4;
     static constexpr int KC = (K + 7) / 8 * 8;              // slots the four shares cover (even share each); slots >= K are masked
     static constexpr int KPL = KC / LPC;
-    static constexpr int PARTS = (K + WV - 1) / WV;          // DMA instructions per row (64 neighbours = 1 KiB each)
+    static constexpr int ROWB = K * DIM * 8;                 // bytes of a row (a multiple of 16: K * DIM even)
+    static constexpr int PARTS = (ROWB + 1023) / 1024;       // DMA instructions per row (64 lanes x 16 B = 1 KiB each)
     static constexpr int NI = TC * PARTS;                    // DMA instructions per tile
-    // padded row stride in doubles: == 2 (mod 4), so that 16 consecutive lanes reading one neighbour of 16 consecutive rows
-    // with ds_read_b128 hit 16 different 4-bank groups; rows cover KC slots (a padded share reads up to KC - K slots past K)
-    static constexpr int RS = ((2 * KC + 1) / 4) * 4 + 2;
+    // padded row stride in doubles, even (16-byte DMA destinations).  2D: == 2 (mod 4), so that 16 consecutive lanes reading one
+    // neighbour of 16 consecutive rows with ds_read_b128 hit 16 different 4-bank groups; 3D (ds_read_b64 x 3): == 2 (mod 32)
+    // spreads the 16 rows over the even bank pairs (the second share of a case lands 2-way on some of them: accepted).
+    // Rows cover KC slots (a padded share reads up to KC - K slots past K).
+    static constexpr int RS = (DIM == 2) ? ((2 * KC + 1) / 4) * 4 + 2 : ((KC * DIM + 31) / 32) * 32 + 2;
     static constexpr int SLOT = TC * RS + 2 * WV;            // doubles per ring slot (+ slack: the last row's DMA writes whole 16-B lanes only)
     static constexpr size_t LDS_BYTES = sizeof(double) * 2 * SLOT;
-    static_assert(K % 2 == 0 && K >= 8, "rows must be multiples of 16 bytes");
-    static_assert(RS >= 2 * KC && RS % 4 == 2, "row stride");
+    static_assert((K * DIM) % 2 == 0 && K % 2 == 0 && K >= 8, "rows must be multiples of 16 bytes");
+    static_assert(RS >= DIM * KC && RS % 2 == 0, "row stride");
 };
 
-template <int ORDER, int K, int UNR>
-__global__ __launch_bounds__(64, 1) void fit_ring_kernel(const KParams p, const long long ntiles, const int tiles_per_wg) {
-    using G = RingGeom<K>;
-    constexpr int DIM = 2, WV = 64, TC = G::TC, KPL = G::KPL, RS = G::RS;
+template <int DIM, int ORDER, int K, int UNR, int MINW>
+__global__ __launch_bounds__(64, MINW) void fit_ring_kernel(const KParams p, const long long ntiles, const int tiles_per_wg) {
+    using G = RingGeom<DIM, K>;
+    constexpr int WV = 64, TC = G::TC, KPL = G::KPL, RS = G::RS;
     constexpr int NO = ndofs(DIM, ORDER), NE = NO * (NO + 1) / 2, NM = mom_count<DIM>(2 * ORDER), NN = mom_count<DIM>(ORDER);
     static_assert(NN == NO, "one right-hand-side moment per DOF");
     extern __shared__ __attribute__((aligned(16))) double lds[];          // [2][SLOT]
 
     const int lane = threadIdx.x, c = lane % TC, h = lane / TC, k0 = h * KPL;
 
-    struct Meta { int nk, wm; long long kn; double xi0, xi1; };
+    struct Meta { int nk, wm; long long kn; double xi[DIM]; };
     Meta nxt;
     double fnext[KPL];
 
@@ -94,12 +97,12 @@ __global__ __launch_bounds__(64, 1) void fit_ring_kernel(const KParams p, const 
         // once for the low and once for the high lanes: wrong rows for K > 64, measured)
 #pragma unroll
         for (int pp = 0; pp < G::PARTS; ++pp) {
-            if ((pp + 1) * WV <= K || pp * WV + lane < K) {
+            if ((pp + 1) * 1024 <= G::ROWB || pp * 1024 + (int)lane16 < G::ROWB) {
 #pragma unroll
                 for (int r = 0; r < TC; ++r) {
                     const int rs = r < nvalid ? r : nvalid - 1;                    // tail tile: replay the last valid row
-                    const char* src = xbase + (size_t)(rs * K + pp * WV) * 16u;   // uniform
-                    __builtin_amdgcn_global_load_lds((ring_glb_ptr_t)(src + lane16), (ring_lds_ptr_t)(dst + r * RS + pp * WV * DIM),
+                    const char* src = xbase + (size_t)rs * G::ROWB + (size_t)pp * 1024u;   // uniform
+                    __builtin_amdgcn_global_load_lds((ring_glb_ptr_t)(src + lane16), (ring_lds_ptr_t)(dst + r * RS + pp * 128),
                                                      16, 0, 0);
                 }
             }
@@ -107,7 +110,8 @@ __global__ __launch_bounds__(64, 1) void fit_ring_kernel(const KParams p, const 
         const int cc = c < nvalid ? c : nvalid - 1;                                // tail tile: replay the last valid case
         const long long jc = j0 + cc;
         nxt.nk = p.nk[jc * p.snk]; nxt.wm = p.wm[jc * p.swm]; nxt.kn = p.knowns[jc * p.sknowns];
-        nxt.xi0 = p.xi[jc * p.sxi_j]; nxt.xi1 = p.xi[jc * p.sxi_j + 1];
+#pragma unroll
+        for (int m = 0; m < DIM; ++m) nxt.xi[m] = p.xi[jc * p.sxi_j + m];
         const char* fbase = reinterpret_cast<const char*>(p.fk + j0 * (long long)K);
 #pragma unroll
         for (int i = 0; i < KPL / 2; ++i) {
@@ -124,8 +128,7 @@ __global__ __launch_bounds__(64, 1) void fit_ring_kernel(const KParams p, const 
     // keeps them in PQ[it % 4].  After four tiles a 4 x 4 transpose between the four lanes of a case (two more swap steps, no
     // arithmetic) leaves lane (c, h) with all 60 moments of case c of the tile of iteration it % 4 == h: the 64 lanes hold 64
     // different cases and the whole wave solves.
-    constexpr int NV = NM + NO, NQ = NV / 4;
-    static_assert(NV % 4 == 0, "the moments split into four equal quarters");
+    constexpr int NV = (NM + NO + 3) / 4 * 4, NQ = NV / 4;          // the list (mu, nu), padded with zeros to four equal quarters
     double PQ[4][NQ];
     long long jp = 0;
     unsigned long long knownp = 0, droppedp = 0;
@@ -147,6 +150,8 @@ __global__ __launch_bounds__(64, 1) void fit_ring_kernel(const KParams p, const 
                 const int r = (qtr == 0) ? 0 : (qtr == 1) ? 2 : (qtr == 2) ? 1 : 3;
                 return PQ[r][e];
             };
+            // (nu in graded order is the right-hand-side moment of DOF order for every (dimension, order) here: mom_index == DOF index
+            // is not assumed — expand_moments_from asks for nu by moment index)
             expand_moments_from<DIM, ORDER>([&](int i) { return entry(i); }, [&](int i) { return entry(NM + i); }, M, rhs);
             if (knownp) {
                 double val[NO];
@@ -176,7 +181,9 @@ __global__ __launch_bounds__(64, 1) void fit_ring_kernel(const KParams p, const 
         const bool uniform = (nxt.wm == WLSQM_WEIGHT_UNIFORM);
         unsigned long long known, dropped;
         effective_mask<NO>(nxt.kn, known, dropped);
-        const double xi[DIM] = {nxt.xi0, nxt.xi1};
+        double xi[DIM];
+#pragma unroll
+        for (int m = 0; m < DIM; ++m) xi[m] = nxt.xi[m];
         double f[KPL];
 #pragma unroll
         for (int i = 0; i < KPL; ++i) f[i] = fnext[i];
@@ -185,9 +192,20 @@ __global__ __launch_bounds__(64, 1) void fit_ring_kernel(const KParams p, const 
 
         // (squared distances are written as explicit fma(dy, dy, dx * dx) everywhere: the ragged and the full-tile code paths
         // must round identically, or a case's result would depend on which other cases share its tile)
-        auto offset = [&](int kk, double (&d)[DIM]) {  // neighbour k0 + kk of this lane's case (ds_read_b128, immediate offset)
-            const rd2_ xy = *reinterpret_cast<const rd2_*>(row + kk * DIM);
-            d[0] = xy.x - xi[0]; d[1] = xy.y - xi[1];
+        auto offset = [&](int kk, double (&d)[DIM]) {  // neighbour k0 + kk of this lane's case (immediate offsets)
+            if constexpr (DIM == 2) {
+                const rd2_ xy = *reinterpret_cast<const rd2_*>(row + kk * DIM);      // ds_read_b128
+                d[0] = xy.x - xi[0]; d[1] = xy.y - xi[1];
+            } else {
+#pragma unroll
+                for (int m = 0; m < DIM; ++m) d[m] = row[kk * DIM + m] - xi[m];
+            }
+        };
+        auto sqdist = [&](const double (&d)[DIM]) {    // one rounding sequence for every code path (see above)
+            double d2 = d[0] * d[0];
+#pragma unroll
+            for (int m = 1; m < DIM; ++m) d2 = fma(d[m], d[m], d2);
+            return d2;
         };
         const bool full = (G::KC == K) && __all(nkc >= K);     // wave-uniform: no ragged case in this tile
         double max_d2 = 0.0;
@@ -196,7 +214,7 @@ __global__ __launch_bounds__(64, 1) void fit_ring_kernel(const KParams p, const 
             for (int kk = 0; kk < KPL; ++kk) {
                 double d[DIM];
                 offset(kk, d);
-                const double d2 = fma(d[1], d[1], d[0] * d[0]);
+                const double d2 = sqdist(d);
                 max_d2 = d2 > max_d2 ? d2 : max_d2;
             }
         } else {
@@ -204,7 +222,7 @@ __global__ __launch_bounds__(64, 1) void fit_ring_kernel(const KParams p, const 
             for (int kk = 0; kk < KPL; ++kk) {
                 double d[DIM];
                 offset(kk, d);
-                double d2 = fma(d[1], d[1], d[0] * d[0]);
+                double d2 = sqdist(d);
                 d2 = (k0 + kk < nkc) ? d2 : 0.0;
                 max_d2 = d2 > max_d2 ? d2 : max_d2;
             }
@@ -221,8 +239,9 @@ __global__ __launch_bounds__(64, 1) void fit_ring_kernel(const KParams p, const 
         auto neighbour = [&](int kk, bool live) {
             double d[DIM];
             offset(kk, d);
-            d[0] = live ? d[0] : 0.0; d[1] = live ? d[1] : 0.0;
-            const double d2 = fma(d[1], d[1], d[0] * d[0]);
+#pragma unroll
+            for (int m = 0; m < DIM; ++m) d[m] = live ? d[m] : 0.0;
+            const double d2 = sqdist(d);
             const double w = live ? weight(d2, inv_max, uniform) : 0.0;
             accumulate_moments_best<DIM, ORDER>(mu, nu, d, w, live ? f[kk] : 0.0);
         };
@@ -239,12 +258,15 @@ __global__ __launch_bounds__(64, 1) void fit_ring_kernel(const KParams p, const 
         // ((h, h^1) first), so the sums are bit-identical to it; 135 instead of 360 instructions and nothing through LDS.
         {
             double Rr[NV / 2], Qq[NQ];
-            auto V = [&](int i) -> double& { return i < NM ? mu[i] : nu[i - NM]; };
+            double pad[NV - NM - NO + 1];
+#pragma unroll
+            for (int i = 0; i < NV - NM - NO + 1; ++i) pad[i] = 0.0;
+            auto V = [&](int i) -> double& { return i < NM ? mu[i] : (i < NM + NO ? nu[i - NM] : pad[i - NM - NO]); };
 #pragma unroll
             for (int e = 0; e < NV / 2; ++e) { swap16(V(e), V(e + NV / 2)); Rr[e] = V(e) + V(e + NV / 2); }
 #pragma unroll
             for (int e = 0; e < NQ; ++e) { swap32(Rr[e], Rr[e + NQ]); Qq[e] = Rr[e] + Rr[e + NQ]; }
-            // lane h now holds quarter {0, 2, 1, 3}[h] (h = 0: entries 0..14, h = 1: 30..44, h = 2: 15..29, h = 3: 45..59)
+            // lane h now holds quarter {0, 2, 1, 3}[h] of the list (2D order 4: h = 0: entries 0..14, 1: 30..44, 2: 15..29, 3: 45..59)
             const int slot = it & 3;                   // wave-uniform
             if (slot == 0) {
 #pragma unroll
@@ -274,14 +296,14 @@ static int ring_tiles_per_wg() {
     return v >= 1 ? v : 4;
 }
 
-template <int ORDER, int K, int UNR>
+template <int DIM, int ORDER, int K, int UNR, int MINW>
 static int launch_ring_impl(const KParams& p, hipStream_t stream) {
-    using G = RingGeom<K>;
+    using G = RingGeom<DIM, K>;
     const long long ntiles = (p.ncases + G::TC - 1) / G::TC;
     const int T = ring_tiles_per_wg();
     const long long grid = (ntiles + T - 1) / T;
     if (grid > 0x7fffffffll) { set_error("fit_ring: batch too large for one launch"); return WLSQM_EVALUE; }
-    auto kern = fit_ring_kernel<ORDER, K, UNR>;
+    auto kern = fit_ring_kernel<DIM, ORDER, K, UNR, MINW>;
     static bool optin[16] = {};
     int dev = 0;
     WLSQM_HIP_CHECK(hipGetDevice(&dev));
@@ -306,14 +328,30 @@ int launch_fit_ring(int dimension, int order, const KParams& p, long long max_nk
     if (off && off[0] == '1') return WLSQM_OK;
     const char* noring = getenv("WLSQM_HIP_DISABLE_RING");       // A/B against the two-kernel moment path
     if (noring && noring[0] == '1') return WLSQM_OK;
-    if (dimension != 2 || order != 4 || p.hoods) return WLSQM_OK;
-    if (p.do_sens || p.iterative || p.case_index) return WLSQM_OK;
+    if (p.hoods || p.do_sens || p.iterative || p.case_index) return WLSQM_OK;
+    const char* v = getenv("WLSQM_TILE_VARIANT");                // tools/tune.py: A/B of the ring shapes against the tile kernels
+    const int var = v ? atoi(v) : 0;
+    // 3D order 2 with 40 neighbour slots (BASELINE configs[4]): the ring shape is 5 % ahead of the one-wave tile kernel (interleaved
+    // A/B at 1M cases: 0.341 against 0.359 ms; unroll 5 instead of 10: 0.350; compiled for two waves per SIMD it spills 524 B per
+    // lane: 1.01 ms).  WLSQM_TILE_VARIANT = 1 keeps the tile kernel (tools/tune.py).
+    // 2D order 2 with 32 slots (the headline shape) ties: 0.1616 ms (two waves per SIMD, 242 registers, no spills) against 0.1604 ms
+    // for the tile kernel of fit_tile.hip — two unrelated designs at the same 5.3 TB/s: that shape sits at what the memory system
+    // gives this access mix; the tile kernel stays (WLSQM_TILE_VARIANT = 60 selects the ring for A/B).
+    if (dimension == 3 && order == 2 && max_nk == 40 && var != 1 && tile_dense_eligible(dimension, p, max_nk)) {
+        *handled = true;
+        return launch_ring_impl<3, 2, 40, 10, 1>(p, stream);
+    }
+    if (dimension == 2 && order == 2 && max_nk == 32 && var == 60 && tile_dense_eligible(dimension, p, max_nk)) {
+        *handled = true;
+        return launch_ring_impl<2, 2, 32, 8, 2>(p, stream);
+    }
+    if (dimension != 2 || order != 4) return WLSQM_OK;
     if (!tile_dense_eligible(dimension, p, max_nk)) return WLSQM_OK;
     // Every even K from 26 to 64 (400k cases, ms per launch, two-kernel moment path -> this kernel): K = 26 / 32 / 40 / 48 / 56 / 64:
     // 0.220 / 0.192 / 0.281 / 0.238 / 0.323 / 0.260 -> 0.179 / 0.184 / 0.189 / 0.212 / 0.228 / 0.213.  Below 26 the two paths tie
     // (K = 16 / 24: 0.147 / 0.167 against 0.151 / 0.170); beyond 64 a row needs two DMA instructions and the ring 43-56 KB of
     // LDS (three waves per CU): K = 80 / 100: 0.424 / 0.644 against 0.361 / 0.504 — those stay on the two-kernel path.
-#define RING_CASE(KK) if (max_nk == KK) { *handled = true; return launch_ring_impl<4, KK, 16>(p, stream); }
+#define RING_CASE(KK) if (max_nk == KK) { *handled = true; return launch_ring_impl<2, 4, KK, 16, 1>(p, stream); }
     RING_CASE(26) RING_CASE(28) RING_CASE(30) RING_CASE(32) RING_CASE(34) RING_CASE(36) RING_CASE(38) RING_CASE(40) RING_CASE(42) RING_CASE(44)
     RING_CASE(46) RING_CASE(48) RING_CASE(50) RING_CASE(52) RING_CASE(54) RING_CASE(56) RING_CASE(58) RING_CASE(60) RING_CASE(62) RING_CASE(64)
 #undef RING_CASE

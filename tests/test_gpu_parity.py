@@ -276,7 +276,8 @@ def test_every_even_neighbourhood_size_has_a_fixed_shape(wlsqm, dim, order, K, m
         pytest.skip("fewer neighbours than unknowns + 2")
     # (ragged nk stays clear of the nearly determined systems, whose rounding noise differs between any two summation orders
     # by more than the parity bar; those are the business of test_tile_path_equals_lane_path and tools/fuzz.py)
-    _tile_vs_lane(wlsqm, dim, order, K, 16 * 9 + 5 + K, monkeypatch, expect="tile", spare=6)
+    # (3D order 2 with 40 slots, the BASELINE configs[4] shape, takes the ring kernel of csrc/fit_ring.hip)
+    _tile_vs_lane(wlsqm, dim, order, K, 16 * 9 + 5 + K, monkeypatch, expect="tile-solve" if (dim, order, K) == (3, 2, 40) else "tile", spare=6)
 
 
 @pytest.mark.parametrize("K", list(range(22, 102, 2)))
@@ -1302,7 +1303,7 @@ def test_index_based_input_has_a_fixed_shape_for_every_even_K(wlsqm, dim, order,
     whip.fit_cloud_device(dim, order, S_d, F_d, h_d, fi_b, nk_d, kn_d, wm_d, point_index=p_d)
     assert whip.last_kernel() == "tile-gather"
     whip.fit_many_device(dim, order, xk_d, fk_d, nk_d, xi_d, fi_a, kn_d, wm_d)
-    assert whip.last_kernel() == "tile"
+    assert whip.last_kernel() in ("tile", "tile-solve")
     torch.cuda.synchronize()
     truth = P.truth_fit(dim, xk_d.cpu().numpy(), fk_d.cpu().numpy(), nk, xi_d.cpu().numpy(), fi0, np.full(n, order, np.int32), kn, wm)
     P.assert_parity(fi_b.cpu().numpy(), fi_a.cpu().numpy(), truth, "index-based vs dense path")

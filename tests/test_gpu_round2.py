@@ -39,7 +39,7 @@ def _t(a, dev="cuda:0"):
 # ----------------------------------------------------------------------------------------------------------------------
 # parity at the headline density, against the REFERENCE (simple.pyx:379-421 output captured in tests/golden/config_*_1M.npz)
 
-FAST_KERNELS = {"C2_1M": ("tile",), "C3_1M": ("tile-solve",), "C5_1M": ("tile",), "C5_16M": ("tile",)}
+FAST_KERNELS = {"C2_1M": ("tile",), "C3_1M": ("tile-solve",), "C5_1M": ("tile-solve",), "C5_16M": ("tile-solve",)}
 
 
 @pytest.mark.parametrize("name", K.DENSE)
@@ -352,6 +352,45 @@ def test_hip_kernels_under_world_size_2(wlsqm, tmp_path):
 
 # ----------------------------------------------------------------------------------------------------------------------
 # the one-kernel 2D order-4 fit (csrc/fit_ring.hip: LDS-DMA ring + register-parked solve)
+
+@pytest.mark.parametrize("n,ragged,kn", [(300, False, 0), (277, True, 0b1000010001), (37, True, 1), (64, False, 0), (1, False, 0), (17, True, 0)])
+def test_ring_fit_3d_order2(wlsqm, oracle, n, ragged, kn, monkeypatch):
+    """The same kernel template on the 3D order-2 / 40-slot shape of BASELINE configs[4] (45 moments padded to four quarters of 12):
+    against the oracle and against the one-wave tile kernel it replaces (WLSQM_TILE_VARIANT=1)."""
+    import torch
+    import synth
+    import wlsqm.hip as whip
+    Kn = 40
+    rng = np.random.default_rng(n)
+    S = synth.halton(5000, 3, skip=1); F = synth.field(S)
+    hoods = synth.knn(S, Kn, workers=4)[:n]
+    xk = S[hoods]; fk = F[hoods]; xi = S[:n].copy()
+    nk = np.full(n, Kn, np.int32); wm = np.full(n, 2, np.int32)
+    if ragged:
+        nk = rng.integers(Kn - 9, Kn + 1, n).astype(np.int32); nk[0] = Kn
+        wm[::3] = 1
+    order = np.full(n, 2, np.int32); knowns = np.full(n, kn, np.int64)
+    fi0 = rng.uniform(-1, 1, (n, 10)); fi0[:, 0] = F[:n]
+    out = {}
+    for name, var in (("ring", None), ("tile", "1")):
+        if var:
+            monkeypatch.setenv("WLSQM_TILE_VARIANT", var)
+        fi = _t(fi0)
+        whip.fit_many_device(3, 2, _t(xk), _t(fk), _t(nk), _t(xi), fi, _t(knowns), _t(wm))
+        torch.cuda.synchronize()
+        out[name] = (fi.cpu().numpy(), whip.last_kernel())
+        monkeypatch.delenv("WLSQM_TILE_VARIANT", raising=False)
+    assert out["ring"][1] == "tile-solve" and out["tile"][1] == "tile", (out["ring"][1], out["tile"][1])
+    for a in range(10):
+        if (kn >> a) & 1:
+            assert np.array_equal(out["ring"][0][:, a], fi0[:, a])
+    fo = fi0.copy()
+    oracle.fit_many(3, xk, fk, nk, xi, fo, None, 0, order, knowns, wm)
+    truth = P.truth_fit(3, xk, fk, nk, xi, fi0, order, knowns, wm)
+    e_ring = P.column_metric(out["ring"][0], truth).max()
+    e_ref = max(P.column_metric(fo, truth).max(), P.column_metric(out["tile"][0], truth).max())
+    assert e_ring <= P.TOL + P.NOISE_MULT * e_ref, (e_ring, e_ref)
+
 
 @pytest.mark.parametrize("Kn", [26, 40, 50, 64])
 @pytest.mark.parametrize("n,ragged,kn", [(300, False, 1), (277, True, 0), (37, True, 0b101), (64, False, 0), (1, False, 1), (17, True, 1)])
