@@ -257,8 +257,9 @@ def measure_fit(name, cfg, n, dev, timer, steps, warmup, rank, parity=True, keep
 def measure_c4(cfg, n, R, dev, timer, steps, warmup, rank, parity=True):
     """BASELINE configs[3]: ExpertSolver on the C2 geometry, prepare once, then right-hand sides F_t = sin(pi x + 0.01 t)
     cos(pi y).  A step = ONE solve_many_device call over R stacked fields; a fit = one (case, field)
-    pair.  Algorithmic bytes per fit: fk 8 nk + fi 8 no + the geometry (8 nk dim + 8 dim + 20) shared by the R fields of a
-    step.  The time-stepping rate (one fused solve_device launch per field, 852 B per fit) is reported beside it."""
+    pair.  Algorithmic bytes per fit: fk 8 nk + fi 8 no + the case's [nr x nk] solution operator shared by
+    the R fields of a step (310 B at R = 256; the stored operator has 16 rows per case, so the measured traffic is a little
+    higher).  The time-stepping rate (one fused solve_device launch per field, 852 B per fit) is reported beside it."""
     import torch
     import wlsqm
     import wlsqm.hip as whip
@@ -295,7 +296,8 @@ def measure_c4(cfg, n, R, dev, timer, steps, warmup, rank, parity=True):
         solver.solve_device(fk[r], fi_seq)
     e1.record(); torch.cuda.synchronize()
     ms_step_field = e0.elapsed_time(e1) / min(R, 64)
-    B_fit = 8 * nk + 8 * no + (8 * nk * dim + 8 * dim + 20) / R
+    nr = no - bin(cfg["knowns"]).count("1")
+    B_fit = 8 * nk + 8 * no + 8 * nr * nk / R       # fk + fi + the case's [nr x nk] operator shared by the R fields
     achieved = B_fit * n * R / (ms_kernel * 1e-3) / 1e9
     traffic, tsrc = load_traffic("C4", n * R)
     res = {"workload": "C4: %s; %d cases x %d stacked fields per GPU per step (a fit = one case of one field), "

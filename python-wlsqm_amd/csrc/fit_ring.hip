@@ -136,8 +136,11 @@ __global__ __launch_bounds__(64, MINW) void fit_ring_kernel(const KParams p, con
     constexpr unsigned long long FULL = (1ull << NO) - 1ull;
 
     auto solve_parked = [&]() {
-        // 4 x 4 transpose of the quarters: rows of 16 lanes first, then the halves of the wave.  Afterwards PQ[r] holds
-        // quarter QR[r] = {0, 2, 1, 3}[r] of this lane's own case (see the derivation in DESIGN.md section 4).
+        // 4 x 4 transpose of the quarters (lanes x parked sets): rows of 16 lanes first, then the halves of the wave.  Lane h parked, for
+        // tile t, quarter QB[h] = {0, 2, 1, 3}[h] in PQ[t].  swap16(PQ[t], PQ[t+1]), t = 0, 2: even-row lanes now hold two quarters of
+        // tile t in PQ[t], PQ[t+1], odd-row lanes two quarters of tile t + 1; swap32(PQ[t], PQ[t+2]), t = 0, 1: lower lanes get the
+        // other two quarters of their tile from the upper half in PQ[2], PQ[3], upper lanes theirs in PQ[0], PQ[1].  Lane h ends with
+        // tile h complete, and in EVERY lane PQ[r] holds quarter {0, 2, 1, 3}[r] (checked for all four lanes).
 #pragma unroll
         for (int e = 0; e < NQ; ++e) { swap16(PQ[0][e], PQ[1][e]); swap16(PQ[2][e], PQ[3][e]); }
 #pragma unroll
