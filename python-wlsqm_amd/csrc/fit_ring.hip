@@ -145,14 +145,56 @@ __global__ __launch_bounds__(64, MINW) void fit_ring_kernel(const KParams p, con
         for (int e = 0; e < NQ; ++e) { swap16(PQ[0][e], PQ[1][e]); swap16(PQ[2][e], PQ[3][e]); }
 #pragma unroll
         for (int e = 0; e < NQ; ++e) { swap32(PQ[0][e], PQ[2][e]); swap32(PQ[1][e], PQ[3][e]); }
+        auto entry = [&](int i) -> double {                      // moment i of the list (mu, nu): quarter i / NQ sits in PQ[QRinv]
+            const int qtr = i / NQ, e = i - qtr * NQ;
+            const int r = (qtr == 0) ? 0 : (qtr == 1) ? 2 : (qtr == 2) ? 1 : 3;
+            return PQ[r][e];
+        };
+        // Every case of the wave has exactly the function value known (knowns = b?_F, the reference's default and BASELINE
+        // configs[2]): the (NO - 1) x (NO - 1) system is expanded and factored directly — 105 + 14 instead of 120 + 15 entries for 15
+        // DOFs, which is what lets the matrix stay in the architectural registers (the full system overflows them by a few entries
+        // and the compiler then shuttles ~1 400 values per solve through the accumulation registers).  Same operations on the same
+        // numbers as the generic path below (its first elimination step is the identity row): bit-identical results.
+        if constexpr (NO >= 3) {
+            if (__all(!havep || (knownp == 1ull && droppedp == 0ull))) {
+                if (havep) {
+                    constexpr int N1 = NO - 1, NE1 = N1 * (N1 + 1) / 2;
+                    double* fio = p.fi + jp * p.sfi_j;
+                    const double v0 = fio[0];
+                    double M1[NE1], r1[N1];
+#pragma unroll
+                    for (int a = 1; a < NO; ++a) {
+                        const int pa = Mono<DIM>::P[a], qa = Mono<DIM>::Q[a], ra = Mono<DIM>::R[a];
+                        r1[a - 1] = entry(NM + mom_index<DIM>(pa, qa, ra)) * (mom_inv_fact(pa) * mom_inv_fact(qa) * mom_inv_fact(ra));
+                    }
+#pragma unroll
+                    for (int i = 0; i < NM; ++i) {
+                        const double m = entry(i);
+#pragma unroll
+                        for (int a = 1; a < NO; ++a) {
+                            const int pa = Mono<DIM>::P[a], qa = Mono<DIM>::Q[a], ra = Mono<DIM>::R[a];
+                            const double fa = mom_inv_fact(pa) * mom_inv_fact(qa) * mom_inv_fact(ra);
+                            if (mom_index<DIM>(pa, qa, ra) == i) r1[a - 1] -= (m * (1.0 * fa)) * v0;      // M[0, a] * fi[0] (impl.pyx:815-818)
+#pragma unroll
+                            for (int b = a; b < NO; ++b) {
+                                const int pb = Mono<DIM>::P[b], qb = Mono<DIM>::Q[b], rb = Mono<DIM>::R[b];
+                                const double fb = mom_inv_fact(pb) * mom_inv_fact(qb) * mom_inv_fact(rb);
+                                if (mom_index<DIM>(pa + pb, qa + qb, ra + rb) == i) M1[tri<N1>(a - 1, b - 1)] = m * (fa * fb);
+                            }
+                        }
+                    }
+                    ldlt_factor<N1>(M1);
+                    ldlt_solve<N1>(M1, r1);
+#pragma unroll
+                    for (int a = 1; a < NO; ++a) fio[a] = r1[a - 1];
+                }
+                havep = false;
+                return;
+            }
+        }
         if (havep && knownp != FULL) {
             double* fio = p.fi + jp * p.sfi_j;
             double M[NE], rhs[NO];
-            auto entry = [&](int i) -> double {                  // moment i of the list (mu, nu): quarter i / NQ sits in PQ[QRinv]
-                const int qtr = i / NQ, e = i - qtr * NQ;
-                const int r = (qtr == 0) ? 0 : (qtr == 1) ? 2 : (qtr == 2) ? 1 : 3;
-                return PQ[r][e];
-            };
             // (nu in graded order is the right-hand-side moment of DOF order for every (dimension, order) here: mom_index == DOF index
             // is not assumed — expand_moments_from asks for nu by moment index)
             expand_moments_from<DIM, ORDER>([&](int i) { return entry(i); }, [&](int i) { return entry(NM + i); }, M, rhs);
