@@ -167,6 +167,29 @@ class Timer:
         return dt
 
 
+def golden_parity_c1(dev):
+    """C1 (BASELINE configs[0]) against the reference: the first 512 cases of the specified 10 000-point cloud, outputs captured
+    from the reference's fit_1D_many (tests/golden/config_C1.npz)."""
+    import torch
+    import _cases
+    import _parity
+    import wlsqm.hip as whip
+    from oracle import oracle
+    c = _cases.config("C1")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    fi_d = t(c["fi0"])
+    whip.fit_many_device(1, c["order"], t(c["xk"]), t(c["fk"]), t(c["nk_a"]), t(c["xi"]), fi_d, t(c["knowns_a"]), t(c["wm_a"]))
+    torch.cuda.synchronize()
+    kernel = whip.last_kernel()
+    fi_o = c["fi0"].copy()
+    oracle.fit_many(1, c["xk"], c["fk"], c["nk_a"], c["xi"], fi_o, None, 0, c["order_a"], c["knowns_a"], c["wm_a"], ntasks=8)
+    truth = _parity.truth_fit(1, c["xk"], c["fk"], c["nk_a"], c["xi"], c["fi0"], c["order_a"], c["knowns_a"], c["wm_a"])
+    acc = _parity.accounting(fi_d.cpu().numpy(), c["g"]["fi"], truth=truth, oracle=fi_o, conds=c["g"]["conds"])
+    acc["golden"] = "tests/golden/config_C1.npz"
+    acc["kernel"] = kernel
+    return acc
+
+
 def golden_parity(name, dev):
     """Parity of the device-resident fast kernel against the REFERENCE at the density the metric is quoted on: the 1 024
     cases of tests/golden/config_<name>.npz (every 977th case of the full cloud; inputs rebuilt bit-for-bit, outputs
@@ -249,6 +272,8 @@ def measure_fit(name, cfg, n, dev, timer, steps, warmup, rank, parity=True, keep
            "roofline": roof}
     if parity and rank == 0 and name in GOLDEN_OF:
         res["parity"] = {"vs_reference_golden": golden_parity(GOLDEN_OF[name], dev)}
+    elif parity and rank == 0 and name == "C1":
+        res["parity"] = {"vs_reference_golden": golden_parity_c1(dev)}
     if keep:
         res["_tensors"] = dict(xk=xk_d, fk=fk_d, xi=xi_d, fi=fi_d, F=F)
     return res, dt
@@ -516,7 +541,7 @@ def side_configs(a, dev, timer, rank, parity):
             side[key] = {"error": "%s: %s" % (type(e).__name__, e)}
         torch.cuda.empty_cache()
 
-    add("C1@10k", lambda: measure_fit("C1", CONFIGS["C1"], 10_000, dev, timer, a.steps, a.warmup, rank, False))
+    add("C1@10k", lambda: measure_fit("C1", CONFIGS["C1"], 10_000, dev, timer, a.steps, a.warmup, rank, parity))
     add("C1@4M", lambda: measure_fit("C1", CONFIGS["C1"], 4_000_000, dev, timer, a.steps, a.warmup, rank, False))
     add("C3@1M", lambda: measure_fit("C3", CONFIGS["C3"], 1_000_000, dev, timer, a.steps, a.warmup, rank, parity))
     add("C4@1M,R=%d" % (a.nrhs or 256), lambda: measure_c4(CONFIGS["C4"], 1_000_000, a.nrhs or 256, dev, timer, short["steps"],

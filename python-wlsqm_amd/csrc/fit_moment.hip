@@ -34,9 +34,46 @@ __global__ __launch_bounds__(64) void moment_solve_kernel(const KParams p) {
     effective_mask<NO>(p.knowns[j * p.sknowns], known, dropped);
     constexpr unsigned long long FULL = (1ull << NO) - 1ull;
     if (known == FULL) return;
+    const double* w = p.ws + j;
+    // Every case of the wave has exactly F known (the reference's default knowns, BASELINE configs[2]): expand and factor the
+    // reduced (NO - 1) system directly — 105 + 14 entries instead of 120 + 15 for 15 DOFs (see fit_ring.hip: bit-identical to the
+    // generic path, whose first elimination step is the identity row).
+    if constexpr (NO >= 3) {
+        if (__all(known == 1ull && dropped == 0ull)) {
+            constexpr int N1 = NO - 1, NE1 = N1 * (N1 + 1) / 2;
+            double* fio1 = p.fi + j * p.sfi_j;
+            const double v0 = fio1[0];
+            double M1[NE1], r1[N1];
+#pragma unroll
+            for (int a = 1; a < NO; ++a) {
+                const int pa = Mono<DIM>::P[a], qa = Mono<DIM>::Q[a], ra = Mono<DIM>::R[a];
+                r1[a - 1] = w[(long long)(NM + mom_index<DIM>(pa, qa, ra)) * p.ws_stride] * (mom_inv_fact(pa) * mom_inv_fact(qa) * mom_inv_fact(ra));
+            }
+#pragma unroll
+            for (int i = 0; i < NM; ++i) {
+                const double m = w[(long long)i * p.ws_stride];
+#pragma unroll
+                for (int a = 1; a < NO; ++a) {
+                    const int pa = Mono<DIM>::P[a], qa = Mono<DIM>::Q[a], ra = Mono<DIM>::R[a];
+                    const double fa = mom_inv_fact(pa) * mom_inv_fact(qa) * mom_inv_fact(ra);
+                    if (mom_index<DIM>(pa, qa, ra) == i) r1[a - 1] -= (m * (1.0 * fa)) * v0;
+#pragma unroll
+                    for (int b = a; b < NO; ++b) {
+                        const int pb = Mono<DIM>::P[b], qb = Mono<DIM>::Q[b], rb = Mono<DIM>::R[b];
+                        const double fb = mom_inv_fact(pb) * mom_inv_fact(qb) * mom_inv_fact(rb);
+                        if (mom_index<DIM>(pa + pb, qa + qb, ra + rb) == i) M1[tri<N1>(a - 1, b - 1)] = m * (fa * fb);
+                    }
+                }
+            }
+            ldlt_factor<N1>(M1);
+            ldlt_solve<N1>(M1, r1);
+#pragma unroll
+            for (int a = 1; a < NO; ++a) fio1[a] = r1[a - 1];
+            return;
+        }
+    }
     double M[NE], g[NO];
     // every moment is loaded once (coalesced: consecutive lanes, consecutive cases) and scattered to its entries
-    const double* w = p.ws + j;
     expand_moments_from<DIM, ORDER>([&](int i) { return w[(long long)i * p.ws_stride]; },
                                     [&](int i) { return w[(long long)(NM + i) * p.ws_stride]; }, M, g);
     double* fio = p.fi + j * p.sfi_j;
