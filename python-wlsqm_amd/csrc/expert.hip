@@ -316,8 +316,17 @@ static int ensure_operator(wlsqm_expert* h, hipStream_t s) {
     if (g.op_state != 0) return WLSQM_OK;
     bool ok = false;
     KParams p = expert_params(h, nullptr, 0, nullptr, 0);
+    // the operator is 8 * 16 * K bytes per case (plus a temporary sensitivity block of 256k cases): only when it comfortably fits
+    // what is free now; otherwise (and if an allocation fails all the same) the stacked solve takes the other kernels
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
+        const double need = (double)g.ncases * 16.0 * (double)g.slots * 8.0 + 256.0 * 1024 * (double)g.slots * (g.max_no + 2) * 8.0;
+        if (need > 0.6 * (double)free_b) { g.op_state = -1; return WLSQM_OK; }
+    }
     int rc = solve_op_build(g.dimension, g.order[0], p, g.slots, reinterpret_cast<const long long*>(g.kn.data()), g.ncases,
                             g.d_op, g.d_T, &g.op_any_known, s, &ok);
+    if (rc == WLSQM_EMEMORY) { g.d_op.alloc(0); g.d_T.alloc(0); g.op_state = -1; set_error(""); return WLSQM_OK; }
     if (rc != WLSQM_OK) { g.d_op.alloc(0); g.d_T.alloc(0); return rc; }
     g.op_state = ok ? 1 : -1;
     if (!ok) { g.d_op.alloc(0); g.d_T.alloc(0); }
