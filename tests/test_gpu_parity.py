@@ -325,6 +325,12 @@ def _tile_vs_lane(wlsqm, dim, order, K, ncases, monkeypatch, expect=None, spare=
     _check_untouched(fi_t, fi0, orders, knowns, dim)
     assert np.array_equal(fi_t == fi0, fi_l == fi0)
     truth = P.truth_fit(dim, xk, fk, nk, xi, fi0, orders, knowns, wm)
+    # the reference of the comparison is the CPU oracle (pinned on the real reference's goldens), not another HIP kernel
+    from oracle import oracle as O
+    fi_o = fi0.copy()
+    O.fit_many(dim, xk, fk, nk, xi, fi_o, None, 0, orders, knowns, wm)
+    P.assert_parity(fi_t, fi_o, truth, "tile vs oracle")
+    P.assert_parity(fi_l, fi_o, truth, "lane vs oracle")
     P.assert_parity(fi_t, fi_l, truth, "tile vs lane")
 
 
@@ -674,6 +680,11 @@ def test_expert_solve_many_matches_sequential_solves(wlsqm, name, knowns):
             pass
         else:
             truth = P.truth_fit(dim, c["xk"], fks[r], nk_a, c["xi"], fi0[r], c["order_a"], kn, c["wm_a"])
+            from oracle import oracle as O
+            fi_o = fi0[r].copy()
+            O.fit_many(dim, c["xk"], fks[r], nk_a, c["xi"], fi_o, None, 0, c["order_a"], kn, c["wm_a"])
+            P.assert_parity(got[r], fi_o, truth, "%s solve_many host vs oracle, field %d" % (name, r))
+            P.assert_parity(got_d[r], fi_o, truth, "%s solve_many device vs oracle, field %d" % (name, r))
             P.assert_parity(got[r], ref[r], truth, "%s solve_many host, field %d" % (name, r))
             P.assert_parity(got_d[r], ref[r], truth, "%s solve_many device, field %d" % (name, r))
     s.close()
@@ -1306,6 +1317,11 @@ def test_index_based_input_has_a_fixed_shape_for_every_even_K(wlsqm, dim, order,
     assert whip.last_kernel() in ("tile", "tile-solve")
     torch.cuda.synchronize()
     truth = P.truth_fit(dim, xk_d.cpu().numpy(), fk_d.cpu().numpy(), nk, xi_d.cpu().numpy(), fi0, np.full(n, order, np.int32), kn, wm)
+    from oracle import oracle as O
+    fi_o = fi0.copy()
+    O.fit_many(dim, xk_d.cpu().numpy(), fk_d.cpu().numpy(), nk, xi_d.cpu().numpy(), fi_o, None, 0, np.full(n, order, np.int32), kn, wm)
+    P.assert_parity(fi_b.cpu().numpy(), fi_o, truth, "index-based path vs oracle")
+    P.assert_parity(fi_a.cpu().numpy(), fi_o, truth, "dense path vs oracle")
     P.assert_parity(fi_b.cpu().numpy(), fi_a.cpu().numpy(), truth, "index-based vs dense path")
     untouched = (kn[:, None] >> np.arange(no)[None, :]) & 1 == 1
     assert np.array_equal(fi_b.cpu().numpy()[untouched], fi0[untouched])
