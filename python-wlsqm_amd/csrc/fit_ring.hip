@@ -135,7 +135,7 @@ __global__ __launch_bounds__(64, MINW) void fit_ring_kernel(const KParams p, con
     bool havep = false;
     constexpr unsigned long long FULL = (1ull << NO) - 1ull;
 
-    auto solve_parked = [&]() {
+    auto solve_parked = [&](double* dead_slot) {
         // 4 x 4 transpose of the quarters (lanes x parked sets): rows of 16 lanes first, then the halves of the wave.  Lane h parked, for
         // tile t, quarter QB[h] = {0, 2, 1, 3}[h] in PQ[t].  swap16(PQ[t], PQ[t+1]), t = 0, 2: even-row lanes now hold two quarters of
         // tile t in PQ[t], PQ[t+1], odd-row lanes two quarters of tile t + 1; swap32(PQ[t], PQ[t+2]), t = 0, 1: lower lanes get the
@@ -157,6 +157,7 @@ __global__ __launch_bounds__(64, MINW) void fit_ring_kernel(const KParams p, con
         // numbers as the generic path below (its first elimination step is the identity row): bit-identical results.
         if constexpr (NO >= 3) {
             if (__all(!havep || (knownp == 1ull && droppedp == 0ull))) {
+                const bool all_have = __all(havep);              // (asked outside the divergent region below: every lane votes)
                 if (havep) {
                     constexpr int N1 = NO - 1, NE1 = N1 * (N1 + 1) / 2;
                     double* fio = p.fi + jp * p.sfi_j;
@@ -185,8 +186,28 @@ __global__ __launch_bounds__(64, MINW) void fit_ring_kernel(const KParams p, con
                     }
                     ldlt_factor<N1>(M1);
                     ldlt_solve<N1>(M1, r1);
+                    // Results.  With all 64 cases valid and contiguous fi rows the wave's 64 rows are ONE run of 64 NO doubles
+                    // (its cases are consecutive): they go through the ring slot that has just been consumed and leave as whole
+                    // 16-byte pieces, the known value re-written with its own bits — what the reference's Case_get_fi does too
+                    // (infra.pyx:780-795 copies all `no` doubles back).  Separate 8-byte stores at a 120-byte pitch with the
+                    // known DOF left out made every row a partial-sector write: 200 instead of 120 MB written and 150 MB of
+                    // extra sector fetches per 1M cases (profiles/r02c_C3_pmc_summary.json).
+                    const bool whole_rows = p.sfi_j == NO && all_have && ((reinterpret_cast<uintptr_t>(p.fi) & 15u) == 0);
+                    if (whole_rows) {
+                        double* mine = dead_slot + lane * NO;
+                        mine[0] = v0;
 #pragma unroll
-                    for (int a = 1; a < NO; ++a) fio[a] = r1[a - 1];
+                        for (int a = 1; a < NO; ++a) mine[a] = r1[a - 1];
+                        __syncthreads();
+                        const long long jbase = jp - lane;                       // case of lane 0: the 64 cases are jbase + lane
+                        rd2_* out = reinterpret_cast<rd2_*>(p.fi + jbase * NO);
+                        const rd2_* src = reinterpret_cast<const rd2_*>(dead_slot);
+#pragma unroll
+                        for (int q = lane; q < 64 * NO / 2; q += 64) out[q] = src[q];
+                    } else {
+#pragma unroll
+                        for (int a = 1; a < NO; ++a) fio[a] = r1[a - 1];
+                    }
                 }
                 havep = false;
                 return;
@@ -328,9 +349,9 @@ __global__ __launch_bounds__(64, MINW) void fit_ring_kernel(const KParams p, con
             }
         }
         if (h == (it & 3)) { jp = j; knownp = known; droppedp = dropped; havep = valid; }
-        if ((it & 3) == 3) solve_parked();             // the 64 lanes hold 64 different cases
+        if ((it & 3) == 3) solve_parked(lds + (it & 1) * G::SLOT);      // the 64 lanes hold 64 different cases (this tile's slot is dead)
     }
-    if (it & 3) solve_parked();                        // leftovers of a run that is not a multiple of 4 tiles
+    if (it & 3) solve_parked(lds + ((it - 1) & 1) * G::SLOT);   // leftovers of a run that is not a multiple of 4 tiles
 }
 
 // tiles per workgroup: a multiple of 4 (one solve per 4 tiles); WLSQM_HIP_RING_TILES overrides (A/B: 1M C3 cases at
