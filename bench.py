@@ -455,12 +455,14 @@ def run_sharded(a, dev, dist, rank, world, timer, parity=True):
                        "sent_values_max_over_ranks": int(send_max), "halo_bytes_received_per_step": int(halo_max) * 8,
                        "full_allgather_bytes_per_step": 8 * (N - n_local), "halo_radius": solver.halo_radius,
                        "setup_s": t_setup}}
+    if parity:
+        solver.exchange_begin(); solver.exchange_end()          # a collective: every rank takes part; rank 0 then checks its shard
+        torch.cuda.synchronize()
     if parity and rank == 0:
         # first 1 024 local cases against the oracle on the same (dense-gathered) inputs of the CURRENT field
         from oracle import oracle
         import _parity
         ns = min(solver.n_own, 1024)
-        solver.exchange_begin(); solver.exchange_end()
         h = solver.hoods32[:ns].long()
         xk_h = solver.S_tab[h].cpu().numpy(); fk_h = solver.values[h].cpu().numpy(); xi_h = solver.S_tab[:ns].cpu().numpy()
         fi_d = torch.zeros((ns, no), dtype=torch.float64, device=dev); fi_d[:, 0] = solver.values[:ns]

@@ -1,5 +1,9 @@
+#!/usr/bin/env python3
+"""Chunked any-K kernel (csrc/fit_chunk.hip) against the lane-per-case kernel at large neighbour counts (200k cases).
+usage: python tools/time_chunk.py"""
 import os, sys
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/python-wlsqm_amd")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "python-wlsqm_amd"))
 import numpy as np, torch
 import wlsqm.hip as whip
 dev = "cuda:0"
