@@ -413,13 +413,16 @@ int launch_fit_ring(int dimension, int order, const KParams& p, long long max_nk
     }
     if (dimension != 2 || order != 4) return WLSQM_OK;
     if (!tile_dense_eligible(dimension, p, max_nk)) return WLSQM_OK;
-    // Every even K from 26 to 64 (400k cases, ms per launch, two-kernel moment path -> this kernel): K = 26 / 32 / 40 / 48 / 56 / 64:
+    // Every even K from 26 to 72 (400k cases, ms per launch, two-kernel moment path -> this kernel): K = 26 / 32 / 40 / 48 / 56 / 64:
     // 0.220 / 0.192 / 0.281 / 0.238 / 0.323 / 0.260 -> 0.179 / 0.184 / 0.189 / 0.212 / 0.228 / 0.213.  Below 26 the two paths tie
-    // (K = 16 / 24: 0.147 / 0.167 against 0.151 / 0.170); beyond 64 a row needs two DMA instructions and the ring 43-56 KB of
-    // LDS (three waves per CU): K = 80 / 100: 0.424 / 0.644 against 0.361 / 0.504 — those stay on the two-kernel path.
+    // (K = 16 / 24: 0.147 / 0.167 against 0.151 / 0.170); beyond 64 a row needs two DMA instructions and the shares are padded
+    // (masked loop): K = 66 / 68 / 70 / 72: 0.314 / 0.306 / 0.307 / 0.342 against 0.308 / 0.374 / 0.384 / 0.356 — kept up to 72, where
+    // four ring slots still fit a CU; from 74 on the ring takes 43-56 KB of LDS (three waves per CU): K = 80 / 100: 0.424 / 0.644
+    // against 0.361 / 0.504 — those stay on the two-kernel path.
 #define RING_CASE(KK) if (max_nk == KK) { *handled = true; return launch_ring_impl<2, 4, KK, 16, 1>(p, stream); }
     RING_CASE(26) RING_CASE(28) RING_CASE(30) RING_CASE(32) RING_CASE(34) RING_CASE(36) RING_CASE(38) RING_CASE(40) RING_CASE(42) RING_CASE(44)
     RING_CASE(46) RING_CASE(48) RING_CASE(50) RING_CASE(52) RING_CASE(54) RING_CASE(56) RING_CASE(58) RING_CASE(60) RING_CASE(62) RING_CASE(64)
+    RING_CASE(66) RING_CASE(68) RING_CASE(70) RING_CASE(72)
 #undef RING_CASE
     return WLSQM_OK;
 }

@@ -285,8 +285,8 @@ def test_every_even_neighbourhood_size_2d_order4_takes_the_moment_kernels(wlsqm,
     """2D order 4: every even K from 16 to 100 has an instantiation of the two-kernel moment path (shares padded to a
     multiple of 4 slots), so no host batch is padded by more than one slot and device batches of any even K avoid the generic
     kernel."""
-    # 26 <= K <= 64: the one-kernel fit (csrc/fit_ring.hip); the other sizes: tile pass + moment_solve_kernel
-    _tile_vs_lane(wlsqm, 2, 4, K, 32 * 5 + 7 + K, monkeypatch, expect="tile-solve" if 26 <= K <= 64 else "moment", spare=8)
+    # 26 <= K <= 72: the one-kernel fit (csrc/fit_ring.hip); the other sizes: tile pass + moment_solve_kernel
+    _tile_vs_lane(wlsqm, 2, 4, K, 32 * 5 + 7 + K, monkeypatch, expect="tile-solve" if 26 <= K <= 72 else "moment", spare=8)
 
 
 @pytest.mark.parametrize("dim,order", [(2, 1), (2, 2), (2, 3), (3, 1), (3, 2)])
