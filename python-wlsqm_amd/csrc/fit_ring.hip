@@ -312,6 +312,8 @@ __global__ __launch_bounds__(64, MINW) void fit_ring_kernel(const KParams p, con
             accumulate_moments_best<DIM, ORDER>(mu, nu, d, w, live ? f[kk] : 0.0);
         };
         if (full) {
+            // (requesting the coordinates of the next four neighbours from LDS before working on the current one — the compiler
+            // issues the ds_reads in pairs and waits right behind the second — measured the same: 0.461 against 0.457 ms on C3)
 #pragma unroll UNR
             for (int kk = 0; kk < KPL; ++kk) neighbour(kk, true);
         } else {
