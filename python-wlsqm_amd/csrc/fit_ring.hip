@@ -356,6 +356,9 @@ __global__ __launch_bounds__(64, MINW) void fit_ring_kernel(const KParams p, con
     if (it & 3) solve_parked(lds + ((it - 1) & 1) * G::SLOT);   // leftovers of a run that is not a multiple of 4 tiles
 }
 
+// (A persistent launch — one workgroup per resident slot, groups of four tiles drawn from a global counter one group ahead, the
+// next group's first tile prefetched under the current group's last — measured SLOWER than one workgroup per group: C5 0.355
+// against 0.328 ms; the dispatcher's balancing of many short workgroups is worth more than the saved first-tile latency.)
 // tiles per workgroup: a multiple of 4 (one solve per 4 tiles); WLSQM_HIP_RING_TILES overrides (A/B: 1M C3 cases at
 // 4 / 8 / 16 / 64 tiles per workgroup 0.532 / 0.539 / 0.536 / 0.539 ms — the dispatcher balances short workgroups best)
 static int ring_tiles_per_wg() {
