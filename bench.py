@@ -137,21 +137,22 @@ class Timer:
             self.dist.barrier()
             torch.cuda.synchronize()
 
-    def run(self, step, steps, warmup, wake_s=0.3):
+    def run(self, step, steps, warmup, wake_s=0.3, collective=False):
         import torch
         # The GPU sat idle through the setup and has dropped to its low power state; the first ~50 ms of kernels run at
         # reduced clocks (measured: 0.214 ms vs 0.183 ms per step).  Bring it back to the clocks of a long-running job before
-        # the untimed warm-up, so a short --warmup does not measure the ramp.  (Collective steps: a fixed count, the same on
-        # every rank.)
-        if self.dist is None:
+        # the untimed warm-up, so a short --warmup does not measure the ramp.  Steps that contain a collective run a fixed
+        # count instead (the same on every rank).
+        if collective and self.dist is not None:
+            for _ in range(200):
+                step()
+            torch.cuda.synchronize()
+        else:
             t_wake = time.perf_counter()
             while time.perf_counter() - t_wake < wake_s:
                 for _ in range(8):
                     step()
                 torch.cuda.synchronize()
-        else:
-            for _ in range(8):
-                step()
         for _ in range(warmup):
             step()
         self.barrier()
@@ -414,7 +415,7 @@ def run_sharded(a, dev, dist, rank, world, timer, parity=True):
     def step():
         fi = solver.step()
         solver.values[: solver.n_own] = fi[:, 0] + 1e-7 * (fi[:, 4] + fi[:, 6] + fi[:, 8])      # i3_X2, i3_Y2, i3_Z2
-    dt = timer.run(step, a.steps, a.warmup)
+    dt = timer.run(step, a.steps, a.warmup, collective=True)
     kernel = whip.last_kernel()
     # the two parts alone (events on the launch stream): fits without the exchange, exchange without the fits
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
