@@ -321,7 +321,7 @@ static int ensure_operator(wlsqm_expert* h, hipStream_t s) {
     {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
-        const double need = (double)g.ncases * 16.0 * (double)g.slots * 8.0 + 256.0 * 1024 * (double)g.slots * (g.max_no + 2) * 8.0;
+        const double need = (double)g.ncases * 16.0 * (double)((g.slots + 7) / 8 * 8) * 8.0 + 256.0 * 1024 * (double)g.slots * (g.max_no + 2) * 8.0;
         if (need > 0.6 * (double)free_b) { g.op_state = -1; return WLSQM_OK; }
     }
     int rc = solve_op_build(g.dimension, g.order[0], p, g.slots, reinterpret_cast<const long long*>(g.kn.data()), g.ncases,

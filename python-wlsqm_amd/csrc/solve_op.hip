@@ -39,7 +39,7 @@ __host__ __device__ constexpr int op_row_of_dof(int a) { return 4 * (a % 4) + a 
 __host__ __device__ constexpr int op_dof_of_row(int i) { return 4 * (i % 4) + i / 4; }
 
 // sens[ncases, K, no] (NaN for knowns, slots >= nk untouched) -> op[ncases, 16, K] (zero rows for knowns and padding)
-__global__ void op_transpose_kernel(const double* __restrict__ sens, const int* __restrict__ nk, long long ncases, int K, int no,
+__global__ void op_transpose_kernel(const double* __restrict__ sens, const int* __restrict__ nk, long long ncases, int K, int KP, int no,
                                     double* __restrict__ op) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ncases * K) return;
@@ -48,14 +48,14 @@ __global__ void op_transpose_kernel(const double* __restrict__ sens, const int* 
     const double* s = sens + t * no;
     for (int a = 0; a < no; ++a) {
         const double v = live ? s[a] : 0.0;
-        op[(j * OP_ROWS + op_row_of_dof(a)) * K + k] = (v == v) ? v : 0.0;
+        op[(j * OP_ROWS + op_row_of_dof(a)) * KP + k] = (v == v) ? v : 0.0;
     }
 }
 
 // T[j][row][t] = sum_k op[j][row][k] * c_k[a_t]   (a_t = t-th true known DOF of the case, ascending)
 template <int DIM, int ORDER>
 __global__ void op_known_kernel(const double* __restrict__ op, const double* __restrict__ xk, const double* __restrict__ xi,
-                                const int* __restrict__ nk, const long long* __restrict__ knowns, long long ncases, int K,
+                                const int* __restrict__ nk, const long long* __restrict__ knowns, long long ncases, int K, int KP,
                                 double* __restrict__ T) {
     constexpr int NO = ndofs(DIM, ORDER);
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -72,7 +72,7 @@ __global__ void op_known_kernel(const double* __restrict__ op, const double* __r
 #pragma unroll
             for (int m = 0; m < DIM; ++m) d[m] = xk[(j * K + k) * DIM + m] - xi[j * DIM + m];
             monomials<DIM, ORDER>(d, cc);
-            const double s = op[(j * OP_ROWS + row) * K + k];
+            const double s = op[(j * OP_ROWS + row) * KP + k];
             int slot = 0;
 #pragma unroll
             for (int a = 0; a < NO; ++a)
@@ -86,7 +86,7 @@ __global__ void op_known_kernel(const double* __restrict__ op, const double* __r
 struct OpParams {
     const double* op; const double* T;
     const int* nk; const long long* knowns;
-    long long ncases; int K, no; int any_known; int dbg;
+    long long ncases; int K, no; int any_known; int dbg;       // K: fk slots per row (even); the operator rows hold KP = 4 KQ >= K
     unsigned inv_no;               // ceil(2^32 / no): exact quotients for the store phase's small indices
     long long nrhs;
     const double* fk; long long sfk_r, sfk_j;
@@ -103,7 +103,7 @@ struct OpParams {
 // are in flight while one is multiplied (three register sets in rotation).
 template <int KQ, bool KNOWN, int WPG>
 __global__ __launch_bounds__(64 * WPG) void solve_op_mfma_kernel(const OpParams P) {
-    constexpr int K = 4 * KQ;
+    constexpr int KP = 4 * KQ;                                        // operator row length: the fk row length P.K rounded up to 8
     extern __shared__ __attribute__((aligned(16))) double lds[];      // [2][16][WPG][no] results, then [WPG] known masks
     const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, q = l >> 4, c16 = l & 15;
     const int no = P.no, run = WPG * no;                              // doubles per field and workgroup
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(64 * WPG) void solve_op_mfma_kernel(const OpParams 
         const bool have = j < P.ncases;                               // wave-uniform
         const long long jc = have ? j : P.ncases - 1;
         // per-case scalars (wave-uniform)
-        const int nkc = min(P.nk[jc], K);
+        const int nkc = min(P.nk[jc], P.K);
         const unsigned long long raw = (unsigned long long)P.knowns[jc];
         unsigned long long known = raw & full, dropped = 0;
         {
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(64 * WPG) void solve_op_mfma_kernel(const OpParams 
         // operator piece of this lane: row c16, k in [q KQ, (q + 1) KQ)
         double A[KQ];
         {
-            const od2_* src = reinterpret_cast<const od2_*>(P.op + (jc * OP_ROWS + c16) * (long long)K + q * KQ);
+            const od2_* src = reinterpret_cast<const od2_*>(P.op + (jc * OP_ROWS + c16) * (long long)KP + q * KQ);
 #pragma unroll
             for (int s = 0; s < KQ / 2; ++s) { const od2_ v = src[s]; A[2 * s] = v.x; A[2 * s + 1] = v.y; }
         }
@@ -143,15 +143,21 @@ __global__ __launch_bounds__(64 * WPG) void solve_op_mfma_kernel(const OpParams 
 #pragma unroll
                 for (int t = 0; t < OP_NKN; ++t) Tl[KNOWN ? v : 0][t] = P.T[((jc * OP_ROWS + 4 * v + q) * OP_NKN) + t];
         }
-        const bool ragged = nkc < K;
-        const double* frow = P.fk + jc * P.sfk_j + q * KQ;
+        const bool ragged = nkc < KP;
+        const double* frow = P.fk + jc * P.sfk_j;
         auto load_b = [&](long long r0, double (&B)[KQ]) {
             if (r0 >= P.nrhs || !work) return;                                  // wave-uniform
             if ((P.dbg & 2) && r0 > 0) return;
             long long r = r0 + c16; r = r < P.nrhs ? r : P.nrhs - 1;
-            const od2_* src = reinterpret_cast<const od2_*>(frow + r * P.sfk_r);
+            const double* src = frow + r * P.sfk_r;
 #pragma unroll
-            for (int s = 0; s < KQ / 2; ++s) { const od2_ v = src[s]; B[2 * s] = v.x; B[2 * s + 1] = v.y; }
+            for (int s = 0; s < KQ / 2; ++s) {
+                // pieces beyond the fk row (K not a multiple of 8) replay the row's first pair: their operator columns are zero and
+                // the ragged mask below clears them
+                const int e = q * KQ + 2 * s;
+                const od2_ v = *reinterpret_cast<const od2_*>(src + (e < P.K ? e : 0));
+                B[2 * s] = v.x; B[2 * s + 1] = v.y;
+            }
         };
         int parity = 0;
         auto stage = [&](long long r0, double (&B)[KQ]) {
@@ -213,7 +219,7 @@ int launch_fit(int dimension, int order, const KParams& p, long long max_nk, hip
 
 bool solve_op_shape_ok(int dimension, int order, long long K) {
     const int no = ndofs(dimension, order);
-    return order >= 0 && no <= 15 && K >= 16 && K <= 64 && (K % 8) == 0;
+    return order >= 0 && no <= 15 && K >= 10 && K <= 64 && (K % 2) == 0;      // (the operator rows are padded to a multiple of 8)
 }
 
 // Build the operator (and the correction columns) of the dense resident geometry in `geom` (its fk / fi / sens are ignored).
@@ -235,7 +241,8 @@ int solve_op_build(int dimension, int order, const KParams& geom, long long K, c
         if (c) anyk = 1;
     }
     int rc;
-    if ((rc = d_op.alloc((size_t)ncases * OP_ROWS * K * 8))) return rc;
+    const long long KP = (K + 7) / 8 * 8;
+    if ((rc = d_op.alloc((size_t)ncases * OP_ROWS * KP * 8))) return rc;
     if ((rc = d_T.alloc(anyk ? (size_t)ncases * OP_ROWS * OP_NKN * 8 : 16))) return rc;
     WLSQM_HIP_CHECK(hipMemsetAsync(d_op.p, 0, d_op.n, s));
     // sensitivities of the geometry, a chunk of cases at a time (the dense sens block is 8 K no bytes per case)
@@ -256,7 +263,7 @@ int solve_op_build(int dimension, int order, const KParams& geom, long long K, c
         if ((rc = launch_fit(dimension, order, p, K, s))) return rc;
         const long long threads = n * K;
         hipLaunchKernelGGL(op_transpose_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, d_sens.as<double>(),
-                           p.nk, n, (int)K, no, d_op.as<double>() + j0 * OP_ROWS * K);
+                           p.nk, n, (int)K, (int)KP, no, d_op.as<double>() + j0 * OP_ROWS * KP);
         WLSQM_HIP_CHECK(hipGetLastError());
     }
     if (anyk) {
@@ -265,7 +272,7 @@ int solve_op_build(int dimension, int order, const KParams& geom, long long K, c
 #define KN_CASE(D, O)                                                                                                    \
         if (dimension == D && order == O)                                                                               \
             hipLaunchKernelGGL((op_known_kernel<D, O>), grid, block, 0, s, d_op.as<double>(), geom.xk, geom.xi, geom.nk, \
-                               geom.knowns, ncases, (int)K, d_T.as<double>());
+                               geom.knowns, ncases, (int)K, (int)KP, d_T.as<double>());
         KN_CASE(1, 0) KN_CASE(1, 1) KN_CASE(1, 2) KN_CASE(1, 3) KN_CASE(1, 4)
         KN_CASE(2, 0) KN_CASE(2, 1) KN_CASE(2, 2) KN_CASE(2, 3) KN_CASE(2, 4)
         KN_CASE(3, 0) KN_CASE(3, 1) KN_CASE(3, 2)
@@ -309,7 +316,7 @@ int launch_solve_op(int dimension, int order, const KParams& geom, long long K, 
         hipLaunchKernelGGL((solve_op_mfma_kernel<KQ_, KN_, WPG_>), dim3((unsigned)grid), dim3(64 * WPG_), lds_bytes, stream, P); \
     }
 #define OP_CASE(KQ_, WDEF_)                                                                                   \
-    if (K == 4 * KQ_) {                                                                                      \
+    if ((K + 7) / 8 * 8 == 4 * KQ_) {                                                                        \
         const int wpg = wenv ? atoi(wenv) : WDEF_;                                                           \
         if (any_known) { if (wpg >= 8) OP_LAUNCH(KQ_, true, 8) else OP_LAUNCH(KQ_, true, 4) }                \
         else if (wpg >= 16 && KQ_ <= 10) OP_LAUNCH(KQ_, false, 16)                                           \
