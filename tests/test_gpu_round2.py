@@ -593,3 +593,60 @@ def test_strided_and_odd_rows_are_repacked_for_the_tiled_kernels(wlsqm, dim, ord
         whip.fit_many_device(dim, order, xk_c, _t(fk), _t(nk), xi_t, c, _t(kn), _t(wm))
         torch.cuda.synchronize()
         assert torch.equal(a, c), "repacked rows must give the contiguous call's numbers"
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the round-2 paths inside a HIP graph
+
+def test_round2_paths_capture_into_a_hip_graph(wlsqm):
+    """The one-kernel 2D order-4 fit (LDS-DMA ring), the stacked solve on the stored operator (built by an earlier call), the
+    device-side repack of strided rows and the chunked any-K kernel only enqueue work (the repack's scratch comes from the
+    stream-ordered pool): captured once, nothing runs during the capture, replays are bit-identical to eager calls."""
+    import torch
+    import synth
+    import wlsqm.hip as whip
+    dev = torch.device("cuda", 0)
+    n = 3000
+    S = synth.halton(n, 2); S_d = torch.from_numpy(S).to(dev)
+    F = torch.from_numpy(synth.field(S)).to(dev)
+    cases = []
+    # (name, dim, order, K, strided)
+    for name, order, K, strided in (("ring", 4, 64, False), ("repack", 2, 31, True), ("chunk", 2, 140, False)):
+        h = whip.knn(S_d, K).long()
+        xk = S_d[h].contiguous(); fk = F[h].contiguous()
+        if strided:
+            wide = torch.zeros((n, K + 4, 2), dtype=torch.float64, device=dev); wide[:, :K] = xk; xk = wide[:, :K]
+        no = int(wlsqm.number_of_dofs(2, order))
+        fi = torch.zeros((n, no), dtype=torch.float64, device=dev); fi[:, 0] = F
+        args = (2, order, xk, fk, torch.full((n,), K, dtype=torch.int32, device=dev), S_d, fi,
+                torch.ones(n, dtype=torch.int64, device=dev), torch.full((n,), 2, dtype=torch.int32, device=dev))
+        whip.fit_many_device(*args)                                  # warm-up outside the capture
+        cases.append((name, args, whip.last_kernel()))
+    assert [c[2] for c in cases] == ["tile-solve", "tile", "chunk"], [c[2] for c in cases]
+    K2 = 32
+    h2 = whip.knn(S_d, K2).long()
+    solver = wlsqm.ExpertSolver(dimension=2, nk=np.full(n, K2, np.int32), order=np.full(n, 2, np.int32),
+                                knowns=np.ones(n, np.int64), weighting_method=np.full(n, 2, np.int32))
+    solver.prepare_device(S_d, S_d[h2].contiguous())
+    R = 70
+    fks = torch.stack([(torch.sin(np.pi * S_d[:, 0] + 0.1 * r) * torch.cos(np.pi * S_d[:, 1]))[h2] for r in range(R)]).contiguous()
+    fis = torch.zeros((R, n, 6), dtype=torch.float64, device=dev)
+    solver.solve_many_device(fks, fis)                                # builds the operator (synchronises): outside the capture
+    assert whip.last_kernel() == "solve-op-mfma"
+    torch.cuda.synchronize()
+    eager = [c[1][6].clone() for c in cases] + [fis.clone()]
+    for c in cases:
+        c[1][6][:, 1:] = -7.0
+    fis[:, :, 1:] = -7.0
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=torch.cuda.Stream()):
+        for c in cases:
+            whip.fit_many_device(*c[1])
+        solver.solve_many_device(fks, fis)
+    torch.cuda.synchronize()
+    assert all(float(c[1][6][:, 1:].max()) == -7.0 for c in cases) and float(fis[:, :, 1:].max()) == -7.0     # captured, not run
+    g.replay()
+    torch.cuda.synchronize()
+    for c, e in zip(cases, eager[:-1]):
+        assert torch.equal(c[1][6], e), c[0]
+    assert torch.equal(fis, eager[-1])
