@@ -274,6 +274,8 @@ __global__ __launch_bounds__(64, MINW) void fit_ring_kernel(const KParams p, con
             return d2;
         };
         const bool full = (G::KC == K) && __all(nkc >= K);     // wave-uniform: no ragged case in this tile
+        // (keeping the offsets and squared distances of this pass in registers for the moment pass — 40 doubles for the 3D order-2
+        // share — measured 1.6 % slower than reading and subtracting again: C5 ring / tile ratio 0.931 against 0.915)
         double max_d2 = 0.0;
         if (full) {
 #pragma unroll
