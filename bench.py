@@ -449,8 +449,11 @@ def run_sharded(a, dev, dist, rank, world, timer, parity=True):
                       "fits_per_gpu": n_local, "bytes_per_fit": B_fit},
            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                         "traffic": None, "traffic_source": None, "kernel_ms": ms_fit, "kernel": kernel,
-                        "note": "index-based bytes (4 nk + 8 (dim+1) + 8 no + 20 per fit): never mixed with the dense-layout metric; "
-                                "kernel_ms = interior + boundary launch of a step"},
+                        "gathered_bytes_per_fit": 8 * nk * (dim + 1),
+                        "gather_rate_GBps": 8 * nk * (dim + 1) * solver.n_own / (ms_fit * 1e-3) / 1e9,
+                        "note": "index-based bytes (4 nk + 8 (dim+1) + 8 no + 20 per fit): never mixed with the dense-layout metric, and "
+                                "not an HBM-bound kernel — the 8 nk (dim+1) bytes per fit of neighbour rows are gathered from the local "
+                                "tables through L2 (gather_rate_GBps); kernel_ms = interior + boundary launch of a step"},
            "sharded": {"points": N, "ms_fit": ms_fit, "ms_comm_alone": ms_comm, "ms_step": dt / a.steps * 1e3,
                        "halo_points_max_over_ranks": int(halo_max), "boundary_cases_max_over_ranks": int(bnd_max),
                        "sent_values_max_over_ranks": int(send_max), "halo_bytes_received_per_step": int(halo_max) * 8,

@@ -97,7 +97,8 @@ def _run_halo(rank, world, port, S, nk, F0, steps, out_dir):
     from wlsqm.sharded import HaloCloudSolver, case_range
     if world > 1:
         dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
-    s = HaloCloudSolver(2, S, nk, order=2, knowns=1, weighting_method=2, device="cpu", fit_fn=_oracle_cloud_fit, knn_fn=_cpu_knn)
+    dim = S.shape[1]
+    s = HaloCloudSolver(dim, S, nk, order=2, knowns=1, weighting_method=2, device="cpu", fit_fn=_oracle_cloud_fit, knn_fn=_cpu_knn)
     assert (s.lo, s.hi) == case_range(len(S), rank, world)
     if world > 1:
         assert 0 < s.n_halo < len(S) - s.n_own               # a band, not the rest of the cloud
@@ -106,7 +107,8 @@ def _run_halo(rank, world, port, S, nk, F0, steps, out_dir):
     s.set_own_values_from_global(torch.from_numpy(F0))
     for _ in range(steps):
         fi = s.step()
-        s.values[: s.n_own] = fi[:, 0] + 1e-4 * (fi[:, 3] + fi[:, 5])     # toy explicit step on the owned points
+        lap = (fi[:, 3] + fi[:, 5]) if dim == 2 else (fi[:, 4] + fi[:, 6] + fi[:, 8])       # i2_X2 + i2_Y2 / i3_X2 + i3_Y2 + i3_Z2
+        s.values[: s.n_own] = fi[:, 0] + 1e-4 * lap                        # toy explicit step on the owned points
     g, v = s.own_values_global()
     np.save(os.path.join(out_dir, "halo_g_%d_of_%d.npy" % (rank, world)), g.numpy())
     np.save(os.path.join(out_dir, "halo_v_%d_of_%d.npy" % (rank, world)), v.numpy())
@@ -115,11 +117,11 @@ def _run_halo(rank, world, port, S, nk, F0, steps, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_halo_exchange_time_stepping_equals_single_process(tmp_path, world):
+@pytest.mark.parametrize("world,dim", [(2, 2), (3, 2), (2, 3), (4, 3)])
+def test_halo_exchange_time_stepping_equals_single_process(tmp_path, world, dim):
     import torch.multiprocessing as mp
-    N, nk, steps = 1501, 12, 3                                    # 1501 points: uneven shards
-    S = synth.halton(N, 2)
+    N, nk, steps = (1501, 12, 3) if dim == 2 else (2003, 20, 2)   # odd point counts: uneven shards
+    S = synth.halton(N, dim)
     S = np.ascontiguousarray(S[synth.morton_order(S)])            # contiguous blocks = compact regions
     F0 = synth.field(S)
     _run_halo(0, 1, 0, S, nk, F0, steps, str(tmp_path))
