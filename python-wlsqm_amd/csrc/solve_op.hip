@@ -195,7 +195,7 @@ __global__ __launch_bounds__(64 * WPG) void solve_op_mfma_kernel(const OpParams 
             const long long nfield = (P.nrhs - r0 < 16) ? (P.nrhs - r0) : 16;
             const int total = (int)nfield * run;
             for (int e = threadIdx.x; e < total; e += 64 * WPG) {
-                const int row = (int)__umulhi((unsigned)e, P.inv_no);          // e / no  = f * WPG + cs   (e < 2^12: exact)
+                const int row = no == 1 ? e : (int)__umulhi((unsigned)e, P.inv_no);   // e / no = f * WPG + cs (e < 2^12: exact; no == 1: 2^32 does not fit inv_no)
                 const int a = e - row * no;
                 const int f = row / WPG, cs = row - f * WPG;                    // WPG is a power of two
                 const int pos = cs * no + a; (void)pos;

@@ -444,7 +444,8 @@ def test_ring_fit_vs_oracle_and_two_kernel_path(wlsqm, oracle, Kn, n, ragged, kn
 
 @pytest.mark.parametrize("dim,order,Kn,knowns", [(2, 2, 32, 0), (2, 2, 32, 0b1), (3, 2, 40, 0), (3, 2, 40, 0b10001), (2, 4, 64, 1),
                                                  (2, 3, 24, 0b1011), (1, 3, 16, 0), (2, 1, 16, 0b100),
-                                                 (2, 2, 30, 1), (3, 2, 36, 0), (2, 3, 50, 0b10), (1, 2, 12, 0), (2, 2, 62, 0)])
+                                                 (2, 2, 30, 1), (3, 2, 36, 0), (2, 3, 50, 0b10), (1, 2, 12, 0), (2, 2, 62, 0),
+                                                 (1, 0, 32, 0), (2, 0, 48, 0), (3, 0, 14, 0), (2, 1, 10, 0)])
 @pytest.mark.parametrize("R", [1, 5, 16, 37])
 def test_solve_many_operator_path(wlsqm, oracle, dim, order, Kn, knowns, R, monkeypatch):
     """R stacked fields through the operator kernel (forced with WLSQM_HIP_SOLVE_MANY=op) against one fused solve per field and

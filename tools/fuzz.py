@@ -15,7 +15,7 @@ import _parity as P
 NDOF = {1: [1, 2, 3, 4, 5], 2: [1, 3, 6, 10, 15], 3: [1, 4, 10, 20, 35]}
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-t0 = time.time(); trials = 0; worst = 0.0; ratios = []; acc = []; cloud_trials = 0; expert_trials = 0
+t0 = time.time(); trials = 0; worst = 0.0; ratios = []; acc = []; cloud_trials = 0; expert_trials = 0; stacked_trials = 0
 dev = torch.device("cuda", 0)
 while time.time() - t0 < budget:
     dim = int(rng.integers(1, 4)); mixed = rng.random() < 0.25
@@ -95,12 +95,33 @@ while time.time() - t0 < budget:
         assert np.array_equal(fi_e, fi_g, equal_nan=True), desc + ": ExpertSolver differs from the one-shot driver"
         if mode == "sens":
             assert np.array_equal(sens_e, sens_g, equal_nan=True), desc + ": ExpertSolver sens differs"
+        if mode == "basic" and not mixed and rng.random() < 0.5:
+            # ... and a short stack of fields through the stored-operator kernel (solve_op.hip) against one solve() per field
+            R = int(rng.integers(2, 6))
+            fks = np.stack([fk * (1.0 + 0.1 * r) + 0.05 * r * np.cos(xk[..., 0]) for r in range(R)])
+            fi_s = np.stack([fi0.copy() for _ in range(R)]); fi_m = fi_s.copy()
+            for r in range(R):
+                es.solve(fk=fks[r], fi=fi_s[r])
+            os.environ["WLSQM_HIP_SOLVE_MANY"] = "op"
+            try:
+                es.solve_many(fk=fks, fi=fi_m)
+            finally:
+                os.environ.pop("WLSQM_HIP_SOLVE_MANY", None)
+            no = NDOF[dim][order]
+            for r in range(R):
+                tr = P.truth_fit(dim, xk_a, fks[r], nk, xi_a, fi0[:, :no_max], orders, knowns, wm)
+                Em = P.column_metric(fi_m[r][:, :no], tr[:, :no]); Es = P.column_metric(fi_s[r][:, :no], tr[:, :no])
+                E = P.column_metric(fi_m[r][:, :no], fi_s[r][:, :no])
+                ratios.append((float(np.max(np.minimum(E, Em) / (1e-10 + 8.0 * Es))), n, desc + " STACKED (%s): vs solve %.1e" % (whip.last_kernel(), E.max())))
+                assert np.array_equal(fi_m[r][:, no:], fi0[:, no:]), desc + " stacked: columns beyond no touched"
+                assert np.array_equal(np.isfinite(fi_m[r][:, :no]), np.isfinite(fi_s[r][:, :no])), desc + " stacked: finiteness differs"
+            stacked_trials += 1
         es.close(); expert_trials += 1
     trials += 1
 ratios.sort(reverse=True)
 over = [r for r in ratios if r[0] > 1.0]
-print("fuzz: %d random batches (%d of them also index-based, %d also through ExpertSolver; %d order buckets) in %.0f s; largest column metric vs oracle %.2e; buckets over the 1e-10 + 8 N criterion: %d"
-      % (trials, cloud_trials, expert_trials, len(ratios), time.time() - t0, worst, len(over)))
+print("fuzz: %d random batches (%d of them also index-based, %d also through ExpertSolver, %d of those with a stacked solve; %d order buckets) in %.0f s; largest column metric vs oracle %.2e; buckets over the 1e-10 + 8 N criterion: %d"
+      % (trials, cloud_trials, expert_trials, stacked_trials, len(ratios), time.time() - t0, worst, len(over)))
 for r, _, d in ratios[:8]:
     print("   ratio %.2f  %s" % (r, d))
 if acc:
