@@ -15,12 +15,14 @@ import _parity as P
 NDOF = {1: [1, 2, 3, 4, 5], 2: [1, 3, 6, 10, 15], 3: [1, 4, 10, 20, 35]}
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-t0 = time.time(); trials = 0; worst = 0.0; ratios = []; acc = []; cloud_trials = 0; expert_trials = 0; stacked_trials = 0
+t0 = time.time(); trials = 0; worst = 0.0; ratios = []; acc = []; cloud_trials = 0; expert_trials = 0; stacked_trials = 0; strided_trials = 0
 dev = torch.device("cuda", 0)
 while time.time() - t0 < budget:
     dim = int(rng.integers(1, 4)); mixed = rng.random() < 0.25
     order = int(rng.integers(0, 5)); no_max = NDOF[dim][4 if mixed else order]
     K = int(rng.integers(NDOF[dim][order] + 2, 90)) if not mixed else int(rng.integers(no_max + 2, 70))
+    if not mixed and NDOF[dim][order] <= 15 and rng.random() < 0.06:
+        K = int(rng.integers(130, 280))                  # beyond every fixed-K kernel: the chunked kernel (fit_chunk.hip)
     n = int(rng.choice([1, 2, 15, 16, 17, 63, 64, 65, 200, 777, 2049]))
     mode = rng.choice(["basic", "basic", "sens", "iter"])
     orders = rng.integers(0, 5, n).astype(np.int32) if mixed else np.full(n, order, np.int32)
@@ -84,6 +86,24 @@ while time.time() - t0 < budget:
             sc = sens_c.cpu().numpy()
             assert np.array_equal(np.isnan(sc), np.isnan(sens_o)) and np.array_equal(sc == 777.0, sens_o == 777.0), desc + " index-based sens pattern"
         cloud_trials += 1
+    if mode == "basic" and not mixed and rng.random() < 0.3:
+        # the same batch through the device-resident API from STRIDED views (neighbour axis of xk and fk inside wider arrays):
+        # repacked on the device from 256 cases on (api.hip), lane kernel below; same criterion as above
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        no = NDOF[dim][order]
+        if dim == 1:
+            wide = torch.zeros((n, K, 2), dtype=torch.float64, device=dev); xs = wide[:, :, 0]; xs.copy_(t(xk_a)); xi_t = t(xi_a)
+        else:
+            wide = torch.zeros((n, K + 3, dim), dtype=torch.float64, device=dev); xs = wide[:, :K]; xs.copy_(t(xk_a)); xi_t = t(xi_a)
+        fwide = torch.zeros((n, 2 * K), dtype=torch.float64, device=dev); fs = fwide[:, ::2]; fs.copy_(t(fk))
+        fi_d = t(fi0)
+        whip.fit_many_device(dim, order, xs, fs, t(nk), xi_t, fi_d, t(knowns), t(wm))
+        torch.cuda.synchronize()
+        fi_d = fi_d.cpu().numpy()
+        E = P.column_metric(fi_d[:, :no], fi_o[:, :no]); Ec = P.column_metric(fi_d[:, :no], truth[:, :no]); N = P.column_metric(fi_o[:, :no], truth[:, :no])
+        ratios.append((float(np.max(np.minimum(E, Ec) / (1e-10 + 8.0 * N))), n, desc + " STRIDED DEVICE (%s): GPU vs oracle %.1e" % (whip.last_kernel(), E.max())))
+        assert np.array_equal(fi_d[:, no:], fi0[:, no:]), desc + " strided device: columns beyond no touched"
+        strided_trials += 1
     if rng.random() < 0.3:
         # the same batch through ExpertSolver (prepare once, solve): the same kernels on the same device layout -> same bits
         es = wlsqm.ExpertSolver(dimension=dim, nk=nk, order=orders, knowns=knowns, weighting_method=wm,
@@ -120,8 +140,8 @@ while time.time() - t0 < budget:
     trials += 1
 ratios.sort(reverse=True)
 over = [r for r in ratios if r[0] > 1.0]
-print("fuzz: %d random batches (%d of them also index-based, %d also through ExpertSolver, %d of those with a stacked solve; %d order buckets) in %.0f s; largest column metric vs oracle %.2e; buckets over the 1e-10 + 8 N criterion: %d"
-      % (trials, cloud_trials, expert_trials, stacked_trials, len(ratios), time.time() - t0, worst, len(over)))
+print("fuzz: %d random batches (%d of them also index-based, %d also from strided device views, %d also through ExpertSolver, %d of those with a stacked solve; %d order buckets) in %.0f s; largest column metric vs oracle %.2e; buckets over the 1e-10 + 8 N criterion: %d"
+      % (trials, cloud_trials, strided_trials, expert_trials, stacked_trials, len(ratios), time.time() - t0, worst, len(over)))
 for r, _, d in ratios[:8]:
     print("   ratio %.2f  %s" % (r, d))
 if acc:
