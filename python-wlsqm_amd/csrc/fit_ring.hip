@@ -358,6 +358,10 @@ __global__ __launch_bounds__(64, MINW) void fit_ring_kernel(const KParams p, con
     if (it & 3) solve_parked(lds + ((it - 1) & 1) * G::SLOT);   // leftovers of a run that is not a multiple of 4 tiles
 }
 
+// (Two tiles ahead — the DMAs of tile t + 2 issued as soon as tile t has read its slot for the last time, the wait before a tile
+// written as `s_waitcnt vmcnt(<DMAs of one prefetch>)` so that the younger prefetch stays in flight — does not survive the
+// compiler: it puts its own `s_waitcnt vmcnt(0)` behind the hand-written one (an LDS read after LDS-DMA writes it cannot tell
+// apart, conditional or not), and the prefetch in the middle of the tile spills 416-496 B per lane around the live moments.)
 // (A persistent launch — one workgroup per resident slot, groups of four tiles drawn from a global counter one group ahead, the
 // next group's first tile prefetched under the current group's last — measured SLOWER than one workgroup per group: C5 0.355
 // against 0.328 ms; the dispatcher's balancing of many short workgroups is worth more than the saved first-tile latency.)
