@@ -138,6 +138,7 @@ class HaloCloudSolver:
             cand_g = torch.arange(N, device=dev)
             hl = knn_fn(own.contiguous() if dim > 1 else own[:, 0].contiguous(), self.nk, n_own)
             self.halo_radius = 0.0
+            self.halo_attempts = 0
         else:
             ext = (S.max(0).values - S.min(0).values).clamp_min(1e-300)
             ball = {1: 2.0, 2: np.pi, 3: 4.0 * np.pi / 3.0}[dim]
@@ -151,6 +152,7 @@ class HaloCloudSolver:
                 cand = S[cand_g].contiguous()
                 hl = knn_fn(cand if dim > 1 else cand[:, 0].contiguous(), self.nk, n_own)
                 dk = (cand[hl[:, -1]] - own).pow(2).sum(1).max().sqrt().item()
+                self.halo_attempts = attempt + 1
                 if dk <= r:
                     break
                 r = 1.25 * dk

@@ -91,7 +91,7 @@ def _oracle_cloud_fit(dimension, order, S_tab, values, hoods, fi, nk, knowns, wm
     oracle.fit_many(dimension, xk, fk, nk.numpy(), xi, fi_np, None, 0, np.full(n, order, np.int32), knowns.numpy(), wm.numpy())
 
 
-def _run_halo(rank, world, port, S, nk, F0, steps, out_dir):
+def _run_halo(rank, world, port, S, nk, F0, steps, out_dir, expect_widening=False):
     import torch
     import torch.distributed as dist
     from wlsqm.sharded import HaloCloudSolver, case_range
@@ -104,6 +104,10 @@ def _run_halo(rank, world, port, S, nk, F0, steps, out_dir):
         assert 0 < s.n_halo < len(S) - s.n_own               # a band, not the rest of the cloud
         assert 0 < s.n_int < s.n_own                         # interior and boundary cases both exist
         assert sum(s.recv_splits) == s.n_halo and s.recv_splits[rank] == 0
+        attempts = [None] * world
+        dist.all_gather_object(attempts, s.halo_attempts)
+        if expect_widening:
+            assert max(attempts) >= 2, attempts                 # some rank had to widen its band
     s.set_own_values_from_global(torch.from_numpy(F0))
     for _ in range(steps):
         fi = s.step()
@@ -117,16 +121,19 @@ def _run_halo(rank, world, port, S, nk, F0, steps, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,dim", [(2, 2), (3, 2), (2, 3), (4, 3)])
-def test_halo_exchange_time_stepping_equals_single_process(tmp_path, world, dim):
+@pytest.mark.parametrize("world,dim,clustered", [(2, 2, False), (3, 2, False), (2, 3, False), (4, 3, False), (2, 2, True), (3, 3, True)])
+def test_halo_exchange_time_stepping_equals_single_process(tmp_path, world, dim, clustered):
     import torch.multiprocessing as mp
     N, nk, steps = (1501, 12, 3) if dim == 2 else (2003, 20, 2)   # odd point counts: uneven shards
     S = synth.halton(N, dim)
+    if clustered:
+        S = S ** 2.5              # density varies by orders of magnitude: the first halo radius (from the mean density) is too
+                                  # small in the sparse corner, so the verified widening of the band has to kick in
     S = np.ascontiguousarray(S[synth.morton_order(S)])            # contiguous blocks = compact regions
     F0 = synth.field(S)
     _run_halo(0, 1, 0, S, nk, F0, steps, str(tmp_path))
     port = _free_port()
-    mp.spawn(_run_halo, args=(world, port, S, nk, F0, steps, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_run_halo, args=(world, port, S, nk, F0, steps, str(tmp_path), clustered), nprocs=world, join=True)
     ref = np.empty(N); ref[np.load(tmp_path / "halo_g_0_of_1.npy")] = np.load(tmp_path / "halo_v_0_of_1.npy")
     got = np.full(N, np.nan)
     for r in range(world):
