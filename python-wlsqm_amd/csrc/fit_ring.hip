@@ -360,8 +360,9 @@ __global__ __launch_bounds__(64, MINW) void fit_ring_kernel(const KParams p, con
 
 // (Two tiles ahead — the DMAs of tile t + 2 issued as soon as tile t has read its slot for the last time, the wait before a tile
 // written as `s_waitcnt vmcnt(<DMAs of one prefetch>)` so that the younger prefetch stays in flight — does not survive the
-// compiler: it puts its own `s_waitcnt vmcnt(0)` behind the hand-written one (an LDS read after LDS-DMA writes it cannot tell
-// apart, conditional or not), and the prefetch in the middle of the tile spills 416-496 B per lane around the live moments.)
+// compiler: it puts its own `s_waitcnt vmcnt(0)` behind the hand-written one — for the prefetched scalar / fk REGISTER loads, whose
+// pending count it no longer knows at the loop header (conditional or unconditional prefetch, with or without s_barrier) — and the
+// prefetch in the middle of the tile spills 416-496 B per lane around the live moments.)
 // (A persistent launch — one workgroup per resident slot, groups of four tiles drawn from a global counter one group ahead, the
 // next group's first tile prefetched under the current group's last — measured SLOWER than one workgroup per group: C5 0.355
 // against 0.328 ms; the dispatcher's balancing of many short workgroups is worth more than the saved first-tile latency.)
