@@ -15,7 +15,7 @@ import _parity as P
 NDOF = {1: [1, 2, 3, 4, 5], 2: [1, 3, 6, 10, 15], 3: [1, 4, 10, 20, 35]}
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-t0 = time.time(); trials = 0; worst = 0.0; ratios = []; acc = []; cloud_trials = 0; expert_trials = 0; stacked_trials = 0; strided_trials = 0
+t0 = time.time(); trials = 0; worst = 0.0; ratios = []; acc = []; cloud_trials = 0; expert_trials = 0; stacked_trials = 0; strided_trials = 0; t_progress = time.time()
 dev = torch.device("cuda", 0)
 while time.time() - t0 < budget:
     dim = int(rng.integers(1, 4)); mixed = rng.random() < 0.25
@@ -138,6 +138,9 @@ while time.time() - t0 < budget:
             stacked_trials += 1
         es.close(); expert_trials += 1
     trials += 1
+    if time.time() - t_progress > 60.0:                 # a line a minute: long runs must not look hung
+        t_progress = time.time()
+        print("fuzz: %d batches after %.0f s" % (trials, time.time() - t0), flush=True)
 ratios.sort(reverse=True)
 over = [r for r in ratios if r[0] > 1.0]
 print("fuzz: %d random batches (%d of them also index-based, %d also from strided device views, %d also through ExpertSolver, %d of those with a stacked solve; %d order buckets) in %.0f s; largest column metric vs oracle %.2e; buckets over the 1e-10 + 8 N criterion: %d"
