@@ -172,10 +172,19 @@ int wlsqm_hip_ball_device(int dimension, int64_t npoints, const double* S, doubl
 int wlsqm_hip_nearest_device(int dimension, int64_t ndata, const double* S, int64_t nquery, const double* X,
                              int64_t x_stride, int64_t* nearest, int device, void* stream);
 
+/* Extension: build the stored solution operator of the prepared geometry now (8 x 16 x K' bytes per case, K' = the neighbour
+ * slots rounded up to a multiple of 8; shared with guests), so that later stacked solves only enqueue work — e.g. before a stream
+ * capture.  Without this call the first wlsqm_hip_expert_solve_many[_device] that wants the operator builds it and synchronises
+ * `stream`.  *built = 1 when the operator exists afterwards, 0 when the shape has none (more than 15 unknowns, more than 64 or an
+ * odd number of slots, more than 4 knowns per case, mixed orders, ALGO_ITERATIVE) or it does not fit the free device memory: the
+ * stacked solve then takes its other kernels. */
+int wlsqm_hip_expert_prepare_operator(wlsqm_expert* h, void* stream, int* built);
 /* Extension (no reference counterpart; BASELINE config 4 "prepare once + 256 RHS solves"): nrhs fields on the prepared
  * geometry in one call.  Equivalent to nrhs calls of expert.pyx:467-655 solve() with ALGO_BASIC and no sensitivities,
- * but the geometry work (weights, monomials, normal matrix, factorisation) is shared between the fields where a
- * shape has the fast kernel (no <= 6, max_nk <= 32; csrc/solve_many.hip).  Device variant: fk[nrhs][ncases][max_nk]
+ * in one launch: stacks of 64 fields or more, and every stack on a shape with more than 6 unknowns or 32 neighbour slots,
+ * apply the stored solution operator (wlsqm_hip_expert_prepare_operator; csrc/solve_op.hip, one batched GEMM on the matrix
+ * cores); short stacks on small shapes share the geometry work (weights, monomials, normal matrix, factorisation) inside the
+ * launch (csrc/solve_many.hip); anything else runs one fused launch per field.  Device variant: fk[nrhs][ncases][max_nk]
  * and fi[nrhs][ncases][fi_stride_case] are device pointers with the given element strides (k contiguous), enqueued on
  * `stream`.  Host variant: strided host arrays, transferred in chunks of right-hand sides. */
 int wlsqm_hip_expert_solve_many_device(wlsqm_expert* h, void* stream, int64_t nrhs,

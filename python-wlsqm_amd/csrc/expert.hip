@@ -372,6 +372,18 @@ static int solve_many_on_device(wlsqm_expert* h, hipStream_t s, int64_t nrhs, co
     return WLSQM_OK;
 }
 
+int wlsqm_hip_expert_prepare_operator(wlsqm_expert* h, void* stream, int* built) {
+    if (built) *built = 0;
+    if (!h) { set_error("null argument"); return WLSQM_EVALUE; }
+    if (!h->g->ready) { set_error("Solver is not in the ready state; prepare() must be called before solve()"); return WLSQM_ERUNTIME; }
+    if (!h->g->uniform_order || h->algorithm != WLSQM_ALGO_BASIC) return WLSQM_OK;
+    DeviceScope scope; int rc = scope.enter(h->g->device);
+    if (rc != WLSQM_OK) return rc;
+    rc = ensure_operator(h, (hipStream_t)stream);
+    if (rc == WLSQM_OK && built) *built = h->g->op_state == 1 ? 1 : 0;
+    return rc;
+}
+
 int wlsqm_hip_expert_solve_many_device(wlsqm_expert* h, void* stream, int64_t nrhs,
                                        const double* fk, int64_t fk_stride_rhs, int64_t fk_stride_case,
                                        double* fi, int64_t fi_stride_rhs, int64_t fi_stride_case) {

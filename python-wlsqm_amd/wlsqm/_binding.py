@@ -99,6 +99,7 @@ def lib():
     L.wlsqm_hip_expert_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,
                                          C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_int32)]
     L.wlsqm_hip_expert_solve_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
+    L.wlsqm_hip_expert_prepare_operator.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.wlsqm_hip_expert_solve_many_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64,
                                                      C.c_void_p, C.c_int64, C.c_int64]
     L.wlsqm_hip_expert_solve_many.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
@@ -112,7 +113,7 @@ def lib():
                                                  C.c_int64, C.c_int, C.c_void_p, C.c_int]
     for name in ("wlsqm_hip_fit_many_host", "wlsqm_hip_fit_many_device", "wlsqm_hip_time_fit_device",
                  "wlsqm_hip_expert_create", "wlsqm_hip_expert_create_guest", "wlsqm_hip_expert_prepare", "wlsqm_hip_expert_prepare_device", "wlsqm_hip_expert_solve",
-                 "wlsqm_hip_expert_solve_device", "wlsqm_hip_expert_solve_many_device", "wlsqm_hip_expert_solve_many",
+                 "wlsqm_hip_expert_solve_device", "wlsqm_hip_expert_prepare_operator", "wlsqm_hip_expert_solve_many_device", "wlsqm_hip_expert_solve_many",
                  "wlsqm_hip_expert_memory_used", "wlsqm_hip_expert_destroy",
                  "wlsqm_hip_expert_conds", "wlsqm_hip_expert_interpolate", "wlsqm_hip_interpolate_fit_host",
                  "wlsqm_hip_fit_cloud_device", "wlsqm_hip_time_fit_cloud_device", "wlsqm_hip_knn_device", "wlsqm_hip_knn_subset_device", "wlsqm_hip_ball_device", "wlsqm_hip_nearest_device",

@@ -302,13 +302,32 @@ class ExpertSolver:
                                                       C.c_void_p(fi.data_ptr()), fi.stride(0)))
         return 0
 
+    def prepare_operator(self, stream=None):
+        """Build the stored solution operator of the prepared geometry now (extension): the stacked solves of 64 fields or more
+        (and every stacked solve of a shape with more than 6 unknowns or 32 neighbour slots) apply it as one batched GEMM on the
+        matrix cores; without this call the first such solve builds it and synchronises.  Returns True when the operator exists
+        afterwards (False: the shape has none, or it does not fit the free device memory — the other kernels are used)."""
+        if not self.ready:
+            raise RuntimeError("Solver is not in the ready state; prepare() must be called before solve()")
+        built = C.c_int(0)
+        if stream is None:
+            try:
+                import torch
+                stream = torch.cuda.current_stream().cuda_stream
+            except Exception:
+                stream = 0
+        B.check(B.lib().wlsqm_hip_expert_prepare_operator(self._handle, C.c_void_p(int(stream) if stream else 0), C.byref(built)))
+        return bool(built.value)
+
     def solve_many_device(self, fk, fi, stream=None):
         """Many fields on the prepared geometry, device-resident (extension; no reference counterpart).
 
         fk (nrhs, ncases, max_nk) and fi (nrhs, ncases, >= no) are torch CUDA tensors (float64, contiguous last axis);
         field r is fitted from fk[r] into fi[r] exactly as solve_device(fk[r], fi[r]) would (ALGO_BASIC, no
-        sensitivities; knowns are read from fi[r]), but in ONE launch that shares the geometry work between the fields
-        where the shape allows (no <= 6, max_nk <= 32): per case and field only fk[r] is read and fi[r] written."""
+        sensitivities; knowns are read from fi[r]), but in ONE launch: per case and field only fk[r] is read and fi[r] written.
+        Stacks of 64 fields or more, and every stack on a shape with more than 6 unknowns or 32 neighbour slots, apply the stored
+        solution operator (prepare_operator(); built by the first such call otherwise) as a batched GEMM on the matrix cores; short
+        stacks on small shapes share the geometry work inside the launch instead."""
         if not self.ready:
             raise RuntimeError("Solver is not in the ready state; prepare() must be called before solve()")
         import torch

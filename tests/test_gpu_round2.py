@@ -632,7 +632,8 @@ def test_round2_paths_capture_into_a_hip_graph(wlsqm):
     R = 70
     fks = torch.stack([(torch.sin(np.pi * S_d[:, 0] + 0.1 * r) * torch.cos(np.pi * S_d[:, 1]))[h2] for r in range(R)]).contiguous()
     fis = torch.zeros((R, n, 6), dtype=torch.float64, device=dev)
-    solver.solve_many_device(fks, fis)                                # builds the operator (synchronises): outside the capture
+    assert solver.prepare_operator() is True                          # builds the operator (synchronises): outside the capture
+    solver.solve_many_device(fks, fis)
     assert whip.last_kernel() == "solve-op-mfma"
     torch.cuda.synchronize()
     eager = [c[1][6].clone() for c in cases] + [fis.clone()]
