@@ -36,6 +36,7 @@ int launch_fit_tilek(int dimension, int order, const KParams& p, long long max_n
 long long preferred_slots(int dimension, int order, long long max_nk);
 int launch_fit_rows(int dimension, int order, const KParams& p, hipStream_t stream, bool* handled);
 int launch_fit_chunk(int dimension, int order, const KParams& p, long long K, hipStream_t stream, bool* handled);
+int launch_fit_sens(int dimension, int order, const KParams& p, long long K, hipStream_t stream, bool* handled);
 
 // Dense rows the tiled kernels cannot take as they are — a strided neighbour or case axis, rows that are not multiples of 16
 // bytes (odd K), misaligned bases — are repacked on the device into contiguous [ncases, K', dim] / [ncases, K'] scratch
@@ -86,7 +87,7 @@ int launch_fit(int dimension, int order, const KParams& p_in, long long max_nk, 
         const char* off = getenv("WLSQM_HIP_DISABLE_TILE");
         const char* norp = getenv("WLSQM_HIP_DISABLE_REPACK");
         const bool tiles_on = !(off && off[0] == '1') && !(norp && norp[0] == '1');
-        if (tiles_on && !p.hoods && !p.case_index && p.xk && p.fk && no <= 15 && max_nk >= 2 && p.ncases >= 256 && !(p.do_sens || p.iterative ? max_nk > 128 : false) &&
+        if (tiles_on && !p.hoods && !p.case_index && p.xk && p.fk && no <= 15 && max_nk >= 2 && p.ncases >= 256 && !(p.iterative && max_nk > 128) &&
             !dense_layout_ok(dimension, p, max_nk)) {
             const long long Kp = preferred_slots(dimension, order, max_nk);
             double* ws = nullptr;
@@ -115,13 +116,15 @@ int launch_fit(int dimension, int order, const KParams& p_in, long long max_nk, 
     if (rc != WLSQM_OK || handled) return rc;
     rc = launch_fit_tilek(dimension, order, p, max_nk, stream, &handled);
     if (rc != WLSQM_OK || handled) return rc;
+    rc = launch_fit_sens(dimension, order, p, max_nk, stream, &handled);     // sensitivities of the shapes without a tile kernel
+    if (rc != WLSQM_OK || handled) return rc;
     {
         // index-based input no tiled kernel took: gather it into dense rows and dispatch again (the dense tables are complete)
         const char* off = getenv("WLSQM_HIP_DISABLE_TILE");
         const char* norp = getenv("WLSQM_HIP_DISABLE_REPACK");
         const bool tiles_on = !(off && off[0] == '1') && !(norp && norp[0] == '1');
         if (tiles_on && p.hoods && !p.case_index && no <= 15 && max_nk >= 2 && p.ncases >= 256 &&
-            !((p.do_sens || p.iterative) && max_nk > 128)) {
+            !(p.iterative && max_nk > 128)) {
             const long long Kp = preferred_slots(dimension, order, max_nk);
             double* ws = nullptr;
             const size_t nx = (size_t)p.ncases * Kp * dimension, nf = (size_t)p.ncases * Kp, ni = (size_t)p.ncases * dimension;

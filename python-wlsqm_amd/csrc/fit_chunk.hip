@@ -14,7 +14,10 @@ namespace wlsqm {
 
 typedef double cd2_ __attribute__((ext_vector_type(2)));
 
-template <int DIM, int ORDER, int MINW>
+// INV: besides fi, every case leaves the inverse of its (knowns-eliminated) normal matrix at p.ws[j][no][no] for the
+// sensitivities (fit_sens.hip): after the butterfly the four lanes of a case hold the same sums, so each factors the matrix
+// for itself and substitutes its share of the unit vectors (columns h, h + 4, ...).
+template <int DIM, int ORDER, int MINW, bool INV = false>
 __global__ __launch_bounds__(64, MINW) void fit_chunk_kernel(const KParams p, const long long ntiles, const int K) {
     constexpr int WV = 64, TC = 16, LPC = 4, CH = 32, SPL = CH / LPC;          // slots per lane and chunk
     constexpr int NO = ndofs(DIM, ORDER), NE = NO * (NO + 1) / 2, NM = mom_count<DIM>(2 * ORDER);
@@ -125,6 +128,37 @@ __global__ __launch_bounds__(64, MINW) void fit_chunk_kernel(const KParams p, co
             for (int a = 0; a < NO; ++a) nu[a] += __shfl_xor(nu[a], off, WV);
         }
         constexpr unsigned long long FULL = (1ull << NO) - 1ull;
+        if constexpr (INV) {
+            double* fio = p.fi + jc * p.sfi_j;
+            double M[NE], rhs[NO];
+            expand_moments<DIM, ORDER>(mu, nu, M, rhs);
+            {
+                double val[NO];
+#pragma unroll
+                for (int a = 0; a < NO; ++a) val[a] = (((known & ~dropped) >> a) & 1ull) ? fio[a] : 0.0;
+                eliminate_knowns<NO>(M, rhs, known, val);
+            }
+            ldlt_factor<NO>(M);
+            ldlt_solve<NO>(M, rhs);
+            if (valid && known != FULL) {
+                if (h == 0) {
+#pragma unroll
+                    for (int a = 0; a < NO; ++a)
+                        if (!((known >> a) & 1ull)) fio[a] = rhs[a];
+                }
+                double* wi = p.ws + j * (long long)(NO * NO);
+#pragma unroll 1
+                for (int col = h; col < NO; col += LPC) {
+                    double sv[NO];
+                    const bool kcol = (known >> col) & 1ull;           // known: zero row and column
+#pragma unroll
+                    for (int a = 0; a < NO; ++a) sv[a] = (a == col && !kcol) ? 1.0 : 0.0;
+                    ldlt_solve<NO>(M, sv);
+#pragma unroll
+                    for (int a = 0; a < NO; ++a) wi[col * NO + a] = sv[a];
+                }
+            }
+        } else
         if (valid && h == 0 && known != FULL) {
             double* fio = p.fi + j * p.sfi_j;
             double M[NE], rhs[NO];
@@ -144,20 +178,26 @@ __global__ __launch_bounds__(64, MINW) void fit_chunk_kernel(const KParams p, co
     }
 }
 
-template <int DIM, int ORDER>
+template <int DIM, int ORDER, bool INV = false>
 static int launch_chunk(const KParams& p, long long K, hipStream_t stream) {
-    constexpr int MINW = (ndofs(DIM, ORDER) > 10) ? 1 : 2;
+    constexpr int MINW = (ndofs(DIM, ORDER) > (INV ? 6 : 10)) ? 1 : 2;
     const long long ntiles = (p.ncases + 15) / 16;
     static KernelSetup setup;
-    auto kern = fit_chunk_kernel<DIM, ORDER, MINW>;
+    auto kern = fit_chunk_kernel<DIM, ORDER, MINW, INV>;
     long long grid = 0;
     int rc = persistent_grid(reinterpret_cast<const void*>(kern), 64, 0, 0, true, setup, &grid);
     if (rc != WLSQM_OK) return rc;
     if (grid > ntiles) grid = ntiles;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), 0, stream, p, ntiles, (int)K);
     WLSQM_HIP_CHECK(hipGetLastError());
-    note_kernel("chunk");
+    note_kernel(INV ? "chunk-inverse" : "chunk");
     return WLSQM_OK;
+}
+
+static bool chunk_layout_ok(int dimension, const KParams& p, long long K) {
+    if (p.hoods || p.case_index || K < 2 || (K % 2) != 0 || K > 0x3fffffff) return false;
+    if (p.sxk_k != dimension || p.sxk_j != K * dimension || p.sfk_k != 1 || p.sfk_j != K) return false;
+    return ((reinterpret_cast<uintptr_t>(p.xk) | reinterpret_cast<uintptr_t>(p.fk)) & 15u) == 0;
 }
 
 // Dense contiguous basic fits of any K (even, 16-byte aligned rows) with at most 15 unknowns.
@@ -165,15 +205,27 @@ int launch_fit_chunk(int dimension, int order, const KParams& p, long long K, hi
     *handled = false;
     const char* off = getenv("WLSQM_HIP_DISABLE_TILE");
     if (off && off[0] == '1') return WLSQM_OK;
-    if (p.hoods || p.case_index || p.do_sens || p.iterative || K < 2 || (K % 2) != 0 || K > 0x3fffffff) return WLSQM_OK;
-    if (p.sxk_k != dimension || p.sxk_j != K * dimension || p.sfk_k != 1 || p.sfk_j != K) return WLSQM_OK;
-    if ((reinterpret_cast<uintptr_t>(p.xk) | reinterpret_cast<uintptr_t>(p.fk)) & 15u) return WLSQM_OK;
+    if (p.do_sens || p.iterative || !chunk_layout_ok(dimension, p, K)) return WLSQM_OK;
 #define CCASE(D, O) if (dimension == D && order == O) { *handled = true; return launch_chunk<D, O>(p, K, stream); }
     CCASE(1, 0) CCASE(1, 1) CCASE(1, 2) CCASE(1, 3) CCASE(1, 4)
     CCASE(2, 0) CCASE(2, 1) CCASE(2, 2) CCASE(2, 3) CCASE(2, 4)
     CCASE(3, 0) CCASE(3, 1) CCASE(3, 2)
 #undef CCASE
     return WLSQM_OK;
+}
+
+// The same fit, which also leaves every case's inverse normal matrix at p.ws[j][no][no] (first kernel of fit_sens.hip).
+bool chunk_inverse_ok(int dimension, int order, const KParams& p, long long K) {
+    return ndofs(dimension, order) <= 15 && chunk_layout_ok(dimension, p, K);
+}
+int launch_fit_chunk_inverse(int dimension, int order, const KParams& p, long long K, hipStream_t stream) {
+#define CCASE(D, O) if (dimension == D && order == O) return launch_chunk<D, O, true>(p, K, stream);
+    CCASE(1, 0) CCASE(1, 1) CCASE(1, 2) CCASE(1, 3) CCASE(1, 4)
+    CCASE(2, 0) CCASE(2, 1) CCASE(2, 2) CCASE(2, 3) CCASE(2, 4)
+    CCASE(3, 0) CCASE(3, 1) CCASE(3, 2)
+#undef CCASE
+    set_error("fit_chunk_inverse: unsupported (dimension, order)");
+    return WLSQM_EVALUE;
 }
 
 }  // namespace wlsqm

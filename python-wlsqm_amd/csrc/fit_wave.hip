@@ -200,6 +200,20 @@ __global__ __launch_bounds__(WAVE) void fit_wave_kernel(const KParams p) {
     // solve for the right-hand side; the solution stays in LDS (sB), one entry per lane
     coop_ldlt_solve<NO, LD>(sM, sB, lane);
 
+    // ---- inverse of the eliminated normal matrix for fit_sens.hip (p.ws[t][no][no]): lane a solves for unit vector a
+    // (zero row and column for a known DOF); the rows leave as they are, the matrix is symmetric
+    if (p.ws) {
+        double* X = sC;
+        __syncthreads();
+#pragma unroll 1
+        for (int a = 0; a < NO; ++a) X[a * WAVE + lane] = (a == lane && !((known >> a) & 1ull)) ? 1.0 : 0.0;
+        column_ldlt_solve<NO, LD>(sM, X, lane);
+        if (mine) {
+            double* wi = p.ws + (t * NO + lane) * (long long)NO;
+            for (int a = 0; a < NO; ++a) wi[a] = X[a * WAVE + lane];
+        }
+        __syncthreads();
+    } else
     // ---- sensitivities: lane k solves for neighbour k's right-hand side (column k of sC, reused as X[NO][64])
     if (p.do_sens && p.sens) {
         double* sr = p.sens + j * p.ss_j;
@@ -295,11 +309,25 @@ static int launch_wave(const KParams& p, hipStream_t stream) {
     return WLSQM_OK;
 }
 
-int launch_fit_wave(int dimension, int order, const KParams& p, hipStream_t stream) {
+int launch_fit_wave(int dimension, int order, const KParams& p_in, hipStream_t stream) {
+    KParams p = p_in;
+    p.ws = nullptr;
     if (dimension == 3 && order == 3) return launch_wave<3, 3>(p, stream);
     if (dimension == 3 && order == 4) return launch_wave<3, 4>(p, stream);
     set_error("fit_wave: unsupported (dimension, order)");
     return WLSQM_EVALUE;
+}
+
+// The basic fit, which also leaves every case's inverse normal matrix at inv[t][no][no] (first kernel of fit_sens.hip).
+int launch_fit_wave_inverse(int dimension, int order, const KParams& p_in, double* inv, hipStream_t stream) {
+    KParams p = p_in;
+    p.ws = inv; p.do_sens = 0; p.sens = nullptr; p.iterative = 0;
+    int rc = WLSQM_EVALUE;
+    if (dimension == 3 && order == 3) rc = launch_wave<3, 3>(p, stream);
+    else if (dimension == 3 && order == 4) rc = launch_wave<3, 4>(p, stream);
+    else set_error("fit_wave_inverse: unsupported (dimension, order)");
+    if (rc == WLSQM_OK) note_kernel("wave-inverse");
+    return rc;
 }
 
 }  // namespace wlsqm

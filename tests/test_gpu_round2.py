@@ -597,6 +597,66 @@ def test_strided_and_odd_rows_are_repacked_for_the_tiled_kernels(wlsqm, dim, ord
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+# sensitivities of the shapes without a tile kernel of their own (csrc/fit_sens.hip): inverse normal matrix + MFMA apply
+
+@pytest.mark.parametrize("dim,order,Kn,n,wide", [(2, 4, 50, 300, False), (2, 4, 27, 280, False), (2, 4, 64, 260, True), (2, 2, 160, 260, False),
+                                                 (3, 2, 130, 260, False), (2, 3, 80, 270, False), (1, 2, 100, 300, False), (1, 4, 131, 260, True),
+                                                 (3, 3, 60, 120, False), (3, 3, 70, 70, True), (3, 4, 70, 80, False), (3, 4, 130, 40, False),
+                                                 (2, 0, 90, 300, False), (2, 4, 16, 257, False)])
+def test_sensitivities_by_inverse_and_mfma(wlsqm, oracle, dim, order, Kn, n, wide, monkeypatch):
+    """do_sens where the lane-per-case / wave-per-case kernels used to run: the fit leaves the inverse of every case's reduced
+    normal matrix, a second kernel multiplies it with the weighted monomial rows on the matrix cores.  Against the oracle
+    (lapack-free restatement of impl.pyx:821-846) and against the generic kernel: ragged nk, knowns (NaN columns), both
+    weightings, rows past nk and spare columns untouched, `wide`: strided sens / fi rows."""
+    import torch
+    import wlsqm.hip as whip
+    rng = np.random.default_rng(11 * Kn + order)
+    no = K.NDOF[dim][order]
+    xi = rng.uniform(0, 1, (n, dim))
+    xk = xi[:, None, :] + 0.08 * rng.uniform(-1, 1, (n, Kn, dim))
+    fk = np.sin(3 * xk[..., 0]) * np.cos(2 * xk[..., -1])
+    nk = rng.integers(min(Kn, max(no + 1, Kn - 30)), Kn + 1, n).astype(np.int32); nk[0] = Kn
+    orders = np.full(n, order, np.int32)
+    masks = [0, 0, 1] + ([1 << (no - 1), 1 | (1 << (no // 2))] if no >= 3 else [])
+    kn = rng.choice(np.array(masks, np.int64), n)
+    wm = rng.choice(np.array([1, 2], np.int32), n)
+    ncol = no + (3 if wide else 0)
+    fi0 = rng.uniform(-1, 1, (n, ncol)); fi0[:, 0] = np.sin(3 * xi[:, 0]) * np.cos(2 * xi[:, -1])
+    xk_a, xi_a = (np.ascontiguousarray(xk[..., 0]), np.ascontiguousarray(xi[:, 0])) if dim == 1 else (xk, xi)
+    args = (_t(xk_a), _t(fk), _t(nk), _t(xi_a))
+    out = {}
+    for tag in ("new", "generic"):
+        if tag == "generic":
+            monkeypatch.setenv("WLSQM_HIP_DISABLE_SENS_APPLY", "1")
+        fi_d = _t(fi0); sens_d = torch.full((n, Kn, ncol), 777.0, dtype=torch.float64, device="cuda:0")
+        whip.fit_many_device(dim, order, *args, fi_d[:, :no] if wide else fi_d, _t(kn), _t(wm), sens=sens_d[:, :, :no] if wide else sens_d)
+        torch.cuda.synchronize()
+        out[tag] = (fi_d.cpu().numpy(), sens_d.cpu().numpy(), whip.last_kernel())
+    monkeypatch.delenv("WLSQM_HIP_DISABLE_SENS_APPLY")
+    (f_n, s_n, k_n), (f_g, s_g, k_g) = out["new"], out["generic"]
+    assert k_n == "sens-apply", k_n
+    assert k_g in ("lane", "wave"), k_g
+    fo = fi0[:, :no].copy(); so = np.full((n, Kn, no), 777.0)
+    oracle.fit_many(dim, xk_a, fk, nk, xi_a, fo, so, 1, orders, kn, wm)
+    truth = P.truth_fit(dim, xk_a, fk, nk, xi_a, fi0[:, :no], orders, kn, wm)
+    P.assert_parity(f_n[:, :no], fo, truth, "fit beside the inverse vs oracle")
+    assert np.array_equal(f_n[:, no:], fi0[:, no:]) and np.array_equal(s_n[:, :, no:], np.full((n, Kn, ncol - no), 777.0))
+    for ref, what in ((so, "oracle"), (s_g[:, :, :no], "generic kernel")):
+        a = s_n[:, :, :no]
+        assert np.array_equal(np.isnan(a), np.isnan(ref)), what               # NaN for knowns (impl.pyx:821-823)
+        assert np.array_equal(a == 777.0, ref == 777.0), what                 # rows k >= nk untouched
+        x, y = np.nan_to_num(a), np.nan_to_num(ref)
+        live = (y != 777.0)
+        scale = np.abs(np.where(live, y, 0.0)).max(axis=(1, 2), keepdims=True) + 1e-300
+        assert (np.abs(x - y) <= 1e-6 * scale).all(), (what, float((np.abs(x - y) / scale).max()))
+    # fi == sens^T fk where nothing is known (the sensitivities are the solution operator)
+    free = np.flatnonzero(kn == 0)[:20]
+    for j in free:
+        rec = s_n[j, :nk[j], :no].T @ fk[j, :nk[j]]
+        assert np.abs(rec - f_n[j, :no]).max() <= 1e-3 * np.abs(f_n[j, :no]).max()        # (sanity: order 4 on 16 points is ill-conditioned)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
 # the round-2 paths inside a HIP graph
 
 def test_round2_paths_capture_into_a_hip_graph(wlsqm):
