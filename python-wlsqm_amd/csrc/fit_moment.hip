@@ -25,16 +25,41 @@ int launch_tile_moments(int dimension, int order, const KParams& p, long long ma
 // Kernel B: expand the normal equations from the moments, eliminate knowns, LDL^T, substitution.  The 120 + 15 entries of
 // an order-4 case take 256 VGPRs + 78 AGPRs: one wave per SIMD.  Capping the kernel at 256 registers for two waves per
 // SIMD spills 324 B per lane and is slower (0.30 vs 0.17 ms per 1M cases).
-template <int DIM, int ORDER>
-__global__ __launch_bounds__(64) void moment_solve_kernel(const KParams p) {
+// INV: besides fi, the wave leaves the INVERSE of every case's eliminated normal matrix for the sensitivities (fit_sens.hip), `no`
+// substitutions with unit vectors on the factor that is in registers anyway.  Layout inv[group of 64 cases][column][case][row]:
+// column c of the wave's 64 cases is one contiguous run of 64 no doubles, staged through LDS and stored as full lines (rows and
+// columns of known DOFs are zero).  No lane leaves early in this variant (the copy-out is cooperative): lanes past the end of
+// the batch replay its last case and store nothing but their slot of the scratch block.
+template <int DIM, int ORDER, bool INV = false>
+__global__ __launch_bounds__(64) void moment_solve_kernel(const KParams p, double* __restrict__ inv) {
     constexpr int NO = ndofs(DIM, ORDER), NM = mom_count<DIM>(2 * ORDER), NE = NO * (NO + 1) / 2;
-    const long long j = (long long)blockIdx.x * 64 + threadIdx.x;
-    if (j >= p.ncases) return;
+    __shared__ double sL[INV ? 64 * NO : 1];
+    const int lane = threadIdx.x;
+    const long long j_raw = (long long)blockIdx.x * 64 + lane;
+    const bool active = j_raw < p.ncases;
+    if (!INV && !active) return;
+    const long long j = active ? j_raw : p.ncases - 1;
     unsigned long long known, dropped;
     effective_mask<NO>(p.knowns[j * p.sknowns], known, dropped);
     constexpr unsigned long long FULL = (1ull << NO) - 1ull;
-    if (known == FULL) return;
+    if (!INV && known == FULL) return;
     const double* w = p.ws + j;
+    // column(col, o): column `col` of the inverse into o[0..NO)
+    auto emit_inverse = [&](auto&& column) {
+        double* blk = inv + (long long)blockIdx.x * (64 * NO * NO);
+#pragma unroll 1
+        for (int col = 0; col < NO; ++col) {
+            double o[NO];
+            column(col, o);
+#pragma unroll
+            for (int a = 0; a < NO; ++a) sL[lane * NO + a] = o[a];
+            __syncthreads();
+            double* dst = blk + col * (64 * NO);
+#pragma unroll
+            for (int i = 0; i < NO; ++i) dst[lane + 64 * i] = sL[lane + 64 * i];
+            __syncthreads();
+        }
+    };
     // Every case of the wave has exactly F known (the reference's default knowns, BASELINE configs[2]): expand and factor the
     // reduced (NO - 1) system directly — 105 + 14 entries instead of 120 + 15 for 15 DOFs (see fit_ring.hip: bit-identical to the
     // generic path, whose first elimination step is the identity row).
@@ -67,8 +92,21 @@ __global__ __launch_bounds__(64) void moment_solve_kernel(const KParams p) {
             }
             ldlt_factor<N1>(M1);
             ldlt_solve<N1>(M1, r1);
+            if (active) {
 #pragma unroll
-            for (int a = 1; a < NO; ++a) fio1[a] = r1[a - 1];
+                for (int a = 1; a < NO; ++a) fio1[a] = r1[a - 1];
+            }
+            if constexpr (INV) {
+                emit_inverse([&](int col, double (&o)[NO]) {
+                    double sv[N1];
+#pragma unroll
+                    for (int a = 0; a < N1; ++a) sv[a] = (a + 1 == col) ? 1.0 : 0.0;      // column 0 (the known DOF): zeros
+                    ldlt_solve<N1>(M1, sv);
+                    o[0] = 0.0;
+#pragma unroll
+                    for (int a = 0; a < N1; ++a) o[a + 1] = sv[a];
+                });
+            }
             return;
         }
     }
@@ -85,9 +123,19 @@ __global__ __launch_bounds__(64) void moment_solve_kernel(const KParams p) {
     }
     ldlt_factor<NO>(M);
     ldlt_solve<NO>(M, g);
+    if (active) {
 #pragma unroll
-    for (int a = 0; a < NO; ++a)
-        if (!((known >> a) & 1ull)) fio[a] = g[a];
+        for (int a = 0; a < NO; ++a)
+            if (!((known >> a) & 1ull)) fio[a] = g[a];
+    }
+    if constexpr (INV) {
+        emit_inverse([&](int col, double (&o)[NO]) {
+            const bool kcol = (known >> col) & 1ull;                     // known: zero row and column (the rows are identity rows)
+#pragma unroll
+            for (int a = 0; a < NO; ++a) o[a] = (a == col && !kcol) ? 1.0 : 0.0;
+            ldlt_solve<NO>(M, o);
+        });
+    }
 }
 
 // cases per chunk
@@ -116,13 +164,42 @@ static int launch_moment(const KParams& p0, long long max_nk, hipStream_t stream
         int rc = launch_tile_moments(DIM, ORDER, p, max_nk, stream, handled);
         if (rc != WLSQM_OK || !*handled) { (void)scratch_free_async(ws, stream); return rc; }
         const long long blocks = (n + 63) / 64;
-        hipLaunchKernelGGL((moment_solve_kernel<DIM, ORDER>), dim3((unsigned)blocks), dim3(64), 0, stream, p);
+        hipLaunchKernelGGL((moment_solve_kernel<DIM, ORDER>), dim3((unsigned)blocks), dim3(64), 0, stream, p, (double*)nullptr);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { (void)scratch_free_async(ws, stream); return hip_fail(e, "moment_solve_kernel"); }
     }
     { const int rc = scratch_free_async(ws, stream); if (rc != WLSQM_OK) return rc; }
     note_kernel(p0.hoods ? "moment-gather" : "moment");
     return WLSQM_OK;
+}
+
+// The fit of ONE slice (p.ncases cases) that also leaves the inverses at inv[ceil(ncases / 64)][no][64][no] (first kernels of
+// fit_sens.hip for 2D order 4).
+bool moment_inverse_ok(int dimension, int order, const KParams& p, long long max_nk) {
+    KParams q = p;
+    q.do_sens = 0; q.sens = nullptr; q.iterative = 0;                    // (what the first kernel is launched with)
+    return !p.case_index && tile_moments_supported(dimension, order, q, max_nk);
+}
+int launch_fit_moment_inverse(int dimension, int order, const KParams& p0, long long max_nk, double* inv, hipStream_t stream) {
+    if (dimension != 2 || order != 4) { set_error("fit_moment_inverse: unsupported (dimension, order)"); return WLSQM_EVALUE; }
+    constexpr int NACC = mom_count<2>(8) + ndofs(2, 4);
+    double* ws = nullptr;
+    int rc = scratch_alloc_async(reinterpret_cast<void**>(&ws), (size_t)NACC * (size_t)p0.ncases * sizeof(double), stream);
+    if (rc != WLSQM_OK) return rc;
+    KParams p = p0;
+    p.ws = ws; p.ws_stride = p0.ncases; p.do_sens = 0; p.sens = nullptr; p.iterative = 0;
+    bool handled = false;
+    rc = launch_tile_moments(dimension, order, p, max_nk, stream, &handled);
+    if (rc == WLSQM_OK && !handled) { set_error("fit_moment_inverse: no moment kernel for this shape"); rc = WLSQM_EVALUE; }
+    if (rc == WLSQM_OK) {
+        const long long blocks = (p.ncases + 63) / 64;
+        hipLaunchKernelGGL((moment_solve_kernel<2, 4, true>), dim3((unsigned)blocks), dim3(64), 0, stream, p, inv);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) rc = hip_fail(e, "moment_solve_kernel (inverse)");
+    }
+    const int rc2 = scratch_free_async(ws, stream);
+    if (rc == WLSQM_OK) note_kernel("moment-inverse");
+    return rc != WLSQM_OK ? rc : rc2;
 }
 
 int launch_fit_moment(int dimension, int order, const KParams& p, long long max_nk, hipStream_t stream, bool* handled) {

@@ -42,8 +42,13 @@ __device__ __forceinline__ double inv_factorial(int n) { return n <= 1 ? 1.0 : n
 // leave two thirds of the lanes idle in the factorisation, so three cases share a wave there (GS = 21).  With G > 1 the
 // pivot row comes from the group's own lane (ds_bpermute instead of v_readlane) and the neighbours go through LDS in
 // chunks of 32 per case.
-template <int DIM, int ORDER, int G, int GS>
+// INV (G == 1): besides fi, the wave leaves the inverse of the case's eliminated normal matrix at p.ws[t][no][no] for the
+// sensitivities (fit_sens.hip).  Lane c substitutes unit vector c through the factor that sits one row per lane in registers:
+// L[i][j] reaches all lanes as a wave-uniform value (two v_readlane + one fma per term, 2 x no (no - 1) / 2 terms), no LDS; the
+// 64 right-hand sides of fit_wave.hip's LDS form cost three LDS operations per term.
+template <int DIM, int ORDER, int G, int GS, bool INV = false>
 __global__ __launch_bounds__(RW) void fit_rows_kernel(const KParams p) {
+    static_assert(!INV || G == 1, "the inverse is written by the one-case-per-wave form");
     static_assert(DIM == 3, "row-per-lane kernel is instantiated for the 3D systems");
     constexpr int NO = ndofs(DIM, ORDER), NM = mom_count<DIM>(2 * ORDER), NP = 2 * ORDER + 1;
     constexpr int TS = DIM * NP, TSP = TS | 1;                    // power-table row: [w dx^n | dy^n | dz^n], odd stride
@@ -229,6 +234,32 @@ __global__ __launch_bounds__(RW) void fit_rows_kernel(const KParams p) {
             const double l = sV[jj * LDV + me] * my_dinv;        // L[jj][i] = V_jj[i] / d_i
             g = (lane < jj) ? fma(-l, xj, g) : g;
         }
+        if constexpr (INV) {
+            // L[i][m] = V_i[m] / d_m in place (m < i; the entries from the diagonal on are not read again)
+#pragma unroll
+            for (int m = 0; m < NO; ++m) V[m] *= dinv[m];
+            const bool col = lane < NO && !((known >> me) & 1ull);           // a known DOF: zero row and column
+            double X[NO];
+#pragma unroll
+            for (int i = 0; i < NO; ++i) X[i] = (i == lane && col) ? 1.0 : 0.0;
+#pragma unroll
+            for (int jj = 0; jj < NO - 1; ++jj)
+#pragma unroll
+                for (int i = jj + 1; i < NO; ++i) X[i] = fma(-lane_bcast(V[jj], i), X[jj], X[i]);
+#pragma unroll
+            for (int jj = NO - 1; jj >= 0; --jj) {
+                double v = X[jj] * dinv[jj];
+#pragma unroll
+                for (int i = jj + 1; i < NO; ++i) v = fma(-lane_bcast(V[jj], i), X[i], v);
+                X[jj] = v;
+            }
+            // lane c holds column c = row c; stored by rows so that a store instruction writes `no` consecutive doubles
+            if (lane < NO && valid) {
+                double* wi = p.ws + t * (long long)(NO * NO) + lane;
+#pragma unroll
+                for (int i = 0; i < NO; ++i) wi[i * NO] = X[i];
+            }
+        }
     } else {
         // ---- left-looking LDL^T, row i in lane i of the group.  Registers keep V[m] = L[i][m] d_m; the scaled entries
         // T[i][m] = L[i][m] are published row by row in LDS as they become final (the tables are dead), so that column c reads
@@ -285,6 +316,19 @@ static int launch_rows(const KParams& p, hipStream_t stream) {
     hipLaunchKernelGGL((fit_rows_kernel<DIM, ORDER, G, GS>), dim3((unsigned)blocks), dim3(RW), 0, stream, p);
     WLSQM_HIP_CHECK(hipGetLastError());
     note_kernel("rows");
+    return WLSQM_OK;
+}
+
+// The basic fit of one slice, which also leaves every case's inverse normal matrix at inv[t][no][no] (first kernel of fit_sens.hip).
+int launch_fit_rows_inverse(int dimension, int order, const KParams& p_in, double* inv, hipStream_t stream) {
+    KParams p = p_in;
+    p.ws = inv; p.do_sens = 0; p.sens = nullptr; p.iterative = 0; p.case_index = nullptr;
+    if (p.ncases > 0x7fffffffLL) { set_error("too many cases for one launch"); return WLSQM_EVALUE; }
+    if (dimension == 3 && order == 3) hipLaunchKernelGGL((fit_rows_kernel<3, 3, 1, 64, true>), dim3((unsigned)p.ncases), dim3(RW), 0, stream, p);
+    else if (dimension == 3 && order == 4) hipLaunchKernelGGL((fit_rows_kernel<3, 4, 1, 64, true>), dim3((unsigned)p.ncases), dim3(RW), 0, stream, p);
+    else { set_error("fit_rows_inverse: unsupported (dimension, order)"); return WLSQM_EVALUE; }
+    WLSQM_HIP_CHECK(hipGetLastError());
+    note_kernel("rows-inverse");
     return WLSQM_OK;
 }
 
