@@ -87,7 +87,7 @@ int launch_fit(int dimension, int order, const KParams& p_in, long long max_nk, 
         const char* off = getenv("WLSQM_HIP_DISABLE_TILE");
         const char* norp = getenv("WLSQM_HIP_DISABLE_REPACK");
         const bool tiles_on = !(off && off[0] == '1') && !(norp && norp[0] == '1');
-        if (tiles_on && !p.hoods && !p.case_index && p.xk && p.fk && no <= 15 && max_nk >= 2 && p.ncases >= 256 && !(p.iterative && max_nk > 128) &&
+        if (tiles_on && !p.hoods && !p.case_index && p.xk && p.fk && no <= 15 && max_nk >= 2 && p.ncases >= 256 &&
             !dense_layout_ok(dimension, p, max_nk)) {
             const long long Kp = preferred_slots(dimension, order, max_nk);
             double* ws = nullptr;
@@ -123,8 +123,7 @@ int launch_fit(int dimension, int order, const KParams& p_in, long long max_nk, 
         const char* off = getenv("WLSQM_HIP_DISABLE_TILE");
         const char* norp = getenv("WLSQM_HIP_DISABLE_REPACK");
         const bool tiles_on = !(off && off[0] == '1') && !(norp && norp[0] == '1');
-        if (tiles_on && p.hoods && !p.case_index && no <= 15 && max_nk >= 2 && p.ncases >= 256 &&
-            !(p.iterative && max_nk > 128)) {
+        if (tiles_on && p.hoods && !p.case_index && no <= 15 && max_nk >= 2 && p.ncases >= 256) {
             const long long Kp = preferred_slots(dimension, order, max_nk);
             double* ws = nullptr;
             const size_t nx = (size_t)p.ncases * Kp * dimension, nf = (size_t)p.ncases * Kp, ni = (size_t)p.ncases * dimension;

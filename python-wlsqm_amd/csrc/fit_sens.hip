@@ -156,6 +156,141 @@ __global__ __launch_bounds__(64) void sens_apply_kernel(const KParams p, const d
   }
 }
 
+// Iterative refinement (impl.pyx:986-1083) on the same inverse: one case at a time per wave, ONE LANE PER NEIGHBOUR.  A sweep
+// evaluates the model at the neighbours (the coefficient vector is wave-uniform, read from LDS), takes the max-norm of the
+// residual with the reference's semantics (the first residual seeds the maximum, so a NaN there poisons it, impl.pyx:1037-1041),
+// sums the lanes' shares of C^T W res through LDS (lane a adds column a: 64 conflict-free reads instead of 6 no shuffles) and
+// lane a forms its component of the correction from row a of the inverse, which it keeps in registers for the whole case.
+// The sweeps stop when the norm repeats exactly (impl.pyx:1057), as every refinement path of this library does.
+template <int DIM, int ORDER>
+__global__ __launch_bounds__(64) void refine_apply_kernel(const KParams p, const double* __restrict__ inv_all, const int grouped) {
+    constexpr int WV = 64, NO = ndofs(DIM, ORDER), NOP = NO | 1;
+    constexpr unsigned long long FULL = (NO >= 64) ? ~0ull : ((1ull << NO) - 1ull);
+    __shared__ double sR[WV * NOP];
+    __shared__ double sF[NO + 1];
+    const int lane = threadIdx.x, me = lane < NO ? lane : NO - 1;
+    const int kmax = (int)p.max_nk;
+    int iters_all = 0;
+    for (long long t = blockIdx.x; t < p.ncases; t += gridDim.x) {
+        const int nkc = min(p.nk[t * p.snk], kmax);
+        const bool uniform = (p.wm[t * p.swm] == WLSQM_WEIGHT_UNIFORM);
+        unsigned long long known, dropped;
+        effective_mask<NO>(p.knowns[t * p.sknowns], known, dropped);
+        if (known == FULL) continue;                                       // nr < 1: no-op (impl.pyx:574, 636, 742)
+        double xi[DIM];
+#pragma unroll
+        for (int m = 0; m < DIM; ++m) xi[m] = p.xi[t * p.sxi_j + m];
+        const double* xr = p.xk + t * p.sxk_j;
+        const double* fr = p.fk + t * p.sfk_j;
+        double* fio = p.fi + t * p.sfi_j;
+        // row `lane` of the (symmetric) inverse; rows and columns of known DOFs are zero there
+        double Arow[NO];
+        {
+            const double* inv = grouped ? inv_all + (t >> 6) * (long long)(64 * NO * NO) + (t & 63) * NO : inv_all + t * (long long)(NO * NO);
+            const int cs = grouped ? 64 * NO : NO;
+#pragma unroll
+            for (int b = 0; b < NO; ++b) Arow[b] = inv[b * cs + me];
+        }
+        double myfi = fio[me];                                             // the basic fit's solution; knowns hold the user's values
+        double max_d2 = 0.0;
+        if (!uniform) {
+            for (int k = lane; k < nkc; k += WV) {
+                double d2 = 0.0;
+#pragma unroll
+                for (int m = 0; m < DIM; ++m) { const double dd = xr[k * p.sxk_k + m] - xi[m]; d2 = fma(dd, dd, d2); }
+                max_d2 = d2 > max_d2 ? d2 : max_d2;
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) { const double o = __shfl_xor(max_d2, off, WV); max_d2 = o > max_d2 ? o : max_d2; }
+        }
+        const double inv_max = inverse_max(max_d2);
+
+        double prev_norm = -1.0;
+        bool broke = false;
+        int i = 0;
+        for (i = 0; i < p.max_iter; ++i) {
+            __syncthreads();
+            if (lane < NO) sF[lane] = myfi;
+            __syncthreads();
+            double fi[NO], racc[NO];
+#pragma unroll
+            for (int a = 0; a < NO; ++a) { fi[a] = sF[a]; racc[a] = 0.0; }
+            double norm = 0.0;
+            bool first = true;
+            for (int kb = 0; kb < nkc; kb += WV) {
+                const int k = kb + lane;
+                const bool live = k < nkc;
+                const int kc = live ? k : kb;
+                double d[DIM], c[NO];
+#pragma unroll
+                for (int m = 0; m < DIM; ++m) d[m] = xr[kc * p.sxk_k + m] - xi[m];
+                const double d2 = monomials<DIM, ORDER>(d, c);
+                const double w = weight(d2, inv_max, uniform);
+                double model = fi[0];                                      // taylor_*D (polyeval.pyx): sum_a c[a] fi[a]
+#pragma unroll
+                for (int a = 1; a < NO; ++a) model += c[a] * fi[a];
+                const double res = live ? fr[kc * p.sfk_k] - model : 0.0;
+                const double ar = live ? fabs(res) : -1.0;                 // lanes without a neighbour never win the maximum
+                const double wr = w * res;
+#pragma unroll
+                for (int a = 0; a < NO; ++a) racc[a] += (a == 0) ? wr : wr * c[a];
+                const double ar0 = __shfl(ar, 0, WV);
+                double cm = (ar == ar) ? ar : -1.0;
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) { const double o = __shfl_xor(cm, off, WV); cm = o > cm ? o : cm; }
+                if (first) { norm = (ar0 == ar0) ? cm : ar0; first = false; }
+                else if (cm > norm) norm = cm;
+            }
+            if (norm == prev_norm) { broke = true; break; }                 // impl.pyx:1057 (wave-uniform)
+            prev_norm = norm;
+#pragma unroll
+            for (int a = 0; a < NO; ++a) sR[lane * NOP + a] = racc[a];
+            __syncthreads();
+            double r = 0.0;
+            if (lane < NO) {
+#pragma unroll 8
+                for (int l = 0; l < WV; ++l) r += sR[l * NOP + lane];
+            }
+            __syncthreads();
+            if (lane < NO) sF[lane] = r;
+            __syncthreads();
+            double corr = 0.0;
+#pragma unroll
+            for (int b = 0; b < NO; ++b) corr = fma(Arow[b], sF[b], corr);
+            if (!((known >> me) & 1ull)) myfi += corr;
+        }
+        const int iters = broke ? i : (p.max_iter > 0 ? p.max_iter : 1);    // for/else, impl.pyx:1080-1081
+        if (lane < NO && !((known >> me) & 1ull)) fio[lane] = myfi;
+        iters_all = iters > iters_all ? iters : iters_all;
+    }
+    if (lane == 0 && p.iters_out && iters_all > 0) atomicMax(p.iters_out, iters_all);
+}
+
+template <int DIM, int ORDER>
+static int launch_refine(const KParams& p, const double* inv, bool grouped, hipStream_t stream) {
+    static KernelSetup setup;
+    auto kern = refine_apply_kernel<DIM, ORDER>;
+    long long grid = 0;
+    int rc = persistent_grid(reinterpret_cast<const void*>(kern), 64, 0, 0, true, setup, &grid);
+    if (rc != WLSQM_OK) return rc;
+    grid = (long long)((double)grid / grid_multiple() * 2.0);
+    if (grid < 1) grid = 1;
+    if (grid > p.ncases) grid = p.ncases;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), 0, stream, p, inv, grouped ? 1 : 0);
+    WLSQM_HIP_CHECK(hipGetLastError());
+    return WLSQM_OK;
+}
+
+static int refine_dispatch(int dimension, int order, const KParams& p, const double* inv, bool grouped, hipStream_t stream) {
+#define ACASE(D, O) if (dimension == D && order == O) return launch_refine<D, O>(p, inv, grouped, stream);
+    ACASE(1, 0) ACASE(1, 1) ACASE(1, 2) ACASE(1, 3) ACASE(1, 4)
+    ACASE(2, 0) ACASE(2, 1) ACASE(2, 2) ACASE(2, 3) ACASE(2, 4)
+    ACASE(3, 0) ACASE(3, 1) ACASE(3, 2) ACASE(3, 3) ACASE(3, 4)
+#undef ACASE
+    set_error("refine_apply: unsupported (dimension, order)");
+    return WLSQM_EVALUE;
+}
+
 // Two workgroups per resident slot walk the batch (WLSQM_HIP_SENS_GRID_MULT: 1 / 2 / 4 / 8 measured within 3 %).
 template <int DIM, int ORDER>
 static int launch_apply(const KParams& p, const double* inv, bool grouped, hipStream_t stream) {
@@ -192,9 +327,16 @@ int launch_fit_sens(int dimension, int order, const KParams& p, long long K, hip
     const char* off = getenv("WLSQM_HIP_DISABLE_SENS_APPLY");
     const char* off2 = getenv("WLSQM_HIP_DISABLE_TILE");
     if ((off && off[0] == '1') || (off2 && off2[0] == '1')) return WLSQM_OK;
-    if (!p.do_sens || !p.sens || p.iterative || p.hoods || p.case_index || !p.xk || !p.fk || K < 1) return WLSQM_OK;
+    const bool want_sens = p.do_sens && p.sens;
+    if ((!want_sens && !p.iterative) || p.hoods || p.case_index || !p.xk || !p.fk || K < 1) return WLSQM_OK;
     const int no = wlsqm_hip_number_of_dofs(dimension, order);
     const bool big = no > 15;
+    // Refinement: a wave per case pays per-case overheads (syncs, the 64-row LDS sums) the lane-per-case kernel does not have, and
+    // that kernel's weakness — strided row reads — matters less when the rows are re-read from cache sweep after sweep.  200k
+    // cases, generic kernel -> inverse + refine_apply_kernel, ms: 2D order 4 at K = 50 / 26: 1.20 / 0.66 -> 2.16 / 2.23, 2D order 3 at
+    // K = 80: 1.64 -> 1.70 (those stay on the generic kernel); 2D order 2 at K = 160: 5.12 -> 1.32, 3D order 2 at K = 160: 3.68 -> 2.03,
+    // 1D order 2 at K = 100: 2.94 -> 0.81, 3D order 3 at K = 60: 6.64 -> 3.74, 3D order 4 at K = 100: 24.6 -> 10.9.
+    if (p.iterative && !(big || K > 128 || no <= 6)) return WLSQM_OK;
     const char* nomom = getenv("WLSQM_HIP_SENS_NO_MOMENT");               // A/B: the chunked kernel for 2D order 4 too
     const bool mom = !big && !(nomom && nomom[0] == '1') && moment_inverse_ok(dimension, order, p, K);
     if (big ? !(dimension == 3 && (order == 3 || order == 4)) : (!mom && !chunk_inverse_ok(dimension, order, p, K))) return WLSQM_OK;
@@ -219,13 +361,14 @@ int launch_fit_sens(int dimension, int order, const KParams& p, long long K, hip
         else if (mom) rc = launch_fit_moment_inverse(dimension, order, q, K, inv, stream);
         else {
             KParams a = q;
-            a.ws = inv; a.do_sens = 0; a.sens = nullptr;
+            a.ws = inv; a.do_sens = 0; a.sens = nullptr; a.iterative = 0;
             rc = launch_fit_chunk_inverse(dimension, order, a, K, stream);
         }
-        if (rc == WLSQM_OK) rc = apply_dispatch(dimension, order, q, inv, mom, stream);
+        if (rc == WLSQM_OK && want_sens) rc = apply_dispatch(dimension, order, q, inv, mom, stream);
+        if (rc == WLSQM_OK && p.iterative) rc = refine_dispatch(dimension, order, q, inv, mom, stream);
     }
     const int rc2 = scratch_free_async(inv, stream);
-    if (rc == WLSQM_OK) note_kernel("sens-apply");
+    if (rc == WLSQM_OK) note_kernel(p.iterative ? (want_sens ? "sens-refine-apply" : "refine-apply") : "sens-apply");
     return rc != WLSQM_OK ? rc : rc2;
 }
 

@@ -654,6 +654,31 @@ def test_sensitivities_by_inverse_and_mfma(wlsqm, oracle, dim, order, Kn, n, wid
     for j in free:
         rec = s_n[j, :nk[j], :no].T @ fk[j, :nk[j]]
         assert np.abs(rec - f_n[j, :no]).max() <= 1e-3 * np.abs(f_n[j, :no]).max()        # (sanity: order 4 on 16 points is ill-conditioned)
+    # iterative refinement on the same inverse (one lane per neighbour), alone and together with the sensitivities
+    it = {}
+    for tag in ("new", "generic", "both"):
+        if tag == "generic":
+            monkeypatch.setenv("WLSQM_HIP_DISABLE_SENS_APPLY", "1")
+        fi_d = _t(fi0); sens_d = torch.full((n, Kn, ncol), 777.0, dtype=torch.float64, device="cuda:0")
+        iters = whip.fit_many_device(dim, order, *args, fi_d[:, :no] if wide else fi_d, _t(kn), _t(wm), iterative=True, max_iter=8, want_iterations=True,
+                                     sens=(sens_d[:, :, :no] if wide else sens_d) if tag == "both" else None)
+        it[tag] = (fi_d.cpu().numpy(), iters, whip.last_kernel(), sens_d.cpu().numpy())
+        if tag == "generic":
+            monkeypatch.delenv("WLSQM_HIP_DISABLE_SENS_APPLY")
+    if no > 15 or Kn > 128 or no <= 6:
+        assert it["new"][2] == "refine-apply" and it["both"][2] == "sens-refine-apply", [v[2] for v in it.values()]
+    else:                                                                      # (measured: the lane-per-case kernel is as fast there)
+        assert it["new"][2] == "lane" and it["both"][2] == "lane", [v[2] for v in it.values()]
+    assert it["generic"][2] in ("lane", "wave"), it["generic"][2]
+    assert 1 <= it["new"][1] <= 8 and 1 <= it["generic"][1] <= 8
+    fo_i = fi0[:, :no].copy()
+    oracle.fit_many(dim, xk_a, fk, nk, xi_a, fo_i, None, 0, orders, kn, wm, iterative=True, max_iter=8)
+    P.assert_parity(it["new"][0][:, :no], fo_i, truth, "refinement on the inverse vs oracle")
+    P.assert_parity(it["new"][0][:, :no], it["generic"][0][:, :no], truth, "refinement on the inverse vs generic kernel")
+    assert np.array_equal(it["new"][0][:, no:], fi0[:, no:])
+    assert np.array_equal(it["both"][0], it["new"][0])                        # the sensitivities do not disturb the refinement
+    if it["both"][2] == "sens-refine-apply":
+        assert np.array_equal(it["both"][3], s_n, equal_nan=True)             # ... nor the refinement the sensitivities
 
 
 # ----------------------------------------------------------------------------------------------------------------------
