@@ -30,6 +30,7 @@ for dim in (1, 2, 3):
             whip.fit_many_device(dim, order, xk_a, fk, nk, xi_a, fi, kn, wm); names.append(whip.last_kernel())
             sens = torch.zeros((n, K, no), dtype=torch.float64, device=dev)
             whip.fit_many_device(dim, order, xk_a, fk, nk, xi_a, fi, kn, wm, sens=sens); names.append(whip.last_kernel())
+            whip.fit_many_device(dim, order, xk_a, fk, nk, xi_a, fi, kn, wm, iterative=True, max_iter=3); names.append(whip.last_kernel())
             # simply-strided dense input: the neighbour axis of xk and fk has a stride (views into wider arrays)
             if dim == 1:
                 xk_s = torch.zeros((n, K, 2), dtype=torch.float64, device=dev)[:, :, 0]; xk_s.copy_(xk_a)
@@ -47,4 +48,4 @@ for dim in (1, 2, 3):
         for k, r in zip(Ks, row):
             print("    K=%d %s" % (k, r))
 torch.cuda.synchronize()
-print("(dense basic / dense with sensitivities / strided dense basic / index-based basic)")
+print("(dense basic / dense with sensitivities / dense iterative / strided dense basic / index-based basic)")
