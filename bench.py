@@ -222,8 +222,9 @@ def golden_parity(name, dev):
     return acc
 
 
-def measure_fit(name, cfg, n, dev, timer, steps, warmup, rank, parity=True, keep=False):
-    """One BASELINE config through the device-resident dense API: build, time, roofline, parity."""
+def measure_fit(name, cfg, n, dev, timer, steps, warmup, rank, parity=True, keep=False, extras=None):
+    """One BASELINE config through the device-resident dense API: build, time, roofline, parity.
+    extras: None (basic fit), "sens" (do_sens: + 8 nk no bytes written per fit) or "iter" (iterative refinement, max_iter 10)."""
     import torch
     import wlsqm.hip as whip
     dim, order, nk = cfg["dim"], cfg["order"], cfg["nk"]
@@ -248,6 +249,26 @@ def measure_fit(name, cfg, n, dev, timer, steps, warmup, rank, parity=True, keep
     wm_d = torch.full((n,), cfg["wm"], dtype=torch.int32, device=dev)
     del h_d
     args = (dim, order, xk_d, fk_d, nk_d, xi_d, fi_d, kn_d, wm_d)
+    if extras:
+        # the fit with sensitivities / refinement is one or several kernels per call: the whole call is timed with events on its stream
+        kw = dict(sens=torch.zeros((n, nk, no), dtype=torch.float64, device=dev)) if extras == "sens" else dict(iterative=True, max_iter=10)
+        dt = timer.run(lambda: whip.fit_many_device(*args, **kw), steps, warmup)
+        kernel = whip.last_kernel()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        reps = min(max(steps, 5), 50)
+        e0.record()
+        for _ in range(reps):
+            whip.fit_many_device(*args, **kw)
+        e1.record(); torch.cuda.synchronize()
+        ms_kernel = e0.elapsed_time(e1) / reps
+        B_fit = bytes_per_fit(dim, order, nk, cfg["knowns"]) + (8 * nk * no if extras == "sens" else 0)
+        achieved = B_fit * n / (ms_kernel * 1e-3) / 1e9
+        return {"workload": "%s with %s: %s; %d local fits per GPU per step, device-resident dense xk/fk"
+                            % (name, "sensitivities (do_sens)" if extras == "sens" else "iterative refinement (max_iter 10)", cfg["desc"], n),
+                "fits_per_gpu": n, "bytes_per_fit": B_fit, "ms_per_step": dt / steps * 1e3, "fits_per_s": n * steps / dt,
+                "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                             "traffic": None, "kernel_ms": ms_kernel, "kernel": kernel, "algorithmic_bytes_per_launch": B_fit * n,
+                             "note": "whole call (every kernel of the path), HIP events on the launch stream"}}, dt
     dt = timer.run(lambda: whip.fit_many_device(*args), steps, warmup)
     kernel = whip.last_kernel()
     # dominant kernel, timed live with HIP events on the stream it is launched on
@@ -554,6 +575,11 @@ def side_configs(a, dev, timer, rank, parity):
                                                            short["warmup"], rank, parity))
     add("C5@1M", lambda: measure_fit("C5", CONFIGS["C5"], 1_000_000, dev, timer, a.steps, a.warmup, rank, parity))
     add("C5@16M", lambda: measure_fit("C5", CONFIGS["C5"], 16_000_000, dev, timer, short["steps"], short["warmup"], rank, False))
+    # the same functions with their flags (do_sens, the *_iterative_* entry points): not BASELINE configs, driver-timed all the same
+    for cname, cn in (("C2", 1_000_000), ("C3", 400_000), ("C5", 1_000_000)):
+        for ex in ("sens", "iter"):
+            add("%s+%s@%s" % (cname, ex, "1M" if cn == 1_000_000 else "400k"),
+                lambda cname=cname, cn=cn, ex=ex: measure_fit(cname, CONFIGS[cname], cn, dev, timer, short["steps"], short["warmup"], rank, False, extras=ex))
 
     def sharded():
         b = copy.copy(a)
