@@ -47,6 +47,10 @@ typedef double sd4_ __attribute__((ext_vector_type(4)));
 //   - weighted monomial rows computed once per 64 neighbours and passed to the blocks through LDS, results staged in LDS and
 //     stored as 512-byte runs, persistent waves with the next case prefetched: 0.54 ms (201 registers, two waves per SIMD);
 //     capped at 128 registers it spills: 1.04 ms;
+//   - the same with direct stores (LDS only for the monomial rows, 86 registers): 0.54 ms, no change — and this kernel with its
+//     stores removed still takes 55 % (15 unknowns) to 78 % (2D order 2, K = 160) of its time: neither the redundant VALU work
+//     nor the store pattern is what bounds it, the dependent chain load -> reduce -> weights -> MFMA -> store of ONE case per
+//     wave is (8 waves per SIMD is the hardware's limit);
 //   - one workgroup per case instead of waves walking the batch: the same time;
 //   - workgroups sharing an L2 (blockIdx % 8) walking a contiguous eighth of the batch: 43 % less fetched (the 120-byte runs of
 //     two neighbouring cases share lines), 5 % slower.
