@@ -720,20 +720,35 @@ def test_round2_paths_capture_into_a_hip_graph(wlsqm):
     assert solver.prepare_operator() is True                          # builds the operator (synchronises): outside the capture
     solver.solve_many_device(fks, fis)
     assert whip.last_kernel() == "solve-op-mfma"
+    # sensitivities through the inverse + MFMA path (scratch for the inverses from the stream-ordered pool) and refinement on it
+    sens = torch.zeros((n, 64, 15), dtype=torch.float64, device=dev)
+    fi_s = cases[0][1][6].clone(); fi_r = cases[2][1][6].clone()
+    args_s = cases[0][1][:6] + (fi_s,) + cases[0][1][7:]
+    args_r = cases[2][1][:6] + (fi_r,) + cases[2][1][7:]
+    whip.fit_many_device(*args_s, sens=sens); k_s = whip.last_kernel()
+    whip.fit_many_device(*args_r, iterative=True, max_iter=5); k_r = whip.last_kernel()
+    assert (k_s, k_r) == ("sens-apply", "refine-apply"), (k_s, k_r)
     torch.cuda.synchronize()
     eager = [c[1][6].clone() for c in cases] + [fis.clone()]
+    eager_x = (sens.clone(), fi_s.clone(), fi_r.clone())
     for c in cases:
         c[1][6][:, 1:] = -7.0
     fis[:, :, 1:] = -7.0
+    sens.fill_(-7.0); fi_s[:, 1:] = -7.0; fi_r[:, 1:] = -7.0
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g, stream=torch.cuda.Stream()):
         for c in cases:
             whip.fit_many_device(*c[1])
         solver.solve_many_device(fks, fis)
+        whip.fit_many_device(*args_s, sens=sens)
+        whip.fit_many_device(*args_r, iterative=True, max_iter=5)
     torch.cuda.synchronize()
     assert all(float(c[1][6][:, 1:].max()) == -7.0 for c in cases) and float(fis[:, :, 1:].max()) == -7.0     # captured, not run
+    assert float(sens.max()) == -7.0 and float(fi_r[:, 1:].max()) == -7.0
     g.replay()
     torch.cuda.synchronize()
     for c, e in zip(cases, eager[:-1]):
         assert torch.equal(c[1][6], e), c[0]
     assert torch.equal(fis, eager[-1])
+    assert torch.equal(torch.nan_to_num(sens, nan=123.0), torch.nan_to_num(eager_x[0], nan=123.0))       # (NaN columns of the known DOF)
+    assert torch.equal(fi_s, eager_x[1]) and torch.equal(fi_r, eager_x[2])
