@@ -618,6 +618,8 @@ def test_sensitivities_by_inverse_and_mfma(wlsqm, oracle, dim, order, Kn, n, wid
     nk = rng.integers(min(Kn, max(no + 1, Kn - 30)), Kn + 1, n).astype(np.int32); nk[0] = Kn
     orders = np.full(n, order, np.int32)
     masks = [0, 0, 1] + ([1 << (no - 1), 1 | (1 << (no // 2))] if no >= 3 else [])
+    if no >= 3:
+        masks += [1 << no, 1 | (1 << (no + 2))]          # stray bits beyond `no`: the last unknowns drop out (infra.pyx:119-121)
     kn = rng.choice(np.array(masks, np.int64), n)
     wm = rng.choice(np.array([1, 2], np.int32), n)
     ncol = no + (3 if wide else 0)
