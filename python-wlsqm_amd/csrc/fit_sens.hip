@@ -12,11 +12,11 @@
 //      has to reach all of the case's neighbour lanes; the MFMA does that broadcast in hardware.  Measured alternative: the
 //      inverse as SGPR operands of v_fma_f64 (scalar loads, the case is wave-uniform) — every row of the inverse is a
 //      scalar-cache miss the wave waits out (15 serialised ~1 us round trips per case, 100 SGPRs hold two rows): 3.7 us per
-//      1000 C3 cases against the lane kernel's 5.7 and 2.7-3.0 here.
+//      1000 C3 cases against the lane kernel's 5.7 and 2.1 here.
 //
 // 200k cases, ms per launch, generic kernels (lane per case; wave per case for 3D orders 3 / 4) -> this path: 2D order 4 at
-// K = 50 / 26: 1.14 / 0.59 -> 0.87 / 0.57; 2D order 3 at K = 80: 1.31 -> 0.71; 2D order 2 at K = 160: 2.70 -> 0.74; 3D order 2 at K = 160:
-// 3.02 -> 1.42; 1D order 2 at K = 100: 1.42 -> 0.36; 3D order 3 at K = 60: 4.05 -> 2.59; 3D order 4 at K = 100: 22.7 -> 7.9
+// K = 50 / 26: 1.14 / 0.59 -> 0.72 / 0.55; 2D order 3 at K = 80: 1.31 -> 0.61; 2D order 2 at K = 160: 2.70 -> 0.78; 3D order 2 at K = 160:
+// 3.02 -> 1.15; 1D order 2 at K = 100: 1.42 -> 0.32; 3D order 3 at K = 60: 4.05 -> 2.39; 3D order 4 at K = 100: 22.7 -> 7.7
 // (tools/time_sens.py, profiles/r02e_time_sens.txt).
 //
 // The sensitivities are a linear map of the right-hand side (sens[k, :] = A^-1 (w c[k, :]), known DOFs masked), so the explicit
@@ -38,26 +38,49 @@ int launch_fit_moment_inverse(int dimension, int order, const KParams& p, long l
 
 typedef double sd4_ __attribute__((ext_vector_type(4)));
 
-// One case at a time per wave, no LDS, 41 registers for 15 unknowns (8 waves per SIMD hide the latencies).  Every lane of a
-// 16-neighbour block computes the monomials of ITS neighbour itself (the four lanes of a neighbour redundantly: ~60 VALU
-// instructions against an LDS round trip and two wave syncs) and stores its four results — DOFs 4 v + g of neighbour n — straight
-// from the MFMA accumulator: 32-byte pieces, four instructions covering the block's contiguous 16 no doubles.
-// Measured alternatives, 200k C3-like cases (2D order 4, K = 50), this kernel 0.54-0.60 ms (2.0-2.2 TB/s of output; PMC: 500 VALU +
-// 233 SALU + 16 MFMA instructions per case, SIMDs 53 % busy, 55 % of the wave cycles in s_waitcnt, HBM writes = the output):
-//   - weighted monomial rows computed once per 64 neighbours and passed to the blocks through LDS, results staged in LDS and
-//     stored as 512-byte runs, persistent waves with the next case prefetched: 0.54 ms (201 registers, two waves per SIMD);
-//     capped at 128 registers it spills: 1.04 ms;
-//   - the same with direct stores (LDS only for the monomial rows, 86 registers): 0.54 ms, no change — and this kernel with its
-//     stores removed still takes 55 % (15 unknowns) to 78 % (2D order 2, K = 160) of its time: neither the redundant VALU work
-//     nor the store pattern is what bounds it, the dependent chain load -> reduce -> weights -> MFMA -> store of ONE case per
-//     wave is (8 waves per SIMD is the hardware's limit);
+// One case at a time per wave, waves walking the batch; 16 neighbours per MFMA block; results of the systems with >= 10 unknowns
+// leave as 16-byte pieces of the block's contiguous run (through a 16-row LDS image), the small systems store straight from
+// the accumulator.  What was measured on the way, 200k C3-like cases (2D order 4, K = 50), ms per launch of this kernel
+// (100k cases each):
+//   - every lane computing the monomials of its block's neighbour (no LDS at all, 41 registers, 8 waves per SIMD), 8-byte
+//     stores of the accumulator's 32-byte pieces at a 120-byte pitch: 0.29-0.30 — and 0.31 with the arithmetic REMOVED, 0.16
+//     with the stores removed: that store pattern runs at 1.9 TB/s whatever is computed beside it (HBM writes = the output,
+//     no read-modify-write; PMC: 500 VALU + 233 SALU + 16 MFMA instructions per case);
+//   - the same with the block's run stored as 16-byte pieces through a 16 x no LDS image: 0.23; with the monomial rows computed
+//     once per 64 neighbours and handed to the blocks through LDS (the image in place of the block's rows): 0.21 (2.7 TB/s);
+//   - rows and images in LDS, results staged for the whole 64-neighbour group, persistent waves with the next case
+//     prefetched (201 registers, two waves per SIMD): 0.27; capped at 128 registers it spills: 0.52;
 //   - one workgroup per case instead of waves walking the batch: the same time;
 //   - workgroups sharing an L2 (blockIdx % 8) walking a contiguous eighth of the batch: 43 % less fetched (the 120-byte runs of
-//     two neighbouring cases share lines), 5 % slower.
+//     two neighbouring cases share lines), 5 % slower;
+//   - a coordinate load per 16-neighbour block (behind the previous block's stores: vmcnt is one in-order queue): no change
+//     once the store pattern was the bound, kept out anyway.
+// LDS traffic between the lanes of ONE wave (one wave per workgroup): LDS operations of a wave complete in order, so only the
+// compiler has to be kept from moving a read above the write it depends on — no s_barrier, and no vmcnt(0) (which
+// __syncthreads() implies and which would wait out the stores in flight).
+__device__ __forceinline__ void lds_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+typedef double sd2_ __attribute__((ext_vector_type(2)));
+
 template <int DIM, int ORDER>
 __global__ __launch_bounds__(64) void sens_apply_kernel(const KParams p, const double* __restrict__ inv_all, const int grouped) {
     constexpr int WV = 64, NO = ndofs(DIM, ORDER);
     constexpr int RB = (NO + 15) / 16, KS = (NO + 3) / 4;
+    // From 10 unknowns on a block's results leave through LDS as 16-byte pieces of its contiguous run (200k cases, 15 unknowns,
+    // K = 50: 0.29 -> 0.23 ms; 3D order 2 at K = 160: 1.42 -> 1.20 ms).  The small systems are bound by their arithmetic
+    // (2D order 2 at K = 160: 0.46 of 0.60 ms without any store) and lose with the staging (0.60 -> 0.61, four blocks per image: 0.66).
+    constexpr bool STAGE = NO >= 10;
+    constexpr int IMG = 1;                                                 // 16-neighbour blocks per output image
+    // Up to 15 unknowns the weighted monomial rows of a 64-neighbour group are computed ONCE, one neighbour per lane, and handed
+    // to the blocks through LDS (row stride `no`); a block's rows are dead once its B operand has been read, and its output
+    // image takes their place.  (Without it every lane computes the row of its block's neighbour, four lanes the same one:
+    // the SIMD pays 4 x ~85 VALU instructions per 64 neighbours instead of 85 + 15 LDS writes + 4 x 4 reads.)
+    constexpr bool SHARE = NO <= 15;
+    __shared__ __attribute__((aligned(16))) double sO[SHARE ? WV * NO : (STAGE ? IMG * 16 * NO : 2)];
     constexpr unsigned long long FULL = (NO >= 64) ? ~0ull : ((1ull << NO) - 1ull);
     const int lane = threadIdx.x, n = lane & 15, g = lane >> 4;
     const int kmax = (int)p.max_nk;
@@ -110,6 +133,9 @@ __global__ __launch_bounds__(64) void sens_apply_kernel(const KParams p, const d
     }
     const double inv_max = inverse_max(max_d2);
     double* out = p.sens + t * p.ss_j + g;
+    // rows of exactly `no` doubles, every DOF written, 16-byte aligned blocks: the block's 16 no consecutive doubles leave as
+    // 16-byte pieces through LDS (wave-uniform)
+    const bool runs = STAGE && p.ss_k == NO && dropped == 0 && ((reinterpret_cast<uintptr_t>(p.sens + t * p.ss_j)) & 15u) == 0;
 #pragma unroll 1
     for (int kb = 0; kb < nkc; kb += WV) {
         if (kb > 0) {
@@ -117,14 +143,30 @@ __global__ __launch_bounds__(64) void sens_apply_kernel(const KParams p, const d
 #pragma unroll
             for (int m = 0; m < DIM; ++m) x0[m] = xr[kk * p.sxk_k + m];
         }
+        if constexpr (SHARE) {
+            lds_wave_sync();                                               // the previous group's rows and images have been read
+            double d[DIM], c[NO];
+#pragma unroll
+            for (int m = 0; m < DIM; ++m) d[m] = x0[m] - xi[m];            // (rows past nk: computed, not stored)
+            const double d2 = monomials<DIM, ORDER>(d, c);
+            const double w = weight(d2, inv_max, uniform);
+#pragma unroll
+            for (int b = 0; b < NO; ++b) sO[lane * NO + b] = (b == 0) ? w : w * c[b];
+            lds_wave_sync();
+        }
 #pragma unroll 1
         for (int nb = 0; nb < 4; ++nb) {
             const int k0 = kb + nb * 16;
             if (k0 >= nkc) break;                                          // wave-uniform
             const int k = k0 + n;
             const bool live = k < nkc;
+            double* img = SHARE ? sO + nb * 16 * NO : sO;                  // this block's rows / output image
             double B[KS];
-            {
+            if constexpr (SHARE) {
+                // B operand (lane l: B[l / 16][l % 16]): entry 4 s + g of neighbour n's row
+#pragma unroll
+                for (int s = 0; s < KS; ++s) B[s] = (4 * s + 3 < NO || 4 * s + g < NO) ? img[n * NO + 4 * s + g] : 0.0;
+            } else {
                 double d[DIM], c[NO];
 #pragma unroll
                 for (int m = 0; m < DIM; ++m) d[m] = __shfl(x0[m], nb * 16 + n, WV) - xi[m];      // (rows past nk: computed, not stored)
@@ -140,6 +182,8 @@ __global__ __launch_bounds__(64) void sens_apply_kernel(const KParams p, const d
                 }
             }
             double* row = out + (long long)k * p.ss_k;
+            const int ib = SHARE ? 0 : nb % IMG;                           // block of the image
+            if (runs && ib == 0) lds_wave_sync();                          // the previous image / this block's rows have been read
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
                 sd4_ acc = {0.0, 0.0, 0.0, 0.0};
@@ -149,10 +193,27 @@ __global__ __launch_bounds__(64) void sens_apply_kernel(const KParams p, const d
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     const int a = 16 * rb + 4 * v + g;
-                    if (live && (16 * rb + 4 * v + 3 < NO || a < NO)) {
-                        if (!((known >> a) & 1ull)) row[16 * rb + 4 * v] = acc[v];
-                        else if (!((dropped >> a) & 1ull)) row[16 * rb + 4 * v] = qnan;
+                    if (16 * rb + 4 * v + 3 < NO || a < NO) {
+                        if (runs) img[(ib * 16 + n) * NO + a] = ((known >> a) & 1ull) ? qnan : acc[v];
+                        else if (live) {
+                            if (!((known >> a) & 1ull)) row[16 * rb + 4 * v] = acc[v];
+                            else if (!((dropped >> a) & 1ull)) row[16 * rb + 4 * v] = qnan;
+                        }
                     }
+                }
+            }
+            if (runs && (ib == IMG - 1 || k0 + 16 >= nkc)) {
+                // Separate 8-byte stores of 32-byte pieces at a 120-byte pitch (the accumulator layout) run at 1.9 TB/s whatever
+                // is computed beside them (measured with the arithmetic removed); whole 16-byte pieces of the image's run do not.
+                lds_wave_sync();
+                const int k_img = k0 - ib * 16;                            // first neighbour of the image
+                const int total = min(IMG * 16, nkc - k_img) * NO;         // doubles of its run
+                double* run = p.sens + t * p.ss_j + (long long)k_img * NO;
+#pragma unroll
+                for (int q0 = 0; q0 < IMG * 16 * NO / 2; q0 += WV) {
+                    const int q = q0 + lane;
+                    if (2 * q + 1 < total) *reinterpret_cast<sd2_*>(run + 2 * q) = *reinterpret_cast<const sd2_*>(img + 2 * q);
+                    else if (2 * q < total) run[2 * q] = img[2 * q];
                 }
             }
         }
