@@ -15,7 +15,7 @@ import _parity as P
 NDOF = {1: [1, 2, 3, 4, 5], 2: [1, 3, 6, 10, 15], 3: [1, 4, 10, 20, 35]}
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-t0 = time.time(); trials = 0; worst = 0.0; ratios = []; acc = []; cloud_trials = 0; expert_trials = 0; stacked_trials = 0; strided_trials = 0; t_progress = time.time()
+t0 = time.time(); trials = 0; worst = 0.0; sens_worst = 0.0; sens_trials = 0; ratios = []; acc = []; cloud_trials = 0; expert_trials = 0; stacked_trials = 0; strided_trials = 0; t_progress = time.time()
 dev = torch.device("cuda", 0)
 while time.time() - t0 < budget:
     dim = int(rng.integers(1, 4)); mixed = rng.random() < 0.25
@@ -66,6 +66,16 @@ while time.time() - t0 < budget:
     if mode == "sens":
         assert np.array_equal(np.isnan(sens_g), np.isnan(sens_o)), desc
         assert np.array_equal(sens_g == 777.0, sens_o == 777.0), desc
+        # values: per case, relative to the case's largest sensitivity; binding where the case is well conditioned (its fi agrees
+        # with the oracle's to 1e-8), recorded for all
+        a, b = np.nan_to_num(sens_g), np.nan_to_num(sens_o)
+        live = b != 777.0
+        scale = np.abs(np.where(live, b, 0.0)).max(axis=(1, 2)) + 1e-300
+        rel = np.abs(np.where(live, a - b, 0.0)).max(axis=(1, 2)) / scale
+        fscale = np.abs(fi_o[:, :no_max]).max(axis=1) + 1e-300
+        well = (np.abs(fi_g[:, :no_max] - fi_o[:, :no_max]).max(axis=1) / fscale) < 1e-8
+        sens_worst = max(sens_worst, float(rel[well].max()) if well.any() else 0.0); sens_trials += 1
+        assert not well.any() or rel[well].max() < 1e-4, desc + ": sensitivities differ from the oracle's by %.1e (%s)" % (rel[well].max(), whip.last_kernel())
     if not mixed and mode != "iter" and n >= 15 and rng.random() < 0.5 and not (mode == "sens" and NDOF[dim][order] > 15):
         # the same batch through the index-based entry point: S = all neighbour points followed by the origins
         S = np.ascontiguousarray(np.concatenate([xk.reshape(n * K, dim), xi], axis=0)); Fv = np.concatenate([fk.reshape(n * K), fi0[:, 0]])
@@ -142,6 +152,7 @@ while time.time() - t0 < budget:
         t_progress = time.time()
         print("fuzz: %d batches after %.0f s" % (trials, time.time() - t0), flush=True)
 ratios.sort(reverse=True)
+print("fuzz: sensitivities of %d batches compared with the oracle's: largest per-case relative difference among well-conditioned cases %.1e" % (sens_trials, sens_worst))
 over = [r for r in ratios if r[0] > 1.0]
 print("fuzz: %d random batches (%d of them also index-based, %d also from strided device views, %d also through ExpertSolver, %d of those with a stacked solve; %d order buckets) in %.0f s; largest column metric vs oracle %.2e; buckets over the 1e-10 + 8 N criterion: %d"
       % (trials, cloud_trials, strided_trials, expert_trials, stacked_trials, len(ratios), time.time() - t0, worst, len(over)))
