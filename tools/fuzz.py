@@ -15,7 +15,7 @@ import _parity as P
 NDOF = {1: [1, 2, 3, 4, 5], 2: [1, 3, 6, 10, 15], 3: [1, 4, 10, 20, 35]}
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-t0 = time.time(); trials = 0; worst = 0.0; sens_worst = 0.0; sens_trials = 0; ratios = []; acc = []; cloud_trials = 0; expert_trials = 0; stacked_trials = 0; strided_trials = 0; t_progress = time.time()
+t0 = time.time(); trials = 0; worst = 0.0; sens_worst = 0.0; sens_trials = 0; acc_desc = []; ratios = []; acc = []; cloud_trials = 0; expert_trials = 0; stacked_trials = 0; strided_trials = 0; t_progress = time.time()
 dev = torch.device("cuda", 0)
 while time.time() - t0 < budget:
     dim = int(rng.integers(1, 4)); mixed = rng.random() < 0.25
@@ -61,6 +61,7 @@ while time.time() - t0 < budget:
         worst = max(worst, float(E.max()))
         if sel.sum() >= 16 and N.max() > 0:
             acc.append(float(Ec.max() / N.max()))          # accuracy of the GPU result relative to the oracle's, both against the truth
+            acc_desc.append((acc[-1], desc + " (order %d, %d cases, %s): GPU vs truth %.1e, oracle vs truth %.1e" % (o, int(sel.sum()), whip.last_kernel(), Ec.max(), N.max())))
         assert np.isfinite(fi_g[sel, :no]).all() == np.isfinite(fi_o[sel, :no]).all(), desc
         assert np.array_equal(fi_g[sel, no:], fi0[sel, no:]), desc + ": columns beyond no touched"
     if mode == "sens":
@@ -162,6 +163,8 @@ if acc:
     a = np.sort(np.array(acc))
     print("accuracy against the extended-precision truth, GPU error / oracle error over %d buckets of >= 16 cases: "
           "median %.2f, 10%% %.2f, 90%% %.2f, max %.1f" % (len(a), np.median(a), a[len(a) // 10], a[(9 * len(a)) // 10], a[-1]))
+    for r, d in sorted(acc_desc, reverse=True)[:6]:
+        print("   accuracy ratio %.1f  %s" % (r, d))
 # single-case buckets make the noise floor N a sample of one (the oracle may be accurate by luck), so the ratio is only
 # binding where a bucket has enough cases to make N a floor
 big = [r for r in ratios if r[0] >= 25.0 and r[1] >= 16]
