@@ -192,7 +192,7 @@ __global__ __launch_bounds__(64, MINW) void fit_ring_kernel(const KParams p, con
                     // (infra.pyx:780-795 copies all `no` doubles back).  Separate 8-byte stores at a 120-byte pitch with the
                     // known DOF left out made every row a partial-sector write: 200 instead of 120 MB written and 150 MB of
                     // extra sector fetches per 1M cases (profiles/r02c_C3_pmc_summary.json).
-                    const bool whole_rows = p.sfi_j == NO && all_have && ((reinterpret_cast<uintptr_t>(p.fi) & 15u) == 0);
+                    const bool whole_rows = dead_slot != nullptr && p.sfi_j == NO && all_have && ((reinterpret_cast<uintptr_t>(p.fi) & 15u) == 0);
                     if (whole_rows) {
                         double* mine = dead_slot + lane * NO;
                         mine[0] = v0;
@@ -234,6 +234,8 @@ __global__ __launch_bounds__(64, MINW) void fit_ring_kernel(const KParams p, con
         havep = false;
     };
 
+    constexpr bool DELAY = (DIM == 3);
+    bool pending = false;
     const long long tile0 = (long long)blockIdx.x * tiles_per_wg;
     long long tend = tile0 + tiles_per_wg;
     if (tend > ntiles) tend = ntiles;
@@ -255,6 +257,12 @@ __global__ __launch_bounds__(64, MINW) void fit_ring_kernel(const KParams p, con
         for (int i = 0; i < KPL; ++i) f[i] = fnext[i];
         const double* row = lds + (it & 1) * G::SLOT + c * RS + k0 * DIM;       // this lane's share of its case's row
         if (tile + 1 < tend) prefetch(tile + 1, (it + 1) & 1);
+        // DELAY: the solve of the previous four tiles runs HERE, behind the prefetch, so that its fi stores are acknowledged
+        // while this tile accumulates instead of at the next barrier (vmcnt counts the stores too); no ring slot is dead at
+        // this point, so the rows are stored directly
+        if constexpr (DELAY) {
+            if (pending) { solve_parked(nullptr); pending = false; }
+        }
 
         // (squared distances are written as explicit fma(dy, dy, dx * dx) everywhere: the ragged and the full-tile code paths
         // must round identically, or a case's result would depend on which other cases share its tile)
@@ -353,7 +361,10 @@ __global__ __launch_bounds__(64, MINW) void fit_ring_kernel(const KParams p, con
             }
         }
         if (h == (it & 3)) { jp = j; knownp = known; droppedp = dropped; havep = valid; }
-        if ((it & 3) == 3) solve_parked(lds + (it & 1) * G::SLOT);      // the 64 lanes hold 64 different cases (this tile's slot is dead)
+        if ((it & 3) == 3) {                                            // the 64 lanes hold 64 different cases (this tile's slot is dead)
+            if (DELAY && tile + 1 < tend) pending = true;
+            else solve_parked(lds + (it & 1) * G::SLOT);
+        }
     }
     if (it & 3) solve_parked(lds + ((it - 1) & 1) * G::SLOT);   // leftovers of a run that is not a multiple of 4 tiles
 }
@@ -378,9 +389,6 @@ template <int DIM, int ORDER, int K, int UNR, int MINW>
 static int launch_ring_impl(const KParams& p, hipStream_t stream) {
     using G = RingGeom<DIM, K>;
     const long long ntiles = (p.ncases + G::TC - 1) / G::TC;
-    const int T = ring_tiles_per_wg();
-    const long long grid = (ntiles + T - 1) / T;
-    if (grid > 0x7fffffffll) { set_error("fit_ring: batch too large for one launch"); return WLSQM_EVALUE; }
     auto kern = fit_ring_kernel<DIM, ORDER, K, UNR, MINW>;
     static bool optin[16] = {};
     int dev = 0;
@@ -391,6 +399,28 @@ static int launch_ring_impl(const KParams& p, hipStream_t stream) {
                                                 (int)G::LDS_BYTES));
         optin[dev] = true;
     }
+    int T = ring_tiles_per_wg();
+    if (DIM == 3 && !getenv("WLSQM_HIP_RING_TILES")) {
+        // The 3D kernel solves a group of four tiles behind the NEXT tile's prefetch (its fi stores are acknowledged under that
+        // tile's arithmetic), so long workgroups hide all but their last solve — if the launch still fills its rounds: with W
+        // resident waves, ceil(ntiles / T / W) rounds should be nearly full.  1M C5 cases (62 500 tiles, 1 024 waves), T = 4 / 16 / 20 /
+        // 24 / 28 / 32 / 48: 0.342 / 0.339 / 0.380 / 0.347 / 0.387 / 0.320 / 0.437 ms.  Small launches keep four tiles per workgroup.
+        static KernelSetup setup;
+        long long slots = 0;
+        int rc = persistent_grid(reinterpret_cast<const void*>(kern), 64, G::LDS_BYTES, 0, true, setup, &slots);
+        if (rc != WLSQM_OK) return rc;
+        slots = (long long)((double)slots / grid_multiple());
+        if (slots >= 1 && ntiles >= 8 * slots) {
+            double best = 0.0;
+            for (int t = 16; t <= 32; t += 4) {
+                const double rounds = (double)ntiles / t / (double)slots;
+                const double eff = rounds / (double)(long long)(rounds + 0.999999);
+                if (eff >= best - 0.01) { best = eff > best ? eff : best; T = t; }      // ties: the longer workgroup
+            }
+        }
+    }
+    const long long grid = (ntiles + T - 1) / T;
+    if (grid > 0x7fffffffll) { set_error("fit_ring: batch too large for one launch"); return WLSQM_EVALUE; }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), G::LDS_BYTES, stream, p, ntiles, T);
     WLSQM_HIP_CHECK(hipGetLastError());
     note_kernel("tile-solve");
