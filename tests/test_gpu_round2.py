@@ -683,6 +683,38 @@ def test_sensitivities_by_inverse_and_mfma(wlsqm, oracle, dim, order, Kn, n, wid
         assert np.array_equal(it["both"][3], s_n, equal_nan=True)             # ... nor the refinement the sensitivities
 
 
+@pytest.mark.parametrize("dim,order,Kn,n", [(2, 4, 50, 2500), (3, 3, 40, 1500), (2, 2, 140, 2100), (3, 2, 130, 1100)])
+def test_sensitivities_path_in_slices(wlsqm, dim, order, Kn, n, monkeypatch):
+    """The batch is cut into slices that share one scratch block for the inverses (1 024 cases per slice here): every slice must
+    find its own inverses — same numbers as one slice, sensitivities and refinement."""
+    import torch
+    import wlsqm.hip as whip
+    rng = np.random.default_rng(Kn + n)
+    no = K.NDOF[dim][order]
+    xi = rng.uniform(0, 1, (n, dim))
+    xk = xi[:, None, :] + 0.08 * rng.uniform(-1, 1, (n, Kn, dim))
+    fk = np.sin(3 * xk[..., 0]) * np.cos(2 * xk[..., -1])
+    nk = rng.integers(Kn - 8, Kn + 1, n).astype(np.int32)
+    kn = rng.choice(np.array([0, 1], np.int64), n); wm = np.full(n, 2, np.int32)
+    fi0 = np.zeros((n, no)); fi0[:, 0] = np.sin(3 * xi[:, 0]) * np.cos(2 * xi[:, -1])
+    args = (_t(xk), _t(fk), _t(nk), _t(xi))
+    out = {}
+    for tag in ("one", "sliced"):
+        if tag == "sliced":
+            monkeypatch.setenv("WLSQM_HIP_SENS_SLICE_MB", "0.001")
+        fi_s = _t(fi0); sens = torch.full((n, Kn, no), 777.0, dtype=torch.float64, device="cuda:0")
+        whip.fit_many_device(dim, order, *args, fi_s, _t(kn), _t(wm), sens=sens)
+        k1 = whip.last_kernel()
+        fi_r = _t(fi0)
+        whip.fit_many_device(dim, order, *args, fi_r, _t(kn), _t(wm), iterative=True, max_iter=4)
+        torch.cuda.synchronize()
+        out[tag] = (fi_s.cpu().numpy(), sens.cpu().numpy(), fi_r.cpu().numpy(), k1, whip.last_kernel())
+    assert out["one"][3] == "sens-apply" and out["sliced"][3] == "sens-apply"
+    assert np.array_equal(out["one"][0], out["sliced"][0])
+    assert np.array_equal(out["one"][1], out["sliced"][1], equal_nan=True)
+    assert np.array_equal(out["one"][2], out["sliced"][2])
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # the round-2 paths inside a HIP graph
 
