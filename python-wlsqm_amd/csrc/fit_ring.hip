@@ -404,7 +404,8 @@ static int launch_ring_impl(const KParams& p, hipStream_t stream) {
         // The 3D kernel solves a group of four tiles behind the NEXT tile's prefetch (its fi stores are acknowledged under that
         // tile's arithmetic), so long workgroups hide all but their last solve — if the launch still fills its rounds: with W
         // resident waves, ceil(ntiles / T / W) rounds should be nearly full.  1M C5 cases (62 500 tiles, 1 024 waves), T = 4 / 16 / 20 /
-        // 24 / 28 / 32 / 48: 0.342 / 0.339 / 0.380 / 0.347 / 0.387 / 0.320 / 0.437 ms.  Small launches keep four tiles per workgroup.
+        // 24 / 28 / 32 / 48: 0.342 / 0.339 / 0.380 / 0.347 / 0.387 / 0.320 / 0.437 ms; T = 30 / 31 / 32 / 61 / 62: 0.419 / 0.330 / 0.330 / 0.436 / 0.324 on another
+        // box.  Small launches keep four tiles per workgroup.
         static KernelSetup setup;
         long long slots = 0;
         int rc = persistent_grid(reinterpret_cast<const void*>(kern), 64, G::LDS_BYTES, 0, true, setup, &slots);
@@ -412,7 +413,7 @@ static int launch_ring_impl(const KParams& p, hipStream_t stream) {
         slots = (long long)((double)slots / grid_multiple());
         if (slots >= 1 && ntiles >= 8 * slots) {
             double best = 0.0;
-            for (int t = 16; t <= 32; t += 4) {
+            for (int t = 16; t <= 64; ++t) {            // (a run that is not a multiple of 4 tiles ends with a partial solve group)
                 const double rounds = (double)ntiles / t / (double)slots;
                 const double eff = rounds / (double)(long long)(rounds + 0.999999);
                 if (eff >= best - 0.01) { best = eff > best ? eff : best; T = t; }      // ties: the longer workgroup
