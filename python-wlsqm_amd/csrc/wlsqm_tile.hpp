@@ -106,7 +106,9 @@ struct TileGeom {
 //        kernel): for systems whose expanded matrix does not fit the register file next to the accumulators.
 template <int DIM, int ORDER, int K, int KSPLIT, int LPC, int UNR, int MINW, bool GATHER, bool FKD = false, bool MOM = false,
           bool SPLIT = false, int KC = K>
-__global__ __launch_bounds__(WV * KSPLIT, MINW) void fit_tile_kernel(const KParams p, const long long ntiles) {
+__global__ __launch_bounds__(WV * KSPLIT, MINW) void fit_tile_kernel(const KParams p, const long long ntiles_in) {
+    const bool no_run_store = (ntiles_in >> 40) & 1;            // A/B switch (WLSQM_HIP_TILE_RUN_STORE=0)
+    const long long ntiles = ntiles_in & ((1ll << 40) - 1);
     using G = TileGeom<DIM, ORDER, K, KSPLIT, LPC, FKD, MOM, KC>;
     static_assert(!SPLIT || MOM, "the workspace holds moments");
     static_assert(!(FKD && GATHER), "direct fk loads are a dense-path option");
@@ -363,6 +365,17 @@ __global__ __launch_bounds__(WV * KSPLIT, MINW) void fit_tile_kernel(const KPara
             }
         } else if (wave == 0) {
             constexpr unsigned long long FULL = (1ull << NO) - 1ull;
+            // One wave per tile, no knowns anywhere in it, whole tile, contiguous 16-byte aligned fi rows: the tile's TC rows are
+            // ONE run of TC no doubles; they go through LDS (the tile's image is dead: a wave's LDS operations complete in order)
+            // and leave as 16-byte pieces.  Separate 8-byte stores at a `no`-double pitch are the slow pattern of this memory system
+            // (csrc/fit_sens.hip), and the wave waits for their acknowledgement before the next tile's loads can be consumed.
+            // 1M C2 cases, interleaved A/B (WLSQM_HIP_TILE_RUN_STORE=0 / default), three runs: 0.171 / 0.173 / 0.174 -> 0.168 / 0.168 /
+            // 0.166 ms on a slow box of the pool; without any fi store: -10 %.  Three unknowns (C1: 96 doubles per tile) lose 2 %
+            // and keep the direct stores.
+            bool run_store = false;
+            if constexpr (KSPLIT == 1 && (TC * NO) % 2 == 0 && NO >= 6) {
+                run_store = !no_run_store && nvalid == TC && p.sfi_j == NO && __all(known == 0ull) && ((reinterpret_cast<uintptr_t>(p.fi) & 15u) == 0);
+            }
             if (valid && h == 0 && known != FULL) {
                 double* fio = p.fi + j * p.sfi_j;
                 auto finish = [&](double (&M)[NE], double (&rhs)[NO]) {
@@ -374,9 +387,14 @@ __global__ __launch_bounds__(WV * KSPLIT, MINW) void fit_tile_kernel(const KPara
                     }
                     ldlt_factor<NO>(M);
                     ldlt_solve<NO>(M, rhs);
+                    if (run_store) {
 #pragma unroll
-                    for (int a = 0; a < NO; ++a)
-                        if (!((known >> a) & 1ull)) fio[a] = rhs[a];
+                        for (int a = 0; a < NO; ++a) lds[c * NO + a] = rhs[a];
+                    } else {
+#pragma unroll
+                        for (int a = 0; a < NO; ++a)
+                            if (!((known >> a) & 1ull)) fio[a] = rhs[a];
+                    }
                 };
                 if constexpr (MOM) {
                     double M[NE], rhs[NO];
@@ -386,8 +404,31 @@ __global__ __launch_bounds__(WV * KSPLIT, MINW) void fit_tile_kernel(const KPara
                     finish(A, g);
                 }
             }
+            if constexpr (KSPLIT == 1 && (TC * NO) % 2 == 0 && NO >= 6) {
+                if (run_store) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    double2_* out = reinterpret_cast<double2_*>(p.fi + j0 * NO);
+                    const double2_* src = reinterpret_cast<const double2_*>(lds);
+#pragma unroll
+                    for (int q0 = 0; q0 < TC * NO / 2; q0 += WV) {
+                        const int q = q0 + lane;
+                        if ((TC * NO / 2) % WV == 0 || q < TC * NO / 2) out[q] = src[q];
+                    }
+                }
+            }
         }
-        __syncthreads();   // the next tile overwrites LDS
+        // the next tile overwrites LDS.  One wave per workgroup: the LDS operations of a wave complete in order, so only the compiler
+        // must not reorder them — __syncthreads() would also be `s_waitcnt vmcnt(0)`, i.e. wait for the fi stores just issued to
+        // be acknowledged BEFORE the next tile's loads go out (1M C2 cases: 0.139 ms without the stores, 0.155 with them)
+        if constexpr (KSPLIT == 1) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        } else {
+            __syncthreads();
+        }
     }
 }
 
@@ -406,7 +447,8 @@ static int launch_tile_impl(const KParams& p, hipStream_t stream) {
     int rc = persistent_grid(reinterpret_cast<const void*>(kern), G::NT, lds_bytes, lds_bytes, true, setup, &grid);
     if (rc != WLSQM_OK) return rc;
     if (grid > ntiles) grid = ntiles;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G::NT), lds_bytes, stream, p, ntiles);
+    const char* rs = getenv("WLSQM_HIP_TILE_RUN_STORE");
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G::NT), lds_bytes, stream, p, ntiles | ((rs && rs[0] == '0') ? (1ll << 40) : 0));
     WLSQM_HIP_CHECK(hipGetLastError());
     if (!SPLIT) note_kernel(GATHER ? "tile-gather" : "tile");
     return WLSQM_OK;

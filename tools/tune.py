@@ -30,7 +30,11 @@ ref = None
 for rnd in range(5):
     for v in variants:
         os.environ.pop("WLSQM_HIP_DISABLE_RING", None); os.environ.pop("WLSQM_HIP_RING_TILES", None)
-        if v == "noring":                  # 2D order 4: the two-kernel moment path instead of the one-kernel ring fit
+        os.environ.pop("WLSQM_HIP_TILE_RUN_STORE", None)
+        if v in ("runs0", "runs1"):        # tile kernel: fi rows as 8-byte pieces per lane / as the tile's contiguous run through LDS
+            os.environ.pop("WLSQM_HIP_DISABLE_TILE", None); os.environ.pop("WLSQM_HIP_DISABLE_FIXEDK", None)
+            os.environ["WLSQM_TILE_VARIANT"] = "0"; os.environ["WLSQM_HIP_TILE_RUN_STORE"] = v[-1]
+        elif v == "noring":                  # 2D order 4: the two-kernel moment path instead of the one-kernel ring fit
             os.environ.pop("WLSQM_HIP_DISABLE_TILE", None); os.environ.pop("WLSQM_HIP_DISABLE_FIXEDK", None)
             os.environ["WLSQM_HIP_DISABLE_RING"] = "1"
         elif v.startswith("ring"):         # ring fit with N tiles per workgroup (ring8, ring16, ...)
