@@ -365,7 +365,7 @@ __global__ __launch_bounds__(WV * KSPLIT, MINW) void fit_tile_kernel(const KPara
             }
         } else if (wave == 0) {
             constexpr unsigned long long FULL = (1ull << NO) - 1ull;
-            // One wave per tile, no knowns anywhere in it, whole tile, contiguous 16-byte aligned fi rows: the tile's TC rows are
+            // One wave per tile, whole tile, no case without unknowns or with dropped DOFs, contiguous 16-byte aligned fi rows: the tile's TC rows are
             // ONE run of TC no doubles; they go through LDS (the tile's image is dead: a wave's LDS operations complete in order)
             // and leave as 16-byte pieces.  Separate 8-byte stores at a `no`-double pitch are the slow pattern of this memory system
             // (csrc/fit_sens.hip), and the wave waits for their acknowledgement before the next tile's loads can be consumed.
@@ -374,7 +374,8 @@ __global__ __launch_bounds__(WV * KSPLIT, MINW) void fit_tile_kernel(const KPara
             // and keep the direct stores.
             bool run_store = false;
             if constexpr (KSPLIT == 1 && (TC * NO) % 2 == 0 && NO >= 6) {
-                run_store = !no_run_store && nvalid == TC && p.sfi_j == NO && __all(known == 0ull) && ((reinterpret_cast<uintptr_t>(p.fi) & 15u) == 0);
+                run_store = !no_run_store && nvalid == TC && p.sfi_j == NO && __all(dropped == 0ull && known != FULL) &&
+                            ((reinterpret_cast<uintptr_t>(p.fi) & 15u) == 0);
             }
             if (valid && h == 0 && known != FULL) {
                 double* fio = p.fi + j * p.sfi_j;
@@ -388,8 +389,9 @@ __global__ __launch_bounds__(WV * KSPLIT, MINW) void fit_tile_kernel(const KPara
                     ldlt_factor<NO>(M);
                     ldlt_solve<NO>(M, rhs);
                     if (run_store) {
+                        // (a known DOF is re-written with its own bits, as the reference's Case_get_fi does: infra.pyx:780-795)
 #pragma unroll
-                        for (int a = 0; a < NO; ++a) lds[c * NO + a] = rhs[a];
+                        for (int a = 0; a < NO; ++a) lds[c * NO + a] = ((known >> a) & 1ull) ? fio[a] : rhs[a];
                     } else {
 #pragma unroll
                         for (int a = 0; a < NO; ++a)
