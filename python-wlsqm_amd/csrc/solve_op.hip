@@ -12,10 +12,13 @@
 //     A[i][k] = S (rows padded to 16, DOF a = 4 (i % 4) + i / 4 in row i),  B[k][j] = fk of field r0 + j,  D[i][j] -> fi.
 // Register layout measured on gfx950 (tools/ubench/mfma_f64_layout.hip): lane l holds A[l % 16][l / 16], B[l / 16][l % 16] and
 // D[4 v + l / 16][l % 16] in accumulator element v.  The k index of MFMA step s in lane group q = l / 16 is chosen as
-// q * (K / 4) + s: every lane then reads ONE contiguous K/4-double piece of its operator row and of its field's fk row
-// (128 B for K = 64: whole-line, 16-byte loads), and with the row permutation above a lane's four accumulator elements are four
-// consecutive DOFs of one fi row.  The operator of the case (K/4 doubles per lane) stays in registers for all R fields; per case
-// and field only fk (8 nk B) is read and fi (8 no B) written.  The next block of 16 fields is prefetched under the MFMAs.
+// 8 (s / 2) + 2 q + s % 2: with every 16-byte load instruction the four lane groups of a row read four CONSECUTIVE pieces — 64
+// contiguous bytes of the field's fk row (and of the operator row) per instruction.  (First version: k = q K/4 + s, every lane
+// one contiguous K/4-double piece of its own: each load instruction then touched four 16-byte pieces 64 bytes apart in each of its
+// 16 rows; BASELINE configs[3]: 17.0 -> 15.4 ms per 256 fields, 0.58 -> 0.64 of the HBM peak.)  With the row permutation above a
+// lane's four accumulator elements are four consecutive DOFs of one fi row.  The operator of the case (K/4 doubles per lane) stays
+// in registers for all R fields; per case and field only fk (8 nk B) is read and fi (8 no B) written.  The fk pieces of four
+// (three) blocks of 16 fields are requested at the top of an iteration and every block waits for its own set only.
 //
 // Rate measured with the same microbenchmark: 106 cycles per v_mfma_f64_16x16x4_f64 per SIMD at four waves per SIMD (47 TFLOP/s;
 // the fp64 VECTOR pipe reaches 74) — the matrix cores are not the faster fp64 engine on MI355X, but the GEMM is bound by the fk
@@ -129,9 +132,12 @@ __global__ __launch_bounds__(64 * WPG) void solve_op_mfma_kernel(const OpParams 
         // operator piece of this lane: row c16, k in [q KQ, (q + 1) KQ)
         double A[KQ];
         {
-            const od2_* src = reinterpret_cast<const od2_*>(P.op + (jc * OP_ROWS + c16) * (long long)KP + q * KQ);
+            // k index of element s of lane group q: 8 (s / 2) + 2 q + s % 2 — the four lane groups of a row read four CONSECUTIVE 16-byte
+            // pieces with every load instruction (64 contiguous bytes per field / operator row) instead of one piece each from four
+            // places 64 bytes apart; the sum over k does not care about the order, operator and fk use the same one
+            const od2_* src = reinterpret_cast<const od2_*>(P.op + (jc * OP_ROWS + c16) * (long long)KP + 2 * q);
 #pragma unroll
-            for (int s = 0; s < KQ / 2; ++s) { const od2_ v = src[s]; A[2 * s] = v.x; A[2 * s + 1] = v.y; }
+            for (int s = 0; s < KQ / 2; ++s) { const od2_ v = src[4 * s]; A[2 * s] = v.x; A[2 * s + 1] = v.y; }
         }
         // correction rows of this lane's four output DOFs (rows 4 v + q) and the known DOFs' positions
         double Tl[KNOWN ? 4 : 1][OP_NKN];
@@ -146,15 +152,15 @@ __global__ __launch_bounds__(64 * WPG) void solve_op_mfma_kernel(const OpParams 
         const bool ragged = nkc < KP;
         const double* frow = P.fk + jc * P.sfk_j;
         auto load_b = [&](long long r0, double (&B)[KQ]) {
-            if (r0 >= P.nrhs || !work) return;                                  // wave-uniform
-            if ((P.dbg & 2) && r0 > 0) return;
+            // (always issued — rows past the last field replay it, a case without unknowns loads and ignores: no branch, so that
+            // the compiler can count what is in flight)
             long long r = r0 + c16; r = r < P.nrhs ? r : P.nrhs - 1;
             const double* src = frow + r * P.sfk_r;
 #pragma unroll
             for (int s = 0; s < KQ / 2; ++s) {
                 // pieces beyond the fk row (K not a multiple of 8) replay the row's first pair: their operator columns are zero and
                 // the ragged mask below clears them
-                const int e = q * KQ + 2 * s;
+                const int e = 8 * s + 2 * q;
                 const od2_ v = *reinterpret_cast<const od2_*>(src + (e < P.K ? e : 0));
                 B[2 * s] = v.x; B[2 * s + 1] = v.y;
             }
@@ -166,7 +172,7 @@ __global__ __launch_bounds__(64 * WPG) void solve_op_mfma_kernel(const OpParams 
                 if (ragged) {
                     // slots beyond nk[j] may hold anything (padding of the device rows): 0 * NaN would poison the sum
 #pragma unroll
-                    for (int s = 0; s < KQ; ++s) B[s] = (q * KQ + s < nkc) ? B[s] : 0.0;
+                    for (int s = 0; s < KQ; ++s) B[s] = (8 * (s / 2) + 2 * q + (s & 1) < nkc) ? B[s] : 0.0;
                 }
                 // (two accumulators, to halve the chain of dependent MFMAs: no gain measured on the 64-neighbour geometry at two
                 // waves per SIMD, and the extra registers put the 128-register fit of the 16-wave workgroups at risk)
@@ -190,26 +196,46 @@ __global__ __launch_bounds__(64 * WPG) void solve_op_mfma_kernel(const OpParams 
                 for (int v = 0; v < 4; ++v)
                     if (4 * q + v < no) mine[v] = acc[v];
             }
-            __syncthreads();
+            // LDS-only barrier: __syncthreads() is also `s_waitcnt vmcnt(0)`, which would wait out the fk pieces of the next two
+            // blocks of fields (in flight on purpose) and the previous block's stores at every block
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             // store phase: element e of the [16][WPG * no] block -> field e / run, position e % run of that field's run
             const long long nfield = (P.nrhs - r0 < 16) ? (P.nrhs - r0) : 16;
             const int total = (int)nfield * run;
-            for (int e = threadIdx.x; e < total; e += 64 * WPG) {
+            // Up to 8 unknowns the 16 no / 64 <= 2 rounds are written out: a real loop makes the compiler flush vmcnt in its preheader,
+            // i.e. wait for the fk pieces in flight (four rounds unrolled for every `no` spill 276 B per lane at the 128 registers
+            // of the 16-wave workgroups)
+            auto put = [&](int e) {
                 const int row = no == 1 ? e : (int)__umulhi((unsigned)e, P.inv_no);   // e / no = f * WPG + cs (e < 2^12: exact; no == 1: 2^32 does not fit inv_no)
                 const int a = e - row * no;
                 const int f = row / WPG, cs = row - f * WPG;                    // WPG is a power of two
-                const int pos = cs * no + a; (void)pos;
                 if (!((smask[cs] >> a) & 1ull) && !(P.dbg & 1))
                     P.fi[(r0 + f) * P.sfi_r + (j0 + cs) * P.sfi_j + a] = out[e];
+            };
+            if (no <= 8) {
+                const int e0 = (int)threadIdx.x, e1 = e0 + 64 * WPG;
+                if (e0 < total) put(e0);
+                if (e1 < total) put(e1);
+            } else {
+                for (int e = threadIdx.x; e < total; e += 64 * WPG) put(e);
             }
             parity ^= 1;
         };
-        double B0[KQ], B1[KQ], B2[KQ];
-        load_b(0, B0); load_b(16, B1);
-        for (long long r0 = 0; r0 < P.nrhs; r0 += 48) {
-            load_b(r0 + 32, B2); stage(r0, B0);
-            if (r0 + 16 < P.nrhs) { load_b(r0 + 48, B0); stage(r0 + 16, B1); }
-            if (r0 + 32 < P.nrhs) { load_b(r0 + 64, B1); stage(r0 + 32, B2); }
+        // Four (three) blocks of 16 fields per iteration: the fk pieces of all of them are requested at the top and every block waits
+        // for its own set only (s_waitcnt vmcnt(12 / 8 / 4 / 0) plus the stores in between).  Register sets kept in flight ACROSS the loop
+        // header do not work with this compiler: it loses their pending count there and waits with vmcnt(0) at the first use —
+        // the three rotating sets of the first version were requested and then waited for in every block (ISA), no prefetch at all.
+        constexpr int NSET = (WPG == 16 && KQ >= 8) ? 3 : 4;              // (the 16-wave workgroups have 128 registers per lane)
+        double B[NSET][KQ];
+        for (long long r0 = 0; r0 < P.nrhs; r0 += 16 * NSET) {
+#pragma unroll
+            for (int b = 0; b < NSET; ++b) {
+                load_b(r0 + 16 * b, B[b]);
+                __builtin_amdgcn_sched_barrier(0);                          // in this order: the first block's set must not be the last one requested
+            }
+#pragma unroll
+            for (int b = 0; b < NSET; ++b)
+                if (r0 + 16 * b < P.nrhs) stage(r0 + 16 * b, B[b]);
         }
     }
 }
