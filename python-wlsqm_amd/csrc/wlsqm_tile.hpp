@@ -97,6 +97,9 @@ struct TileGeom {
     static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit LDS");
 };
 
+// (Interleaved 16-byte pieces of a row for the LPC lanes of a case — one fk load instruction then reads LPC x 16 contiguous bytes per
+// row, the change of the k order that was worth 10 % in csrc/solve_op.hip — measured on C2, same box, old / new library: 0.1538-0.1546
+// against 0.1529-0.1545 ms: nothing, not kept.)
 // UNR: unroll factor of the neighbour loops; MINW: min waves per SIMD for the register allocator
 // (__launch_bounds__ 2nd argument).
 // GATHER: index-based ("cloud") input — the tile's rows are gathered from the point tables S/F through
