@@ -33,16 +33,37 @@ int launch_tile_moments(int dimension, int order, const KParams& p, long long ma
 template <int DIM, int ORDER, bool INV = false>
 __global__ __launch_bounds__(64) void moment_solve_kernel(const KParams p, double* __restrict__ inv) {
     constexpr int NO = ndofs(DIM, ORDER), NM = mom_count<DIM>(2 * ORDER), NE = NO * (NO + 1) / 2;
-    __shared__ double sL[INV ? 64 * NO : 1];
+    __shared__ __attribute__((aligned(16))) double sL[64 * NO];
     const int lane = threadIdx.x;
     const long long j_raw = (long long)blockIdx.x * 64 + lane;
     const bool active = j_raw < p.ncases;
-    if (!INV && !active) return;
     const long long j = active ? j_raw : p.ncases - 1;
     unsigned long long known, dropped;
     effective_mask<NO>(p.knowns[j * p.sknowns], known, dropped);
     constexpr unsigned long long FULL = (1ull << NO) - 1ull;
-    if (!INV && known == FULL) return;
+    // The wave's 64 fi rows as ONE run of 16-byte pieces through LDS (a known DOF re-written with its own bits, infra.pyx:780-795)
+    // when every lane has a case with unknowns and no dropped DOF, and the rows are contiguous and aligned; else 8-byte stores per
+    // lane — the slow pattern of this memory system (csrc/fit_sens.hip).  No lane leaves early: the copy-out is cooperative.
+    const bool run_store = p.sfi_j == NO && ((reinterpret_cast<uintptr_t>(p.fi) & 15u) == 0) &&
+                           __all(active && dropped == 0ull && known != FULL);
+    auto store_rows = [&](const double (&row)[NO]) {              // row[a]: the full fi row of this lane's case
+        if (run_store) {
+#pragma unroll
+            for (int a = 0; a < NO; ++a) sL[lane * NO + a] = row[a];
+            __syncthreads();
+            typedef double md2_ __attribute__((ext_vector_type(2)));
+            md2_* out = reinterpret_cast<md2_*>(p.fi + (long long)blockIdx.x * 64 * NO);
+            const md2_* src = reinterpret_cast<const md2_*>(sL);
+#pragma unroll
+            for (int q = lane; q < 64 * NO / 2; q += 64) out[q] = src[q];
+            __syncthreads();
+        } else if (active && known != FULL) {
+            double* fio = p.fi + j * p.sfi_j;
+#pragma unroll
+            for (int a = 0; a < NO; ++a)
+                if (!((known >> a) & 1ull)) fio[a] = row[a];
+        }
+    };
     const double* w = p.ws + j;
     // column(col, o): column `col` of the inverse into o[0..NO)
     auto emit_inverse = [&](auto&& column) {
@@ -92,9 +113,12 @@ __global__ __launch_bounds__(64) void moment_solve_kernel(const KParams p, doubl
             }
             ldlt_factor<N1>(M1);
             ldlt_solve<N1>(M1, r1);
-            if (active) {
+            {
+                double row[NO];
+                row[0] = v0;
 #pragma unroll
-                for (int a = 1; a < NO; ++a) fio1[a] = r1[a - 1];
+                for (int a = 1; a < NO; ++a) row[a] = r1[a - 1];
+                store_rows(row);
             }
             if constexpr (INV) {
                 emit_inverse([&](int col, double (&o)[NO]) {
@@ -123,10 +147,11 @@ __global__ __launch_bounds__(64) void moment_solve_kernel(const KParams p, doubl
     }
     ldlt_factor<NO>(M);
     ldlt_solve<NO>(M, g);
-    if (active) {
+    {
+        double row[NO];
 #pragma unroll
-        for (int a = 0; a < NO; ++a)
-            if (!((known >> a) & 1ull)) fio[a] = g[a];
+        for (int a = 0; a < NO; ++a) row[a] = ((known >> a) & 1ull) ? fio[a] : g[a];
+        store_rows(row);
     }
     if constexpr (INV) {
         emit_inverse([&](int col, double (&o)[NO]) {
