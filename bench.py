@@ -17,7 +17,8 @@ partitioned over the ranks, own-points-only neighbour search against a halo band
 exchanged per step on a side stream under the interior fits; wlsqm/sharded.py HaloCloudSolver).
 `--config Cx` measures one config as `value` instead.
 
-Prints ONE JSON line on rank 0 (see DESIGN.md §Measurement for every field).
+Rank 0 prints the full record on a line prefixed "# full: " and then, as the LAST line of stdout, the compact headline
+JSON (< 1.5 KB: the contract's fields + roofline + cpu_baseline + a parity digest + one [ms, frac] pair per side config).
 """
 import argparse
 import json
@@ -550,6 +551,89 @@ def headline_line(res, world, a, dt, units):
     return out
 
 
+def _sig(x, nd=4):
+    """x rounded to nd significant digits (compact line only)."""
+    if x is None or isinstance(x, (str, bool, int)):
+        return x
+    try:
+        return float("%.*g" % (nd, float(x)))
+    except (TypeError, ValueError):
+        return x
+
+
+COMPACT_LIMIT = 1500        # bytes: the driver keeps a 2 KB tail of stdout and parses its last line
+
+
+def compact_line(full, full_path=None):
+    """The LAST stdout line: the contract's fields + roofline + cpu_baseline + a parity digest + ONE [ms_per_step, frac] pair
+    per side config, guaranteed under COMPACT_LIMIT bytes (fields are dropped from the end of `optional` until it fits).
+    Everything else (per-config roofline / parity blocks, cond histograms) is in the full record: an earlier stdout line
+    prefixed '# full: ' and, when writable, gpurun_out/bench_full.json."""
+    out = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                    "scaling", "vs_baseline", "dtype", "data")}
+    for k in ("value", "ms_per_step"):
+        out[k] = _sig(out[k], 6)
+    cfg = full.get("config", {})
+    out["config"] = {"workload": str(cfg.get("workload", ""))[:200], "fits_per_gpu": cfg.get("fits_per_gpu"),
+                     "bytes_per_fit": _sig(cfg.get("bytes_per_fit"), 6)}
+    r = full.get("roofline", {})
+    out["roofline"] = {"bound": r.get("bound"), "achieved": _sig(r.get("achieved"), 5), "peak": r.get("peak"), "unit": r.get("unit"),
+                       "frac": _sig(r.get("frac")), "traffic": _sig(r.get("traffic"), 5), "traffic_source": r.get("traffic_source"),
+                       "kernel_ms": _sig(r.get("kernel_ms"), 5), "kernel": r.get("kernel")}
+    c = full.get("cpu_baseline")
+    if c:
+        out["cpu_baseline"] = {"value": _sig(c.get("value")), "unit": c.get("unit"), "cores": c.get("cores"), "kind": c.get("kind"),
+                               "sample": str(c.get("sample", ""))[:60], "value_8_threads": _sig(c.get("value_8_threads"))}
+    optional = []
+    p = full.get("parity", {})
+    g = p.get("vs_reference_golden") or p.get("vs_oracle")
+    if g:
+        d = {"E_max": _sig(g.get("E_max"), 3), "N_max": _sig(g.get("N_max"), 3), "strict_columns": g.get("strict_1e-10_columns"),
+             "columns": g.get("columns"), "golden": g.get("golden") or "oracle"}
+        s = p.get("strict_mode")
+        if s:
+            d["strict_mode"] = {"E_max": _sig(s.get("E_max"), 3), "strict_columns": s.get("strict_1e-10_columns"),
+                                "ms_per_step": _sig(s.get("ms_per_step"), 4)}
+        optional.append(("parity", d))
+    for k in ("sharded", "rccl"):
+        if k in full and isinstance(full[k], dict):
+            optional.append((k, {kk: _sig(v) for kk, v in full[k].items() if isinstance(v, (int, float, bool)) or v is None}))
+    side = full.get("configs")
+    if side:
+        summ = {}
+        for k, v in side.items():
+            if "error" in v:
+                summ[k] = "error"
+            else:
+                summ[k] = [_sig(v.get("ms_per_step")), _sig(v.get("roofline", {}).get("frac"), 3)]
+        optional.append(("configs_summary", summ))
+    if full_path:
+        optional.append(("full", full_path))
+    for k, v in optional:
+        out[k] = v
+    drop = [k for k, _ in optional][::-1]
+    while len(json.dumps(out, separators=(",", ":"))) > COMPACT_LIMIT and drop:
+        out.pop(drop.pop(0), None)
+    return out
+
+
+def emit(full):
+    """Rank 0's output: the full record on an EARLIER line (not parseable as the headline: prefixed), then the compact headline
+    as the last line of stdout."""
+    path = None
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        path = os.path.join(d, "bench_full.json")
+        with open(path, "w") as f:
+            json.dump(full, f)
+        path = "gpurun_out/bench_full.json"
+    except OSError:
+        path = None
+    print("# full: " + json.dumps(full), flush=True)
+    print(json.dumps(compact_line(full, path), separators=(",", ":")), flush=True)
+
+
 def side_configs(a, dev, timer, rank, parity):
     """Every other BASELINE config with the same --steps / --warmup (single GPU).  Each entry carries its own roofline block."""
     import copy
@@ -645,7 +729,7 @@ def main():
         if a.config is None and world == 1 and not a.no_side_configs:
             out["configs"] = side_configs(a, dev, timer, rank, parity)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -5,6 +5,7 @@ product fails loudly (no CPU fallback) when there is no HIP device."""
 import ctypes as C
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -218,3 +219,33 @@ def test_missing_library_is_an_import_error(monkeypatch):
     monkeypatch.setattr(_binding, "LIB_PATH", "/nonexistent/libwlsqm_hip.so")
     with pytest.raises(ImportError, match="no CPU fallback"):
         _binding.lib()
+
+
+def test_bench_headline_is_compact_and_parseable(capsys, tmp_path, monkeypatch):
+    """The driver keeps a 2 KB tail of bench.py's stdout and parses its last line: the headline must fit, whatever the full
+    record holds (round 2's one-line 20 KB record left BENCH_r02.parsed = null).  Canned data: the full record of round 2."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_final.json")))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    bench.emit(full)
+    out = capsys.readouterr().out
+    last = out[-2000:].splitlines()[-1]
+    line = json.loads(last)
+    assert len(last) < 1800 and len(last) <= bench.COMPACT_LIMIT
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert set(line["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+    assert line["config"]["workload"].startswith("C2") and "model" not in line["config"]
+    assert abs(line["roofline"]["frac"] - full["roofline"]["frac"]) < 1e-3
+    assert abs(line["value"] / full["value"] - 1) < 1e-5
+    assert "configs_summary" in line and len(line["configs_summary"]) == len(full["configs"])
+    # the full record is on an earlier line and in the side file
+    assert out.splitlines()[0].startswith("# full: ")
+    assert json.load(open(tmp_path / "gpurun_out" / "bench_full.json"))["value"] == full["value"]
+    # a pathological record still yields a parseable headline under the limit
+    full["configs"] = {"side%03d" % i: {"ms_per_step": 1.0, "roofline": {"frac": 0.5}} for i in range(400)}
+    assert len(json.dumps(bench.compact_line(full), separators=(",", ":"))) <= bench.COMPACT_LIMIT
