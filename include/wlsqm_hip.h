@@ -100,6 +100,27 @@ int wlsqm_hip_fit_many_host(const wlsqm_batch* b, int device, int32_t* iteration
 int wlsqm_hip_fit_many_device(const wlsqm_batch* b, int device, void* stream, int order_uniform,
                               const int64_t* case_index, int64_t ncases_sel, int32_t* iterations_out);
 
+/* ---- numerics mode (extension) ----
+ * 0 (default): the fast kernels — moment form, neighbour sums split over lanes, FMA contraction, LDL^T: results agree with the
+ *    reference to kappa * eps rounding.
+ * 1: reference-order arithmetic (csrc/fit_strict.hip): every floating-point operation of make_c_nD / Case_make_weights / make_A
+ *    (impl.pyx:70-602, infra.pyx:668-702), rescale_ruiz2001_c (lapackdrivers.pyx:553-623), dgetrf / dgetrs (:1628-1665), solve
+ *    and solve_iterative (impl.pyx:731-1083) in the reference's order, one lane per case, IEEE divide and sqrt, no FMA contraction.
+ *    Applies to every entry point that fits (wlsqm_hip_fit_many_*, wlsqm_hip_fit_cloud_device, wlsqm_hip_expert_solve*; a stacked
+ *    solve runs one fit per field).  Several times slower; for validation against the reference at 1e-10.
+ * The mode belongs to the calling thread; its initial value is the environment variable WLSQM_HIP_STRICT (unset / 0: fast).
+ * wlsqm_hip_set_strict returns the previous mode. */
+int wlsqm_hip_set_strict(int on);
+int wlsqm_hip_get_strict(void);
+
+/* Test hook of the strict mode: runs the reference-order fit of `b` (uniform order) and also stores the reference's intermediates,
+ * for bit-for-bit comparison with values captured from the reference (tests/golden/sweep_*.npz): w[j * w_stride + k]
+ * (Case_make_weights), the unscaled A and the scaled LU factor as nr x nr Fortran-order blocks at [j * mat_stride]
+ * (make_A impl.pyx:566-602; dgetrf), row_scale / col_scale (Ruiz) and the 1-based ipiv at [j * vec_stride + i]. */
+int wlsqm_hip_strict_intermediates_device(const wlsqm_batch* b, int device, void* stream, int order_uniform,
+                                          double* w, int64_t w_stride, double* A, double* LU, int64_t mat_stride,
+                                          double* row_scale, double* col_scale, int32_t* ipiv, int64_t vec_stride);
+
 /* Index-based ("cloud") variant of wlsqm_hip_fit_many_device — an EXTENSION of the reference surface (the step
  * before the path: examples/expertsolver_example.py:91-92 builds xk = S[hoods], fk = F[hoods] on the host).
  * The kernels gather the neighbour rows themselves from the device-resident point tables S[npoints, dim] and

@@ -37,6 +37,18 @@ long long preferred_slots(int dimension, int order, long long max_nk);
 int launch_fit_rows(int dimension, int order, const KParams& p, hipStream_t stream, bool* handled);
 int launch_fit_chunk(int dimension, int order, const KParams& p, long long K, hipStream_t stream, bool* handled);
 int launch_fit_sens(int dimension, int order, const KParams& p, long long K, hipStream_t stream, bool* handled);
+int launch_fit_strict(int dimension, int order, const KParams& p, const StrictDebug* dbg, hipStream_t stream);
+
+// Numerics mode of the calling thread: 0 = the fast kernels, 1 = reference-order arithmetic (fit_strict.hip).  The first use on a
+// thread takes WLSQM_HIP_STRICT from the environment; wlsqm_hip_set_strict() overrides it.
+static thread_local int g_strict = -1;
+bool strict_mode() {
+    if (g_strict < 0) {
+        const char* e = getenv("WLSQM_HIP_STRICT");
+        g_strict = (e && e[0] && e[0] != '0') ? 1 : 0;
+    }
+    return g_strict == 1;
+}
 
 // Dense rows the tiled kernels cannot take as they are — a strided neighbour or case axis, rows that are not multiples of 16
 // bytes (odd K), misaligned bases — are repacked on the device into contiguous [ncases, K', dim] / [ncases, K'] scratch
@@ -80,9 +92,12 @@ int launch_fit(int dimension, int order, const KParams& p_in, long long max_nk, 
     if (no < 0) { set_error("bad dimension/order"); return WLSQM_EVALUE; }
     if (p.ncases <= 0) return WLSQM_OK;
     if (p.hoods && no > 15 && (p.do_sens || p.iterative)) {
-        set_error("index-based input with sensitivities or refinement supports systems with at most 15 DOFs");
-        return WLSQM_EVALUE;
+        if (!strict_mode()) {
+            set_error("index-based input with sensitivities or refinement supports systems with at most 15 DOFs");
+            return WLSQM_EVALUE;
+        }
     }
+    if (strict_mode()) return launch_fit_strict(dimension, order, p, nullptr, stream);   // any layout, any shape, all extras
     {
         const char* off = getenv("WLSQM_HIP_DISABLE_TILE");
         const char* norp = getenv("WLSQM_HIP_DISABLE_REPACK");
@@ -239,6 +254,13 @@ int wlsqm_hip_device_count(void) {
     return n;
 }
 
+int wlsqm_hip_set_strict(int on) {
+    const int prev = strict_mode() ? 1 : 0;
+    g_strict = on ? 1 : 0;
+    return prev;
+}
+int wlsqm_hip_get_strict(void) { return strict_mode() ? 1 : 0; }
+
 int wlsqm_hip_number_of_dofs(int dimension, int order) {
     if (dimension < 1 || dimension > 3) return -1;
     if (order < 0 || order > 4) return -2;
@@ -292,6 +314,24 @@ int wlsqm_hip_fit_many_device(const wlsqm_batch* b, int device, void* stream, in
         }
     }
     return rc;
+}
+
+int wlsqm_hip_strict_intermediates_device(const wlsqm_batch* b, int device, void* stream, int order_uniform,
+                                          double* w, int64_t w_stride, double* A, double* LU, int64_t mat_stride,
+                                          double* row_scale, double* col_scale, int32_t* ipiv, int64_t vec_stride) {
+    int rc = validate_batch(b);
+    if (rc != WLSQM_OK) return rc;
+    DeviceScope scope;
+    rc = scope.enter(device);
+    if (rc != WLSQM_OK) return rc;
+    const int no = wlsqm_hip_number_of_dofs(b->dimension, order_uniform);
+    if (no < 0) { set_error("order_uniform must be 0..4"); return WLSQM_EVALUE; }
+    if (!w || !A || !LU || !row_scale || !col_scale || !ipiv) { set_error("null output array"); return WLSQM_EVALUE; }
+    if (w_stride < b->max_nk || mat_stride < (int64_t)no * no || vec_stride < no) { set_error("output strides too small"); return WLSQM_EVALUE; }
+    KParams p = params_from(b);
+    p.max_nk = b->max_nk;
+    StrictDebug dbg{w, w_stride, A, LU, mat_stride, row_scale, col_scale, vec_stride, ipiv};
+    return launch_fit_strict(b->dimension, order_uniform, p, &dbg, (hipStream_t)stream);
 }
 
 // Per-thread, per-device transfer context of the host-array entry points (never freed: it must not outlive

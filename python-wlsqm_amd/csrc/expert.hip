@@ -340,7 +340,8 @@ static int solve_many_on_device(wlsqm_expert* h, hipStream_t s, int64_t nrhs, co
                                 double* fi, int64_t sfi_r, int64_t sfi_j) {
     wlsqm_expert_geometry& g = *h->g;
     bool handled = false;
-    if (g.uniform_order && h->algorithm == WLSQM_ALGO_BASIC) {
+    // reference-order numerics (fit_strict.hip): one strict fit per field, as the reference's solve() per field
+    if (g.uniform_order && h->algorithm == WLSQM_ALGO_BASIC && !strict_mode()) {
         KParams p = expert_params(h, nullptr, 0, nullptr, 0);
         const int choice = solve_many_choice();
         const int no = wlsqm_hip_number_of_dofs(g.dimension, g.order[0]);

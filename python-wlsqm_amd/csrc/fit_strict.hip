@@ -1,0 +1,502 @@
+// fit_strict.hip — the REFERENCE-ORDER numerics mode (WLSQM_HIP_STRICT=1 / wlsqm_hip_set_strict(1)) for gfx950.
+//
+// The fast kernels (fit_tile / fit_ring / ...) compute the same fit with MI355X-first arithmetic: moment form, neighbour sums
+// split over lanes, rsq / rcp seeded weights, FMA contraction, unpivoted LDL^T.  Their result differs from the reference's by
+// kappa * eps-type rounding, which at the density the metric is quoted on (1M points: h ~ 0.003) exceeds 1e-10 on the second
+// derivatives.  This kernel instead replays the reference's floating-point operations ONE FOR ONE, so that its output differs
+// from the reference's only where LAPACK's internal summation order differs from the textbook algorithm:
+//
+//   make_c_{1,2,3}D      impl.pyx:449-544, 286-432, 70-269   same grouping of every scaled monomial
+//   Case_make_weights    infra.pyx:668-702                    IEEE divide and IEEE sqrt per neighbour
+//   make_A               impl.pyx:566-602                     ALL nr^2 entries, each summed over k ascending in ONE lane,
+//                                                             term (w[k] * c[k,om]) * c[k,oj], no FMA contraction
+//   rescale_ruiz2001_c   lapackdrivers.pyx:553-623            iterative equilibration, same stop test, <= 100 sweeps
+//   apply_scaling_c      lapackdrivers.pyx:293-299
+//   dgetrf               lapackdrivers.pyx:1628-1635          unblocked partial-pivot LU (first maximum wins, reciprocal pivot)
+//   solve / solve_contig impl.pyx:731-974                     RHS, knowns elimination term by term, dgetrs, un-scaling, do_sens
+//   solve_iterative      impl.pyx:986-1083                    refinement with the FMA Horner model of polyeval.pyx
+//
+// Mapping: one lane per case (no sum is ever split), the reduced matrix and every per-case vector in LDS as [slot][lane]
+// (conflict-free for any per-lane row index: the pivot row of a lane is data-dependent), 64 / 32 / 16 / 8 cases per workgroup
+// depending on the system size so that the image stays under 80-104 KB.  It is a correctness mode: 4-15x the time of the fast kernels
+// (DESIGN.md section 2), chosen per call or per process, never silently.
+#include "wlsqm_internal.hpp"
+#include "wlsqm_kernels.hpp"
+
+#pragma clang fp contract(off)      // the reference is gcc -O2 on x86-64: no contraction; the explicit fma() calls below are polyeval.pyx's own
+
+namespace wlsqm {
+
+namespace strict {
+
+constexpr double onesixth = 1. / 6.;      // impl.pyx:30-31
+constexpr double one24th = 1. / 24.;
+constexpr double weights_alpha = 1e-4;    // infra.pyx:45-46
+constexpr double weights_beta = 1. - 1e-4;
+constexpr double ruiz_epsilon = 1e-15;    // lapackdrivers.pyx:87
+
+// Cases per 64-thread workgroup for a system of NO DOFs: the LDS image is slots(NO) doubles per case.
+__host__ __device__ constexpr int slots(int NO) { return NO * NO + 10 * NO; }
+__host__ __device__ constexpr int lanes_for(int NO) {
+    return slots(NO) * 8 * 64 <= 80 * 1024 ? 64 : slots(NO) * 8 * 32 <= 80 * 1024 ? 32 : slots(NO) * 8 * 16 <= 80 * 1024 ? 16 : 8;
+}
+
+template <int DIM>
+struct Rows {       // row access of one case: dense rows with strides, or index-based (hoods row into the S / F point tables)
+    const double* xr; long long sxk_k;
+    const double* fr; long long sfk_k;
+    const int* hr; const double* S; const double* F;
+    __device__ __forceinline__ void offset(int k, const double (&xi)[DIM], double (&d)[DIM]) const {
+        const double* q = hr ? S + (long long)hr[k] * DIM : xr + k * sxk_k;
+#pragma unroll
+        for (int m = 0; m < DIM; ++m) d[m] = q[m] - xi[m];
+    }
+    __device__ __forceinline__ double value(int k) const { return hr ? F[hr[k]] : fr[k * sfk_k]; }
+};
+
+// c[k, :] with the reference's own grouping of every product; returns the squared distance (its w[k] before the weighting).
+template <int DIM, int ORDER>
+__device__ __forceinline__ double make_c(const double (&d)[DIM], double (&c)[ndofs(DIM, ORDER)]) {
+    if constexpr (DIM == 1) {                                   // impl.pyx:449-544
+        const double dx = d[0], dx2 = dx * dx;
+        c[0] = 1.;
+        if constexpr (ORDER >= 1) c[1] = dx;
+        if constexpr (ORDER >= 2) c[2] = 0.5 * dx2;
+        if constexpr (ORDER >= 3) c[3] = onesixth * dx * dx2;
+        if constexpr (ORDER >= 4) c[4] = one24th * dx2 * dx2;
+        return dx2;
+    } else if constexpr (DIM == 2) {                            // impl.pyx:286-432
+        const double dx = d[0], dy = d[1];
+        const double dx2 = dx * dx, dy2 = dy * dy;
+        const double d2 = dx2 + dy2;
+        c[0] = 1.;
+        if constexpr (ORDER >= 1) { c[1] = dx; c[2] = dy; }
+        if constexpr (ORDER >= 2) { c[3] = 0.5 * dx2; c[4] = dx * dy; c[5] = 0.5 * dy2; }
+        if constexpr (ORDER == 3) {
+            c[6] = onesixth * dx2 * dx; c[7] = 0.5 * dx2 * dy; c[8] = 0.5 * dx * dy2; c[9] = onesixth * dy * dy2;
+        }
+        if constexpr (ORDER == 4) {
+            const double dx3 = dx2 * dx, dy3 = dy2 * dy;
+            c[6] = onesixth * dx3; c[7] = 0.5 * dx2 * dy; c[8] = 0.5 * dx * dy2; c[9] = onesixth * dy3;
+            c[10] = one24th * dx2 * dx2; c[11] = onesixth * dx3 * dy; c[12] = 0.25 * dx2 * dy2; c[13] = onesixth * dx * dy3;
+            c[14] = one24th * dy2 * dy2;
+        }
+        return d2;
+    } else {                                                    // impl.pyx:70-269, DOF order defs.pyx:137-171
+        const double dx = d[0], dy = d[1], dz = d[2];
+        const double dx2 = dx * dx, dy2 = dy * dy, dz2 = dz * dz;
+        const double d2 = dx2 + dy2 + dz2;
+        c[0] = 1.;
+        if constexpr (ORDER >= 1) { c[1] = dx; c[2] = dy; c[3] = dz; }
+        if constexpr (ORDER >= 2) {
+            c[4] = 0.5 * dx2; c[5] = dx * dy; c[6] = 0.5 * dy2; c[7] = dy * dz; c[8] = 0.5 * dz2; c[9] = dx * dz;
+        }
+        if constexpr (ORDER == 3) {
+            c[10] = onesixth * dx2 * dx; c[11] = 0.5 * dx2 * dy; c[12] = 0.5 * dx * dy2; c[13] = onesixth * dy * dy2;
+            c[14] = 0.5 * dy2 * dz; c[15] = 0.5 * dy * dz2; c[16] = onesixth * dz * dz2; c[17] = 0.5 * dx * dz2;
+            c[18] = 0.5 * dx2 * dz; c[19] = dx * dy * dz;
+        }
+        if constexpr (ORDER == 4) {
+            const double dx3 = dx2 * dx, dy3 = dy2 * dy, dz3 = dz2 * dz;
+            c[10] = onesixth * dx3; c[11] = 0.5 * dx2 * dy; c[12] = 0.5 * dx * dy2; c[13] = onesixth * dy3;
+            c[14] = 0.5 * dy2 * dz; c[15] = 0.5 * dy * dz2; c[16] = onesixth * dz3; c[17] = 0.5 * dx * dz2;
+            c[18] = 0.5 * dx2 * dz; c[19] = dx * dy * dz;
+            c[20] = one24th * dx2 * dx2; c[21] = onesixth * dx3 * dy; c[22] = 0.25 * dx2 * dy2; c[23] = onesixth * dx * dy3;
+            c[24] = one24th * dy2 * dy2; c[25] = onesixth * dy3 * dz; c[26] = 0.25 * dy2 * dz2; c[27] = onesixth * dy * dz3;
+            c[28] = one24th * dz2 * dz2; c[29] = onesixth * dx * dz3; c[30] = 0.25 * dx2 * dz2; c[31] = onesixth * dx3 * dz;
+            c[32] = 0.5 * dx2 * dy * dz; c[33] = 0.5 * dx * dy2 * dz; c[34] = 0.5 * dx * dy * dz2;
+        }
+        return d2;
+    }
+}
+
+// infra.pyx:668-702: IEEE quotient and IEEE root (hipcc expands both to correctly rounded sequences)
+__device__ __forceinline__ double make_weight(double d2, double max_d2, bool uniform) {
+    if (uniform) return 1.;
+    const double tmp = 1. - sqrt(d2 / max_d2);
+    return weights_alpha + weights_beta * tmp * tmp;
+}
+
+// polyeval.pyx:874-951 (1D), :550-735 (2D), :82-355 (3D): the model at one neighbour, fi[] read through `f(a)`
+template <int DIM, int ORDER, class FI>
+__device__ __forceinline__ double taylor(const double (&d)[DIM], const FI& f) {
+    if constexpr (ORDER == 0) return f(0);
+    if constexpr (DIM == 1) {
+        const double dx = d[0];
+        double acc;
+        if constexpr (ORDER == 4) {
+            acc = fma(dx, one24th * f(4), onesixth * f(3)); acc = fma(dx, acc, 0.5 * f(2)); acc = fma(dx, acc, f(1));
+            return fma(dx, acc, f(0));
+        } else if constexpr (ORDER == 3) {
+            acc = fma(dx, onesixth * f(3), 0.5 * f(2)); acc = fma(dx, acc, f(1));
+            return fma(dx, acc, f(0));
+        } else if constexpr (ORDER == 2) {
+            acc = fma(dx, 0.5 * f(2), f(1));
+            return fma(dx, acc, f(0));
+        } else {
+            return fma(dx, f(1), f(0));
+        }
+    } else if constexpr (DIM == 2) {
+        const double dx = d[0], dy = d[1], dxdy = dx * dy;
+        double acc1, acc2, resX, resY;
+        if constexpr (ORDER == 4) {
+            acc1 = fma(dy, f(11), f(6)); acc1 *= onesixth; acc1 = fma(dx, one24th * f(10), acc1);
+            acc2 = fma(dy, f(7), f(3)); acc2 *= 0.5; acc2 = fma(dx, acc1, acc2);
+            resX = fma(dx, acc2, f(1));
+            acc1 = fma(dx, f(13), f(9)); acc1 *= onesixth; acc1 = fma(dy, one24th * f(14), acc1);
+            acc2 = fma(dx, f(8), f(5)); acc2 *= 0.5; acc2 = fma(dy, acc1, acc2);
+            resY = fma(dy, acc2, f(2));
+            const double resXY = fma(dxdy, 0.25 * f(12), f(4));
+            acc1 = dxdy * resXY;
+        } else if constexpr (ORDER == 3) {
+            acc2 = fma(dy, f(7), f(3)); acc2 *= 0.5; acc2 = fma(dx, onesixth * f(6), acc2);
+            resX = fma(dx, acc2, f(1));
+            acc2 = fma(dx, f(8), f(5)); acc2 *= 0.5; acc2 = fma(dy, onesixth * f(9), acc2);
+            resY = fma(dy, acc2, f(2));
+            acc1 = dxdy * f(4);
+        } else if constexpr (ORDER == 2) {
+            resX = fma(dx, 0.5 * f(3), f(1));
+            resY = fma(dy, 0.5 * f(5), f(2));
+            acc1 = dxdy * f(4);
+        } else {
+            acc1 = dx * f(1); acc1 = fma(dy, f(2), acc1); acc1 += f(0);
+            return acc1;
+        }
+        acc1 = fma(dx, resX, acc1); acc1 = fma(dy, resY, acc1); acc1 += f(0);
+        return acc1;
+    } else {
+        const double dx = d[0], dy = d[1], dz = d[2];
+        const double dxdy = dx * dy, dydz = dy * dz, dxdz = dx * dz;
+        double acc1, acc2, resX, resY, resZ;
+        if constexpr (ORDER == 4) {
+            acc1 = fma(dy, f(21), f(10)); acc1 = fma(dz, f(31), acc1); acc1 *= onesixth; acc1 = fma(dx, one24th * f(20), acc1);
+            acc2 = fma(dy, f(11), f(4)); acc2 = fma(dz, f(18), acc2); acc2 = fma(dydz, f(32), acc2); acc2 *= 0.5;
+            acc2 = fma(dx, acc1, acc2);
+            resX = fma(dx, acc2, f(1));
+            acc1 = fma(dx, f(23), f(13)); acc1 = fma(dz, f(25), acc1); acc1 *= onesixth; acc1 = fma(dy, one24th * f(24), acc1);
+            acc2 = fma(dx, f(12), f(6)); acc2 = fma(dz, f(14), acc2); acc2 = fma(dxdz, f(33), acc2); acc2 *= 0.5;
+            acc2 = fma(dy, acc1, acc2);
+            resY = fma(dy, acc2, f(2));
+            acc1 = fma(dx, f(29), f(16)); acc1 = fma(dy, f(27), acc1); acc1 *= onesixth; acc1 = fma(dz, one24th * f(28), acc1);
+            acc2 = fma(dx, f(17), f(8)); acc2 = fma(dy, f(15), acc2); acc2 = fma(dxdy, f(34), acc2); acc2 *= 0.5;
+            acc2 = fma(dz, acc1, acc2);
+            resZ = fma(dz, acc2, f(3));
+            const double resXY = fma(dxdy, 0.25 * f(22), f(5));
+            const double resYZ = fma(dydz, 0.25 * f(26), f(7));
+            const double resXZ = fma(dxdz, 0.25 * f(30), f(9));
+            acc1 = dx * dy * dz * f(19);
+            acc1 = fma(dxdy, resXY, acc1); acc1 = fma(dydz, resYZ, acc1); acc1 = fma(dxdz, resXZ, acc1);
+        } else if constexpr (ORDER == 3) {
+            acc2 = fma(dy, f(11), f(4)); acc2 = fma(dz, f(18), acc2); acc2 *= 0.5; acc2 = fma(dx, onesixth * f(10), acc2);
+            resX = fma(dx, acc2, f(1));
+            acc2 = fma(dx, f(12), f(6)); acc2 = fma(dz, f(14), acc2); acc2 *= 0.5; acc2 = fma(dy, onesixth * f(13), acc2);
+            resY = fma(dy, acc2, f(2));
+            acc2 = fma(dx, f(17), f(8)); acc2 = fma(dy, f(15), acc2); acc2 *= 0.5; acc2 = fma(dz, onesixth * f(16), acc2);
+            resZ = fma(dz, acc2, f(3));
+            acc1 = dx * dy * dz * f(19);
+            acc1 = fma(dxdy, f(5), acc1); acc1 = fma(dydz, f(7), acc1); acc1 = fma(dxdz, f(9), acc1);
+        } else if constexpr (ORDER == 2) {
+            resX = fma(dx, 0.5 * f(4), f(1));
+            resY = fma(dy, 0.5 * f(6), f(2));
+            resZ = fma(dz, 0.5 * f(8), f(3));
+            acc1 = dxdy * f(5);
+            acc1 = fma(dydz, f(7), acc1); acc1 = fma(dxdz, f(9), acc1);
+        } else {
+            acc1 = dx * f(1); acc1 = fma(dy, f(2), acc1); acc1 = fma(dz, f(3), acc1); acc1 += f(0);
+            return acc1;
+        }
+        acc1 = fma(dx, resX, acc1); acc1 = fma(dy, resY, acc1); acc1 = fma(dz, resZ, acc1); acc1 += f(0);
+        return acc1;
+    }
+}
+
+}  // namespace strict
+
+template <int DIM, int ORDER>
+__global__ __launch_bounds__(64) void fit_strict_kernel(const KParams p, const StrictDebug dbg) {
+    using namespace strict;
+    constexpr int NO = ndofs(DIM, ORDER);
+    constexpr int LPW = lanes_for(NO);
+    extern __shared__ double smem[];
+    const int lane = threadIdx.x;
+    if (lane >= LPW) return;
+    const long long t = (long long)blockIdx.x * LPW + lane;
+    if (t >= p.ncases) return;
+    const long long j = p.case_index ? p.case_index[t] : t;
+
+    // LDS image of this case: slot s at smem[s * LPW + lane]
+    double* const base = smem + lane;
+    auto A = [&](int e) -> double& { return base[e * LPW]; };                    // NO*NO, then nr*nr packed at the front
+    auto V = [&](int v, int i) -> double& { return base[(NO * NO + v * NO + i) * LPW]; };
+    enum { RS = 0, CS, DRP, DCP, DR, DC, BB, R2O, FI, WFI };                     // 10 vectors of NO slots
+
+    const int nk = min(p.nk[j * p.snk], (int)p.max_nk);
+    const bool uniform = (p.wm[j * p.swm] == WLSQM_WEIGHT_UNIFORM);
+    const long long knowns = p.knowns[j * p.sknowns];
+    const int nr = NO - __popcll((unsigned long long)knowns);                    // infra.pyx:119-121: bits >= no are not masked
+    if (nr < 1) return;                                                          // impl.pyx:574, 636, 742
+    {   // infra.pyx:145-200 (remap): r2o of the unknowns in ascending DOF order
+        int k = 0;
+        for (int a = 0; a < NO; ++a)
+            if (!((knowns >> a) & 1ll)) { V(R2O, k) = (double)a; ++k; }
+    }
+
+    double xi[DIM];
+    Rows<DIM> rows;
+    if (p.hoods) {
+        const long long pj = p.pidx ? p.pidx[j] : j;
+#pragma unroll
+        for (int m = 0; m < DIM; ++m) xi[m] = p.S[pj * DIM + m];
+        rows = Rows<DIM>{nullptr, 0, nullptr, 0, p.hoods + j * p.shoods_j, p.S, p.F};
+    } else {
+#pragma unroll
+        for (int m = 0; m < DIM; ++m) xi[m] = p.xi[j * p.sxi_j + m];
+        rows = Rows<DIM>{p.xk + j * p.sxk_j, p.sxk_k, p.fk + j * p.sfk_j, p.sfk_k, nullptr, nullptr, nullptr};
+    }
+    double* const fio = p.fi + j * p.sfi_j;
+
+    // ---- make_c pass 1: largest squared distance
+    double max_d2 = 0.;
+    for (int k = 0; k < nk; ++k) {
+        double d[DIM], c[NO];
+        rows.offset(k, xi, d);
+        const double d2 = make_c<DIM, ORDER>(d, c);
+        if (d2 > max_d2) max_d2 = d2;
+    }
+
+    // ---- make_A (impl.pyx:566-602) on the FULL index set: entry (oj, om) = sum_k (w c_om) c_oj, k ascending; the reduced matrix
+    // is the sub-array picked by r2o (each entry is its own sum, so computing the unused ones changes nothing)
+    for (int e = 0; e < NO * NO; ++e) A(e) = 0.;
+    for (int k = 0; k < nk; ++k) {
+        double d[DIM], c[NO];
+        rows.offset(k, xi, d);
+        const double d2 = make_c<DIM, ORDER>(d, c);
+        const double w = make_weight(d2, max_d2, uniform);
+        if (dbg.w) dbg.w[j * dbg.w_stride + k] = w;
+#pragma unroll
+        for (int om = 0; om < NO; ++om) {
+            const double wc = w * c[om];
+#pragma unroll
+            for (int oj = 0; oj < NO; ++oj) A(oj + NO * om) += wc * c[oj];
+        }
+    }
+    // compact to A[jj + nr * m] = full[r2o[jj] + NO * r2o[m]]: targets ascend and never pass their sources
+    if (nr < NO) {
+        for (int m = 0; m < nr; ++m) {
+            const int om = (int)V(R2O, m);
+            for (int jj = 0; jj < nr; ++jj) A(jj + nr * m) = A((int)V(R2O, jj) + NO * om);
+        }
+    }
+    if (dbg.A)
+        for (int e = 0; e < nr * nr; ++e) dbg.A[j * dbg.mat_stride + e] = A(e);
+
+    // ---- rescale_ruiz2001_c (lapackdrivers.pyx:553-623) with init_scaling_c (:285-290).  The row pass divides A[j,m] by
+    // DRprev[j] * DCprev[m] and the column pass by DCprev[m] * DRprev[j]: the same double, so one quotient serves both maxima.
+    for (int i = 0; i < nr; ++i) { V(RS, i) = 1.; V(CS, i) = 1.; V(DRP, i) = 1.; V(DCP, i) = 1.; }
+    for (int it = 0; it < 100; ++it) {
+        for (int i = 0; i < nr; ++i) { V(DR, i) = 0.; V(DC, i) = 0.; }
+        for (int m = 0; m < nr; ++m) {
+            const double cc = V(DCP, m);
+            double cmax = 0.;
+            for (int jj = 0; jj < nr; ++jj) {
+                const double q = fabs(A(jj + nr * m) / (V(DRP, jj) * cc));
+                if (q > cmax) cmax = q;
+                if (q > V(DR, jj)) V(DR, jj) = q;
+            }
+            V(DC, m) = sqrt(cmax);
+        }
+        for (int i = 0; i < nr; ++i) V(DR, i) = sqrt(V(DR, i));
+        for (int i = 0; i < nr; ++i) { V(DRP, i) *= V(DR, i); V(RS, i) /= V(DR, i); }
+        for (int i = 0; i < nr; ++i) { V(DCP, i) *= V(DC, i); V(CS, i) /= V(DC, i); }
+        double acc = fabs(1. - V(DR, 0) * V(DR, 0));
+        for (int i = 1; i < nr; ++i) { const double tmp = fabs(1. - V(DR, i) * V(DR, i)); if (tmp > acc) acc = tmp; }
+        if (acc < ruiz_epsilon) {
+            acc = fabs(1. - V(DC, 0) * V(DC, 0));
+            for (int i = 1; i < nr; ++i) { const double tmp = fabs(1. - V(DC, i) * V(DC, i)); if (tmp > acc) acc = tmp; }
+            if (acc < ruiz_epsilon) break;
+        }
+    }
+    // apply_scaling_c (lapackdrivers.pyx:293-299)
+    for (int m = 0; m < nr; ++m) {
+        const double cc = V(CS, m);
+        for (int jj = 0; jj < nr; ++jj) A(jj + nr * m) *= (V(RS, jj) * cc);
+    }
+
+    // ---- dgetrf (lapackdrivers.pyx:1628-1635; unblocked dgetf2: first maximal |a_ik|, column scaled by the reciprocal pivot).
+    // ipiv lives in the DR vector from here on (the equilibration is over).
+    for (int c0 = 0; c0 < nr; ++c0) {
+        int pv = c0; double best = fabs(A(c0 + nr * c0));
+        for (int i = c0 + 1; i < nr; ++i) { const double v = fabs(A(i + nr * c0)); if (v > best) { best = v; pv = i; } }
+        V(DR, c0) = (double)(pv + 1);
+        if (A(pv + nr * c0) != 0.) {
+            if (pv != c0)
+                for (int m = 0; m < nr; ++m) { const double tmp = A(c0 + nr * m); A(c0 + nr * m) = A(pv + nr * m); A(pv + nr * m) = tmp; }
+            const double r = 1. / A(c0 + nr * c0);
+            for (int i = c0 + 1; i < nr; ++i) A(i + nr * c0) *= r;
+        }
+        for (int m = c0 + 1; m < nr; ++m) {
+            const double u = A(c0 + nr * m);
+            for (int i = c0 + 1; i < nr; ++i) A(i + nr * m) -= A(i + nr * c0) * u;
+        }
+    }
+    if (dbg.LU) {
+        for (int e = 0; e < nr * nr; ++e) dbg.LU[j * dbg.mat_stride + e] = A(e);
+        for (int i = 0; i < nr; ++i) {
+            dbg.row_scale[j * dbg.vec_stride + i] = V(RS, i); dbg.col_scale[j * dbg.vec_stride + i] = V(CS, i);
+            dbg.ipiv[j * dbg.vec_stride + i] = (int)V(DR, i);
+        }
+    }
+    // dgetrs('N') (lapackdrivers.pyx:1657-1665) on the vector BB
+    auto lu_solve = [&]() {
+        for (int i = 0; i < nr; ++i) {
+            const int pv = (int)V(DR, i) - 1;
+            if (pv != i) { const double tmp = V(BB, i); V(BB, i) = V(BB, pv); V(BB, pv) = tmp; }
+        }
+        for (int c0 = 0; c0 < nr; ++c0) {
+            const double bj = V(BB, c0);
+            for (int i = c0 + 1; i < nr; ++i) V(BB, i) -= A(i + nr * c0) * bj;
+        }
+        for (int c0 = nr - 1; c0 >= 0; --c0) {
+            const double bj = V(BB, c0) / A(c0 + nr * c0);
+            V(BB, c0) = bj;
+            for (int i = 0; i < c0; ++i) V(BB, i) -= A(i + nr * c0) * bj;
+        }
+    };
+
+    // ---- solve (impl.pyx:731-846).  `rhs(k)` is fk[k] (first solve) or the residual (refinement); `fin(om)` the known values.
+    // Leaves the reduced solution b[jj] * col_scale[jj] in BB.
+    auto solve = [&](auto&& rhs, auto&& fin) {
+        for (int jj = 0; jj < nr; ++jj) V(BB, jj) = 0.;
+        for (int k = 0; k < nk; ++k) {
+            double d[DIM], c[NO];
+            rows.offset(k, xi, d);
+            const double d2 = make_c<DIM, ORDER>(d, c);
+            const double wf = make_weight(d2, max_d2, uniform) * rhs(k, d);
+            // static walk over the DOFs keeps c[] in registers; jj counts the unknowns passed so far
+            int jj = 0;
+#pragma unroll
+            for (int a = 0; a < NO; ++a) {
+                if (!((knowns >> a) & 1ll) && jj < nr) { V(BB, jj) += wf * c[a]; ++jj; }
+            }
+        }
+        for (int jj = 0; jj < nr; ++jj) V(BB, jj) = V(RS, jj) * V(BB, jj);
+        // knowns move to the right-hand side, term by term into b[jj] (impl.pyx:792-818)
+#pragma unroll 1
+        for (int om = 0; om < NO; ++om) {
+            if (!((knowns >> om) & 1ll)) continue;
+            const double fom = fin(om);
+            for (int k = 0; k < nk; ++k) {
+                double d[DIM], c[NO];
+                rows.offset(k, xi, d);
+                const double d2 = make_c<DIM, ORDER>(d, c);
+                const double w = make_weight(d2, max_d2, uniform);
+                double com = 0.;
+#pragma unroll
+                for (int a = 0; a < NO; ++a) if (a == om) com = c[a];
+                const double fwc = fom * w * com;
+                int jj = 0;
+#pragma unroll
+                for (int a = 0; a < NO; ++a) {
+                    if (!((knowns >> a) & 1ll) && jj < nr) { V(BB, jj) -= fwc * c[a] * V(RS, jj); ++jj; }
+                }
+            }
+        }
+        lu_solve();
+        for (int jj = 0; jj < nr; ++jj) V(BB, jj) = V(BB, jj) * V(CS, jj);
+    };
+
+    solve([&](int k, const double (&)[DIM]) { return rows.value(k); }, [&](int om) { return fio[om]; });
+
+    // ---- sensitivities (impl.pyx:776-778, 821-846): one dgetrs per neighbour
+    if (p.do_sens && p.sens) {
+        // the first solve's result must survive: park it in WFI
+        for (int jj = 0; jj < nr; ++jj) V(WFI, jj) = V(BB, jj);
+        double* const sr = p.sens + j * p.ss_j;
+        for (int k = 0; k < nk; ++k) {
+            double d[DIM], c[NO];
+            rows.offset(k, xi, d);
+            const double d2 = make_c<DIM, ORDER>(d, c);
+            const double w = make_weight(d2, max_d2, uniform);
+            int jj = 0;
+#pragma unroll
+            for (int a = 0; a < NO; ++a) {
+                if (!((knowns >> a) & 1ll) && jj < nr) { V(BB, jj) = V(RS, jj) * w * c[a]; ++jj; }
+            }
+            lu_solve();
+            for (int q = 0; q < nr; ++q) sr[k * p.ss_k + (int)V(R2O, q)] = V(BB, q) * V(CS, q);
+            for (int om = 0; om < NO; ++om)
+                if ((knowns >> om) & 1ll) sr[k * p.ss_k + om] = __longlong_as_double(0x7ff8000000000000LL);
+        }
+        for (int jj = 0; jj < nr; ++jj) V(BB, jj) = V(WFI, jj);
+    }
+
+    if (!p.iterative) {
+        for (int q = 0; q < nr; ++q) fio[(int)V(R2O, q)] = V(BB, q);
+        return;
+    }
+
+    // ---- solve_iterative (impl.pyx:986-1083): fi = the case's copy of the user's row with the unknowns just solved
+    for (int a = 0; a < NO; ++a) V(FI, a) = fio[a];
+    for (int q = 0; q < nr; ++q) V(FI, (int)V(R2O, q)) = V(BB, q);
+    double prev_norm = -1.;
+    bool broke = false;
+    int i = 0;
+    for (i = 0; i < p.max_iter; ++i) {
+        // the residual's maximum norm first (impl.pyx:1037-1057): exact equality with the previous one stops the loop
+        double norm = 0.;
+        for (int k = 0; k < nk; ++k) {
+            double d[DIM];
+            rows.offset(k, xi, d);
+            const double res = rows.value(k) - taylor<DIM, ORDER>(d, [&](int a) { return V(FI, a); });
+            const double ar = fabs(res);
+            if (k == 0) norm = ar; else if (ar > norm) norm = ar;
+        }
+        if (norm == prev_norm) { broke = true; break; }
+        prev_norm = norm;
+        // the correction: the same solve on the residual, knowns of the correction are zero (impl.pyx:1015-1017)
+        solve([&](int k, const double (&d)[DIM]) { return rows.value(k) - taylor<DIM, ORDER>(d, [&](int a) { return V(FI, a); }); },
+              [&](int) { return 0.; });
+        for (int q = 0; q < nr; ++q) { const int a = (int)V(R2O, q); V(FI, a) = V(FI, a) + V(BB, q); }
+    }
+    const int iters = broke ? i : (p.max_iter > 0 ? p.max_iter : 1);      // for/else, impl.pyx:1080-1081
+    for (int q = 0; q < nr; ++q) { const int a = (int)V(R2O, q); fio[a] = V(FI, a); }
+    if (p.iters_out) atomicMax(p.iters_out, iters);
+}
+
+template <int DIM, int ORDER>
+static int launch_strict(const KParams& p, const StrictDebug& dbg, hipStream_t stream) {
+    constexpr int NO = ndofs(DIM, ORDER);
+    constexpr int LPW = strict::lanes_for(NO);
+    constexpr size_t lds = (size_t)strict::slots(NO) * LPW * sizeof(double);
+    static_assert(lds <= 160 * 1024, "strict image exceeds the LDS of a CU");
+    const long long blocks = (p.ncases + LPW - 1) / LPW;
+    if (blocks <= 0) return WLSQM_OK;
+    if (blocks > 0x7fffffffLL) { set_error("too many cases for one launch"); return WLSQM_EVALUE; }
+    if (lds > 64 * 1024) {
+        static bool optin[16] = {};
+        int dev = 0;
+        WLSQM_HIP_CHECK(hipGetDevice(&dev));
+        if (dev >= 0 && dev < 16 && !optin[dev]) {
+            WLSQM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&fit_strict_kernel<DIM, ORDER>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            optin[dev] = true;
+        }
+    }
+    hipLaunchKernelGGL((fit_strict_kernel<DIM, ORDER>), dim3((unsigned)blocks), dim3(64), lds, stream, p, dbg);
+    WLSQM_HIP_CHECK(hipGetLastError());
+    note_kernel("strict");
+    return WLSQM_OK;
+}
+
+int launch_fit_strict(int dimension, int order, const KParams& p, const StrictDebug* dbg_in, hipStream_t stream) {
+    const StrictDebug dbg = dbg_in ? *dbg_in : StrictDebug{};
+#define CASE(D, O) if (dimension == D && order == O) return launch_strict<D, O>(p, dbg, stream);
+    CASE(1, 0) CASE(1, 1) CASE(1, 2) CASE(1, 3) CASE(1, 4)
+    CASE(2, 0) CASE(2, 1) CASE(2, 2) CASE(2, 3) CASE(2, 4)
+    CASE(3, 0) CASE(3, 1) CASE(3, 2) CASE(3, 3) CASE(3, 4)
+#undef CASE
+    set_error("fit_strict: unsupported (dimension, order)");
+    return WLSQM_EVALUE;
+}
+
+}  // namespace wlsqm

@@ -64,6 +64,18 @@ int hip_fail(hipError_t e, const char* what);
 // max_nk: extent of the neighbour axis (upper bound of nk[j]).
 int launch_fit(int dimension, int order, const KParams& p, long long max_nk, hipStream_t stream);
 
+// Optional capture of the reference's intermediates by the strict kernel (tests: bit-for-bit against tests/golden/sweep_*.npz).
+struct StrictDebug {
+    double* w; long long w_stride;                  // [case, k]
+    double* A; double* LU; long long mat_stride;    // [case, j + nr * m]: unscaled normal matrix / scaled LU factor
+    double* row_scale; double* col_scale; long long vec_stride;
+    int* ipiv;                                      // [case, j] at vec_stride, 1-based
+};
+
+// true when the calling thread asked for reference-order numerics (WLSQM_HIP_STRICT / wlsqm_hip_set_strict): launch_fit then
+// dispatches every shape to fit_strict.hip
+bool strict_mode();
+
 // name of the kernel family the last launch_fit on this thread dispatched to ("lane", "tile", "wave")
 const char* last_kernel_name();
 void note_kernel(const char* name);

@@ -74,6 +74,13 @@ def lib():
     L.wlsqm_hip_fit_many_host.argtypes = [C.POINTER(Batch), C.c_int, C.POINTER(C.c_int32)]
     L.wlsqm_hip_fit_many_device.argtypes = [C.POINTER(Batch), C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                             C.c_int64, C.POINTER(C.c_int32)]
+    L.wlsqm_hip_set_strict.argtypes = [C.c_int]
+    L.wlsqm_hip_set_strict.restype = C.c_int
+    L.wlsqm_hip_get_strict.restype = C.c_int
+    L.wlsqm_hip_strict_intermediates_device.argtypes = [C.POINTER(Batch), C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64,
+                                                        C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                        C.c_int64]
+    L.wlsqm_hip_strict_intermediates_device.restype = C.c_int
     L.wlsqm_hip_time_fit_device.argtypes = [C.POINTER(Batch), C.c_int, C.c_void_p, C.c_int, C.c_int,
                                             C.POINTER(C.c_float)]
     cloud = [C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
@@ -137,20 +144,26 @@ def check(rc):
 
 
 def default_device():
-    """Device of the host-array entry points: WLSQM_HIP_DEVICE if set; otherwise torch's current device when torch has
-    initialised the GPU in this process (so the library follows torch.cuda.set_device / torch.cuda.device), otherwise
-    LOCAL_RANK (one process per GPU under torch.distributed.run), otherwise 0."""
+    """Device of the host-array entry points, in this order: WLSQM_HIP_DEVICE if set; torch's current device when torch has
+    initialised the GPU in this process AND that device is not the default 0 (the caller said torch.cuda.set_device /
+    torch.cuda.device); LOCAL_RANK when set (one process per GPU under torch.distributed.run: a rank that only ever named
+    'cuda:<local_rank>' explicitly still has current_device() == 0); otherwise torch's current device, otherwise 0."""
     if "WLSQM_HIP_DEVICE" in os.environ:
         return int(os.environ["WLSQM_HIP_DEVICE"])
     import sys
     torch = sys.modules.get("torch")
+    cur = None
     if torch is not None:
         try:
             if torch.cuda.is_initialized():
-                return int(torch.cuda.current_device())
+                cur = int(torch.cuda.current_device())
         except Exception:
-            pass
-    return int(os.environ.get("LOCAL_RANK", "0"))
+            cur = None
+    if cur:
+        return cur
+    if "LOCAL_RANK" in os.environ:
+        return int(os.environ["LOCAL_RANK"])
+    return cur or 0
 
 
 # ---- argument coercion with the reference's typed-memoryview rules (SURVEY §8b 'Array typing') ----

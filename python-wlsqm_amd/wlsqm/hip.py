@@ -10,8 +10,35 @@ import ctypes as C
 
 from . import _binding as B
 
+import contextlib
+
 __all__ = ["fit_many_device", "time_fit_device", "fit_cloud_device", "time_fit_cloud_device", "device_count", "knn", "ball", "nearest",
-           "last_kernel"]
+           "last_kernel", "set_strict", "get_strict", "strict", "strict_intermediates"]
+
+
+def set_strict(on):
+    """Numerics mode of the calling thread (wlsqm_hip_set_strict): False = the fast kernels (default, or WLSQM_HIP_STRICT in
+    the environment), True = reference-order arithmetic (csrc/fit_strict.hip: the reference's operations one for one, IEEE
+    divide / sqrt, no FMA contraction, Ruiz scaling + pivoted LU), for every entry point that fits — the reference-signature
+    functions of wlsqm.fitter included.  Returns the previous mode."""
+    return bool(B.lib().wlsqm_hip_set_strict(1 if on else 0))
+
+
+def get_strict():
+    return bool(B.lib().wlsqm_hip_get_strict())
+
+
+@contextlib.contextmanager
+def strict(on=True):
+    """``with wlsqm.hip.strict(): ...`` — reference-order numerics inside the block (None: leave the mode alone)."""
+    if on is None:
+        yield
+        return
+    prev = set_strict(on)
+    try:
+        yield
+    finally:
+        set_strict(prev)
 
 
 def device_count():
@@ -100,6 +127,10 @@ def _batch(dimension, order, xk, fk, nk, xi, fi, knowns, weighting_method, sens,
     return b
 
 
+def _strict_ctx(flag):
+    return strict(flag)
+
+
 def _stream_and_device(t, stream):
     import torch
     dev = t.device.index if t.device.index is not None else torch.cuda.current_device()
@@ -109,8 +140,9 @@ def _stream_and_device(t, stream):
 
 
 def fit_many_device(dimension, order, xk, fk, nk, xi, fi, knowns, weighting_method, sens=None, iterative=False,
-                    max_iter=10, case_index=None, stream=None, want_iterations=False):
+                    max_iter=10, case_index=None, stream=None, want_iterations=False, strict=None):
     """fit_{1,2,3}D[_iterative]_many on device-resident tensors, all cases of polynomial order `order`.
+    strict=True / False selects reference-order / fast numerics for this call (None: the thread's mode, see set_strict).
 
     xk (n, K, dim) [1D: (n, K)], fk (n, K), nk (n,) int32, xi (n, dim) [1D: (n,)], fi (n, >=no) in/out,
     knowns (n,) int64, weighting_method (n,) int32, sens (n, K, >=no) or None.  `case_index` (int64 device
@@ -125,9 +157,26 @@ def fit_many_device(dimension, order, xk, fk, nk, xi, fi, knowns, weighting_meth
     if case_index is not None:
         _check(case_index, "case_index", "int64", 1)
         ci, nsel = C.c_void_p(case_index.data_ptr()), int(case_index.shape[0])
-    B.check(B.lib().wlsqm_hip_fit_many_device(C.byref(b), dev, s, int(order), ci, nsel,
-                                              C.byref(its) if want_iterations else None))
+    with _strict_ctx(strict):
+        B.check(B.lib().wlsqm_hip_fit_many_device(C.byref(b), dev, s, int(order), ci, nsel,
+                                                  C.byref(its) if want_iterations else None))
     return int(its.value)
+
+
+def strict_intermediates(dimension, order, xk, fk, nk, xi, fi, knowns, weighting_method, stream=None):
+    """Test hook (wlsqm_hip_strict_intermediates_device): the reference-order fit of a uniform-order batch, which also returns
+    the reference's intermediates as device tensors: dict(w (n, K), A (n, no*no), LU (n, no*no), row_scale (n, no),
+    col_scale (n, no), ipiv (n, no) int32).  A / LU hold the nr x nr Fortran-order block of each case at the front of its row."""
+    import torch
+    b = _batch(dimension, order, xk, fk, nk, xi, fi, knowns, weighting_method, None, False, 0, nk)
+    s, dev = _stream_and_device(fi, stream)
+    n, K, no = int(nk.shape[0]), int(fk.shape[1]), _ndofs(dimension, order)
+    z = lambda *shape, dt=torch.float64: torch.zeros(shape, dtype=dt, device=fi.device)
+    out = dict(w=z(n, K), A=z(n, no * no), LU=z(n, no * no), row_scale=z(n, no), col_scale=z(n, no), ipiv=z(n, no, dt=torch.int32))
+    B.check(B.lib().wlsqm_hip_strict_intermediates_device(C.byref(b), dev, s, int(order), _ptr(out["w"]), K, _ptr(out["A"]),
+                                                          _ptr(out["LU"]), no * no, _ptr(out["row_scale"]), _ptr(out["col_scale"]),
+                                                          _ptr(out["ipiv"]), no))
+    return out
 
 
 def time_fit_device(dimension, order, xk, fk, nk, xi, fi, knowns, weighting_method, reps=10, stream=None):
@@ -168,7 +217,7 @@ def _cloud_args(dimension, order, S, F, hoods, fi, nk, knowns, weighting_method,
 
 
 def fit_cloud_device(dimension, order, S, F, hoods, fi, nk, knowns, weighting_method, point_index=None, sens=None,
-                     iterative=False, max_iter=10, stream=None, want_iterations=False):
+                     iterative=False, max_iter=10, stream=None, want_iterations=False, strict=None):
     """Index-based fit (extension): the kernels gather xk = S[hoods], fk = F[hoods] themselves.
 
     S (npoints, dim) [1D: (npoints,)] and F (npoints,) are the device-resident point tables, hoods (ncases, K)
@@ -186,9 +235,10 @@ def fit_cloud_device(dimension, order, S, F, hoods, fi, nk, knowns, weighting_me
                 or sens.shape[2] < _ndofs(dimension, order):
             raise ValueError("sens must be at least (ncases, max_nk, no) with a contiguous last axis; got %s" % (tuple(sens.shape),))
     its = C.c_int32(0)
-    B.check(B.lib().wlsqm_hip_fit_cloud_device(*a, _ptr(sens), ss[0], ss[1], 1 if sens is not None else 0,
-                                               1 if iterative else 0, int(max_iter), dev, s,
-                                               C.byref(its) if want_iterations else None))
+    with _strict_ctx(strict):
+        B.check(B.lib().wlsqm_hip_fit_cloud_device(*a, _ptr(sens), ss[0], ss[1], 1 if sens is not None else 0,
+                                                   1 if iterative else 0, int(max_iter), dev, s,
+                                                   C.byref(its) if want_iterations else None))
     return int(its.value)
 
 
