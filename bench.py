@@ -220,6 +220,17 @@ def golden_parity(name, dev):
     acc["golden"] = "tests/golden/config_%s.npz" % name
     acc["kernel"] = kernel
     acc["knowns_bit_identical"] = bool(all(np.array_equal(fi[:, a], c["fi0"][:, a]) for a in known_cols))
+    # the same cases in the reference-order numerics mode (csrc/fit_strict.hip): bit-identical to the oracle by construction,
+    # so its distance to the reference is LAPACK's summation order and nothing else
+    fi_s = t(c["fi0"])
+    whip.fit_many_device(dim, order, t(xk), t(c["fk"]), t(c["nk_a"]), t(c["xi"]), fi_s, t(c["knowns_a"]), t(c["wm_a"]), strict=True)
+    torch.cuda.synchronize()
+    fi_s = fi_s.cpu().numpy()
+    cols = [m for m in range(no) if m not in known_cols]
+    Es = _parity.column_metric(fi_s, c["g"]["fi"])
+    acc["strict_mode"] = {"kernel": whip.last_kernel(), "E": [float(Es[m]) for m in cols], "E_max": float(max(Es[m] for m in cols)),
+                          "strict_1e-10_columns": int(sum(Es[m] <= 1e-10 for m in cols)), "columns": len(cols),
+                          "bit_identical_to_oracle": bool(np.array_equal(fi_s, fi_o))}
     return acc
 
 
@@ -295,6 +306,13 @@ def measure_fit(name, cfg, n, dev, timer, steps, warmup, rank, parity=True, keep
            "roofline": roof}
     if parity and rank == 0 and name in GOLDEN_OF:
         res["parity"] = {"vs_reference_golden": golden_parity(GOLDEN_OF[name], dev)}
+        # what the reference-order mode costs on the full batch (a validation mode: never the `value`)
+        with whip.strict():
+            ms_strict = whip.time_fit_device(*args, reps=3)
+        sm = res["parity"]["vs_reference_golden"]["strict_mode"]
+        sm["ms_per_step"] = ms_strict
+        sm["slowdown_vs_fast"] = ms_strict / ms_kernel
+        res["parity"]["strict_mode"] = sm
     elif parity and rank == 0 and name == "C1":
         res["parity"] = {"vs_reference_golden": golden_parity_c1(dev)}
     if keep:
@@ -418,19 +436,24 @@ def run_sharded(a, dev, dist, rank, world, timer, parity=True):
     (F <- fitted value + 1e-7 x fitted Laplacian).  value = points of the whole cloud x steps / time."""
     import torch
     import wlsqm.hip as whip
-    from wlsqm.sharded import HaloCloudSolver
+    from wlsqm.sharded import HaloCloudSolver, case_range
     cfg = CONFIGS["C5"]
     dim, order, nk = cfg["dim"], cfg["order"], cfg["nk"]
     no = NDOF[dim][order]
     n_local = a.ncases
     N = n_local * world
     t0 = time.perf_counter()
+    # the synthetic cloud: every rank generates the Halton points, orders them along the Morton curve and KEEPS ITS BLOCK ONLY;
+    # the solver is handed that block and finds its halo band by exchanging boxes and band points with the other ranks
     S = halton_device(N, dim, dev)
-    S = S[morton_order_device(S)].contiguous()
-    solver = HaloCloudSolver(dim, S, nk, order=order, knowns=cfg["knowns"], weighting_method=cfg["wm"], device=dev)
-    F0 = torch.sin(np.pi * S[:, 0]) * torch.cos(np.pi * S[:, 1]) * torch.exp(S[:, 2])
-    solver.set_own_values_from_global(F0)
-    del F0
+    lo, hi = case_range(N, rank, world)
+    own = S[morton_order_device(S)[lo:hi]].contiguous()
+    del S
+    torch.cuda.empty_cache()
+    solver = HaloCloudSolver(dim, own, nk, order=order, knowns=cfg["knowns"], weighting_method=cfg["wm"], device=dev,
+                             own_range=(lo, N))
+    solver.set_own_values(torch.sin(np.pi * own[:, 0]) * torch.cos(np.pi * own[:, 1]) * torch.exp(own[:, 2]))
+    del own
     torch.cuda.synchronize()
     t_setup = time.perf_counter() - t0
 
@@ -480,7 +503,8 @@ def run_sharded(a, dev, dist, rank, world, timer, parity=True):
                        "halo_points_max_over_ranks": int(halo_max), "boundary_cases_max_over_ranks": int(bnd_max),
                        "sent_values_max_over_ranks": int(send_max), "halo_bytes_received_per_step": int(halo_max) * 8,
                        "full_allgather_bytes_per_step": 8 * (N - n_local), "halo_radius": solver.halo_radius,
-                       "setup_s": t_setup}}
+                       "band_points_received_in_setup": int(getattr(solver, "band_points_received", 0)),
+                       "overlap_efficiency": ms_fit / (dt / a.steps * 1e3), "setup_s": t_setup}}
     if parity:
         solver.exchange_begin(); solver.exchange_end()          # a collective: every rank takes part; rank 0 then checks its shard
         torch.cuda.synchronize()
@@ -595,9 +619,12 @@ def compact_line(full, full_path=None):
             d["strict_mode"] = {"E_max": _sig(s.get("E_max"), 3), "strict_columns": s.get("strict_1e-10_columns"),
                                 "ms_per_step": _sig(s.get("ms_per_step"), 4)}
         optional.append(("parity", d))
+    keep = {"sharded": ("points", "points_per_rank", "fits_per_s", "ms_step", "ms_fit", "ms_comm_alone", "overlap_efficiency",
+                        "halo_points_max_over_ranks", "halo_bytes_received_per_step", "full_allgather_bytes_per_step"),
+            "rccl": ("world_size", "backend", "allreduce_sum_ok")}
     for k in ("sharded", "rccl"):
         if k in full and isinstance(full[k], dict):
-            optional.append((k, {kk: _sig(v) for kk, v in full[k].items() if isinstance(v, (int, float, bool)) or v is None}))
+            optional.append((k, {kk: _sig(full[k][kk], 5) for kk in keep[k] if kk in full[k]}))
     side = full.get("configs")
     if side:
         summ = {}
@@ -728,6 +755,23 @@ def main():
         torch.cuda.empty_cache()
         if a.config is None and world == 1 and not a.no_side_configs:
             out["configs"] = side_configs(a, dev, timer, rank, parity)
+        if a.config is None and world > 1 and not a.no_side_configs:
+            # BASELINE configs[4] in its literal form, in the driver's own scaling run: ONE 16M-point 3D cloud partitioned over the
+            # N ranks, halo values exchanged over RCCL every step (wlsqm/sharded.py).  Reported beside the C2 weak-scaling value.
+            import copy
+            b = copy.copy(a)
+            b.ncases, b.steps, b.warmup = 16_000_000 // world, max(1, min(a.steps, 20)), min(a.warmup, 3)
+            chk = torch.full((1 << 16,), float(rank + 1), dtype=torch.float64, device=dev)
+            dist.all_reduce(chk)
+            line = run_sharded(b, dev, dist, rank, world, timer, parity)
+            sh = dict(line["sharded"])
+            sh.update({"fits_per_s": line["value"], "points_per_rank": b.ncases, "steps": b.steps,
+                       "kernel": line["roofline"]["kernel"], "gather_rate_GBps": line["roofline"]["gather_rate_GBps"]})
+            out["sharded"] = sh
+            out["rccl"] = {"world_size": world, "backend": dist.get_backend(),
+                           "allreduce_sum_ok": bool((chk == world * (world + 1) / 2).all().item())}
+            if "parity" in line:
+                out["sharded_parity"] = line["parity"]
     if rank == 0:
         emit(out)
     if dist is not None:

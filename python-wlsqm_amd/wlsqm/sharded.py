@@ -98,60 +98,105 @@ def _default_knn(cand, k, nquery):
 class HaloCloudSolver:
     """ONE global cloud partitioned over the ranks, halo exchange only (the literal form of BASELINE configs[4]).
 
-    Points are owned in contiguous index blocks (`case_range`; order the cloud along a space-filling curve first —
-    synth.morton_order — so that a block is a compact region).  Every rank
-      * searches the neighbours of ITS OWN points only, against its own points plus a halo band of candidates (all points inside
-        its bounding box inflated by a radius that is verified afterwards: the largest k-th neighbour distance must not exceed
-        it, otherwise the band is widened and the search repeated) — `wlsqm.hip.knn(..., nquery=n_own)`;
+    Points are owned in contiguous index blocks, rank by rank (order the cloud along a space-filling curve first —
+    synth.morton_order — so that a block is a compact region).  A rank holds ITS OWN block only; nothing in the set-up or in a
+    step scans or stores the coordinates of the whole cloud.  Every rank
+      * publishes the bounding box of its block inflated by a halo radius (all_gather of 2 dim doubles) and receives from every
+        other rank exactly the points of THAT rank's block inside the box (all_to_all of coordinates + global indices); the radius
+        is verified afterwards — the largest k-th neighbour distance over all ranks must not exceed it, otherwise the bands widen
+        and the exchange repeats;
+      * searches the neighbours of its own points only, against [own | received band] — `wlsqm.hip.knn(..., nquery=n_own)`;
       * keeps a LOCAL point table [interior own | boundary own | halo] (coordinates and values) and local neighbour lists, so the
         index-based fit kernel gathers from a table of its shard's size;
-      * per step exchanges only halo values: the owned values other ranks' neighbour lists name, sent with one
-        `all_to_all_single` (uneven splits; RCCL over xGMI, gloo in the CPU tests) on a side stream while the INTERIOR cases
-        (all neighbours owned) are fitted; the boundary cases follow when the halo has arrived.
-    The coordinates of the global cloud are needed once, at construction (every rank passes the same S)."""
+      * tells each owner which of its points it names (all_to_all of the need lists, set-up only) and per step exchanges only
+        those values: one `all_to_all_single` (uneven splits; RCCL over xGMI, gloo in the CPU tests) on a side stream while the
+        INTERIOR cases (all neighbours owned) are fitted; the boundary cases follow when the halo has arrived.
+    Neighbour lists are put in the canonical order (distance, GLOBAL index), so a partitioned run reproduces the one-rank run
+    bit for bit whenever the k-th neighbour distance of every point is unique (generic clouds; on lattice-like clouds a tie at
+    the k-th distance may be cut differently, because the search numbers its candidates [own | band] rather than globally).
+
+    S: either the whole cloud (N, dim), the same on every rank — the constructor keeps rows case_range(N, rank, world) and drops
+    the rest (legacy form, tests) — or, with own_range=(lo, N), this rank's block only, whose first point is global point lo."""
 
     def __init__(self, dimension, S, nk, order, knowns, weighting_method, device, group=None, fit_fn=None, knn_fn=None,
-                 single=False):
+                 single=False, own_range=None):
         import numpy as np
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.group = torch, dist, group
         self.rank = dist.get_rank(group) if dist.is_initialized() and not single else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() and not single else 1
+        world, rank = self.world, self.rank
         self.dimension, self.order, self.nk = int(dimension), int(order), int(nk)
         self.fit_fn = fit_fn
         knn_fn = knn_fn or _default_knn
         dev = torch.device(device)
         self.device = dev
+        # gloo has no device-memory collectives: stage through the host (tests with several ranks on one GPU; RCCL takes the
+        # device tensors)
+        self._host_stage = bool(world > 1 and dev.type == "cuda" and dist.get_backend(group) == "gloo")
         S = torch.as_tensor(S, dtype=torch.float64)
         if S.dim() == 1:
             S = S[:, None]
-        S = S.to(dev)
-        N, dim = int(S.shape[0]), int(S.shape[1])
-        self.N = N
-        self.lo, self.hi = case_range(N, self.rank, self.world)
-        lo, hi = self.lo, self.hi
-        n_own = hi - lo
-        own = S[lo:hi]
-        # ---- 1. candidates: own points + halo band, verified
-        if self.world == 1:
-            cand_g = torch.arange(N, device=dev)
-            hl = knn_fn(own.contiguous() if dim > 1 else own[:, 0].contiguous(), self.nk, n_own)
-            self.halo_radius = 0.0
-            self.halo_attempts = 0
+        dim = int(S.shape[1])
+        if own_range is None:
+            N = int(S.shape[0])
+            lo, hi = case_range(N, rank, world)
+            own = S[lo:hi].to(dev).contiguous()
         else:
-            ext = (S.max(0).values - S.min(0).values).clamp_min(1e-300)
+            lo, N = int(own_range[0]), int(own_range[1])
+            own = S.to(dev).contiguous()
+            hi = lo + int(own.shape[0])
+        del S
+        self.N, self.lo, self.hi = N, lo, hi
+        n_own = hi - lo
+        # block bounds of every rank (blocks are contiguous and ascend with the rank)
+        if world > 1:
+            b = self._allgather(torch.tensor([lo, hi], dtype=torch.int64, device=dev)).cpu().numpy().reshape(world, 2)
+            if b[0, 0] != 0 or b[-1, 1] != N or any(b[q, 1] != b[q + 1, 0] for q in range(world - 1)):
+                raise ValueError("the ranks' blocks must tile [0, N) in rank order; got %s" % b.tolist())
+            bounds = np.concatenate([b[:, 0], [N]])
+        else:
+            bounds = np.array([0, N])
+        self._bounds = bounds
+        own_g = torch.arange(lo, hi, device=dev)
+        # ---- 1. candidates: own points + the band received from the other ranks, verified
+        if world == 1:
+            cand, cand_g = own, own_g
+            hl = knn_fn(own if dim > 1 else own[:, 0].contiguous(), self.nk, n_own)
+            self.halo_radius, self.halo_attempts = 0.0, 0
+        else:
+            inf = float("inf")
+            blo = own.min(0).values if n_own else torch.full((dim,), inf, dtype=torch.float64, device=dev)
+            bhi = own.max(0).values if n_own else torch.full((dim,), -inf, dtype=torch.float64, device=dev)
+            glo = self._allreduce(blo.clone(), "min"); ghi = self._allreduce(bhi.clone(), "max")
+            ext = (ghi - glo).clamp_min(1e-300)
             ball = {1: 2.0, 2: np.pi, 3: 4.0 * np.pi / 3.0}[dim]
             r = 1.5 * float((self.nk * float(ext.prod()) / (N * ball)) ** (1.0 / dim))
-            blo, bhi = own.min(0).values, own.max(0).values
             for attempt in range(8):
-                inside = ((S >= blo - r) & (S <= bhi + r)).all(1)
-                inside[lo:hi] = False
-                halo_g = torch.nonzero(inside)[:, 0]
-                cand_g = torch.cat([torch.arange(lo, hi, device=dev), halo_g])
-                cand = S[cand_g].contiguous()
-                hl = knn_fn(cand if dim > 1 else cand[:, 0].contiguous(), self.nk, n_own)
-                dk = (cand[hl[:, -1]] - own).pow(2).sum(1).max().sqrt().item()
+                boxes = self._allgather(torch.cat([blo - r, bhi + r])).reshape(world, 2 * dim)
+                parts, counts = [], []
+                for q in range(world):
+                    if q == rank or n_own == 0:
+                        parts.append(torch.zeros(0, dtype=torch.int64, device=dev)); counts.append(0)
+                        continue
+                    inside = ((own >= boxes[q, :dim]) & (own <= boxes[q, dim:])).all(1)
+                    idx = torch.nonzero(inside)[:, 0]
+                    parts.append(idx); counts.append(int(idx.numel()))
+                sel = torch.cat(parts)
+                payload = torch.cat([own[sel], (own_g[sel]).to(torch.float64)[:, None]], 1).contiguous()      # indices < 2^53: exact
+                got_counts = self._alltoall_counts(counts)
+                recv = self._alltoall(payload.reshape(-1), [c * (dim + 1) for c in counts],
+                                      [c * (dim + 1) for c in got_counts]).reshape(-1, dim + 1)
+                cand = torch.cat([own, recv[:, :dim]]).contiguous()
+                cand_g = torch.cat([own_g, recv[:, dim].to(torch.int64)])
+                if n_own:
+                    hl = knn_fn(cand if dim > 1 else cand[:, 0].contiguous(), self.nk, n_own)
+                    dk = (cand[hl[:, -1]] - own).pow(2).sum(1).max().sqrt().reshape(1)
+                else:
+                    hl = torch.zeros((0, self.nk), dtype=torch.int64, device=dev)
+                    dk = torch.zeros(1, dtype=torch.float64, device=dev)
+                dk = float(self._allreduce(dk.to(torch.float64), "max").item())
                 self.halo_attempts = attempt + 1
                 if dk <= r:
                     break
@@ -159,10 +204,10 @@ class HaloCloudSolver:
             else:
                 raise RuntimeError("halo band did not converge")
             self.halo_radius = r
-        # ---- 2. canonical neighbour order: ascending (distance, GLOBAL index) — independent of the candidate numbering, so a
-        # partitioned run reproduces the one-rank run bit for bit
+            self.band_points_received = int(recv.shape[0])
+        # ---- 2. canonical neighbour order: ascending (distance, GLOBAL index) — independent of the candidate numbering
         hg = cand_g[hl]                                           # (n_own, nk) global indices
-        d2 = (S[hg] - own[:, None, :]).pow(2).sum(2)
+        d2 = (cand[hl] - own[:, None, :]).pow(2).sum(2)
         o1 = torch.argsort(hg, dim=1, stable=True)
         hg = torch.gather(hg, 1, o1); d2 = torch.gather(d2, 1, o1)
         o2 = torch.argsort(d2, dim=1, stable=True)
@@ -178,12 +223,20 @@ class HaloCloudSolver:
         self.gidx_own = (order_own + lo)                          # global index of local own point i
         loc_of_own = torch.empty(n_own, dtype=torch.int64, device=dev)
         loc_of_own[order_own] = torch.arange(n_own, device=dev)
-        hl = torch.where(foreign, torch.zeros_like(hg), loc_of_own[(hg - lo).clamp(0, n_own - 1)])
+        hl = torch.where(foreign, torch.zeros_like(hg), loc_of_own[(hg - lo).clamp(0, max(n_own - 1, 0))]) if n_own else hg
         if self.n_halo:
             hl = torch.where(foreign, n_own + torch.searchsorted(need_g, hg.clamp(0, N - 1)), hl)
         hl = hl[order_own]                                        # rows in local case order
-        tab_g = torch.cat([self.gidx_own, need_g])
-        S_tab = S[tab_g]
+        S_own = own[order_own]
+        if self.n_halo:
+            # coordinates of the named halo points, from the received band (every global index arrives at most once)
+            rg = cand_g[n_own:]
+            ro = torch.argsort(rg)
+            pos = ro[torch.searchsorted(rg[ro], need_g)]
+            S_tab = torch.cat([S_own, cand[n_own:][pos]])
+        else:
+            S_tab = S_own
+        del cand, cand_g
         self.S_tab = (S_tab[:, 0] if self.dimension == 1 else S_tab).contiguous()
         self.hoods32 = hl.to(torch.int32).contiguous()
         self.values = torch.zeros(n_own + self.n_halo, dtype=torch.float64, device=dev)     # field on the local table
@@ -193,32 +246,77 @@ class HaloCloudSolver:
         self.kn_t = torch.full((n_own,), int(knowns), dtype=torch.int64, device=dev)
         self.wm_t = torch.full((n_own,), int(weighting_method), dtype=torch.int32, device=dev)
         self.pidx = torch.arange(n_own, dtype=torch.int32, device=dev)
-        # ---- 4. exchange plan (set-up only: object all-gather of the need lists)
+        # ---- 4. exchange plan (set-up only): every owner learns which of its points the others name.  need_g is sorted, so
+        # it is already grouped by owner in rank order, and the owner answers in the order it was asked
         self.send_idx = torch.zeros(0, dtype=torch.int64, device=dev)
-        self.send_splits, self.recv_splits = [0] * self.world, [0] * self.world
-        if self.world > 1:
-            needs = [None] * self.world
-            dist.all_gather_object(needs, need_g.cpu().numpy(), group=group)
-            bounds = np.array([case_range(N, q, self.world)[0] for q in range(self.world)] + [N])
+        self.send_splits, self.recv_splits = [0] * world, [0] * world
+        if world > 1:
             mine = need_g.cpu().numpy()
-            self.recv_splits = [int(np.searchsorted(mine, bounds[q + 1]) - np.searchsorted(mine, bounds[q])) for q in range(self.world)]
-            parts = []
-            loc_cpu = loc_of_own.cpu().numpy()
-            for q in range(self.world):
-                want = needs[q][(needs[q] >= lo) & (needs[q] < hi)] if q != self.rank else np.zeros(0, np.int64)
-                parts.append(loc_cpu[want - lo])
-                self.send_splits[q] = int(len(want))
-            self.send_idx = torch.from_numpy(np.concatenate(parts).astype(np.int64)).to(dev)
+            self.recv_splits = [int(np.searchsorted(mine, bounds[q + 1]) - np.searchsorted(mine, bounds[q])) for q in range(world)]
+            self.send_splits = self._alltoall_counts(self.recv_splits)
+            want = self._alltoall(need_g, self.recv_splits, self.send_splits)      # global indices of MY points, by asking rank
+            self.send_idx = loc_of_own[want - lo]
+        self._exchange_on = world > 1
         self._send = torch.empty(int(self.send_idx.numel()), dtype=torch.float64, device=dev)
         self._recv = torch.empty(self.n_halo, dtype=torch.float64, device=dev)
         self._comm_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
-        # gloo has no device-memory all_to_all: stage through the host (tests with several ranks on one GPU; RCCL takes the device tensors)
-        self._host_stage = bool(self.world > 1 and dev.type == "cuda" and dist.get_backend(group) == "gloo")
+
+    # -- collectives of the set-up (host-staged when the backend has no device collectives) -----------------------------------
+    def _stage(self, t):
+        return t.cpu() if self._host_stage else t
+
+    def _allgather(self, t):
+        torch, dist = self.torch, self.dist
+        src = self._stage(t.contiguous())
+        out = torch.empty((self.world,) + tuple(src.shape), dtype=src.dtype, device=src.device)
+        dist.all_gather_into_tensor(out.reshape(-1), src.reshape(-1), group=self.group)
+        return out.to(self.device)
+
+    def _allreduce(self, t, op):
+        dist = self.dist
+        src = self._stage(t.contiguous())
+        dist.all_reduce(src, op={"min": dist.ReduceOp.MIN, "max": dist.ReduceOp.MAX, "sum": dist.ReduceOp.SUM}[op], group=self.group)
+        return src.to(self.device)
+
+    def _alltoall_counts(self, counts):
+        torch, dist = self.torch, self.dist
+        dev = "cpu" if self._host_stage or self.device.type == "cpu" else self.device
+        src = torch.tensor(counts, dtype=torch.int64, device=dev)
+        out = torch.empty_like(src)
+        dist.all_to_all_single(out, src, group=self.group)
+        return [int(v) for v in out.cpu().tolist()]
+
+    def _alltoall(self, t, send_splits, recv_splits):
+        torch, dist = self.torch, self.dist
+        src = self._stage(t.contiguous())
+        out = torch.empty(int(sum(recv_splits)), dtype=src.dtype, device=src.device)
+        dist.all_to_all_single(out, src, list(recv_splits), list(send_splits), group=self.group)
+        return out.to(self.device)
+
+    def install_loopback_halo(self, own_local_idx):
+        """Test hook: make this rank its own neighbour — the values of the local own points `own_local_idx` are sent through the
+        step's all_to_all_single to THIS rank and land in freshly appended halo slots of the value table.  Lets a one-rank
+        process group (e.g. RCCL on a one-GPU box) drive exchange_begin / exchange_end exactly as a partitioned run does."""
+        torch = self.torch
+        idx = torch.as_tensor(own_local_idx, dtype=torch.int64, device=self.device)
+        m = int(idx.numel())
+        self.send_idx = idx
+        self.send_splits = [0] * self.world; self.recv_splits = [0] * self.world
+        self.send_splits[self.rank] = m; self.recv_splits[self.rank] = m
+        self.n_halo = m
+        self.values = torch.cat([self.values[: self.n_own], torch.zeros(m, dtype=torch.float64, device=self.device)])
+        self._send = torch.empty(m, dtype=torch.float64, device=self.device)
+        self._recv = torch.empty(m, dtype=torch.float64, device=self.device)
+        self._exchange_on = True
 
     # -- values ------------------------------------------------------------------------------------------------------------
     def set_own_values_from_global(self, F_global):
         """Own part of the local value table from a global (N,) vector."""
         self.values[: self.n_own] = F_global.to(self.device)[self.gidx_own]
+
+    def set_own_values(self, v_block):
+        """Own part of the local value table from this rank's block of the field (block order: global points lo .. hi - 1)."""
+        self.values[: self.n_own] = v_block.to(self.device)[self.gidx_own - self.lo]
 
     def own_values_global(self):
         """(global indices, values) of the owned points."""
@@ -228,7 +326,7 @@ class HaloCloudSolver:
     def exchange_begin(self):
         """Pack the owned values the other ranks name and start the halo exchange (side stream on a GPU)."""
         torch, dist = self.torch, self.dist
-        if self.world == 1:
+        if not self._exchange_on:
             return
         torch.index_select(self.values, 0, self.send_idx, out=self._send)
         if self._host_stage:
@@ -249,7 +347,7 @@ class HaloCloudSolver:
             self.values[self.n_own:] = self._recv
 
     def exchange_end(self):
-        if self.world > 1 and self._comm_stream is not None:
+        if self._exchange_on and self._comm_stream is not None:
             self.torch.cuda.current_stream().wait_event(self._halo_ready)
 
     def _fit_rows(self, a, b):

@@ -139,3 +139,64 @@ def test_halo_exchange_time_stepping_equals_single_process(tmp_path, world, dim,
     for r in range(world):
         got[np.load(tmp_path / ("halo_g_%d_of_%d.npy" % (r, world)))] = np.load(tmp_path / ("halo_v_%d_of_%d.npy" % (r, world)))
     assert np.array_equal(got, ref)                               # same neighbours in the same order, same arithmetic per case
+
+
+def _run_halo_blocks(rank, world, port, S, nk, F0, steps, out_dir, blocks):
+    """As _run_halo, but every rank hands the solver ITS OWN block only (own_range form): no rank ever holds the whole cloud."""
+    import torch
+    import torch.distributed as dist
+    from wlsqm.sharded import HaloCloudSolver
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    lo, hi = blocks[rank]
+    s = HaloCloudSolver(S.shape[1], S[lo:hi].copy(), nk, order=2, knowns=1, weighting_method=2, device="cpu", fit_fn=_oracle_cloud_fit,
+                        knn_fn=_cpu_knn, own_range=(lo, len(S)))
+    assert (s.lo, s.hi, s.n_own) == (lo, hi, hi - lo)
+    s.set_own_values(torch.from_numpy(F0[lo:hi].copy()))
+    for _ in range(steps):
+        fi = s.step()
+        s.values[: s.n_own] = fi[:, 0] + 1e-4 * (fi[:, 3] + fi[:, 5])
+    g, v = s.own_values_global()
+    np.save(os.path.join(out_dir, "blk_g_%d.npy" % rank), g.numpy())
+    np.save(os.path.join(out_dir, "blk_v_%d.npy" % rank), v.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("blocks", [[(0, 700), (700, 1501)], [(0, 400), (400, 400), (400, 1501)]])
+def test_halo_solver_from_own_blocks_only(tmp_path, blocks):
+    """Uneven blocks chosen by the caller, one of them EMPTY: the set-up exchanges boxes, band points and need lists between the
+    ranks (no rank sees the whole cloud) and the time-stepped result equals the one-process run bit for bit."""
+    import torch.multiprocessing as mp
+    N, nk, steps = 1501, 12, 3
+    S = synth.halton(N, 2)
+    S = np.ascontiguousarray(S[synth.morton_order(S)])
+    F0 = synth.field(S)
+    _run_halo(0, 1, 0, S, nk, F0, steps, str(tmp_path))
+    world = len(blocks)
+    mp.spawn(_run_halo_blocks, args=(world, _free_port(), S, nk, F0, steps, str(tmp_path), blocks), nprocs=world, join=True)
+    ref = np.empty(N); ref[np.load(tmp_path / "halo_g_0_of_1.npy")] = np.load(tmp_path / "halo_v_0_of_1.npy")
+    got = np.full(N, np.nan)
+    for r in range(world):
+        got[np.load(tmp_path / ("blk_g_%d.npy" % r))] = np.load(tmp_path / ("blk_v_%d.npy" % r))
+    assert np.array_equal(got, ref)
+
+
+def _run_loopback(rank, world, port, S, nk, F0):
+    import torch
+    import torch.distributed as dist
+    from wlsqm.sharded import HaloCloudSolver
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    s = HaloCloudSolver(2, S, nk, order=2, knowns=1, weighting_method=2, device="cpu", fit_fn=_oracle_cloud_fit, knn_fn=_cpu_knn)
+    s.set_own_values_from_global(torch.from_numpy(F0))
+    idx = torch.arange(0, s.n_own, 7)
+    s.install_loopback_halo(idx)
+    s.exchange_begin(); s.exchange_end()
+    assert torch.equal(s.values[s.n_own:], s.values[idx])
+    dist.destroy_process_group()
+
+
+def test_loopback_halo_hook_on_a_one_rank_group():
+    """The hook the GPU test uses to drive the step's all_to_all_single over RCCL with one rank (tests/test_gpu_rccl.py)."""
+    import torch.multiprocessing as mp
+    S = synth.halton(600, 2)
+    mp.spawn(_run_loopback, args=(1, _free_port(), S, 10, synth.field(S)), nprocs=1, join=True)
