@@ -163,7 +163,7 @@ class Timer:
         self.barrier()
         dt = time.perf_counter() - t0
         if self.dist is not None:
-            t = torch.tensor([dt], dtype=torch.float64, device=self.dev)
+            t = torch.tensor([dt], dtype=torch.float64, device=(self.dev if self.dist.get_backend() == "nccl" else "cpu"))
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt
@@ -478,7 +478,7 @@ def run_sharded(a, dev, dist, rank, world, timer, parity=True):
     ms_fit = ev[0].elapsed_time(ev[1]) / reps
     ms_comm = ev[2].elapsed_time(ev[3]) / reps
     stats = torch.tensor([ms_fit, ms_comm, float(solver.n_halo), float(solver.n_own - solver.n_int), float(solver.send_idx.numel())],
-                         dtype=torch.float64, device=dev)
+                         dtype=torch.float64, device=(dev if dist is None or dist.get_backend() == "nccl" else "cpu"))
     if dist is not None:
         dist.all_reduce(stats, op=dist.ReduceOp.MAX)
     ms_fit, ms_comm, halo_max, bnd_max, send_max = stats.tolist()
@@ -726,12 +726,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if a.gpus > 1 and world != a.gpus:
         raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
+    # REHEARSAL ONLY (never the driver's path): WLSQM_BENCH_REHEARSAL=1 runs the N > 1 flow with all ranks on GPU 0 over gloo, to
+    # exercise the multi-rank control flow on a one-GPU box (RCCL needs one GPU per rank); the line is marked "rehearsal"
+    rehearsal = os.environ.get("WLSQM_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if "RANK" in os.environ:        # launched by torch.distributed.run: one rank per GPU, RCCL ("nccl") process group
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     timer = Timer(dist, dev)
     headline = a.config or "C2"
     cfg = CONFIGS[headline]
@@ -761,7 +769,7 @@ def main():
             import copy
             b = copy.copy(a)
             b.ncases, b.steps, b.warmup = 16_000_000 // world, max(1, min(a.steps, 20)), min(a.warmup, 3)
-            chk = torch.full((1 << 16,), float(rank + 1), dtype=torch.float64, device=dev)
+            chk = torch.full((1 << 16,), float(rank + 1), dtype=torch.float64, device=("cpu" if rehearsal else dev))
             dist.all_reduce(chk)
             line = run_sharded(b, dev, dist, rank, world, timer, parity)
             sh = dict(line["sharded"])
@@ -772,6 +780,8 @@ def main():
                            "allreduce_sum_ok": bool((chk == world * (world + 1) / 2).all().item())}
             if "parity" in line:
                 out["sharded_parity"] = line["parity"]
+    if rehearsal:
+        out["rehearsal"] = "all ranks on GPU 0, gloo: control-flow check only, not a measurement"
     if rank == 0:
         emit(out)
     if dist is not None:
