@@ -42,11 +42,17 @@ for f in "${units[@]}"; do
   fi
 done
 for p in "${pids[@]:-}"; do [[ -n "$p" ]] && wait "$p"; done
-# objects of translation units that no longer exist must not be linked
+# objects of translation units that no longer exist must not be linked: the library is relinked whenever the LIST of units
+# changed (a removed or renamed .hip compiles nothing, but the old .so would still hold its object)
 objs=(); for f in "${units[@]}"; do objs+=("$OBJ/$f.o"); done
-if (( compiled > 0 )) || [[ ! -f "$OUT/libwlsqm_hip.so" ]]; then
+unitsig="$(printf '%s\n' "${units[@]}" | sort | sha256sum | cut -d' ' -f1)"
+relink=0
+if [[ ! -f "$OBJ/.units" || "$(cat "$OBJ/.units")" != "$unitsig" ]]; then relink=1; fi
+if (( compiled > 0 )) || (( relink )) || [[ ! -f "$OUT/libwlsqm_hip.so" ]]; then
+  rm -f "$OUT/libwlsqm_hip.manifest"
   "$HIPCC" --offload-arch=gfx950 -shared -fPIC -fopenmp -o "$OUT/libwlsqm_hip.so" "${objs[@]}"
 fi
+echo "$unitsig" > "$OBJ/.units"
 echo "$flagsig" > "$OBJ/.flags"
 # manifest: what the library was built from (checked by wlsqm._binding.build_manifest_ok and tests/test_abi_and_host.py)
 ( cd "$HERE" && sha256sum csrc/*.hip csrc/*.hpp ../include/*.h | sed 's#\.\./include#include#' ) > "$OUT/libwlsqm_hip.manifest"

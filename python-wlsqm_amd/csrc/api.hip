@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <ctime>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -55,7 +56,8 @@ bool strict_mode() {
 // (K' = preferred_slots: even, and a moment size for 2D order 4) in front of the same kernels: two extra passes over xk and fk
 // instead of the lane-per-case kernel (8.5 % of the HBM peak on C2).  Only slots k < K are read; the pad slot replays slot 0 and
 // is masked by nk like every unused slot.
-__global__ void repack_rows_kernel(const KParams p, int dim, long long K, long long Kp, double* __restrict__ xk, double* __restrict__ fk) {
+__global__ void repack_rows_kernel(const KParams p, int dim, long long K, long long Kp, double* __restrict__ xk, double* __restrict__ fk,
+                                   int* __restrict__ nkc) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= p.ncases * Kp) return;
     const long long j = t / Kp; const long long k = t - j * Kp;
@@ -63,21 +65,81 @@ __global__ void repack_rows_kernel(const KParams p, int dim, long long K, long l
     const double* src = p.xk + j * p.sxk_j + ks * p.sxk_k;
     for (int m = 0; m < dim; ++m) xk[t * dim + m] = src[m];
     fk[t] = p.fk[j * p.sfk_j + ks * p.sfk_k];
+    // the LOGICAL neighbour count stays clamped to the caller's K: the kernels behind the repack clamp to the slot count Kp,
+    // which may be K + 1 (a bad nk[j] > K must not count the pad slot, nor write a sens row for it)
+    if (k == 0) nkc[j] = (int)min((long long)p.nk[j * p.snk], K);
 }
 
 // Index-based rows (S / F / hoods) of a shape without an index-based tile kernel: gathered once into dense scratch rows
 // (slots k >= nk[j] are never dereferenced: they replay the case's own point and stay masked).
 __global__ void gather_rows_kernel(const KParams p, int dim, long long K, long long Kp, double* __restrict__ xk, double* __restrict__ fk,
-                                   double* __restrict__ xi) {
+                                   double* __restrict__ xi, int* __restrict__ nkc, long long pbase) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= p.ncases * Kp) return;
     const long long j = t / Kp; const long long k = t - j * Kp;
-    const long long pj = p.pidx ? (long long)p.pidx[j] : j;
+    const long long pj = p.pidx ? (long long)p.pidx[j] : pbase + j;       // without point_index, case j of the batch sits at point j
     const long long idx = (k < K && k < p.nk[j * p.snk]) ? (long long)p.hoods[j * p.shoods_j + k] : pj;
     for (int m = 0; m < dim; ++m) xk[t * dim + m] = p.S[idx * dim + m];
     fk[t] = p.F[idx];
-    if (k == 0)
+    if (k == 0) {
         for (int m = 0; m < dim; ++m) xi[j * dim + m] = p.S[pj * dim + m];
+        nkc[j] = (int)min((long long)p.nk[j * p.snk], K);
+    }
+}
+
+// Scratch of the repack / gather passes is bounded: the batch goes through in slices of at most this many bytes of dense rows
+// (WLSQM_HIP_REPACK_MB, default 512), so a 16M-case odd-K or index-based call needs O(slice) extra memory, not a second copy
+// of the batch.  The slices run back to back on the stream and reuse the same block.
+static size_t repack_slice_bytes() {
+    const char* e = getenv("WLSQM_HIP_REPACK_MB");
+    const long long mb = e ? atoll(e) : 512;
+    return (size_t)(mb > 0 ? mb : 512) << 20;
+}
+
+// Runs the batch through `stage` (repack or gather into dense scratch rows) + the tiled kernels, slice by slice.
+// Returns WLSQM_OK with *done = false when the scratch could not be allocated: the caller falls through to the kernels that
+// need none (chunk / lane), as before this path existed.
+static int fit_through_dense_scratch(int dimension, int order, const KParams& p, long long max_nk, hipStream_t stream, bool gather,
+                                     bool* done) {
+    *done = false;
+    const long long Kp = preferred_slots(dimension, order, max_nk);
+    const size_t per_case = ((size_t)Kp * (dimension + 1) + (gather ? dimension : 0)) * sizeof(double) + sizeof(int) + 8;
+    long long per_slice = (long long)(repack_slice_bytes() / per_case);
+    per_slice = std::max(4096LL, per_slice - per_slice % 64);
+    const long long ns = std::min(per_slice, p.ncases);
+    const size_t nx = (size_t)ns * Kp * dimension, nf = (size_t)ns * Kp, ni = gather ? (size_t)ns * dimension : 0;
+    double* ws = nullptr;
+    int rc = scratch_alloc_async(reinterpret_cast<void**>(&ws), (nx + nf + ni) * sizeof(double) + (size_t)ns * sizeof(int) + 16, stream);
+    if (rc != WLSQM_OK) {
+        if (rc == WLSQM_EMEMORY) { (void)hipGetLastError(); set_error(""); return WLSQM_OK; }      // no scratch: not an error
+        return rc;
+    }
+    int* nkc = reinterpret_cast<int*>(ws + nx + nf + ni);
+    for (long long j0 = 0; j0 < p.ncases && rc == WLSQM_OK; j0 += ns) {
+        const long long n = std::min(ns, p.ncases - j0);
+        const KParams src = slice_cases(p, j0, n);
+        const long long threads = n * Kp;
+        if (gather)
+            hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, src, dimension, max_nk, Kp,
+                               ws, ws + nx, ws + nx + nf, nkc, j0);
+        else
+            hipLaunchKernelGGL(repack_rows_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, src, dimension, max_nk, Kp,
+                               ws, ws + nx, nkc);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { rc = hip_fail(e, gather ? "gather_rows_kernel" : "repack_rows_kernel"); break; }
+        KParams q = src;
+        q.xk = ws; q.sxk_j = Kp * dimension; q.sxk_k = dimension;
+        q.fk = ws + nx; q.sfk_j = Kp; q.sfk_k = 1;
+        q.nk = nkc; q.snk = 1;
+        if (gather) {
+            q.hoods = nullptr; q.S = nullptr; q.F = nullptr; q.pidx = nullptr; q.shoods_j = 0;
+            q.xi = ws + nx + nf; q.sxi_j = dimension;
+        }
+        rc = launch_fit(dimension, order, q, Kp, stream);          // contiguous now: takes the tiled kernels
+    }
+    const int rc2 = scratch_free_async(ws, stream);
+    *done = true;
+    return rc != WLSQM_OK ? rc : rc2;
 }
 
 static bool dense_layout_ok(int dim, const KParams& p, long long K) {
@@ -104,22 +166,9 @@ int launch_fit(int dimension, int order, const KParams& p_in, long long max_nk, 
         const bool tiles_on = !(off && off[0] == '1') && !(norp && norp[0] == '1');
         if (tiles_on && !p.hoods && !p.case_index && p.xk && p.fk && no <= 15 && max_nk >= 2 && p.ncases >= 256 &&
             !dense_layout_ok(dimension, p, max_nk)) {
-            const long long Kp = preferred_slots(dimension, order, max_nk);
-            double* ws = nullptr;
-            const size_t nx = (size_t)p.ncases * Kp * dimension, nf = (size_t)p.ncases * Kp;
-            int rc = scratch_alloc_async(reinterpret_cast<void**>(&ws), (nx + nf) * sizeof(double), stream);
-            if (rc != WLSQM_OK) return rc;
-            const long long threads = p.ncases * Kp;
-            hipLaunchKernelGGL(repack_rows_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, p, dimension, max_nk, Kp,
-                               ws, ws + nx);
-            hipError_t e = hipGetLastError();
-            if (e != hipSuccess) { (void)scratch_free_async(ws, stream); return hip_fail(e, "repack_rows_kernel"); }
-            KParams q = p;
-            q.xk = ws; q.sxk_j = Kp * dimension; q.sxk_k = dimension;
-            q.fk = ws + nx; q.sfk_j = Kp; q.sfk_k = 1;
-            rc = launch_fit(dimension, order, q, Kp, stream);          // contiguous now: takes the tiled kernels
-            const int rc2 = scratch_free_async(ws, stream);
-            return rc != WLSQM_OK ? rc : rc2;
+            bool done = false;
+            const int rc = fit_through_dense_scratch(dimension, order, p, max_nk, stream, /*gather=*/false, &done);
+            if (rc != WLSQM_OK || done) return rc;
         }
     }
     bool handled = false;
@@ -139,24 +188,9 @@ int launch_fit(int dimension, int order, const KParams& p_in, long long max_nk, 
         const char* norp = getenv("WLSQM_HIP_DISABLE_REPACK");
         const bool tiles_on = !(off && off[0] == '1') && !(norp && norp[0] == '1');
         if (tiles_on && p.hoods && !p.case_index && no <= 15 && max_nk >= 2 && p.ncases >= 256) {
-            const long long Kp = preferred_slots(dimension, order, max_nk);
-            double* ws = nullptr;
-            const size_t nx = (size_t)p.ncases * Kp * dimension, nf = (size_t)p.ncases * Kp, ni = (size_t)p.ncases * dimension;
-            rc = scratch_alloc_async(reinterpret_cast<void**>(&ws), (nx + nf + ni) * sizeof(double), stream);
-            if (rc != WLSQM_OK) return rc;
-            const long long threads = p.ncases * Kp;
-            hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, p, dimension, max_nk, Kp,
-                               ws, ws + nx, ws + nx + nf);
-            hipError_t e = hipGetLastError();
-            if (e != hipSuccess) { (void)scratch_free_async(ws, stream); return hip_fail(e, "gather_rows_kernel"); }
-            KParams q = p;
-            q.hoods = nullptr; q.S = nullptr; q.F = nullptr; q.pidx = nullptr; q.shoods_j = 0;
-            q.xk = ws; q.sxk_j = Kp * dimension; q.sxk_k = dimension;
-            q.fk = ws + nx; q.sfk_j = Kp; q.sfk_k = 1;
-            q.xi = ws + nx + nf; q.sxi_j = dimension;
-            rc = launch_fit(dimension, order, q, Kp, stream);
-            const int rc2 = scratch_free_async(ws, stream);
-            return rc != WLSQM_OK ? rc : rc2;
+            bool done = false;
+            rc = fit_through_dense_scratch(dimension, order, p, max_nk, stream, /*gather=*/true, &done);
+            if (rc != WLSQM_OK || done) return rc;
         }
     }
     if (no <= 15) {
@@ -184,9 +218,11 @@ int check_device(int device) {
 
 int scratch_alloc_async(void** out, size_t bytes, hipStream_t stream) {
     static hipMemPool_t pools[16] = {};
+    static std::mutex pools_mutex;                               // the first calls of two threads must not both create the pool
     int dev = 0;
     WLSQM_HIP_CHECK(hipGetDevice(&dev));
     if (dev < 0 || dev >= 16) { set_error("device ordinal out of range"); return WLSQM_EVALUE; }
+    std::lock_guard<std::mutex> lock(pools_mutex);
     if (!pools[dev]) {
         hipMemPoolProps props{};
         props.allocType = hipMemAllocationTypePinned;
@@ -195,7 +231,10 @@ int scratch_alloc_async(void** out, size_t bytes, hipStream_t stream) {
         props.location.id = dev;
         hipMemPool_t pool;
         WLSQM_HIP_CHECK(hipMemPoolCreate(&pool, &props));
-        uint64_t keep = ~0ull;                                   // keep freed blocks across synchronisations
+        // freed blocks up to this much stay in the pool across synchronisations (the next call gets them back without a device
+        // synchronisation); anything above goes back to the device at the next synchronisation, so that one large call does
+        // not pin its scratch until the process exits (torch's allocator cannot see this pool)
+        uint64_t keep = 1ull << 30;
         WLSQM_HIP_CHECK(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep));
         pools[dev] = pool;
     }

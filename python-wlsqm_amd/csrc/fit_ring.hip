@@ -23,6 +23,8 @@
 // A workgroup owns a CONTIGUOUS run of tiles (so a solve stores 64 consecutive fi rows).
 #include <cstdlib>
 
+#include <atomic>
+
 #include "wlsqm_internal.hpp"
 #include "wlsqm_kernels.hpp"
 #include "wlsqm_moments.hpp"
@@ -390,7 +392,7 @@ static int launch_ring_impl(const KParams& p, hipStream_t stream) {
     using G = RingGeom<DIM, K>;
     const long long ntiles = (p.ncases + G::TC - 1) / G::TC;
     auto kern = fit_ring_kernel<DIM, ORDER, K, UNR, MINW>;
-    static bool optin[16] = {};
+    static std::atomic<bool> optin[16] = {};   // idempotent opt-in: a race only repeats it
     int dev = 0;
     WLSQM_HIP_CHECK(hipGetDevice(&dev));
     if (dev >= 0 && dev < 16 && !optin[dev]) {

@@ -20,6 +20,8 @@
 // (conflict-free for any per-lane row index: the pivot row of a lane is data-dependent), 64 / 32 / 16 / 8 cases per workgroup
 // depending on the system size so that the image stays under 80-104 KB.  It is a correctness mode: 4-15x the time of the fast kernels
 // (DESIGN.md section 2), chosen per call or per process, never silently.
+#include <atomic>
+
 #include "wlsqm_internal.hpp"
 #include "wlsqm_kernels.hpp"
 
@@ -473,7 +475,7 @@ static int launch_strict(const KParams& p, const StrictDebug& dbg, hipStream_t s
     if (blocks <= 0) return WLSQM_OK;
     if (blocks > 0x7fffffffLL) { set_error("too many cases for one launch"); return WLSQM_EVALUE; }
     if (lds > 64 * 1024) {
-        static bool optin[16] = {};
+        static std::atomic<bool> optin[16] = {};   // idempotent opt-in: a race only repeats it
         int dev = 0;
         WLSQM_HIP_CHECK(hipGetDevice(&dev));
         if (dev >= 0 && dev < 16 && !optin[dev]) {
