@@ -345,6 +345,14 @@ def measure_c4(cfg, n, R, dev, timer, steps, warmup, rank, parity=True):
     for r in range(R):
         fk[r] = (torch.sin(np.pi * S_d[:, 0] + 0.01 * r) * torch.cos(np.pi * S_d[:, 1]))[h_d]
     fi = torch.zeros((R, n, no), dtype=torch.float64, device=dev)
+    # the stored solution operator of the geometry: built ONCE per prepare() (sensitivities of every case + transpose), timed here
+    # on its own; `value` is the rate of the solves with the operator in place, `value_including_prepare` charges the build to ONE
+    # step of R fields (the worst case: a geometry that is used for a single stack)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    built = solver.prepare_operator()
+    torch.cuda.synchronize()
+    t_operator = time.perf_counter() - t0
     dt = timer.run(lambda: solver.solve_many_device(fk, fi), steps, warmup)
     kernel = whip.last_kernel()
     # the kernel alone, events on the stream it is launched on (torch's current stream is passed to the launch)
@@ -369,7 +377,9 @@ def measure_c4(cfg, n, R, dev, timer, steps, warmup, rank, parity=True):
     res = {"workload": "C4: %s; %d cases x %d stacked fields per GPU per step (a fit = one case of one field), "
                        "geometry and fields device-resident" % (cfg["desc"], n, R),
            "fits_per_gpu": n * R, "nrhs": R, "bytes_per_fit": B_fit, "prepare_ms_device_arrays": t_prepare * 1e3,
+           "prepare_operator_ms": t_operator * 1e3, "operator_built": bool(built),
            "ms_per_step": dt / steps * 1e3, "fits_per_s": n * R * steps / dt,
+           "value_including_prepare": n * R / (dt / steps + t_operator + t_prepare),
            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": tsrc, "kernel_ms": ms_kernel,
                         "kernel": kernel, "algorithmic_bytes_per_launch": B_fit * n * R},
@@ -569,7 +579,7 @@ def headline_line(res, world, a, dt, units):
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {k: res[k] for k in ("workload", "fits_per_gpu", "bytes_per_fit") if k in res},
            "roofline": res["roofline"]}
-    for k in ("nrhs", "prepare_ms_device_arrays", "time_stepping", "parity"):
+    for k in ("nrhs", "prepare_ms_device_arrays", "prepare_operator_ms", "value_including_prepare", "time_stepping", "parity"):
         if k in res:
             out[k] = res[k]
     return out

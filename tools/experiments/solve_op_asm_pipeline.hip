@@ -113,8 +113,8 @@ __global__ __launch_bounds__(64 * WPG) void solve_op_mfma_kernel(const OpParams 
     const int no = P.no, run = WPG * no;                              // doubles per field and workgroup
     // Field pitch of the result slab: ODD.  A ds_write_b64 is served in groups of 16 consecutive lanes on 32 dword banks, and the
     // 16 lanes of a group are the 16 fields c16 of one (wave, q): with the pitch = run (96 doubles for 2D order 2: a multiple of
-    // 16) all 16 hit ONE pair of banks (round 2: SQ_LDS_BANK_CONFLICT = 80 % of the LDS-active cycles; now 0: profiles/
-    // r03a_C4_pmc_summary.json); an odd pitch spreads them over all 16 pairs.  The store phase reads a field's run contiguously.
+    // 16) all 16 hit ONE pair of banks (round 2: SQ_LDS_BANK_CONFLICT = 80 % of the LDS-active cycles); an odd pitch spreads
+    // them over all 16 pairs.  The store phase reads a field's run contiguously either way.
     const int runp = run | 1;
     const unsigned long long full = (1ull << no) - 1ull;
     unsigned long long* smask = reinterpret_cast<unsigned long long*>(lds + 2 * 16 * runp);
@@ -161,29 +161,52 @@ __global__ __launch_bounds__(64 * WPG) void solve_op_mfma_kernel(const OpParams 
         }
         const bool ragged = nkc < KP;
         const double* frow = P.fk + jc * P.sfk_j;
-        auto load_b = [&](long long r0, double (&B)[KQ]) {
-            // (always issued — rows past the last field replay it, a case without unknowns loads and ignores: no branch, so that
-            // the compiler can count what is in flight)
-            long long r = r0 + c16; r = r < P.nrhs ? r : P.nrhs - 1;
+        // The fk pieces of a block of 16 fields, requested by INLINE ASSEMBLY: hipcc then neither knows nor waits for them, and the
+        // register sets stay in flight across the loop header (with compiler-visible loads it waits with vmcnt(0) there: the
+        // sets of an iteration were requested, the first one waited for with nothing else in flight, and every iteration paid a
+        // full memory latency — ISA of round 2).  The waits are written by hand in wait_set below.
+        constexpr int LPS = KQ / 2;                                   // load instructions per set
+        auto issue = [&](long long r0, od2_ (&Bv)[LPS]) {
+            long long r = r0 + c16; r = r < P.nrhs ? r : P.nrhs - 1;  // rows past the last field replay it (never staged)
             const double* src = frow + r * P.sfk_r;
 #pragma unroll
-            for (int s = 0; s < KQ / 2; ++s) {
+            for (int s = 0; s < LPS; ++s) {
                 // pieces beyond the fk row (K not a multiple of 8) replay the row's first pair: their operator columns are zero and
                 // the ragged mask below clears them
                 const int e = 8 * s + 2 * q;
-                const od2_ v = *reinterpret_cast<const od2_*>(src + (e < P.K ? e : 0));
-                B[2 * s] = v.x; B[2 * s + 1] = v.y;
+                const double* ptr = src + (e < P.K ? e : 0);
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(Bv[s]) : "v"(ptr) : "memory");
             }
         };
+        // vmcnt counts loads and stores in issue order.  Behind the set of block b the queue holds, per block already staged since
+        // (at most NSET - 1 of them), the fi stores of that block and the set requested after it: `later` sets of LPS loads and
+        // `stores` store instructions of THIS wave (wave-uniform: a wave issues round k of the store phase iff any of its lanes has
+        // an element, and the blocks in between are full blocks).  Waiting for exactly that count leaves them all in flight;
+        // counting fewer would only wait longer — counting more would use the set before it has landed.
+        auto wait_set = [&](int later, int stores, od2_ (&Bv)[LPS]) {
+#define WLSQM_WAIT_CASE(L, S) case (L) * 8 + (S): asm volatile("s_waitcnt vmcnt(%0)" ::"n"((L) * LPS + (S)) : "memory"); break;
+#define WLSQM_WAIT_ROW(L) WLSQM_WAIT_CASE(L, 0) WLSQM_WAIT_CASE(L, 1) WLSQM_WAIT_CASE(L, 2) WLSQM_WAIT_CASE(L, 3) WLSQM_WAIT_CASE(L, 4) \
+                          WLSQM_WAIT_CASE(L, 5) WLSQM_WAIT_CASE(L, 6)
+            switch (later * 8 + stores) {
+                WLSQM_WAIT_ROW(0) WLSQM_WAIT_ROW(1) WLSQM_WAIT_ROW(2) WLSQM_WAIT_ROW(3)
+                default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            }
+#undef WLSQM_WAIT_ROW
+#undef WLSQM_WAIT_CASE
+#pragma unroll
+            for (int s = 0; s < LPS; ++s) asm volatile("" : "+v"(Bv[s]));      // every use of the set is ordered behind the wait
+        };
         int parity = 0;
-        auto stage = [&](long long r0, double (&B)[KQ]) {
+        auto stage = [&](long long r0, const od2_ (&Bv)[LPS]) {
             double* out = lds + parity * 16 * runp;
             if (work) {
-                if (ragged) {
-                    // slots beyond nk[j] may hold anything (padding of the device rows): 0 * NaN would poison the sum
+                double B[KQ];
 #pragma unroll
-                    for (int s = 0; s < KQ; ++s) B[s] = (8 * (s / 2) + 2 * q + (s & 1) < nkc) ? B[s] : 0.0;
-                }
+                for (int s = 0; s < LPS; ++s) { B[2 * s] = Bv[s].x; B[2 * s + 1] = Bv[s].y; }
+                // slots beyond nk[j] may hold anything (padding of the device rows): 0 * NaN would poison the sum.  Unconditional
+                // selects: a branch around them makes the compiler keep a second copy of the set for the path that skips them
+#pragma unroll
+                for (int s = 0; s < KQ; ++s) B[s] = (8 * (s / 2) + 2 * q + (s & 1) < nkc) ? B[s] : 0.0;
                 // (two accumulators, to halve the chain of dependent MFMAs: no gain measured on the 64-neighbour geometry at two
                 // waves per SIMD, and the extra registers put the 128-register fit of the 16-wave workgroups at risk)
                 od4_ acc = {0.0, 0.0, 0.0, 0.0};
@@ -231,30 +254,46 @@ __global__ __launch_bounds__(64 * WPG) void solve_op_mfma_kernel(const OpParams 
             }
             parity ^= 1;
         };
-        // Four (three) blocks of 16 fields per iteration: the fk pieces of all of them are requested at the top and every block waits
-        // for its own set only (s_waitcnt vmcnt(12 / 8 / 4 / 0) plus the stores in between).  Register sets kept in flight ACROSS the loop
-        // header do not work with this compiler: it loses their pending count there and waits with vmcnt(0) at the first use —
-        // the three rotating sets of the first version were requested and then waited for in every block (ISA), no prefetch at all.
-        // Round 3 tried to keep the sets in flight ACROSS the header anyway: fk pieces requested by inline assembly (invisible to
-        // the compiler's wait insertion), hand-written s_waitcnt vmcnt(N) with N counted exactly (later sets x loads + this wave's
-        // stores in between, by ballot), one block per step in rotation.  Correct (all stacked-solve tests) and SLOWER: configs[3]
-        // 14.5 -> 15.8 ms (conservative counts) / 16.1 ms (exact counts) — with one 16-wave workgroup per CU in lock step at the
-        // barrier, a burst of 12 requests per wave followed by three compute + store phases suits this memory system better than
-        // requests interleaved with the stores.  Kept as tools/experiments/solve_op_asm_pipeline.hip.
-#ifndef WLSQM_OP_NSET16
-#define WLSQM_OP_NSET16 3
-#endif
-        constexpr int NSET = (WPG == 16 && KQ >= 8) ? WLSQM_OP_NSET16 : 4;   // (the 16-wave workgroups have 128 registers per lane)
-        double B[NSET][KQ];
-        for (long long r0 = 0; r0 < P.nrhs; r0 += 16 * NSET) {
+        // NSET register sets in rotation, each holding the fk pieces of one block of 16 fields: while block b is multiplied and
+        // stored, the pieces of blocks b + 1 .. b + NSET - 1 are in flight, and the set of block b is re-requested for block
+        // b + NSET as soon as its MFMAs have read it.
+        constexpr int NSET = (WPG == 16 && KQ >= 8) ? 3 : 4;              // (the 16-wave workgroups have 128 registers per lane)
+        od2_ B[NSET][LPS];
+        const long long nblk = (P.nrhs + 15) / 16;
+        // store instructions of this wave per FULL block of 16 fields (the two written-out rounds of the store phase; with more than 8
+        // unknowns the rounds are a loop of unknown trip count to the compiler: not counted, i.e. waited for)
+        int ns = 0;
+        if (no <= 8 && !(P.dbg & 1)) {
+            // exactly the store phase's own condition, evaluated for a full block: a round whose 64 lanes all skip is branched around
+            __syncthreads();                                                // smask of every wave of the group is written
+            const int tot = 16 * run;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int e = (int)threadIdx.x + k * 64 * WPG;
+                bool stores = false;
+                if (e < tot) {
+                    const int row = no == 1 ? e : (int)__umulhi((unsigned)e, P.inv_no);
+                    const int a = e - row * no, cs = row & (WPG - 1);
+                    stores = !((smask[cs] >> a) & 1ull);
+                }
+                ns += (__ballot(stores) != 0ull) ? 1 : 0;
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < NSET; ++b)
+            if (b < nblk) issue(16ll * b, B[b]);
+        for (long long blk0 = 0; blk0 < nblk; blk0 += NSET) {
 #pragma unroll
             for (int b = 0; b < NSET; ++b) {
-                load_b(r0 + 16 * b, B[b]);
-                __builtin_amdgcn_sched_barrier(0);                          // in this order: the first block's set must not be the last one requested
+                const long long blk = blk0 + b;
+                if (blk < nblk) {                                           // wave-uniform
+                    const long long rest = nblk - 1 - blk;
+                    const int sb = blk < NSET - 1 ? (int)blk : NSET - 1;    // blocks staged since this set was requested
+                    wait_set(rest < NSET - 1 ? (int)rest : NSET - 1, sb * ns, B[b]);
+                    stage(16 * blk, B[b]);
+                    if (blk + NSET < nblk) issue(16 * (blk + NSET), B[b]);
+                }
             }
-#pragma unroll
-            for (int b = 0; b < NSET; ++b)
-                if (r0 + 16 * b < P.nrhs) stage(r0 + 16 * b, B[b]);
         }
     }
 }
