@@ -37,6 +37,7 @@ int launch_fit_tilek(int dimension, int order, const KParams& p, long long max_n
 long long preferred_slots(int dimension, int order, long long max_nk);
 int launch_fit_rows(int dimension, int order, const KParams& p, hipStream_t stream, bool* handled);
 int launch_fit_chunk(int dimension, int order, const KParams& p, long long K, hipStream_t stream, bool* handled);
+int launch_fit_chunk_refine(int dimension, int order, const KParams& p, long long K, hipStream_t stream, bool* handled);
 int launch_fit_sens(int dimension, int order, const KParams& p, long long K, hipStream_t stream, bool* handled);
 int launch_fit_strict(int dimension, int order, const KParams& p, const StrictDebug* dbg, hipStream_t stream);
 
@@ -182,6 +183,10 @@ int launch_fit(int dimension, int order, const KParams& p_in, long long max_nk, 
     if (rc != WLSQM_OK || handled) return rc;
     rc = launch_fit_sens(dimension, order, p, max_nk, stream, &handled);     // sensitivities of the shapes without a tile kernel
     if (rc != WLSQM_OK || handled) return rc;
+    if (no <= 15) {
+        rc = launch_fit_chunk_refine(dimension, order, p, max_nk, stream, &handled);   // refinement of the 10- / 15-unknown systems
+        if (rc != WLSQM_OK || handled) return rc;
+    }
     {
         // index-based input no tiled kernel took: gather it into dense rows and dispatch again (the dense tables are complete)
         const char* off = getenv("WLSQM_HIP_DISABLE_TILE");

@@ -123,3 +123,58 @@ def test_bad_nk_behind_a_repack_is_clamped_to_the_callers_k(wlsqm):
         res[name] = (fi.cpu().numpy(), guard[:n].cpu().numpy())
     assert np.array_equal(res["bad"][0], res["ok"][0])
     assert np.array_equal(res["bad"][1], res["ok"][1], equal_nan=True)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# iterative refinement of the 10- / 15-unknown systems in the chunked tile kernel (csrc/fit_chunk.hip ITER; impl.pyx:986-1083)
+
+@pytest.mark.parametrize("dim,order,Kn,kn", [(2, 4, 64, 1), (2, 4, 30, 0), (2, 4, 100, 0b101), (2, 4, 120, 1), (2, 3, 80, 0), (2, 3, 128, 0b10)])
+def test_refinement_in_the_chunked_tile_kernel(wlsqm, oracle, dim, order, Kn, kn, monkeypatch):
+    """Against the oracle's solve_iterative per column (noise-floor bound of tests/_parity.py) and against the lane-per-case
+    kernel these shapes took before; ragged nk, knowns, a partial last tile; K = 120 is beyond the LDS cache of the tile (the sweeps
+    re-stage their chunks)."""
+    import torch
+    import wlsqm.hip as whip
+    n = 1000 + 7
+    b = _batch(dim, order, Kn, n, Kn + kn)
+    knv = np.full(n, kn, np.int64); knv[::9] = 0
+    orders = np.full(n, order, np.int32)
+    res = {}
+    for tag in ("chunk", "lane"):
+        if tag == "lane":
+            monkeypatch.setenv("WLSQM_HIP_DISABLE_CHUNK_REFINE", "1")
+        fi = _t(b["fi0"])
+        it = whip.fit_many_device(dim, order, _t(b["xk"]), _t(b["fk"]), _t(b["nk"]), _t(b["xi"]), fi, _t(knv), _t(b["wm"]), iterative=True,
+                                  max_iter=10, want_iterations=True)
+        res[tag] = (fi.cpu().numpy(), it, whip.last_kernel())
+    monkeypatch.delenv("WLSQM_HIP_DISABLE_CHUNK_REFINE")
+    assert res["chunk"][2] == "chunk-refine" and res["lane"][2] == "lane", (res["chunk"][2], res["lane"][2])
+    assert 1 <= res["chunk"][1] <= 10
+    fo = b["fi0"].copy()
+    oracle.fit_many(dim, b["xk"], b["fk"], b["nk"], b["xi"], fo, None, 0, orders, knv, b["wm"], iterative=True, max_iter=10, ntasks=8)
+    truth = P.truth_fit(dim, b["xk"], b["fk"], b["nk"], b["xi"], b["fi0"], orders, knv, b["wm"])
+    P.assert_parity(res["chunk"][0], fo, truth, "chunk-refine vs oracle")
+    for a in range(b["no"]):                                    # knowns bit-identical
+        sel = (knv >> a) & 1 == 1
+        assert np.array_equal(res["chunk"][0][sel, a], b["fi0"][sel, a])
+    # max_iter <= 0: the for/else of impl.pyx:1080-1081 returns 1 and the result is the unrefined fit
+    fi0_d = _t(b["fi0"]); fi1_d = _t(b["fi0"])
+    it0 = whip.fit_many_device(dim, order, _t(b["xk"]), _t(b["fk"]), _t(b["nk"]), _t(b["xi"]), fi0_d, _t(knv), _t(b["wm"]), iterative=True,
+                               max_iter=0, want_iterations=True)
+    assert it0 == 1 and whip.last_kernel() == "chunk-refine"
+    whip.fit_many_device(dim, order, _t(b["xk"]), _t(b["fk"]), _t(b["nk"]), _t(b["xi"]), fi1_d, _t(knv), _t(b["wm"]))
+    P.assert_parity(fi0_d.cpu().numpy(), fi1_d.cpu().numpy(), truth, "max_iter 0 vs basic fit")
+
+
+def test_c3_iterative_vs_reference_golden_at_the_headline_density(wlsqm):
+    """fit_2D_iterative_many_parallel of the reference on config_C3_1M (fi_iter of the fixture), through the reference's own
+    signature: lands on the chunk-refine kernel."""
+    import wlsqm.hip as whip
+    c = K.config_dense("C3_1M")
+    truth = P.truth_fit(2, c["xk"], c["fk"], c["nk_a"], c["xi"], c["fi0"], c["order_a"], c["knowns_a"], c["wm_a"])
+    fi = c["fi0"].copy()
+    it = wlsqm.fit_2D_iterative_many_parallel(xk=c["xk"], fk=c["fk"], nk=c["nk_a"], xi=c["xi"], fi=fi, sens=None, do_sens=0,
+                                              order=c["order_a"], knowns=c["knowns_a"], weighting_method=c["wm_a"], max_iter=10)
+    assert whip.last_kernel() == "chunk-refine", whip.last_kernel()
+    assert 1 <= it <= 10
+    P.assert_parity(fi, c["g"]["fi_iter"], truth, "C3_1M iterative vs reference")
