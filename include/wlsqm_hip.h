@@ -100,6 +100,14 @@ int wlsqm_hip_fit_many_host(const wlsqm_batch* b, int device, int32_t* iteration
 int wlsqm_hip_fit_many_device(const wlsqm_batch* b, int device, void* stream, int order_uniform,
                               const int64_t* case_index, int64_t ncases_sel, int32_t* iterations_out);
 
+/* Per-case polynomial orders on the device-resident path (the reference takes a per-case `order` array, simple.pyx:379-381):
+ * as wlsqm_hip_fit_many_device, with order_dev[j * order_stride] (int32, DEVICE memory) instead of order_uniform.  The cases are
+ * bucketed by order ON THE DEVICE (one counting kernel, index lists in stream-ordered scratch) and every bucket is launched
+ * with its size left in device memory: no host synchronisation, nothing but kernel launches and stream-ordered allocations
+ * unless iterations_out is given.  b->order is not read.  Cases whose order is not 0..4 are left untouched. */
+int wlsqm_hip_fit_many_device_orders(const wlsqm_batch* b, int device, void* stream, const int32_t* order_dev, int64_t order_stride,
+                                     int32_t* iterations_out);
+
 /* ---- numerics mode (extension) ----
  * 0 (default): the fast kernels — moment form, neighbour sums split over lanes, FMA contraction, LDL^T: results agree with the
  *    reference to kappa * eps rounding.

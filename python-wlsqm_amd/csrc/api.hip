@@ -360,6 +360,75 @@ int wlsqm_hip_fit_many_device(const wlsqm_batch* b, int device, void* stream, in
     return rc;
 }
 
+}  // extern "C"
+
+namespace wlsqm {
+// Order buckets on the device: idx[o * n + pos] = case number, counts[o] = cases of order o (the position inside a bucket is
+// whatever the atomics hand out: every case is fitted on its own, so the order of a bucket does not reach the results).
+__global__ void order_zero_kernel(long long* __restrict__ counts) { counts[threadIdx.x] = 0; }
+__global__ void order_bucket_kernel(const int* __restrict__ order, long long sorder, long long n, long long* __restrict__ counts,
+                                    long long* __restrict__ idx) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int o = order[t * sorder];
+    if (o < 0 || o > 4) return;                       // (the host entry points raise ValueError; here the case is left untouched)
+    const long long pos = (long long)atomicAdd(reinterpret_cast<unsigned long long*>(counts + o), 1ull);
+    idx[o * n + pos] = t;
+}
+}  // namespace wlsqm
+
+extern "C" {
+
+int wlsqm_hip_fit_many_device_orders(const wlsqm_batch* b, int device, void* stream, const int32_t* order_dev, int64_t order_stride,
+                                     int32_t* iterations_out) {
+    int rc = validate_batch(b);
+    if (rc != WLSQM_OK) return rc;
+    if (!order_dev) { set_error("null order array"); return WLSQM_EVALUE; }
+    DeviceScope scope;
+    rc = scope.enter(device);
+    if (rc != WLSQM_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const long long n = b->ncases;
+    long long* ws = nullptr;                          // [5] counts, then [5][n] case numbers
+    rc = scratch_alloc_async(reinterpret_cast<void**>(&ws), (size_t)(5 * n + 8) * sizeof(long long), s);
+    if (rc != WLSQM_OK) return rc;
+    int* d_it = nullptr;
+    auto cleanup = [&](int code) { (void)scratch_free_async(ws, s); (void)scratch_free_async(d_it, s); return code; };
+    // (a kernel, not hipMemsetAsync: a memset node on memory allocated inside a stream capture aborted the replay on ROCm 7.2)
+    hipLaunchKernelGGL(order_zero_kernel, dim3(1), dim3(8), 0, s, ws);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return cleanup(hip_fail(e, "order_zero_kernel"));
+    hipLaunchKernelGGL(order_bucket_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, order_dev, (long long)order_stride, n,
+                       ws, ws + 8);
+    e = hipGetLastError();
+    if (e != hipSuccess) return cleanup(hip_fail(e, "order_bucket_kernel"));
+    KParams p = params_from(b);
+    if (b->iterative && iterations_out) {
+        rc = scratch_alloc_async(reinterpret_cast<void**>(&d_it), sizeof(int), s);
+        if (rc != WLSQM_OK) return cleanup(rc);
+        e = hipMemsetAsync(d_it, 0, sizeof(int), s);
+        if (e != hipSuccess) return cleanup(hip_fail(e, "hipMemsetAsync"));
+        p.iters_out = d_it;
+    }
+    for (int o = 0; o <= 4; ++o) {
+        if (wlsqm_hip_number_of_dofs(b->dimension, o) < 0) continue;
+        p.case_index = ws + 8 + (long long)o * n;
+        p.ncases = n;                                 // the launch is sized for the whole batch; the bucket's real size stays on the device
+        p.ncases_dev = ws + o;
+        rc = launch_fit(b->dimension, o, p, b->max_nk, s);
+        if (rc != WLSQM_OK) return cleanup(rc);
+    }
+    if (iterations_out) {
+        *iterations_out = 0;
+        if (d_it) {
+            e = hipMemcpyAsync(iterations_out, d_it, sizeof(int), hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e != hipSuccess) return cleanup(hip_fail(e, "iterations_out"));
+        }
+    }
+    return cleanup(WLSQM_OK);
+}
+
 int wlsqm_hip_strict_intermediates_device(const wlsqm_batch* b, int device, void* stream, int order_uniform,
                                           double* w, int64_t w_stride, double* A, double* LU, int64_t mat_stride,
                                           double* row_scale, double* col_scale, int32_t* ipiv, int64_t vec_stride) {

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(LANE_BLOCK) void fit_lane_kernel(const KParams p) {
     constexpr int NO = ndofs(DIM, ORDER);
     constexpr int NE = NO * (NO + 1) / 2;
     const long long t = (long long)blockIdx.x * LANE_BLOCK + threadIdx.x;
-    if (t >= p.ncases) return;
+    if (t >= live_cases(p)) return;
     const long long j = p.case_index ? p.case_index[t] : t;
 
     const int nk = min(p.nk[j * p.snk], (int)p.max_nk);      // never past the end of a row

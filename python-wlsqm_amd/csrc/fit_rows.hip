@@ -66,8 +66,10 @@ __global__ __launch_bounds__(RW) void fit_rows_kernel(const KParams p) {
     const bool idle = lane >= G * GS;                             // G = 3: lane 63
     const int grp = idle ? G - 1 : lane / GS, li = idle ? GS - 1 : lane - grp * GS, gbase = grp * GS;
     const long long t = (long long)blockIdx.x * G + grp;
-    const bool valid = t < p.ncases && !idle;
-    const long long tc = t < p.ncases ? t : p.ncases - 1;
+    const long long ncases = live_cases(p);
+    if ((long long)blockIdx.x * G >= ncases) return;             // (block-uniform: before any barrier)
+    const bool valid = t < ncases && !idle;
+    const long long tc = t < ncases ? t : ncases - 1;
     const long long j = p.case_index ? p.case_index[tc] : tc;
     const int nk = min(p.nk[j * p.snk], (int)p.max_nk);      // never past the end of a row
     const bool uniform = (p.wm[j * p.swm] == WLSQM_WEIGHT_UNIFORM);

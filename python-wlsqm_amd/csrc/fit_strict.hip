@@ -223,7 +223,7 @@ __global__ __launch_bounds__(64) void fit_strict_kernel(const KParams p, const S
     const int lane = threadIdx.x;
     if (lane >= LPW) return;
     const long long t = (long long)blockIdx.x * LPW + lane;
-    if (t >= p.ncases) return;
+    if (t >= live_cases(p)) return;
     const long long j = p.case_index ? p.case_index[t] : t;
 
     // LDS image of this case: slot s at smem[s * LPW + lane]

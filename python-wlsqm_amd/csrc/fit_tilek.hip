@@ -212,13 +212,15 @@ __global__ __launch_bounds__(KW, MINW) void fit_tile1_kernel(const KParams p, co
     const int lane = threadIdx.x, c = lane % TC, h = lane / TC;
     const int k0 = h * G.KPL;
 
+    const long long ncases = live_cases(p);
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         // position in the launch -> case number: all cases in order, or the index list of an order bucket (p.case_index)
         const long long j0 = tile * TC, pos = j0 + c;
-        const bool valid = pos < p.ncases;
-        const long long posc = valid ? pos : p.ncases - 1;
+        if (j0 >= ncases) break;                                  // (a bucket sized on the device may be shorter than the launch)
+        const bool valid = pos < ncases;
+        const long long posc = valid ? pos : ncases - 1;
         const long long jc = p.case_index ? p.case_index[posc] : posc, j = jc;
-        const long long nvalid = (p.ncases - j0 < TC) ? (p.ncases - j0) : TC;
+        const long long nvalid = (ncases - j0 < TC) ? (ncases - j0) : TC;
 
         const int nkc = min(p.nk[jc * p.snk], G.K);
         const bool uniform = (p.wm[jc * p.swm] == WLSQM_WEIGHT_UNIFORM);

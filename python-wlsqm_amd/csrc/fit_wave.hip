@@ -86,6 +86,7 @@ __global__ __launch_bounds__(WAVE) void fit_wave_kernel(const KParams p) {
 
     const int lane = threadIdx.x;
     const long long t = blockIdx.x;
+    if (t >= live_cases(p)) return;                               // (block-uniform: before any barrier)
     const long long j = p.case_index ? p.case_index[t] : t;
     const int nk = min(p.nk[j * p.snk], (int)p.max_nk);      // never past the end of a row
     const bool uniform = (p.wm[j * p.swm] == WLSQM_WEIGHT_UNIFORM);

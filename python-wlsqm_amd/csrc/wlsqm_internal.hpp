@@ -33,12 +33,23 @@ struct KParams {
     const int* pidx;
     const long long* case_index;   // nullable
     long long ncases;              // cases this launch processes
+    // Nullable: the number of entries of case_index that are real, in DEVICE memory (the order buckets built on the device by
+    // wlsqm_hip_fit_many_device_orders: the host never learns the bucket sizes).  The launch is sized for `ncases`; the kernels
+    // that take case_index (lane, tile1, rows, wave, strict) stop at min(ncases, *ncases_dev).
+    const long long* ncases_dev;
     int do_sens, iterative, max_iter;
     int* iters_out;                // device int (atomicMax), nullable
     // Two-kernel moment path (fit_moment.hip): the tile kernel parks the reduced moments of case j at
     // ws[e * ws_stride + j] (structure of arrays) and the solve kernel picks them up.
     double* ws;        long long ws_stride;
 };
+
+// Cases a launch really has (see KParams::ncases_dev).
+__device__ __forceinline__ long long live_cases(const KParams& p) {
+    if (!p.ncases_dev) return p.ncases;
+    const long long d = *p.ncases_dev;
+    return d < p.ncases ? d : p.ncases;
+}
 
 // The sub-batch [j0, j0 + n) of a launch (dense or index-based input, no case_index).
 inline KParams slice_cases(const KParams& p, long long j0, long long n) {

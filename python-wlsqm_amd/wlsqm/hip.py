@@ -140,8 +140,10 @@ def _stream_and_device(t, stream):
 
 
 def fit_many_device(dimension, order, xk, fk, nk, xi, fi, knowns, weighting_method, sens=None, iterative=False,
-                    max_iter=10, case_index=None, stream=None, want_iterations=False, strict=None):
-    """fit_{1,2,3}D[_iterative]_many on device-resident tensors, all cases of polynomial order `order`.
+                    max_iter=10, case_index=None, stream=None, want_iterations=False, strict=None, max_order=4):
+    """fit_{1,2,3}D[_iterative]_many on device-resident tensors.  `order`: an int (all cases of that polynomial order: the fast
+    path) or an int32 device tensor of per-case orders (fi / sens must then be wide enough for `max_order`, default 4: the
+    reference's "(ncases, >= max no)" rule with the maximum taken from the caller instead of a host scan of the tensor).
     strict=True / False selects reference-order / fast numerics for this call (None: the thread's mode, see set_strict).
 
     xk (n, K, dim) [1D: (n, K)], fk (n, K), nk (n,) int32, xi (n, dim) [1D: (n,)], fi (n, >=no) in/out,
@@ -149,6 +151,20 @@ def fit_many_device(dimension, order, xk, fk, nk, xi, fi, knowns, weighting_meth
     tensor) restricts the launch to those cases (used to bucket heterogeneous orders).  Asynchronous on
     `stream` (default: torch's current stream) unless want_iterations=True.  The caller guarantees that
     fk/xk do not alias fi (outputs are written in place)."""
+    if hasattr(order, "data_ptr"):
+        # per-case orders (int32 device tensor, as the reference's `order` array): bucketed on the device, no host synchronisation
+        _check(order, "order", "int32", 1)
+        if case_index is not None:
+            raise ValueError("case_index and a per-case order tensor exclude each other")
+        _rows(nk.shape[0], order=order)
+        # extents are checked for `max_order` (default 4): the caller's promise that no case asks for more
+        b = _batch(dimension, int(max_order), xk, fk, nk, xi, fi, knowns, weighting_method, sens, iterative, max_iter, nk)
+        s, dev = _stream_and_device(fi, stream)
+        its = C.c_int32(0)
+        with _strict_ctx(strict):
+            B.check(B.lib().wlsqm_hip_fit_many_device_orders(C.byref(b), dev, s, C.c_void_p(order.data_ptr()), order.stride(0),
+                                                             C.byref(its) if want_iterations else None))
+        return int(its.value)
     b = _batch(dimension, order, xk, fk, nk, xi, fi, knowns, weighting_method, sens, iterative, max_iter, nk)
     s, dev = _stream_and_device(fi, stream)
     its = C.c_int32(0)

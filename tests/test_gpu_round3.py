@@ -178,3 +178,82 @@ def test_c3_iterative_vs_reference_golden_at_the_headline_density(wlsqm):
     assert whip.last_kernel() == "chunk-refine", whip.last_kernel()
     assert 1 <= it <= 10
     P.assert_parity(fi, c["g"]["fi_iter"], truth, "C3_1M iterative vs reference")
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# per-case polynomial orders on the device-resident API (simple.pyx:379-381 takes a per-case array)
+
+@pytest.mark.parametrize("dim", [1, 2, 3])
+@pytest.mark.parametrize("mode", ["basic", "sens", "iter"])
+def test_per_case_orders_on_the_device_api(wlsqm, oracle, dim, mode):
+    """The heterogeneous sweep fixture (orders 0-4 mixed, every knowns mask, ragged nk) in ONE device-resident call with an order
+    TENSOR: bucketed on the device, against the reference's outputs (tests/golden/sweep_*.npz) per order with the noise-floor
+    bound, the NaN / untouched pattern of sens exactly, knowns bit-identical; the same call in strict mode equals the oracle
+    bit for bit."""
+    import torch
+    import wlsqm.hip as whip
+    d = K.sweep(dim)
+    n = len(d["nk"])
+    do_sens, iterative = mode == "sens", mode == "iter"
+    truth = P.truth_fit(dim, d["xk"], d["fk"], d["nk"], d["xi"], d["fi_in"], d["order"], d["knowns"], d["wm"])
+    for strict in (False, True):
+        fi = _t(d["fi_in"])
+        sens = torch.full(tuple(d["sens"].shape), 777.0, dtype=torch.float64, device="cuda:0") if do_sens else None
+        it = whip.fit_many_device(dim, _t(d["order"]), _t(d["xk"]), _t(d["fk"]), _t(d["nk"]), _t(d["xi"]), fi, _t(d["knowns"]), _t(d["wm"]),
+                                  sens=sens, iterative=iterative, max_iter=10, want_iterations=iterative, strict=strict)
+        torch.cuda.synchronize()
+        fi = fi.cpu().numpy()
+        ref = d["fi_iter"] if iterative else d["fi"]
+        for o in range(5):
+            s = d["order"] == o
+            no = K.NDOF[dim][o]
+            P.assert_parity(fi[s, :no], ref[s, :no], truth[s, :no], "order tensor, dim %d order %d %s strict=%s" % (dim, o, mode, strict))
+            assert np.array_equal(fi[s, no:], d["fi_in"][s, no:]), "columns beyond no must stay untouched"
+        for j in range(n):
+            for a in range(K.NDOF[dim][int(d["order"][j])]):
+                if (int(d["knowns"][j]) >> a) & 1:
+                    assert fi[j, a] == d["fi_in"][j, a]
+        if do_sens:
+            sn = sens.cpu().numpy()
+            assert np.array_equal(np.isnan(sn), np.isnan(d["sens"]))
+            assert np.array_equal(sn == 777.0, d["sens"] == 777.0)
+        if iterative:
+            assert 1 <= it <= 10
+        if strict:
+            fo = d["fi_in"].copy()
+            so = np.full(d["sens"].shape, 777.0) if do_sens else None
+            ito = oracle.fit_many(dim, d["xk"], d["fk"], d["nk"], d["xi"], fo, so, do_sens, d["order"], d["knowns"], d["wm"],
+                                  iterative=iterative, max_iter=10)
+            assert np.array_equal(fi, fo), "strict + order tensor must equal the oracle bit for bit"
+            if do_sens:
+                assert np.array_equal(sn, so, equal_nan=True)
+            if iterative:
+                assert it == ito
+
+
+def test_order_tensor_call_captures_into_a_hip_graph(wlsqm):
+    """No host synchronisation in the order-tensor call: it can be captured, and the replay follows the buffers' current contents."""
+    import torch
+    import wlsqm.hip as whip
+    d = K.sweep(2)
+    args = [_t(d[k]) for k in ("xk", "fk", "nk", "xi")]
+    fi = _t(d["fi_in"]); order = _t(d["order"]); kn = _t(d["knowns"]); wm = _t(d["wm"])
+    run = lambda: whip.fit_many_device(2, order, args[0], args[1], args[2], args[3], fi, kn, wm)
+    run(); torch.cuda.synchronize()
+    eager = fi.clone()
+    fi.copy_(_t(d["fi_in"]))
+    g = torch.cuda.CUDAGraph()
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        with torch.cuda.graph(g, stream=stream):
+            run()
+    torch.cuda.synchronize()
+    assert torch.equal(fi, _t(d["fi_in"])), "nothing may run during capture"
+    g.replay(); torch.cuda.synchronize()
+    assert torch.equal(fi, eager)
+    # other data, same graph
+    args[1].mul_(2.0); fi.copy_(_t(d["fi_in"]))
+    g.replay(); torch.cuda.synchronize()
+    replayed = fi.clone()
+    fi.copy_(_t(d["fi_in"])); run(); torch.cuda.synchronize()
+    assert torch.equal(replayed, fi)
