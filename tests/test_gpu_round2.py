@@ -353,6 +353,17 @@ def test_hip_kernels_under_world_size_2(wlsqm, tmp_path):
 # ----------------------------------------------------------------------------------------------------------------------
 # the one-kernel 2D order-4 fit (csrc/fit_ring.hip: LDS-DMA ring + register-parked solve)
 
+def _assert_vs_oracle_floor(cand, fo, truth, n):
+    """The candidate's distance to the 80-bit solution against the ORACLE's own, and nothing else (round 2 also admitted the error
+    of the other HIP kernel into the bound: a bug shared by two kernels would have passed).  Per DOF column from 64 cases on;
+    below that one case's roundoff IS the column, so the largest column of each side is compared."""
+    Ec, No = P.column_metric(cand, truth), P.column_metric(fo, truth)
+    if n >= 64:
+        assert np.all(Ec <= P.TOL + P.NOISE_MULT * No), (Ec, No)
+    else:
+        assert Ec.max() <= P.TOL + P.NOISE_MULT * No.max(), (Ec, No)
+
+
 @pytest.mark.parametrize("n,ragged,kn", [(300, False, 0), (277, True, 0b1000010001), (37, True, 1), (64, False, 0), (1, False, 0), (17, True, 0)])
 def test_ring_fit_3d_order2(wlsqm, oracle, n, ragged, kn, monkeypatch):
     """The same kernel template on the 3D order-2 / 40-slot shape of BASELINE configs[4] (45 moments padded to four quarters of 12):
@@ -387,9 +398,7 @@ def test_ring_fit_3d_order2(wlsqm, oracle, n, ragged, kn, monkeypatch):
     fo = fi0.copy()
     oracle.fit_many(3, xk, fk, nk, xi, fo, None, 0, order, knowns, wm)
     truth = P.truth_fit(3, xk, fk, nk, xi, fi0, order, knowns, wm)
-    e_ring = P.column_metric(out["ring"][0], truth).max()
-    e_ref = max(P.column_metric(fo, truth).max(), P.column_metric(out["tile"][0], truth).max())
-    assert e_ring <= P.TOL + P.NOISE_MULT * e_ref, (e_ring, e_ref)
+    _assert_vs_oracle_floor(out["ring"][0], fo, truth, n)
 
 
 @pytest.mark.parametrize("Kn", [26, 40, 50, 64])
@@ -431,11 +440,7 @@ def test_ring_fit_vs_oracle_and_two_kernel_path(wlsqm, oracle, Kn, n, ragged, kn
     fo = fi0.copy()
     oracle.fit_many(2, xk, fk, nk, xi, fo, None, 0, order, knowns, wm)
     truth = P.truth_fit(2, xk, fk, nk, xi, fi0, order, knowns, wm)
-    # batches this small give no per-column statistics (one case's roundoff IS the column): compare the largest column error
-    # against the 80-bit solution with the largest one of the oracle and of the two-kernel path
-    e_ring = P.column_metric(out["ring"][0], truth).max()
-    e_ref = max(P.column_metric(fo, truth).max(), P.column_metric(out["two"][0], truth).max())
-    assert e_ring <= P.TOL + P.NOISE_MULT * e_ref, (e_ring, e_ref)
+    _assert_vs_oracle_floor(out["ring"][0], fo, truth, n)
     assert np.array_equal(np.isnan(out["ring"][0]), np.isnan(fo))
 
 
@@ -587,8 +592,13 @@ def test_strided_and_odd_rows_are_repacked_for_the_tiled_kernels(wlsqm, dim, ord
     torch.cuda.synchronize()
     assert whip.last_kernel() == "lane"                                  # what these layouts took before
     monkeypatch.delenv("WLSQM_HIP_DISABLE_REPACK")
-    truth = P.truth_fit(dim, xk[..., 0] if dim == 1 else xk, fk, nk, xi[:, 0] if dim == 1 else xi, fi0, np.full(n, order, np.int32), kn, wm)
-    P.assert_parity(a.cpu().numpy(), b.cpu().numpy(), truth, "repacked vs lane kernel")
+    xk_h, xi_h = (xk[..., 0], xi[:, 0]) if dim == 1 else (xk, xi)
+    truth = P.truth_fit(dim, xk_h, fk, nk, xi_h, fi0, np.full(n, order, np.int32), kn, wm)
+    from oracle import oracle as O              # the checker: two HIP results agreeing with each other proves nothing about either
+    fo = fi0.copy()
+    O.fit_many(dim, np.ascontiguousarray(xk_h), fk, nk, np.ascontiguousarray(xi_h), fo, None, 0, np.full(n, order, np.int32), kn, wm)
+    P.assert_parity(a.cpu().numpy(), fo, truth, "repacked rows vs oracle")
+    P.assert_parity(b.cpu().numpy(), fo, truth, "lane kernel vs oracle")
     if Kn % 2 == 0:
         c = _t(fi0)
         whip.fit_many_device(dim, order, xk_c, _t(fk), _t(nk), xi_t, c, _t(kn), _t(wm))
@@ -639,18 +649,23 @@ def test_sensitivities_by_inverse_and_mfma(wlsqm, oracle, dim, order, Kn, n, wid
     assert k_n == "sens-apply", k_n
     assert k_g in ("lane", "wave"), k_g
     fo = fi0[:, :no].copy(); so = np.full((n, Kn, no), 777.0)
-    oracle.fit_many(dim, xk_a, fk, nk, xi_a, fo, so, 1, orders, kn, wm)
+    _, cap = oracle.fit_many(dim, xk_a, fk, nk, xi_a, fo, so, 1, orders, kn, wm, debug_capture=True)
     truth = P.truth_fit(dim, xk_a, fk, nk, xi_a, fi0[:, :no], orders, kn, wm)
     P.assert_parity(f_n[:, :no], fo, truth, "fit beside the inverse vs oracle")
     assert np.array_equal(f_n[:, no:], fi0[:, no:]) and np.array_equal(s_n[:, :, no:], np.full((n, Kn, ncol - no), 777.0))
+    eps = np.finfo(float).eps
     for ref, what in ((so, "oracle"), (s_g[:, :, :no], "generic kernel")):
         a = s_n[:, :, :no]
         assert np.array_equal(np.isnan(a), np.isnan(ref)), what               # NaN for knowns (impl.pyx:821-823)
         assert np.array_equal(a == 777.0, ref == 777.0), what                 # rows k >= nk untouched
-        x, y = np.nan_to_num(a), np.nan_to_num(ref)
-        live = (y != 777.0)
-        scale = np.abs(np.where(live, y, 0.0)).max(axis=(1, 2), keepdims=True) + 1e-300
-        assert (np.abs(x - y) <= 1e-6 * scale).all(), (what, float((np.abs(x - y) / scale).max()))
+        # per case, scaled by the conditioning of the reference's own (Ruiz-scaled) matrix, as tests/test_gpu_parity.py::test_sweep_sens
+        # (round 2 had a flat 1e-6 of the case's largest entry here)
+        for j in range(n):
+            m = ~np.isnan(ref[j]) & (ref[j] != 777.0)
+            if m.any():
+                kappa = K.scaled_cond(cap, j, no, kn[j])
+                err = np.abs(a[j][m] - ref[j][m]).max()
+                assert err <= (1e-10 + 1e3 * kappa * eps) * np.abs(ref[j][m]).max(), (what, j, kappa, err / np.abs(ref[j][m]).max())
     # fi == sens^T fk where nothing is known (the sensitivities are the solution operator)
     free = np.flatnonzero(kn == 0)[:20]
     for j in free:
