@@ -214,13 +214,20 @@ __device__ __forceinline__ double taylor(const double (&d)[DIM], const FI& f) {
 
 }  // namespace strict
 
+__device__ __forceinline__ bool fit_strict_group_is_plain(const KParams& p, long long t, long long ncases);
+
 template <int DIM, int ORDER>
-__global__ __launch_bounds__(64) void fit_strict_kernel(const KParams p, const StrictDebug dbg) {
+__global__ __launch_bounds__(64) void fit_strict_kernel(const KParams p, const StrictDebug dbg, const int skip_plain_groups) {
     using namespace strict;
     constexpr int NO = ndofs(DIM, ORDER);
     constexpr int LPW = lanes_for(NO);
     extern __shared__ double smem[];
     const int lane = threadIdx.x;
+    if (skip_plain_groups) {
+        // the register kernel takes the 64-case groups without any known DOF: this block's cases lie in group (block * LPW) / 64
+        const long long g0 = ((long long)blockIdx.x * LPW) / 64 * 64;
+        if (fit_strict_group_is_plain(p, g0 + lane, live_cases(p))) return;
+    }
     if (lane >= LPW) return;
     const long long t = (long long)blockIdx.x * LPW + lane;
     if (t >= live_cases(p)) return;
@@ -465,6 +472,161 @@ __global__ __launch_bounds__(64) void fit_strict_kernel(const KParams p, const S
     if (p.iters_out) atomicMax(p.iters_out, iters);
 }
 
+// The same operations with EVERYTHING in registers, for the common case of a workgroup whose 64 cases have no knowns at all (the
+// reduced system is the full one: every index is a compile-time constant) and a basic fit: no LDS, so the occupancy is set by
+// the registers (two or more waves per SIMD) instead of by 48 KB of LDS per 64 cases (three waves per CU) — BASELINE configs[1]
+// in strict mode 2.5 -> ~0.5 ms per 1M fits.  The pivot row of a lane is data-dependent, registers cannot be indexed by it: the
+// row exchange is written as selects over the candidate rows (N^3 / 3 of them: nothing against the ~8 Ruiz sweeps of N^2 IEEE
+// divides).  A workgroup with any known DOF, sensitivities, refinement or the debug capture runs the LDS kernel above; both
+// kernels are launched over the same 64-case groups and each group is taken by exactly one of them (fit_strict_group_is_plain).
+__device__ __forceinline__ bool fit_strict_group_is_plain(const KParams& p, long long t, long long ncases) {
+    // (block-uniform result; every thread of the 64-thread block must call it)
+    bool mine = false;
+    if (t < ncases) {
+        const long long j = p.case_index ? p.case_index[t] : t;
+        mine = p.knowns[j * p.sknowns] != 0;
+    }
+    return __syncthreads_or(mine ? 1 : 0) == 0;
+}
+
+template <int DIM, int ORDER>
+__global__ __launch_bounds__(64) void fit_strict_reg_kernel(const KParams p) {
+    using namespace strict;
+    constexpr int N = ndofs(DIM, ORDER);
+    const long long ncases = live_cases(p);
+    const long long t = (long long)blockIdx.x * 64 + threadIdx.x;
+    if (!fit_strict_group_is_plain(p, t, ncases)) return;        // a group with knowns: the LDS kernel has it
+    if (t >= ncases) return;
+    const long long j = p.case_index ? p.case_index[t] : t;
+    const int nk = min(p.nk[j * p.snk], (int)p.max_nk);
+    const bool uniform = (p.wm[j * p.swm] == WLSQM_WEIGHT_UNIFORM);
+    double xi[DIM];
+    Rows<DIM> rows;
+    if (p.hoods) {
+        const long long pj = p.pidx ? p.pidx[j] : j;
+#pragma unroll
+        for (int m = 0; m < DIM; ++m) xi[m] = p.S[pj * DIM + m];
+        rows = Rows<DIM>{nullptr, 0, nullptr, 0, p.hoods + j * p.shoods_j, p.S, p.F};
+    } else {
+#pragma unroll
+        for (int m = 0; m < DIM; ++m) xi[m] = p.xi[j * p.sxi_j + m];
+        rows = Rows<DIM>{p.xk + j * p.sxk_j, p.sxk_k, p.fk + j * p.sfk_j, p.sfk_k, nullptr, nullptr, nullptr};
+    }
+    double max_d2 = 0.;
+    for (int k = 0; k < nk; ++k) {
+        double d[DIM], c[N];
+        rows.offset(k, xi, d);
+        const double d2 = make_c<DIM, ORDER>(d, c);
+        if (d2 > max_d2) max_d2 = d2;
+    }
+    // make_A (impl.pyx:566-602) and the right-hand side sums of solve (impl.pyx:768-787): each its own sum over k ascending
+    double A[N][N], b[N];                                        // A[row][col]
+#pragma unroll
+    for (int i = 0; i < N; ++i) { b[i] = 0.;
+#pragma unroll
+        for (int m = 0; m < N; ++m) A[i][m] = 0.; }
+    for (int k = 0; k < nk; ++k) {
+        double d[DIM], c[N];
+        rows.offset(k, xi, d);
+        const double d2 = make_c<DIM, ORDER>(d, c);
+        const double w = make_weight(d2, max_d2, uniform);
+        const double wf = w * rows.value(k);
+#pragma unroll
+        for (int om = 0; om < N; ++om) {
+            const double wc = w * c[om];
+#pragma unroll
+            for (int oj = 0; oj < N; ++oj) A[oj][om] += wc * c[oj];
+        }
+#pragma unroll
+        for (int oj = 0; oj < N; ++oj) b[oj] += wf * c[oj];
+    }
+    // rescale_ruiz2001_c (lapackdrivers.pyx:553-623)
+    double rs[N], cs[N], DRp[N], DCp[N], DR[N], DC[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { rs[i] = 1.; cs[i] = 1.; DRp[i] = 1.; DCp[i] = 1.; }
+    for (int it = 0; it < 100; ++it) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) { DR[i] = 0.; DC[i] = 0.; }
+#pragma unroll
+        for (int m = 0; m < N; ++m) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const double q = fabs(A[i][m] / (DRp[i] * DCp[m]));
+                if (q > DC[m]) DC[m] = q;
+                if (q > DR[i]) DR[i] = q;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i) { DR[i] = sqrt(DR[i]); DC[i] = sqrt(DC[i]); }
+#pragma unroll
+        for (int i = 0; i < N; ++i) { DRp[i] *= DR[i]; rs[i] /= DR[i]; }
+#pragma unroll
+        for (int i = 0; i < N; ++i) { DCp[i] *= DC[i]; cs[i] /= DC[i]; }
+        double acc = fabs(1. - DR[0] * DR[0]);
+#pragma unroll
+        for (int i = 1; i < N; ++i) { const double tmp = fabs(1. - DR[i] * DR[i]); if (tmp > acc) acc = tmp; }
+        if (acc < ruiz_epsilon) {
+            acc = fabs(1. - DC[0] * DC[0]);
+#pragma unroll
+            for (int i = 1; i < N; ++i) { const double tmp = fabs(1. - DC[i] * DC[i]); if (tmp > acc) acc = tmp; }
+            if (acc < ruiz_epsilon) break;
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < N; ++m)
+#pragma unroll
+        for (int i = 0; i < N; ++i) A[i][m] *= (rs[i] * cs[m]);           // apply_scaling_c (lapackdrivers.pyx:293-299)
+    // dgetrf (unblocked dgetf2 semantics), the row exchange as selects
+    int ipiv[N];
+#pragma unroll
+    for (int c0 = 0; c0 < N; ++c0) {
+        int pv = c0; double best = fabs(A[c0][c0]), pval = A[c0][c0];
+#pragma unroll
+        for (int i = c0 + 1; i < N; ++i) { const double v = fabs(A[i][c0]); if (v > best) { best = v; pv = i; pval = A[i][c0]; } }
+        ipiv[c0] = pv;
+        if (pval != 0.) {
+#pragma unroll
+            for (int i = c0 + 1; i < N; ++i) {
+                const bool sw = (pv == i);
+#pragma unroll
+                for (int m = 0; m < N; ++m) { const double u = A[c0][m], v = A[i][m]; A[c0][m] = sw ? v : u; A[i][m] = sw ? u : v; }
+            }
+            const double r = 1. / A[c0][c0];
+#pragma unroll
+            for (int i = c0 + 1; i < N; ++i) A[i][c0] *= r;
+        }
+#pragma unroll
+        for (int m = c0 + 1; m < N; ++m) {
+            const double u = A[c0][m];
+#pragma unroll
+            for (int i = c0 + 1; i < N; ++i) A[i][m] -= A[i][c0] * u;
+        }
+    }
+    // solve (impl.pyx:731-846) without knowns: b = row_scale * sums, dgetrs('N'), un-scale
+#pragma unroll
+    for (int i = 0; i < N; ++i) b[i] = rs[i] * b[i];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+#pragma unroll
+        for (int q = i + 1; q < N; ++q) { const bool sw = (ipiv[i] == q); const double u = b[i], v = b[q]; b[i] = sw ? v : u; b[q] = sw ? u : v; }
+    }
+#pragma unroll
+    for (int c0 = 0; c0 < N; ++c0)
+#pragma unroll
+        for (int i = c0 + 1; i < N; ++i) b[i] -= A[i][c0] * b[c0];
+#pragma unroll
+    for (int c0 = N - 1; c0 >= 0; --c0) {
+        b[c0] /= A[c0][c0];
+#pragma unroll
+        for (int i = 0; i < c0; ++i) b[i] -= A[i][c0] * b[c0];
+    }
+    double* const fio = p.fi + j * p.sfi_j;
+#pragma unroll
+    for (int i = 0; i < N; ++i) fio[i] = b[i] * cs[i];
+}
+
+constexpr int STRICT_REG_MAX_NO = 10;      // register kernel: systems up to this size (3D order 2 / 2D order 3: one wave per SIMD)
+
 template <int DIM, int ORDER>
 static int launch_strict(const KParams& p, const StrictDebug& dbg, hipStream_t stream) {
     constexpr int NO = ndofs(DIM, ORDER);
@@ -484,7 +646,18 @@ static int launch_strict(const KParams& p, const StrictDebug& dbg, hipStream_t s
             optin[dev] = true;
         }
     }
-    hipLaunchKernelGGL((fit_strict_kernel<DIM, ORDER>), dim3((unsigned)blocks), dim3(64), lds, stream, p, dbg);
+    // basic fits of the small systems: the all-unknown 64-case groups run the register kernel, the others the LDS kernel
+    bool split = false;
+    if constexpr (NO <= STRICT_REG_MAX_NO) {
+        const char* e = getenv("WLSQM_HIP_STRICT_NO_REG");
+        split = !p.do_sens && !p.iterative && !dbg.A && !dbg.w && !(e && e[0] == '1');
+        if (split) {
+            const long long groups = (p.ncases + 63) / 64;
+            hipLaunchKernelGGL((fit_strict_reg_kernel<DIM, ORDER>), dim3((unsigned)groups), dim3(64), 0, stream, p);
+            WLSQM_HIP_CHECK(hipGetLastError());
+        }
+    }
+    hipLaunchKernelGGL((fit_strict_kernel<DIM, ORDER>), dim3((unsigned)blocks), dim3(64), lds, stream, p, dbg, split ? 1 : 0);
     WLSQM_HIP_CHECK(hipGetLastError());
     note_kernel("strict");
     return WLSQM_OK;
