@@ -354,6 +354,9 @@ int wlsqm_hip_fit_many_device(const wlsqm_batch* b, int device, void* stream, in
         if (d_it) {
             WLSQM_HIP_CHECK(hipMemcpyAsync(iterations_out, d_it, sizeof(int), hipMemcpyDeviceToHost, s));
             WLSQM_HIP_CHECK(hipStreamSynchronize(s));
+            // a case without unknowns is a no-op for the kernels, but the reference's loop still runs for it and stops at its
+            // second pass (impl.pyx:1026-1081): the maximum over the cases is never below 1
+            if (*iterations_out < 1) *iterations_out = 1;
             rc = scratch_free_async(d_it, s);
         }
     }
@@ -424,6 +427,7 @@ int wlsqm_hip_fit_many_device_orders(const wlsqm_batch* b, int device, void* str
             e = hipMemcpyAsync(iterations_out, d_it, sizeof(int), hipMemcpyDeviceToHost, s);
             if (e == hipSuccess) e = hipStreamSynchronize(s);
             if (e != hipSuccess) return cleanup(hip_fail(e, "iterations_out"));
+            if (*iterations_out < 1) *iterations_out = 1;
         }
     }
     return cleanup(WLSQM_OK);
@@ -593,7 +597,7 @@ int wlsqm_hip_fit_many_host(const wlsqm_batch* b, int device, int32_t* iteration
     int h_it = 0;
     WLSQM_HIP_CHECK(hipMemcpyAsync(&h_it, cx->it.b.p, 4, hipMemcpyDeviceToHost, s));
     WLSQM_HIP_CHECK(hipStreamSynchronize(s));
-    if (iterations_out) *iterations_out = b->iterative ? h_it : 0;
+    if (iterations_out) *iterations_out = b->iterative ? (h_it < 1 ? 1 : h_it) : 0;     // (never below 1: see wlsqm_hip_fit_many_device)
     mark("commit");
     return WLSQM_OK;
 }
@@ -641,6 +645,7 @@ int wlsqm_hip_fit_cloud_device(int dimension, int order, int64_t ncases, int64_t
     if (d_it) {
         WLSQM_HIP_CHECK(hipMemcpyAsync(iterations_out, d_it, sizeof(int), hipMemcpyDeviceToHost, s));
         WLSQM_HIP_CHECK(hipStreamSynchronize(s));
+        if (*iterations_out < 1) *iterations_out = 1;
         rc = scratch_free_async(d_it, s);
     }
     return rc;

@@ -279,7 +279,7 @@ int wlsqm_hip_expert_solve(wlsqm_expert* h, const double* fk, int64_t fk_stride_
     int h_it = 0;
     WLSQM_HIP_CHECK(hipMemcpyAsync(&h_it, h->d_it.p, 4, hipMemcpyDeviceToHost, s));
     WLSQM_HIP_CHECK(hipStreamSynchronize(s));
-    if (iterations_out) *iterations_out = (h->algorithm == WLSQM_ALGO_ITERATIVE) ? h_it : 0;
+    if (iterations_out) *iterations_out = (h->algorithm == WLSQM_ALGO_ITERATIVE) ? (h_it < 1 ? 1 : h_it) : 0;
     h->solved = true;                  // d_fi now holds the coefficients interpolate() evaluates (case.fi in the reference)
     h->fi_view = h->d_fi.as<double>(); h->fi_view_stride = NO;
     return WLSQM_OK;

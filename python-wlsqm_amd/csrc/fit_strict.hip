@@ -243,7 +243,34 @@ __global__ __launch_bounds__(64) void fit_strict_kernel(const KParams p, const S
     const bool uniform = (p.wm[j * p.swm] == WLSQM_WEIGHT_UNIFORM);
     const long long knowns = p.knowns[j * p.sknowns];
     const int nr = NO - __popcll((unsigned long long)knowns);                    // infra.pyx:119-121: bits >= no are not masked
-    if (nr < 1) return;                                                          // impl.pyx:574, 636, 742
+    if (nr < 1) {                                                                // impl.pyx:574, 636, 742: every step is a no-op ...
+        // ... except the refinement loop itself (impl.pyx:1026-1081), which still runs: fi never changes, so the second pass finds
+        // the residual norm of the first and stops (count 1) — unless the norm is NaN, which equals nothing: then all max_iter
+        // passes run.  norm starts as |res[0]| and `tmp > norm` is false for NaN on either side: it is NaN iff res[0] is.
+        if (p.iterative && p.iters_out) {
+            int iters = 1;
+            if (nk > 0 && p.max_iter > 1) {
+                double xi0[DIM], d0[DIM];
+                const double* fio0 = p.fi + j * p.sfi_j;
+                Rows<DIM> r0;
+                if (p.hoods) {
+                    const long long pj = p.pidx ? p.pidx[j] : j;
+#pragma unroll
+                    for (int m = 0; m < DIM; ++m) xi0[m] = p.S[pj * DIM + m];
+                    r0 = Rows<DIM>{nullptr, 0, nullptr, 0, p.hoods + j * p.shoods_j, p.S, p.F};
+                } else {
+#pragma unroll
+                    for (int m = 0; m < DIM; ++m) xi0[m] = p.xi[j * p.sxi_j + m];
+                    r0 = Rows<DIM>{p.xk + j * p.sxk_j, p.sxk_k, p.fk + j * p.sfk_j, p.sfk_k, nullptr, nullptr, nullptr};
+                }
+                r0.offset(0, xi0, d0);
+                const double res0 = r0.value(0) - taylor<DIM, ORDER>(d0, [&](int a) { return fio0[a]; });
+                if (res0 != res0) iters = p.max_iter;
+            }
+            atomicMax(p.iters_out, iters);
+        }
+        return;
+    }
     {   // infra.pyx:145-200 (remap): r2o of the unknowns in ascending DOF order
         int k = 0;
         for (int a = 0; a < NO; ++a)

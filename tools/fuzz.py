@@ -15,12 +15,13 @@ import _parity as P
 NDOF = {1: [1, 2, 3, 4, 5], 2: [1, 3, 6, 10, 15], 3: [1, 4, 10, 20, 35]}
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-t0 = time.time(); trials = 0; worst = 0.0; sens_worst = 0.0; sens_trials = 0; acc_desc = []; ratios = []; acc = []; cloud_trials = 0; expert_trials = 0; stacked_trials = 0; strided_trials = 0; t_progress = time.time()
+t0 = time.time(); trials = 0; worst = 0.0; sens_worst = 0.0; sens_trials = 0; acc_desc = []; ratios = []; acc = []; cloud_trials = 0; expert_trials = 0; stacked_trials = 0; strided_trials = 0; strict_trials = 0; order_trials = 0; t_progress = time.time()
 dev = torch.device("cuda", 0)
 while time.time() - t0 < budget:
     dim = int(rng.integers(1, 4)); mixed = rng.random() < 0.25
     order = int(rng.integers(0, 5)); no_max = NDOF[dim][4 if mixed else order]
     K = int(rng.integers(NDOF[dim][order] + 2, 90)) if not mixed else int(rng.integers(no_max + 2, 70))
+    os.environ["WLSQM_HIP_REPACK_MB"] = "1" if rng.random() < 0.3 else "512"      # repack / gather scratch in slices
     if not mixed and NDOF[dim][order] <= 15 and rng.random() < 0.06:
         K = int(rng.integers(130, 280))                  # beyond every fixed-K kernel: the chunked kernel (fit_chunk.hip)
     n = int(rng.choice([1, 2, 15, 16, 17, 63, 64, 65, 200, 777, 2049]))
@@ -115,6 +116,41 @@ while time.time() - t0 < budget:
         ratios.append((float(np.max(np.minimum(E, Ec) / (1e-10 + 8.0 * N))), n, desc + " STRIDED DEVICE (%s): GPU vs oracle %.1e" % (whip.last_kernel(), E.max())))
         assert np.array_equal(fi_d[:, no:], fi0[:, no:]), desc + " strided device: columns beyond no touched"
         strided_trials += 1
+    if rng.random() < 0.35:
+        # the same call in the STRICT numerics mode (csrc/fit_strict.hip): the reference's operations one for one, so the result
+        # must equal the oracle's to the last bit — every order bucket, knowns mask, ragged nk, sensitivities, refinement
+        fi_s = fi0.copy(); sens_s = np.full((n, K, ncol), 777.0) if mode == "sens" else None
+        with whip.strict():
+            it_s = f(xk_a, fk, nk, xi_a, fi_s, sens_s, int(mode == "sens"), orders, knowns, wm, **kw)
+            assert whip.last_kernel() == "strict", whip.last_kernel()
+        it_o = oracle.fit_many(dim, xk_a, fk, nk, xi_a, fi0.copy(), None, 0, orders, knowns, wm, iterative=(mode == "iter"), max_iter=6,
+                               ntasks=8) if mode == "iter" else 0
+        assert np.array_equal(fi_s, fi_o, equal_nan=True), desc + ": STRICT mode differs from the oracle (%d of %d doubles)" % (
+            int((fi_s != fi_o).sum()), fi_s.size)
+        if mode == "sens":
+            assert np.array_equal(sens_s, sens_o, equal_nan=True), desc + ": STRICT sensitivities differ from the oracle"
+        if mode == "iter":
+            assert it_s == it_o, desc + ": STRICT iteration count %d vs oracle %d" % (it_s, it_o)
+        strict_trials += 1
+    if mixed and rng.random() < 0.6:
+        # per-case orders as a DEVICE tensor (wlsqm_hip_fit_many_device_orders: bucketed on the device, no host sync)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        fi_d = t(fi0); sens_d = t(np.full((n, K, ncol), 777.0)) if mode == "sens" else None
+        whip.fit_many_device(dim, t(orders), t(xk_a), t(fk), t(nk), t(xi_a), fi_d[:, :no_max] if ncol > no_max else fi_d, t(knowns), t(wm),
+                             sens=(sens_d[:, :, :no_max] if ncol > no_max else sens_d) if mode == "sens" else None,
+                             iterative=(mode == "iter"), max_iter=6)
+        torch.cuda.synchronize()
+        fi_d = fi_d.cpu().numpy()
+        for o in sorted(set(orders.tolist())):
+            sel = orders == o; no = NDOF[dim][o]
+            E = P.column_metric(fi_d[sel, :no], fi_o[sel, :no]); Ec = P.column_metric(fi_d[sel, :no], truth[sel, :no])
+            N = P.column_metric(fi_o[sel, :no], truth[sel, :no])
+            ratios.append((float(np.max(np.minimum(E, Ec) / (1e-10 + 8.0 * N))), int(sel.sum()), desc + " ORDER TENSOR (order %d): GPU vs oracle %.1e" % (o, E.max())))
+            assert np.array_equal(fi_d[sel, no:], fi0[sel, no:]), desc + " order tensor: columns beyond no touched"
+        if mode == "sens":
+            sd = sens_d.cpu().numpy()
+            assert np.array_equal(np.isnan(sd), np.isnan(sens_o)) and np.array_equal(sd == 777.0, sens_o == 777.0), desc + " order tensor sens pattern"
+        order_trials += 1
     if rng.random() < 0.3:
         # the same batch through ExpertSolver (prepare once, solve): the same kernels on the same device layout -> same bits
         es = wlsqm.ExpertSolver(dimension=dim, nk=nk, order=orders, knowns=knowns, weighting_method=wm,
@@ -155,6 +191,7 @@ while time.time() - t0 < budget:
 ratios.sort(reverse=True)
 print("fuzz: sensitivities of %d batches compared with the oracle's: largest per-case relative difference among well-conditioned cases %.1e" % (sens_trials, sens_worst))
 over = [r for r in ratios if r[0] > 1.0]
+print("fuzz: %d batches also in STRICT mode (bit-identical to the oracle), %d mixed-order batches also with a device order tensor" % (strict_trials, order_trials))
 print("fuzz: %d random batches (%d of them also index-based, %d also from strided device views, %d also through ExpertSolver, %d of those with a stacked solve; %d order buckets) in %.0f s; largest column metric vs oracle %.2e; buckets over the 1e-10 + 8 N criterion: %d"
       % (trials, cloud_trials, strided_trials, expert_trials, stacked_trials, len(ratios), time.time() - t0, worst, len(over)))
 for r, _, d in ratios[:8]:
