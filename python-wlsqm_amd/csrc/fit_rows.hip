@@ -203,14 +203,18 @@ __global__ __launch_bounds__(RW) void fit_rows_kernel(const KParams p) {
     if constexpr (G == 1) {
         // ---- left-looking LDL^T, row i in lane i: V[m] = L[i][m] d_m below the diagonal, V[i] = d_i; the pivot row arrives by
         // v_readlane (wave-uniform), no LDS on the critical path.  (The LDS-mailbox form below is 10 % slower here.)
-        double dinv[NO], my_dinv = 1.0;
+        // (round 3: the pivot row is broadcast ALREADY divided — U[m] = V[m] / d_m = L[i][m], one multiply per lane and column —
+        // instead of dividing the broadcast value in every (column, term) pair: 3 instead of 4 instructions per pair,
+        // ~580 of the 4 780 vector instructions of an order-4 case; profiles/r03_rows_sq.txt)
+        double dinv[NO], U[NO], my_dinv = 1.0;
 #pragma unroll
         for (int c = 0; c < NO; ++c) {
             double v = V[c];
 #pragma unroll
-            for (int m = 0; m < c; ++m) v = fma(-V[m], lane_bcast(V[m], c) * dinv[m], v);
+            for (int m = 0; m < c; ++m) v = fma(-V[m], lane_bcast(U[m], c), v);
             V[c] = v;
             dinv[c] = recip(lane_bcast(v, c));
+            U[c] = v * dinv[c];
             my_dinv = (lane == c) ? dinv[c] : my_dinv;
         }
         // ---- forward substitution and the diagonal
