@@ -90,6 +90,9 @@ class ShardedCloudSolver:
         return torch.cat(parts)
 
 
+TIE_PAD = 8          # extra candidates per point fetched by HaloCloudSolver so that ties at the k-th distance are cut canonically
+
+
 def _default_knn(cand, k, nquery):
     from . import hip
     return hip.knn(cand, k, nquery=nquery).long()
@@ -111,9 +114,10 @@ class HaloCloudSolver:
       * tells each owner which of its points it names (all_to_all of the need lists, set-up only) and per step exchanges only
         those values: one `all_to_all_single` (uneven splits; RCCL over xGMI, gloo in the CPU tests) on a side stream while the
         INTERIOR cases (all neighbours owned) are fitted; the boundary cases follow when the halo has arrived.
-    Neighbour lists are put in the canonical order (distance, GLOBAL index), so a partitioned run reproduces the one-rank run
-    bit for bit whenever the k-th neighbour distance of every point is unique (generic clouds; on lattice-like clouds a tie at
-    the k-th distance may be cut differently, because the search numbers its candidates [own | band] rather than globally).
+    Neighbour lists are put in the canonical order (distance, GLOBAL index) and cut to k AFTER that sort (the search fetches
+    k + TIE_PAD candidates), so a partitioned run reproduces the one-rank run bit for bit — also on lattice-like clouds, where many
+    candidates tie at the k-th distance — as long as a run of equal distances does not reach past the padded list
+    (`ties_beyond_pad` counts the points where it does).
 
     S: either the whole cloud (N, dim), the same on every rank — the constructor keeps rows case_range(N, rank, world) and drops
     the rest (legacy form, tests) — or, with own_range=(lo, N), this rank's block only, whose first point is global point lo."""
@@ -163,7 +167,8 @@ class HaloCloudSolver:
         # ---- 1. candidates: own points + the band received from the other ranks, verified
         if world == 1:
             cand, cand_g = own, own_g
-            hl = knn_fn(own if dim > 1 else own[:, 0].contiguous(), self.nk, n_own)
+            kq = max(self.nk, min(self.nk + TIE_PAD, N - 1))
+            hl = knn_fn(own if dim > 1 else own[:, 0].contiguous(), kq, n_own)
             self.halo_radius, self.halo_attempts = 0.0, 0
         else:
             inf = float("inf")
@@ -191,8 +196,9 @@ class HaloCloudSolver:
                 cand = torch.cat([own, recv[:, :dim]]).contiguous()
                 cand_g = torch.cat([own_g, recv[:, dim].to(torch.int64)])
                 if n_own:
-                    hl = knn_fn(cand if dim > 1 else cand[:, 0].contiguous(), self.nk, n_own)
-                    dk = (cand[hl[:, -1]] - own).pow(2).sum(1).max().sqrt().reshape(1)
+                    kq = max(self.nk, min(self.nk + TIE_PAD, int(cand.shape[0]) - 1))
+                    hl = knn_fn(cand if dim > 1 else cand[:, 0].contiguous(), kq, n_own)
+                    dk = (cand[hl[:, self.nk - 1]] - own).pow(2).sum(1).max().sqrt().reshape(1)
                 else:
                     hl = torch.zeros((0, self.nk), dtype=torch.int64, device=dev)
                     dk = torch.zeros(1, dtype=torch.float64, device=dev)
@@ -205,13 +211,18 @@ class HaloCloudSolver:
                 raise RuntimeError("halo band did not converge")
             self.halo_radius = r
             self.band_points_received = int(recv.shape[0])
-        # ---- 2. canonical neighbour order: ascending (distance, GLOBAL index) — independent of the candidate numbering
-        hg = cand_g[hl]                                           # (n_own, nk) global indices
+        # ---- 2. canonical neighbour order: ascending (distance, GLOBAL index) — independent of the candidate numbering.  The search
+        # returned nk + TIE_PAD candidates per point: the cut to nk happens HERE, after the canonical sort, so that a tie at the
+        # nk-th distance (lattice-like clouds) is cut the same way whatever the partition; ties_beyond_pad counts the
+        # points whose run of equal distances reaches past the padded list (there the set may still depend on the partition)
+        hg = cand_g[hl]                                           # (n_own, kq) global indices
         d2 = (cand[hl] - own[:, None, :]).pow(2).sum(2)
         o1 = torch.argsort(hg, dim=1, stable=True)
         hg = torch.gather(hg, 1, o1); d2 = torch.gather(d2, 1, o1)
         o2 = torch.argsort(d2, dim=1, stable=True)
-        hg = torch.gather(hg, 1, o2)
+        hg = torch.gather(hg, 1, o2); d2 = torch.gather(d2, 1, o2)
+        self.ties_beyond_pad = int((d2[:, -1] == d2[:, self.nk - 1]).sum().item()) if (n_own and hg.shape[1] > self.nk) else 0
+        hg = hg[:, : self.nk].contiguous()
         del d2, o1, o2, hl
         # ---- 3. local numbering [interior own | boundary own | halo]
         foreign = (hg < lo) | (hg >= hi)

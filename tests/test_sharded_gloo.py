@@ -200,3 +200,21 @@ def test_loopback_halo_hook_on_a_one_rank_group():
     import torch.multiprocessing as mp
     S = synth.halton(600, 2)
     mp.spawn(_run_loopback, args=(1, _free_port(), S, 10, synth.field(S)), nprocs=1, join=True)
+
+
+def test_halo_solver_on_a_lattice_with_ties(tmp_path):
+    """A regular grid: dozens of candidates tie at the k-th distance of every point.  The neighbour SET must not depend on the
+    partition (the cut to k happens after the canonical (distance, global index) sort): bit-identical to one rank."""
+    import torch.multiprocessing as mp
+    g = np.arange(40) / 39.0
+    S = np.stack(np.meshgrid(g, g, indexing="ij"), -1).reshape(-1, 2)
+    S = np.ascontiguousarray(S[synth.morton_order(S)])
+    N, nk, steps = len(S), 10, 2                                  # 10 of the 12 points at the two nearest lattice distances
+    F0 = synth.field(S)
+    _run_halo(0, 1, 0, S, nk, F0, steps, str(tmp_path))
+    mp.spawn(_run_halo, args=(3, _free_port(), S, nk, F0, steps, str(tmp_path), False), nprocs=3, join=True)
+    ref = np.empty(N); ref[np.load(tmp_path / "halo_g_0_of_1.npy")] = np.load(tmp_path / "halo_v_0_of_1.npy")
+    got = np.full(N, np.nan)
+    for r in range(3):
+        got[np.load(tmp_path / ("halo_g_%d_of_3.npy" % r))] = np.load(tmp_path / ("halo_v_%d_of_3.npy" % r))
+    assert np.array_equal(got, ref)
