@@ -249,3 +249,62 @@ def test_bench_headline_is_compact_and_parseable(capsys, tmp_path, monkeypatch):
     # a pathological record still yields a parseable headline under the limit
     full["configs"] = {"side%03d" % i: {"ms_per_step": 1.0, "roofline": {"frac": 0.5}} for i in range(400)}
     assert len(json.dumps(bench.compact_line(full), separators=(",", ":"))) <= bench.COMPACT_LIMIT
+
+
+def test_strict_mode_flag_is_per_thread_and_restored(binding, monkeypatch):
+    """wlsqm_hip_set_strict / get_strict (no GPU needed): the context manager restores the previous mode, another thread starts
+    from the environment's default, and WLSQM_HIP_STRICT is read by a thread's first use."""
+    import threading
+    sys.path.insert(0, os.path.join(ROOT, "python-wlsqm_amd"))
+    import wlsqm.hip as whip
+    prev = whip.set_strict(False)
+    try:
+        assert whip.get_strict() is False
+        with whip.strict():
+            assert whip.get_strict() is True
+            with whip.strict(False):
+                assert whip.get_strict() is False
+            assert whip.get_strict() is True
+            with whip.strict(None):                      # None: leave the mode alone
+                assert whip.get_strict() is True
+        assert whip.get_strict() is False
+        assert whip.set_strict(True) is False and whip.set_strict(False) is True
+        seen = {}
+        whip.set_strict(True)
+
+        def other():
+            seen["default"] = whip.get_strict()          # a new thread does not inherit this thread's mode
+        t = threading.Thread(target=other); t.start(); t.join()
+        assert seen["default"] is (os.environ.get("WLSQM_HIP_STRICT", "0") not in ("", "0"))
+        monkeypatch.setenv("WLSQM_HIP_STRICT", "1")
+
+        def third():
+            seen["env"] = whip.get_strict()
+        t = threading.Thread(target=third); t.start(); t.join()
+        assert seen["env"] is True
+    finally:
+        whip.set_strict(prev)
+
+
+def test_default_device_precedence(monkeypatch):
+    """Host-array entry points: WLSQM_HIP_DEVICE, then a non-default torch device, then LOCAL_RANK, then torch's device."""
+    import types
+    sys.path.insert(0, os.path.join(ROOT, "python-wlsqm_amd"))
+    from wlsqm import _binding as B
+
+    def fake_torch(initialised, current):
+        t = types.ModuleType("torch")
+        t.cuda = types.SimpleNamespace(is_initialized=lambda: initialised, current_device=lambda: current)
+        return t
+    for k in ("WLSQM_HIP_DEVICE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setitem(sys.modules, "torch", fake_torch(True, 0))
+    assert B.default_device() == 0
+    monkeypatch.setenv("LOCAL_RANK", "3")
+    assert B.default_device() == 3                       # torch still on its default 0: the rank's own GPU
+    monkeypatch.setitem(sys.modules, "torch", fake_torch(True, 5))
+    assert B.default_device() == 5                       # the caller chose a device with torch: follow it
+    monkeypatch.setitem(sys.modules, "torch", fake_torch(False, 5))
+    assert B.default_device() == 3                       # torch has not touched the GPU: LOCAL_RANK
+    monkeypatch.setenv("WLSQM_HIP_DEVICE", "7")
+    assert B.default_device() == 7
