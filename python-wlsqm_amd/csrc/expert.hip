@@ -316,12 +316,12 @@ static int ensure_operator(wlsqm_expert* h, hipStream_t s) {
     if (g.op_state != 0) return WLSQM_OK;
     bool ok = false;
     KParams p = expert_params(h, nullptr, 0, nullptr, 0);
-    // the operator is 8 * 16 * K bytes per case (plus a temporary sensitivity block of 256k cases): only when it comfortably fits
+    // the operator is 8 * no * K bytes per case (plus a temporary sensitivity block of <= 128 MB): only when it comfortably fits
     // what is free now; otherwise (and if an allocation fails all the same) the stacked solve takes the other kernels
     {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
-        const double need = (double)g.ncases * 16.0 * (double)((g.slots + 7) / 8 * 8) * 8.0 + 256.0 * 1024 * (double)g.slots * (g.max_no + 2) * 8.0;
+        const double need = (double)g.ncases * (double)g.max_no * (double)((g.slots + 7) / 8 * 8) * 8.0 + 160.0 * 1048576.0;
         if (need > 0.6 * (double)free_b) { g.op_state = -1; return WLSQM_OK; }
     }
     int rc = solve_op_build(g.dimension, g.order[0], p, g.slots, reinterpret_cast<const long long*>(g.kn.data()), g.ncases,

@@ -43,15 +43,25 @@ __host__ __device__ constexpr int op_dof_of_row(int i) { return 4 * (i % 4) + i 
 
 // sens[ncases, K, no] (NaN for knowns, slots >= nk untouched) -> op[ncases, no, KP] (DOF order; zero rows for knowns).  The rows
 // the MFMA pads to 16 are not stored (round 2 stored all 16: 4 KB instead of 1.5 KB per case of 2D order 2).
-__global__ void op_transpose_kernel(const double* __restrict__ sens, const int* __restrict__ nk, long long ncases, int K, int KP, int no,
-                                    double* __restrict__ op) {
+__global__ void op_transpose_kernel(const double* __restrict__ sens, const int* __restrict__ nk, const long long* __restrict__ knowns,
+                                    long long ncases, int K, int KP, int no, double* __restrict__ op) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ncases * K) return;
     const long long j = t / K; const int k = (int)(t - j * K);
     const bool live = k < nk[j];
+    // DOFs the fit does not solve for (knowns, and the unknowns a mask with stray high bits drops: infra.pyx:119-121): zero rows.
+    // (The sens block is not cleared beforehand: what the fit kernels leave untouched there is never read.)
+    unsigned long long known, dropped;
+    {
+        const unsigned long long full = (1ull << no) - 1ull, raw = (unsigned long long)knowns[j];
+        known = raw & full; dropped = 0;
+        int extra = __popcll(raw & ~full);
+        for (int b = no - 1; b >= 0 && extra > 0; --b)
+            if (!((known >> b) & 1ull)) { known |= 1ull << b; --extra; }
+    }
     const double* s = sens + t * no;
     for (int a = 0; a < no; ++a) {
-        const double v = live ? s[a] : 0.0;
+        const double v = (live && !((known >> a) & 1ull)) ? s[a] : 0.0;
         op[(j * no + a) * KP + k] = (v == v) ? v : 0.0;
     }
 }
@@ -291,28 +301,35 @@ int solve_op_build(int dimension, int order, const KParams& geom, long long K, c
     const long long KP = (K + 7) / 8 * 8;
     if ((rc = d_op.alloc((size_t)ncases * no * KP * 8))) return rc;
     if ((rc = d_T.alloc(anyk ? (size_t)ncases * OP_ROWS * OP_NKN * 8 : 16))) return rc;
-    WLSQM_HIP_CHECK(hipMemsetAsync(d_op.p, 0, d_op.n, s));
-    // sensitivities of the geometry, a chunk of cases at a time (the dense sens block is 8 K no bytes per case)
-    const long long chunk = std::min<long long>(ncases, 1ll << 18);
-    DevBuf d_sens, d_fk, d_fi;
-    if ((rc = d_sens.alloc((size_t)chunk * K * no * 8)) || (rc = d_fk.alloc((size_t)chunk * K * 8)) ||
-        (rc = d_fi.alloc((size_t)chunk * no * 8))) return rc;
-    WLSQM_HIP_CHECK(hipMemsetAsync(d_fk.p, 0, d_fk.n, s));
+    // (the transpose writes every column k < K of every row; only the pad columns K .. KP - 1 need zeros)
+    if (KP != K) WLSQM_HIP_CHECK(hipMemsetAsync(d_op.p, 0, d_op.n, s));
+    // sensitivities of the geometry, a chunk of cases at a time (the dense sens block is 8 K no bytes per case).  Round 3: the
+    // temporaries come from the stream-ordered pool (a chunk is <= 128 MB of sens: no hipMalloc / hipFree per build — those, not
+    // the kernels, were most of the 9-37 ms a build took), the sens block is not cleared (the transpose reads live slots only)
+    long long chunk = (128ll << 20) / ((long long)K * no * 8);
+    chunk = std::max(4096ll, chunk - chunk % 64);
+    chunk = std::min(chunk, ncases);
+    const size_t n_sens = (size_t)chunk * K * no, n_fk = (size_t)chunk * K, n_fi = (size_t)chunk * no;
+    double* tmp = nullptr;
+    if ((rc = scratch_alloc_async(reinterpret_cast<void**>(&tmp), (n_sens + n_fk + n_fi) * sizeof(double), s))) return rc;
+    double* t_sens = tmp; double* t_fk = tmp + n_sens; double* t_fi = t_fk + n_fk;
+    hipError_t e = hipMemsetAsync(t_fk, 0, (n_fk + n_fi) * sizeof(double), s);
+    if (e != hipSuccess) { (void)scratch_free_async(tmp, s); return hip_fail(e, "hipMemsetAsync"); }
     for (long long j0 = 0; j0 < ncases; j0 += chunk) {
         const long long n = std::min(chunk, ncases - j0);
         KParams p = slice_cases(geom, j0, n);
-        p.fk = d_fk.as<double>(); p.sfk_j = K; p.sfk_k = 1;
-        p.fi = d_fi.as<double>(); p.sfi_j = no;
-        p.sens = d_sens.as<double>(); p.ss_j = K * no; p.ss_k = no;
+        p.fk = t_fk; p.sfk_j = K; p.sfk_k = 1;
+        p.fi = t_fi; p.sfi_j = no;
+        p.sens = t_sens; p.ss_j = K * no; p.ss_k = no;
         p.do_sens = 1; p.iterative = 0; p.iters_out = nullptr; p.case_index = nullptr;
-        WLSQM_HIP_CHECK(hipMemsetAsync(d_sens.p, 0, (size_t)n * K * no * 8, s));
-        WLSQM_HIP_CHECK(hipMemsetAsync(d_fi.p, 0, (size_t)n * no * 8, s));
-        if ((rc = launch_fit(dimension, order, p, K, s))) return rc;
+        if ((rc = launch_fit(dimension, order, p, K, s))) { (void)scratch_free_async(tmp, s); return rc; }
         const long long threads = n * K;
-        hipLaunchKernelGGL(op_transpose_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, d_sens.as<double>(),
-                           p.nk, n, (int)K, (int)KP, no, d_op.as<double>() + j0 * no * KP);
-        WLSQM_HIP_CHECK(hipGetLastError());
+        hipLaunchKernelGGL(op_transpose_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, t_sens,
+                           p.nk, p.knowns, n, (int)K, (int)KP, no, d_op.as<double>() + j0 * no * KP);
+        e = hipGetLastError();
+        if (e != hipSuccess) { (void)scratch_free_async(tmp, s); return hip_fail(e, "op_transpose_kernel"); }
     }
+    if ((rc = scratch_free_async(tmp, s))) return rc;
     if (anyk) {
         const long long threads = ncases * OP_ROWS;
         const dim3 grid((unsigned)((threads + 255) / 256)), block(256);
@@ -326,7 +343,7 @@ int solve_op_build(int dimension, int order, const KParams& geom, long long K, c
 #undef KN_CASE
         WLSQM_HIP_CHECK(hipGetLastError());
     }
-    WLSQM_HIP_CHECK(hipStreamSynchronize(s));      // the temporaries are freed on return
+    WLSQM_HIP_CHECK(hipStreamSynchronize(s));      // the operator is complete when this returns (a later solve may use another stream)
     *any_known = anyk;
     *ok = true;
     return WLSQM_OK;
