@@ -257,3 +257,45 @@ def test_order_tensor_call_captures_into_a_hip_graph(wlsqm):
     replayed = fi.clone()
     fi.copy_(_t(d["fi_in"])); run(); torch.cuda.synchronize()
     assert torch.equal(replayed, fi)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the reference's own harness shape on the index-based path (examples/wlsqm_example.py:103-133: ball query, max_nk = 100, order 4)
+
+def test_example_harness_index_based_and_strict(wlsqm, oracle):
+    """testmany2d through the device-resident INDEX-BASED entry point (hoods into the point table, ragged nk, padding = -1 never
+    dereferenced), with the neighbourhoods of the golden and with those of the GPU radius search (same sets), against the
+    reference's captured fi; the same call in strict mode equals the oracle bit for bit."""
+    import torch
+    import synth
+    import wlsqm.hip as whip
+    g = K.golden("testmany2d.npz")
+    N = int(g["N"]); r = float(g["r"])
+    S = synth.halton(N, 2); F = synth.field(S)
+    hoods, nk = g["hoods"], g["nk"]
+    hp = np.where(hoods >= 0, hoods, 0)
+    xk = S[hp]; fk = F[hp]
+    o = np.full(N, 4, np.int32); kn = np.full(N, wlsqm.b2_F, np.int64); w = np.full(N, wlsqm.WEIGHT_CENTER, np.int32)
+    fi0 = np.zeros((N, 15)); fi0[:, 0] = F
+    truth = P.truth_fit(2, xk, fk, nk, S, fi0, o, kn, w)
+    S_d, F_d = _t(S), _t(F)
+    fi = _t(fi0)
+    whip.fit_cloud_device(2, 4, S_d, F_d, _t(hoods), fi, _t(nk), _t(kn), _t(w))
+    torch.cuda.synchronize()
+    assert whip.last_kernel() != "lane", whip.last_kernel()
+    P.assert_parity(fi.cpu().numpy(), g["fi"], truth, "testmany2d index-based")
+    # the GPU radius search finds the same neighbourhoods (as sets: the reference's ball query returns them unsorted)
+    h_gpu, nk_gpu = whip.ball(S_d, r, 100)
+    torch.cuda.synchronize()
+    h_gpu, nk_gpu = h_gpu.cpu().numpy(), nk_gpu.cpu().numpy()
+    assert np.array_equal(nk_gpu, nk)
+    for j in range(0, N, 37):
+        assert set(h_gpu[j, : nk[j]].tolist()) == set(hoods[j, : nk[j]].tolist()), j
+    # strict mode on the index-based path: the oracle's bits (the oracle gets the gathered dense rows of the SAME neighbour order)
+    fi_s = _t(fi0)
+    whip.fit_cloud_device(2, 4, S_d, F_d, _t(hoods), fi_s, _t(nk), _t(kn), _t(w), strict=True)
+    torch.cuda.synchronize()
+    assert whip.last_kernel() == "strict"
+    fo = fi0.copy()
+    oracle.fit_many(2, xk, fk, nk, S, fo, None, 0, o, kn, w, ntasks=8)
+    assert np.array_equal(fi_s.cpu().numpy(), fo)
