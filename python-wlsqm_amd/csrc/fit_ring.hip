@@ -236,6 +236,34 @@ __global__ __launch_bounds__(64, MINW) void fit_ring_kernel(const KParams p, con
         havep = false;
     };
 
+    // The same solve without a single branch, for a wave whose 64 parked cases are all valid and have no known DOF (round 3): it
+    // is emitted INSIDE the straight-line moment pass of the next full tile (below), so that the instruction scheduler can fill the
+    // stalls of its dependent chains (reciprocals, LDL^T column after column, the substitutions) with the independent moment FMAs of
+    // that pass — a lone wave per SIMD has nobody else to issue from.
+    auto solve_simple = [&]() {
+#pragma unroll
+        for (int e = 0; e < NQ; ++e) { swap16(PQ[0][e], PQ[1][e]); swap16(PQ[2][e], PQ[3][e]); }
+#pragma unroll
+        for (int e = 0; e < NQ; ++e) { swap32(PQ[0][e], PQ[2][e]); swap32(PQ[1][e], PQ[3][e]); }
+        auto entry = [&](int i) -> double {
+            const int qtr = i / NQ, e = i - qtr * NQ;
+            const int r = (qtr == 0) ? 0 : (qtr == 1) ? 2 : (qtr == 2) ? 1 : 3;
+            return PQ[r][e];
+        };
+        double* fio = p.fi + jp * p.sfi_j;
+        double M[NE], rhs[NO];
+        expand_moments_from<DIM, ORDER>([&](int i) { return entry(i); }, [&](int i) { return entry(NM + i); }, M, rhs);
+        ldlt_factor<NO>(M);
+        ldlt_solve<NO>(M, rhs);
+#pragma unroll
+        for (int a = 0; a < NO; ++a) fio[a] = rhs[a];
+        havep = false;
+    };
+#ifndef WLSQM_RING_FUSE_SOLVE
+#define WLSQM_RING_FUSE_SOLVE 1
+#endif
+    constexpr bool FUSE = (WLSQM_RING_FUSE_SOLVE != 0) && DIM == 3;
+
     constexpr bool DELAY = (DIM == 3);
     bool pending = false;
     const long long tile0 = (long long)blockIdx.x * tiles_per_wg;
@@ -262,8 +290,14 @@ __global__ __launch_bounds__(64, MINW) void fit_ring_kernel(const KParams p, con
         // DELAY: the solve of the previous four tiles runs HERE, behind the prefetch, so that its fi stores are acknowledged
         // while this tile accumulates instead of at the next barrier (vmcnt counts the stores too); no ring slot is dead at
         // this point, so the rows are stored directly
+        const bool full = (G::KC == K) && __all(nkc >= K);     // wave-uniform: no ragged case in this tile
+        bool fused = false;
         if constexpr (DELAY) {
-            if (pending) { solve_parked(nullptr); pending = false; }
+            if (pending) {
+                if (FUSE && full && __all(havep && knownp == 0ull && droppedp == 0ull)) fused = true;     // solved inside the moment pass below
+                else solve_parked(nullptr);
+                pending = false;
+            }
         }
 
         // (squared distances are written as explicit fma(dy, dy, dx * dx) everywhere: the ragged and the full-tile code paths
@@ -283,7 +317,6 @@ __global__ __launch_bounds__(64, MINW) void fit_ring_kernel(const KParams p, con
             for (int m = 1; m < DIM; ++m) d2 = fma(d[m], d[m], d2);
             return d2;
         };
-        const bool full = (G::KC == K) && __all(nkc >= K);     // wave-uniform: no ragged case in this tile
         // (keeping the offsets and squared distances of this pass in registers for the moment pass — 40 doubles for the 3D order-2
         // share — measured 1.6 % slower than reading and subtracting again: C5 ring / tile ratio 0.931 against 0.915)
         double max_d2 = 0.0;
@@ -323,7 +356,12 @@ __global__ __launch_bounds__(64, MINW) void fit_ring_kernel(const KParams p, con
             const double w = live ? weight(d2, inv_max, uniform) : 0.0;
             accumulate_moments_best<DIM, ORDER>(mu, nu, d, w, live ? f[kk] : 0.0);
         };
-        if (full) {
+        if (full && fused) {
+            // one straight-line region: the previous group's 64-case solve and this tile's moment pass
+            solve_simple();
+#pragma unroll
+            for (int kk = 0; kk < KPL; ++kk) neighbour(kk, true);
+        } else if (full) {
             // (requesting the coordinates of the next four neighbours from LDS before working on the current one — the compiler
             // issues the ds_reads in pairs and waits right behind the second — measured the same: 0.461 against 0.457 ms on C3)
 #pragma unroll UNR
