@@ -236,10 +236,11 @@ __global__ __launch_bounds__(64, MINW) void fit_ring_kernel(const KParams p, con
         havep = false;
     };
 
-    // The same solve without a single branch, for a wave whose 64 parked cases are all valid and have no known DOF (round 3): it
-    // is emitted INSIDE the straight-line moment pass of the next full tile (below), so that the instruction scheduler can fill the
-    // stalls of its dependent chains (reciprocals, LDL^T column after column, the substitutions) with the independent moment FMAs of
-    // that pass — a lone wave per SIMD has nobody else to issue from.
+    // The same solve without a single branch, for a wave whose 64 parked cases are all valid and have no known DOF (round 3:
+    // C5 +1.8 %).  (Emitting it INSIDE the straight-line moment pass of the next tile, in the hope that the scheduler would fill the
+    // stalls of its dependent chains with the independent moment FMAs, changed nothing — the ISA had the solve first and the moments
+    // after it — and the second copy of the moment pass rounded differently from the first: a case's bits then depended on its
+    // position in the launch.  One copy of every arithmetic path.)
     auto solve_simple = [&]() {
 #pragma unroll
         for (int e = 0; e < NQ; ++e) { swap16(PQ[0][e], PQ[1][e]); swap16(PQ[2][e], PQ[3][e]); }
@@ -291,10 +292,10 @@ __global__ __launch_bounds__(64, MINW) void fit_ring_kernel(const KParams p, con
         // while this tile accumulates instead of at the next barrier (vmcnt counts the stores too); no ring slot is dead at
         // this point, so the rows are stored directly
         const bool full = (G::KC == K) && __all(nkc >= K);     // wave-uniform: no ragged case in this tile
-        bool fused = false;
         if constexpr (DELAY) {
             if (pending) {
-                if (FUSE && full && __all(havep && knownp == 0ull && droppedp == 0ull)) fused = true;     // solved inside the moment pass below
+                // all 64 parked cases valid and without knowns: the branch-free copy (same operations on the same numbers)
+                if (FUSE && __all(havep && knownp == 0ull && droppedp == 0ull)) solve_simple();
                 else solve_parked(nullptr);
                 pending = false;
             }
@@ -356,12 +357,7 @@ __global__ __launch_bounds__(64, MINW) void fit_ring_kernel(const KParams p, con
             const double w = live ? weight(d2, inv_max, uniform) : 0.0;
             accumulate_moments_best<DIM, ORDER>(mu, nu, d, w, live ? f[kk] : 0.0);
         };
-        if (full && fused) {
-            // one straight-line region: the previous group's 64-case solve and this tile's moment pass
-            solve_simple();
-#pragma unroll
-            for (int kk = 0; kk < KPL; ++kk) neighbour(kk, true);
-        } else if (full) {
+        if (full) {
             // (requesting the coordinates of the next four neighbours from LDS before working on the current one — the compiler
             // issues the ds_reads in pairs and waits right behind the second — measured the same: 0.461 against 0.457 ms on C3)
 #pragma unroll UNR

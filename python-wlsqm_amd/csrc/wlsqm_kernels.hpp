@@ -133,6 +133,16 @@ __device__ __forceinline__ void effective_mask(long long raw, unsigned long long
 
 // In-register LDL^T of the packed upper triangle (M = U^T D U, unit U stored above the
 // diagonal, D on it).  Replaces lapackdrivers.pyx:1628-1635 (dgetrf) for this SPD system.
+// The updates are written as explicit fma() (here, in ldlt_solve and in eliminate_knowns): `a -= b * c` leaves the compiler a
+// choice when `a` is itself a product — M right after the expansion from the moments is (moment x constant) —, namely which of
+// the two products to fuse, and two inlined copies of the same routine were seen to choose differently (round 3: a branch-free
+// copy of the 3D ring kernel's solve differed from the branching one by 1e-8 relative in 75 % of the cases).  With the fused
+// operation spelled out every copy rounds the same way, so a case's bits do not depend on the kernel variant that solved it.
+// Up to 10 unknowns only: for the 14- / 15-unknown systems the compiler's freedom is what keeps the 2D order-4 ring kernel's
+// matrix out of scratch (it fuses the expansion's products straight into the first updates instead of materialising all 105
+// entries: with explicit fma() there the kernel spilled on its hot path, C3 0.46 -> 0.555 ms); those kernels have one copy of
+// the solve each.
+__host__ __device__ constexpr bool pin_fma(int n) { return n <= 10; }
 template <int N> __device__ __forceinline__ void ldlt_factor(double (&M)[N * (N + 1) / 2]) {
 #pragma unroll
     for (int j = 0; j < N; ++j) {
@@ -141,7 +151,10 @@ template <int N> __device__ __forceinline__ void ldlt_factor(double (&M)[N * (N 
         for (int i = j + 1; i < N; ++i) {
             const double t = M[tri<N>(j, i)] * inv;
 #pragma unroll
-            for (int m = i; m < N; ++m) M[tri<N>(i, m)] -= t * M[tri<N>(j, m)];
+            for (int m = i; m < N; ++m) {
+                if constexpr (pin_fma(N)) M[tri<N>(i, m)] = fma(-t, M[tri<N>(j, m)], M[tri<N>(i, m)]);
+                else M[tri<N>(i, m)] -= t * M[tri<N>(j, m)];
+            }
             M[tri<N>(j, i)] = t;
         }
         M[tri<N>(j, j)] = inv;   // keep 1/d_j: the solves only ever divide by d_j
@@ -154,12 +167,18 @@ template <int N> __device__ __forceinline__ void ldlt_solve(const double (&M)[N 
 #pragma unroll
     for (int j = 0; j < N; ++j)
 #pragma unroll
-        for (int i = j + 1; i < N; ++i) b[i] -= M[tri<N>(j, i)] * b[j];
+        for (int i = j + 1; i < N; ++i) {
+            if constexpr (pin_fma(N)) b[i] = fma(-M[tri<N>(j, i)], b[j], b[i]);
+            else b[i] -= M[tri<N>(j, i)] * b[j];
+        }
 #pragma unroll
     for (int j = N - 1; j >= 0; --j) {
         double v = b[j] * M[tri<N>(j, j)];
 #pragma unroll
-        for (int i = j + 1; i < N; ++i) v -= M[tri<N>(j, i)] * b[i];
+        for (int i = j + 1; i < N; ++i) {
+            if constexpr (pin_fma(N)) v = fma(-M[tri<N>(j, i)], b[i], v);
+            else v -= M[tri<N>(j, i)] * b[i];
+        }
         b[j] = v;
     }
 }
@@ -175,7 +194,10 @@ __device__ __forceinline__ void eliminate_knowns(double (&M)[N * (N + 1) / 2], d
             const double v = val[om];
 #pragma unroll
             for (int a = 0; a < N; ++a)
-                if (a != om) g[a] -= M[sym<N>(a, om)] * v;
+                if (a != om) {
+                    if constexpr (pin_fma(N)) g[a] = fma(-M[sym<N>(a, om)], v, g[a]);
+                    else g[a] -= M[sym<N>(a, om)] * v;
+                }
         }
     }
 #pragma unroll
