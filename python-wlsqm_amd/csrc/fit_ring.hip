@@ -97,6 +97,32 @@ __global__ __launch_bounds__(64, MINW) void fit_ring_kernel(const KParams p, con
         // one region per 64-neighbour part, so that the active lanes of every DMA are a PREFIX of the wave (with the parts
         // interleaved per row the compiler threads the repeated lane condition into two paths and issues the full-row DMAs
         // once for the low and once for the high lanes: wrong rows for K > 64, measured)
+#ifndef WLSQM_RING_IMM_OFFSETS
+#define WLSQM_RING_IMM_OFFSETS 1
+#endif
+        bool dma_done = false;
+#if defined(__HIP_DEVICE_COMPILE__)          // (the host pass drops the kernel's stub when it sees the non-zero immediate: device pass only)
+        if constexpr (WLSQM_RING_IMM_OFFSETS != 0 && G::PARTS == 1 && 3 * G::ROWB < 4096) {
+            if (nvalid == TC) {
+                // full tile: four per-lane base addresses (rows 0, 4, 8, 12) and the instruction's immediate offset for the three rows
+                // behind each (0 .. 3 ROWB < 4 KiB) instead of sixteen 64-bit multiply-adds; the immediate is added to the LDS address
+                // as well, so the LDS base handed to the instruction is the row's position MINUS the offset
+                if ((int)lane16 < G::ROWB) {
+#pragma unroll
+                    for (int g4 = 0; g4 < TC; g4 += 4) {
+                        const char* gb = xbase + (size_t)g4 * G::ROWB + lane16;
+                        char* lb = reinterpret_cast<char*>(dst + g4 * RS);
+                        __builtin_amdgcn_global_load_lds((ring_glb_ptr_t)gb, (ring_lds_ptr_t)(lb), 16, 0, 0);
+                        __builtin_amdgcn_global_load_lds((ring_glb_ptr_t)gb, (ring_lds_ptr_t)(lb + 1 * (RS * 8 - G::ROWB)), 16, 1 * G::ROWB, 0);
+                        __builtin_amdgcn_global_load_lds((ring_glb_ptr_t)gb, (ring_lds_ptr_t)(lb + 2 * (RS * 8 - G::ROWB)), 16, 2 * G::ROWB, 0);
+                        __builtin_amdgcn_global_load_lds((ring_glb_ptr_t)gb, (ring_lds_ptr_t)(lb + 3 * (RS * 8 - G::ROWB)), 16, 3 * G::ROWB, 0);
+                    }
+                }
+                dma_done = true;
+            }
+        }
+#endif
+        if (!dma_done)
 #pragma unroll
         for (int pp = 0; pp < G::PARTS; ++pp) {
             if ((pp + 1) * 1024 <= G::ROWB || pp * 1024 + (int)lane16 < G::ROWB) {
