@@ -214,7 +214,7 @@ __device__ __forceinline__ double taylor(const double (&d)[DIM], const FI& f) {
 
 }  // namespace strict
 
-__device__ __forceinline__ bool fit_strict_group_is_plain(const KParams& p, long long t, long long ncases);
+__device__ __forceinline__ bool fit_strict_group_is_plain(const KParams& p, long long t, long long ncases, long long want = 0);
 
 template <int DIM, int ORDER>
 __global__ __launch_bounds__(64) void fit_strict_kernel(const KParams p, const StrictDebug dbg, const int skip_plain_groups) {
@@ -226,7 +226,8 @@ __global__ __launch_bounds__(64) void fit_strict_kernel(const KParams p, const S
     if (skip_plain_groups) {
         // the register kernel takes the 64-case groups without any known DOF: this block's cases lie in group (block * LPW) / 64
         const long long g0 = ((long long)blockIdx.x * LPW) / 64 * 64;
-        if (fit_strict_group_is_plain(p, g0 + lane, live_cases(p))) return;
+        if (fit_strict_group_is_plain(p, g0 + lane, live_cases(p), 0)) return;
+        if (NO >= 2 && fit_strict_group_is_plain(p, g0 + lane, live_cases(p), 1)) return;      // the F-known register kernel has it
     }
     if (lane >= LPW) return;
     const long long t = (long long)blockIdx.x * LPW + lane;
@@ -506,23 +507,27 @@ __global__ __launch_bounds__(64) void fit_strict_kernel(const KParams p, const S
 // row exchange is written as selects over the candidate rows (N^3 / 3 of them: nothing against the ~8 Ruiz sweeps of N^2 IEEE
 // divides).  A workgroup with any known DOF, sensitivities, refinement or the debug capture runs the LDS kernel above; both
 // kernels are launched over the same 64-case groups and each group is taken by exactly one of them (fit_strict_group_is_plain).
-__device__ __forceinline__ bool fit_strict_group_is_plain(const KParams& p, long long t, long long ncases) {
-    // (block-uniform result; every thread of the 64-thread block must call it)
+__device__ __forceinline__ bool fit_strict_group_is_plain(const KParams& p, long long t, long long ncases, long long want) {
+    // (block-uniform result; every thread of the 64-thread block must call it): every case of the group has knowns == want
     bool mine = false;
     if (t < ncases) {
         const long long j = p.case_index ? p.case_index[t] : t;
-        mine = p.knowns[j * p.sknowns] != 0;
+        mine = p.knowns[j * p.sknowns] != want;
     }
     return __syncthreads_or(mine ? 1 : 0) == 0;
 }
 
-template <int DIM, int ORDER>
+// KN1: the groups whose 64 cases all have exactly the function value known (knowns = b?_F = 1, the reference's default mask): the
+// reduced system is DOFs 1 .. NO - 1, again with compile-time indices; the known value moves to the right-hand side term by term
+// in a third pass over the neighbours (it needs the row scales: impl.pyx:815-818 multiplies every term by row_scale[j]).
+template <int DIM, int ORDER, bool KN1>
 __global__ __launch_bounds__(64) void fit_strict_reg_kernel(const KParams p) {
     using namespace strict;
-    constexpr int N = ndofs(DIM, ORDER);
+    constexpr int NO = ndofs(DIM, ORDER);
+    constexpr int N = NO - (KN1 ? 1 : 0), O0 = KN1 ? 1 : 0;      // reduced size; reduced index i is DOF i + O0
     const long long ncases = live_cases(p);
     const long long t = (long long)blockIdx.x * 64 + threadIdx.x;
-    if (!fit_strict_group_is_plain(p, t, ncases)) return;        // a group with knowns: the LDS kernel has it
+    if (!fit_strict_group_is_plain(p, t, ncases, KN1 ? 1 : 0)) return;     // another kind of group: another kernel has it
     if (t >= ncases) return;
     const long long j = p.case_index ? p.case_index[t] : t;
     const int nk = min(p.nk[j * p.snk], (int)p.max_nk);
@@ -541,7 +546,7 @@ __global__ __launch_bounds__(64) void fit_strict_reg_kernel(const KParams p) {
     }
     double max_d2 = 0.;
     for (int k = 0; k < nk; ++k) {
-        double d[DIM], c[N];
+        double d[DIM], c[NO];
         rows.offset(k, xi, d);
         const double d2 = make_c<DIM, ORDER>(d, c);
         if (d2 > max_d2) max_d2 = d2;
@@ -553,19 +558,19 @@ __global__ __launch_bounds__(64) void fit_strict_reg_kernel(const KParams p) {
 #pragma unroll
         for (int m = 0; m < N; ++m) A[i][m] = 0.; }
     for (int k = 0; k < nk; ++k) {
-        double d[DIM], c[N];
+        double d[DIM], c[NO];
         rows.offset(k, xi, d);
         const double d2 = make_c<DIM, ORDER>(d, c);
         const double w = make_weight(d2, max_d2, uniform);
         const double wf = w * rows.value(k);
 #pragma unroll
         for (int om = 0; om < N; ++om) {
-            const double wc = w * c[om];
+            const double wc = w * c[om + O0];
 #pragma unroll
-            for (int oj = 0; oj < N; ++oj) A[oj][om] += wc * c[oj];
+            for (int oj = 0; oj < N; ++oj) A[oj][om] += wc * c[oj + O0];
         }
 #pragma unroll
-        for (int oj = 0; oj < N; ++oj) b[oj] += wf * c[oj];
+        for (int oj = 0; oj < N; ++oj) b[oj] += wf * c[oj + O0];
     }
     // rescale_ruiz2001_c (lapackdrivers.pyx:553-623)
     double rs[N], cs[N], DRp[N], DCp[N], DR[N], DC[N];
@@ -630,8 +635,22 @@ __global__ __launch_bounds__(64) void fit_strict_reg_kernel(const KParams p) {
         }
     }
     // solve (impl.pyx:731-846) without knowns: b = row_scale * sums, dgetrs('N'), un-scale
+    double* const fio = p.fi + j * p.sfi_j;
 #pragma unroll
     for (int i = 0; i < N; ++i) b[i] = rs[i] * b[i];
+    if constexpr (KN1) {
+        // the known function value moves to the right-hand side, term by term into b[j] (impl.pyx:792-818)
+        const double f0 = fio[0];
+        for (int k = 0; k < nk; ++k) {
+            double d[DIM], c[NO];
+            rows.offset(k, xi, d);
+            const double d2 = make_c<DIM, ORDER>(d, c);
+            const double w = make_weight(d2, max_d2, uniform);
+            const double fwc = f0 * w * c[0];
+#pragma unroll
+            for (int i = 0; i < N; ++i) b[i] -= fwc * c[i + O0] * rs[i];
+        }
+    }
 #pragma unroll
     for (int i = 0; i < N; ++i) {
 #pragma unroll
@@ -647,9 +666,8 @@ __global__ __launch_bounds__(64) void fit_strict_reg_kernel(const KParams p) {
 #pragma unroll
         for (int i = 0; i < c0; ++i) b[i] -= A[i][c0] * b[c0];
     }
-    double* const fio = p.fi + j * p.sfi_j;
 #pragma unroll
-    for (int i = 0; i < N; ++i) fio[i] = b[i] * cs[i];
+    for (int i = 0; i < N; ++i) fio[i + O0] = b[i] * cs[i];
 }
 
 constexpr int STRICT_REG_MAX_NO = 10;      // register kernel: systems up to this size (3D order 2 / 2D order 3: one wave per SIMD)
@@ -680,8 +698,12 @@ static int launch_strict(const KParams& p, const StrictDebug& dbg, hipStream_t s
         split = !p.do_sens && !p.iterative && !dbg.A && !dbg.w && !(e && e[0] == '1');
         if (split) {
             const long long groups = (p.ncases + 63) / 64;
-            hipLaunchKernelGGL((fit_strict_reg_kernel<DIM, ORDER>), dim3((unsigned)groups), dim3(64), 0, stream, p);
+            hipLaunchKernelGGL((fit_strict_reg_kernel<DIM, ORDER, false>), dim3((unsigned)groups), dim3(64), 0, stream, p);
             WLSQM_HIP_CHECK(hipGetLastError());
+            if constexpr (NO >= 2) {
+                hipLaunchKernelGGL((fit_strict_reg_kernel<DIM, ORDER, true>), dim3((unsigned)groups), dim3(64), 0, stream, p);
+                WLSQM_HIP_CHECK(hipGetLastError());
+            }
         }
     }
     hipLaunchKernelGGL((fit_strict_kernel<DIM, ORDER>), dim3((unsigned)blocks), dim3(64), lds, stream, p, dbg, split ? 1 : 0);

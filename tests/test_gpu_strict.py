@@ -216,3 +216,31 @@ def test_strict_mode_from_the_environment(tmp_path):
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     assert out.stdout.split()[-2:] == ["True", "strict"], out.stdout
+
+
+@pytest.mark.parametrize("name,mask_pattern", [("C2", "all1"), ("C5", "all1"), ("C2", "blocks"), ("X2", "all1")])
+def test_strict_register_kernels_with_the_default_knowns_mask(wlsqm, oracle, name, mask_pattern):
+    """The register-resident strict kernels: groups of 64 cases without knowns, groups with exactly F known (the reference's default
+    b?_F) and mixed groups (LDS kernel) in ONE launch — each group taken by exactly one kernel, every case equal to the oracle bit
+    for bit."""
+    import torch
+    import wlsqm.hip as whip
+    c = K.config(name)
+    dim, order, n, no = c["dim"], c["order"], c["n"], c["no"]
+    kn = np.ones(n, np.int64)
+    if mask_pattern == "blocks":
+        kn[:] = 0
+        kn[64:128] = 1                         # one whole group F-known
+        kn[128:192:3] = 1                      # a mixed group
+        kn[200] = 0b110                        # other masks
+        kn[300:364] = 1; kn[330] = 0           # almost uniform
+    fi0 = c["fi0"].copy()
+    fi0[:, 1:] = np.random.default_rng(3).uniform(-1, 1, (n, no - 1))      # values of knowns other than F matter for mask 0b110
+    xk = c["xk"] if dim > 1 else c["xk"][..., 0]
+    fi_d = _t(fi0)
+    whip.fit_many_device(dim, order, _t(xk), _t(c["fk"]), _t(c["nk_a"]), _t(c["xi"]), fi_d, _t(kn), _t(c["wm_a"]), strict=True)
+    torch.cuda.synchronize()
+    assert whip.last_kernel() == "strict"
+    fo = fi0.copy()
+    oracle.fit_many(dim, c["xk"], c["fk"], c["nk_a"], c["xi"], fo, None, 0, c["order_a"], kn, c["wm_a"])
+    assert_bits(fi_d.cpu().numpy(), fo, "%s strict, knowns pattern %s" % (name, mask_pattern))
