@@ -21,6 +21,7 @@
 // depending on the system size so that the image stays under 80-104 KB.  It is a correctness mode: 4-15x the time of the fast kernels
 // (DESIGN.md section 2), chosen per call or per process, never silently.
 #include <atomic>
+#include <type_traits>
 
 #include "wlsqm_internal.hpp"
 #include "wlsqm_kernels.hpp"
@@ -672,6 +673,356 @@ __global__ __launch_bounds__(64) void fit_strict_reg_kernel(const KParams p) {
 
 constexpr int STRICT_REG_MAX_NO = 10;      // register kernel: systems up to this size (3D order 2 / 2D order 3: one wave per SIMD)
 
+// ROW PER LANE: the same operations for the systems too large for the register kernel and for every call with knowns,
+// sensitivities or refinement.  A case is handled by LPC = 16 / 32 / 64 lanes; lane i of the group owns ROW i of the reduced
+// matrix (A[m] = entry (i, m), compile-time m) and element i of every per-case vector, so the matrix of a 14 x 14 system is 14
+// doubles per lane instead of an LDS image of 196 per case (which allowed 16 cases per workgroup: 74 ms per 1M fits of BASELINE
+// configs[2]).  No sum is split: entry (i, m) is still one sum over k ascending in one lane, and the only cross-lane steps are
+// order-free (maxima, with the reference's NaN rules spelled out below) or plain data movement: the column maxima of the
+// equilibration, the pivot search (first maximum wins), the exchange of two rows, and the broadcast of a pivot row / a solution
+// element.  The neighbours of a group (offsets, values, weights — each computed once, neighbour k by lane k mod LPC) sit in LDS
+// and are read back as broadcasts.  Loops whose trip count differs between the groups of a wave (neighbours, equilibration
+// sweeps, refinement passes) run to the wave's maximum with the finished groups frozen, because every lane takes part in the
+// shuffles.
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {       // unrolled in the front end: indices are constants before any pass runs
+    if constexpr (B < E) { f(std::integral_constant<int, B>{}); static_for<B + 1, E>(f); }
+}
+template <int LPC>
+__device__ __forceinline__ double grp_get(double v, int src) { return __shfl(v, src, LPC); }
+template <int LPC>
+__device__ __forceinline__ double grp_max(double v) {       // maximum over the group, never picking a NaN (`o > v` is false for it)
+#pragma unroll
+    for (int s = 1; s < LPC; s <<= 1) { const double o = __shfl_xor(v, s, LPC); if (o > v) v = o; }
+    return v;
+}
+template <int N>
+__device__ __forceinline__ double pick(const double (&c)[N], int a) {      // c[a] for a per-lane index, registers only
+    // (written on the bit patterns: a chain of selects on c[q] is turned into an indexed load from a scratch copy of c)
+    long long r = 0;
+#pragma unroll
+    for (int q = 0; q < N; ++q) r |= (a == q) ? __double_as_longlong(c[q]) : 0ll;
+    return __longlong_as_double(r);
+}
+
+template <int DIM, int ORDER, int LPC>
+__global__ __launch_bounds__(64) void fit_strict_rows_kernel(const KParams p, const int KP) {
+    using namespace strict;
+    constexpr int NO = ndofs(DIM, ORDER);
+    constexpr int G = 64 / LPC;                       // cases per wave
+    static_assert(NO <= LPC, "one lane per row");
+    extern __shared__ double smem[];
+    const int lane = threadIdx.x, g = lane / LPC, i = lane % LPC;
+    const long long ncases = live_cases(p);
+    const long long t = (long long)blockIdx.x * G + g;
+    const bool valid = t < ncases;
+    const long long j = valid ? (p.case_index ? p.case_index[t] : t) : 0;
+    // LDS of the group: w[KP], f[KP], res[KP], d[DIM][KP]; the pitch is odd in 8-byte words so that the G broadcast reads of one
+    // instruction fall into different banks
+    const int pitch = ((3 + DIM) * KP) | 1;
+    double* const sw = smem + (size_t)g * pitch;
+    double* const sf = sw + KP;
+    double* const sres = sf + KP;
+    double* const sd = sres + KP;
+
+    const int nk = valid ? min(p.nk[j * p.snk], (int)p.max_nk) : 0;
+    const bool uniform = valid && (p.wm[j * p.swm] == WLSQM_WEIGHT_UNIFORM);
+    const long long knowns = valid ? p.knowns[j * p.sknowns] : 0;
+    const int nr = NO - __popcll((unsigned long long)knowns);            // infra.pyx:119-121: bits >= no are not masked
+    const bool row = i < nr;                                             // this lane owns a row of the reduced system
+    // infra.pyx:145-200 (remap): reduced index i -> DOF, unknowns in ascending DOF order
+    int dof = 0;
+    {
+        int cnt = 0;
+#pragma unroll
+        for (int a = 0; a < NO; ++a) {
+            const bool unk = !((knowns >> a) & 1ll);
+            if (unk && cnt == i) dof = a;
+            cnt += unk ? 1 : 0;
+        }
+    }
+    int nkmax = nk;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) nkmax = max(nkmax, __shfl_xor(nkmax, s, 64));
+
+    double xi[DIM];
+    Rows<DIM> rows;
+    if (p.hoods) {
+        const long long pj = p.pidx ? p.pidx[j] : j;
+#pragma unroll
+        for (int m = 0; m < DIM; ++m) xi[m] = p.S[pj * DIM + m];
+        rows = Rows<DIM>{nullptr, 0, nullptr, 0, p.hoods + j * p.shoods_j, p.S, p.F};
+    } else {
+#pragma unroll
+        for (int m = 0; m < DIM; ++m) xi[m] = p.xi[j * p.sxi_j + m];
+        rows = Rows<DIM>{p.xk + j * p.sxk_j, p.sxk_k, p.fk + j * p.sfk_j, p.sfk_k, nullptr, nullptr, nullptr};
+    }
+    double* const fio = p.fi + j * p.sfi_j;
+
+    // ---- make_c pass 1 (neighbour k by lane k mod LPC): offsets and values into LDS, largest squared distance.  The reference's
+    // `if d2 > max_d2` skips NaNs and so does every step of the maximum here.
+    double max_d2 = 0.;
+    for (int k = i; k < nk; k += LPC) {
+        double d[DIM], c[NO];
+        rows.offset(k, xi, d);
+        const double d2 = make_c<DIM, ORDER>(d, c);
+        if (d2 > max_d2) max_d2 = d2;
+#pragma unroll
+        for (int m = 0; m < DIM; ++m) sd[m * KP + k] = d[m];
+        sf[k] = rows.value(k);
+    }
+    max_d2 = grp_max<LPC>(max_d2);
+    for (int k = i; k < nk; k += LPC) {
+        double d[DIM], c[NO];
+#pragma unroll
+        for (int m = 0; m < DIM; ++m) d[m] = sd[m * KP + k];
+        const double d2 = make_c<DIM, ORDER>(d, c);
+        sw[k] = make_weight(d2, max_d2, uniform);
+    }
+    __syncthreads();
+
+    // ---- make_A (impl.pyx:566-602), row `dof` of the FULL index set: entry (dof, om) = sum_k (w c_om) c_dof, k ascending, and the
+    // right-hand side sum of solve (impl.pyx:768-787); the reduced row is what is left after the known columns are deleted
+    double A[NO], b = 0.;
+#pragma unroll
+    for (int m = 0; m < NO; ++m) A[m] = 0.;
+    for (int k = 0; k < nkmax; ++k) {
+        if (k < nk) {
+            double d[DIM], c[NO];
+#pragma unroll
+            for (int m = 0; m < DIM; ++m) d[m] = sd[m * KP + k];
+            make_c<DIM, ORDER>(d, c);
+            const double w = sw[k];
+            const double cown = pick<NO>(c, dof);
+#pragma unroll
+            for (int om = 0; om < NO; ++om) { const double wc = w * c[om]; A[om] += wc * cown; }
+            const double wf = w * sf[k];
+            b += wf * cown;
+        }
+    }
+#pragma unroll
+    for (int a = NO - 1; a >= 0; --a) {          // delete column a where DOF a is known (from the top: the lower ones stay put)
+        const bool kn = (knowns >> a) & 1ll;
+#pragma unroll
+        for (int m = a; m < NO - 1; ++m) A[m] = kn ? A[m + 1] : A[m];
+    }
+#pragma unroll
+    for (int m = 0; m < NO; ++m) A[m] = (row && m < nr) ? A[m] : 0.;     // beyond the reduced system: zeros (never win a maximum)
+
+    // ---- rescale_ruiz2001_c (lapackdrivers.pyx:553-623) with init_scaling_c (:285-290).  Lane i keeps the row quantities of row i
+    // and the column quantities of column i.  q is the same double in the reference's row pass and column pass.
+    double rs = 1., cs = 1., DRp = 1., DCp = 1.;
+    {
+        bool live = valid && nr >= 1;
+        for (int it = 0; it < 100; ++it) {
+            double rowmax = 0., colmine = 0.;
+#pragma unroll
+            for (int m = 0; m < NO; ++m) {
+                const double dcp = grp_get<LPC>(DCp, m);
+                const double q = fabs(A[m] / (DRp * dcp));
+                if (q > rowmax) rowmax = q;
+                const double cm = grp_max<LPC>(q > 0. ? q : 0.);         // NaN -> 0: skipped like the reference's `q > cmax`
+                if (i == m) colmine = cm;
+            }
+            const double DR = row ? sqrt(rowmax) : 1., DC = row ? sqrt(colmine) : 1.;
+            if (live) { DRp *= DR; rs /= DR; DCp *= DC; cs /= DC; }
+            // stop test: max_i |1 - DR_i^2| < eps and the same for DC; the scan starts from element 0 and `tmp > acc` never replaces
+            // a NaN there (then acc < eps is false): element 0's NaN counts as +inf, any other NaN is skipped
+            double tr = fabs(1. - DR * DR), tc = fabs(1. - DC * DC);
+            const double inf = __longlong_as_double(0x7ff0000000000000LL);
+            if (tr != tr) tr = (i == 0) ? inf : 0.;
+            if (tc != tc) tc = (i == 0) ? inf : 0.;
+            const double acc = grp_max<LPC>(row ? (tr > tc ? tr : tc) : 0.);
+            if (acc < ruiz_epsilon) live = false;
+            if (!__any(live)) break;
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < NO; ++m) { const double csm = grp_get<LPC>(cs, m); A[m] *= (rs * csm); }   // apply_scaling_c (:293-299)
+
+    // ---- dgetrf (lapackdrivers.pyx:1628-1635; dgetf2: first maximal |a_ik|, column scaled by the reciprocal pivot)
+    int ipiv[NO];
+    static_for<0, NO>([&](auto C0) {
+        constexpr int c0 = decltype(C0)::value;
+        const bool step = c0 < nr;
+        // candidates: rows c0 .. nr-1.  The scan keeps the first value unless a later one is GREATER: a NaN in row c0 stays (as
+        // +inf here, the smaller index winning ties), a NaN elsewhere never wins (-1: below every |a|)
+        double v = fabs(A[c0]);
+        if (i < c0 || !row) v = -1.;
+        else if (v != v) v = (i == c0) ? __longlong_as_double(0x7ff0000000000000LL) : -1.;
+        int pv = i;
+#pragma unroll
+        for (int s = 1; s < LPC; s <<= 1) {
+            const double ov = __shfl_xor(v, s, LPC);
+            const int oi = __shfl_xor(pv, s, LPC);
+            if (ov > v || (ov == v && oi < pv)) { v = ov; pv = oi; }
+        }
+        if (!step) pv = c0;
+        ipiv[c0] = pv;
+        const double pval = grp_get<LPC>(A[c0], pv);
+        const bool nz = step && pval != 0.;
+        const bool sw2 = nz && pv != c0;
+        if (__any(sw2)) {
+            const int src = (i == c0) ? pv : (i == pv) ? c0 : i;
+#pragma unroll
+            for (int m = 0; m < NO; ++m) { const double o = grp_get<LPC>(A[m], src); A[m] = sw2 ? o : A[m]; }
+        }
+        const double r = 1. / pval;
+        const bool below = step && row && i > c0;
+        if (nz && below) A[c0] *= r;
+#pragma unroll
+        for (int m = c0 + 1; m < NO; ++m) {
+            const double u = grp_get<LPC>(A[m], c0);
+            if (below) A[m] -= A[c0] * u;
+        }
+    });
+    // dgetrs('N') (lapackdrivers.pyx:1657-1665) on the group's vector (element i in lane i)
+    auto lu_solve = [&](double x) __attribute__((always_inline)) -> double {
+        static_for<0, NO>([&](auto C0) {
+            constexpr int c0 = decltype(C0)::value;
+            const int pv = ipiv[c0];
+            const bool sw2 = c0 < nr && pv != c0;
+            if (__any(sw2)) {
+                const int src = (i == c0) ? pv : (i == pv) ? c0 : i;
+                const double o = grp_get<LPC>(x, src);
+                x = sw2 ? o : x;
+            }
+        });
+#pragma unroll
+        for (int c0 = 0; c0 < NO; ++c0) {
+            const double bj = grp_get<LPC>(x, c0);
+            if (c0 < nr && row && i > c0) x -= A[c0] * bj;
+        }
+#pragma unroll
+        for (int c0 = NO - 1; c0 >= 0; --c0) {
+            if (i == c0) x = x / A[c0];
+            const double bj = grp_get<LPC>(x, c0);
+            if (c0 < nr && i < c0) x -= A[c0] * bj;
+        }
+        return x;
+    };
+
+    // ---- solve (impl.pyx:731-846): `sum` is this row's sum_k (w rhs_k) c_k, `fin(om)` the known values; returns b * col_scale
+    auto finish = [&](double sum, auto&& fin) __attribute__((always_inline)) -> double {
+        double x = rs * sum;
+        // knowns move to the right-hand side, term by term (impl.pyx:792-818)
+#pragma unroll 1
+        for (int om = 0; om < NO; ++om) {
+            const bool kn = (knowns >> om) & 1ll;
+            if (!__any(kn)) continue;
+            const double fom = kn ? fin(om) : 0.;
+            for (int k = 0; k < nkmax; ++k) {
+                if (kn && k < nk) {
+                    double d[DIM], c[NO];
+#pragma unroll
+                    for (int m = 0; m < DIM; ++m) d[m] = sd[m * KP + k];
+                    make_c<DIM, ORDER>(d, c);
+                    const double fwc = fom * sw[k] * pick<NO>(c, om);
+                    x -= fwc * pick<NO>(c, dof) * rs;
+                }
+            }
+        }
+        x = lu_solve(x);
+        return x * cs;
+    };
+    double x = finish(b, [&](int om) { return fio[om]; });
+
+    // ---- sensitivities (impl.pyx:776-778, 821-846): one dgetrs per neighbour
+    if (p.do_sens && p.sens) {
+        double* const sr = p.sens + j * p.ss_j;
+        for (int k = 0; k < nkmax; ++k) {
+            double d[DIM], c[NO];
+            const int kk = k < nk ? k : 0;
+#pragma unroll
+            for (int m = 0; m < DIM; ++m) d[m] = sd[m * KP + kk];
+            make_c<DIM, ORDER>(d, c);
+            double s = rs * sw[kk] * pick<NO>(c, dof);
+            s = lu_solve(s);
+            if (valid && nr >= 1 && k < nk) {
+                if (row) sr[k * p.ss_k + dof] = s * cs;
+                if (i < NO && ((knowns >> i) & 1ll)) sr[k * p.ss_k + i] = __longlong_as_double(0x7ff8000000000000LL);
+            }
+        }
+    }
+
+    if (!p.iterative) {
+        if (valid && row) fio[dof] = x;
+        return;
+    }
+
+    // ---- solve_iterative (impl.pyx:986-1083).  Every lane keeps the case's whole fi (the model needs all of it): the user's
+    // row with the unknowns just solved.  Reduced index of DOF a = number of unknown DOFs below it.
+    double FI[NO];
+    auto spread = [&](double xr, bool add, bool apply) __attribute__((always_inline)) {       // every lane takes part in the shuffles; `apply` guards the update
+        int cnt = 0;
+#pragma unroll
+        for (int a = 0; a < NO; ++a) {
+            const bool unk = !((knowns >> a) & 1ll);
+            const double o = grp_get<LPC>(xr, cnt < LPC ? cnt : 0);
+            if (apply && unk && cnt < nr) FI[a] = add ? FI[a] + o : o;
+            cnt += unk ? 1 : 0;
+        }
+    };
+#pragma unroll
+    for (int a = 0; a < NO; ++a) FI[a] = valid ? fio[a] : 0.;
+    spread(x, false, true);
+    double prev_norm = -1.;
+    int iters = 0;
+    bool live = valid && nr >= 1, broke = false;
+    if (nr < 1) {
+        // impl.pyx:1026-1081 with every solve a no-op: the second pass finds the first pass's norm and stops (count 1) — unless
+        // the norm is NaN, which equals nothing: then all max_iter passes run.  It is NaN iff res[0] is.
+        iters = 1;
+        if (nk > 0 && p.max_iter > 1) {
+            double d0[DIM];
+#pragma unroll
+            for (int m = 0; m < DIM; ++m) d0[m] = sd[m * KP + 0];
+            const double res0 = sf[0] - taylor<DIM, ORDER>(d0, [&](int a) { return FI[a]; });
+            if (res0 != res0) iters = p.max_iter;
+        }
+    }
+    for (int it = 0; it < p.max_iter; ++it) {
+        if (!__any(live)) break;
+        // residuals (neighbour k by lane k mod LPC) and their maximum norm (impl.pyx:1037-1057): the scan starts from res[0] and
+        // `ar > norm` neither replaces nor picks a NaN
+        double norm = 0.;
+        bool nan0 = false;
+        for (int k = i; k < nk; k += LPC) {
+            double d[DIM];
+#pragma unroll
+            for (int m = 0; m < DIM; ++m) d[m] = sd[m * KP + k];
+            const double res = sf[k] - taylor<DIM, ORDER>(d, [&](int a) { return FI[a]; });
+            sres[k] = res;
+            const double ar = fabs(res);
+            if (k == 0 && ar != ar) nan0 = true;
+            if (ar > norm) norm = ar;
+        }
+        norm = grp_max<LPC>(norm);
+        if (__shfl(nan0 ? 1 : 0, 0, LPC)) norm = __longlong_as_double(0x7ff8000000000000LL);
+        __syncthreads();
+        if (live && norm == prev_norm) { live = false; broke = true; iters = it; }
+        prev_norm = norm;
+        // the correction: the same solve on the residual, knowns of the correction are zero (impl.pyx:1015-1017)
+        double sum = 0.;
+        for (int k = 0; k < nkmax; ++k) {
+            if (k < nk) {
+                double d[DIM], c[NO];
+#pragma unroll
+                for (int m = 0; m < DIM; ++m) d[m] = sd[m * KP + k];
+                make_c<DIM, ORDER>(d, c);
+                const double wf = sw[k] * sres[k];
+                sum += wf * pick<NO>(c, dof);
+            }
+        }
+        const double dx = finish(sum, [&](int) { return 0.; });
+        spread(dx, true, live);
+        __syncthreads();
+    }
+    if (nr >= 1) iters = broke ? iters : (p.max_iter > 0 ? p.max_iter : 1);      // for/else, impl.pyx:1080-1081
+    if (valid && row) fio[dof] = pick<NO>(FI, dof);
+    if (valid && i == 0 && p.iters_out) atomicMax(p.iters_out, iters);
+}
+
 template <int DIM, int ORDER>
 static int launch_strict(const KParams& p, const StrictDebug& dbg, hipStream_t stream) {
     constexpr int NO = ndofs(DIM, ORDER);
@@ -689,6 +1040,27 @@ static int launch_strict(const KParams& p, const StrictDebug& dbg, hipStream_t s
             WLSQM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&fit_strict_kernel<DIM, ORDER>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             optin[dev] = true;
+        }
+    }
+    // row-per-lane kernel: the larger systems always, the small ones whenever the register kernel does not apply to the call
+    // (sensitivities, refinement) — unless the neighbour rows do not fit the LDS or the intermediates are captured
+    {
+        constexpr int LPC = NO <= 8 ? 8 : NO <= 16 ? 16 : NO <= 32 ? 32 : 64;
+        const char* e = getenv("WLSQM_HIP_STRICT_NO_ROWS");
+        const int KP = p.max_nk > 0 ? (int)p.max_nk : 1;
+        const size_t rl = (size_t)((((3 + DIM) * KP) | 1) * (64 / LPC)) * sizeof(double);
+        const bool want = NO > STRICT_REG_MAX_NO || p.do_sens || p.iterative;
+        if (want && !dbg.A && !dbg.w && !dbg.LU && rl <= 160 * 1024 && !(e && e[0] == '1')) {
+            if (rl > 64 * 1024) {
+                WLSQM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&fit_strict_rows_kernel<DIM, ORDER, LPC>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl));
+            }
+            const long long wgs = (p.ncases + (64 / LPC) - 1) / (64 / LPC);
+            if (wgs > 0x7fffffffLL) { set_error("too many cases for one launch"); return WLSQM_EVALUE; }
+            hipLaunchKernelGGL((fit_strict_rows_kernel<DIM, ORDER, LPC>), dim3((unsigned)wgs), dim3(64), rl, stream, p, KP);
+            WLSQM_HIP_CHECK(hipGetLastError());
+            note_kernel("strict-rows");
+            return WLSQM_OK;
         }
     }
     // basic fits of the small systems: the all-unknown 64-case groups run the register kernel, the others the LDS kernel
