@@ -16,10 +16,14 @@
 //   solve / solve_contig impl.pyx:731-974                     RHS, knowns elimination term by term, dgetrs, un-scaling, do_sens
 //   solve_iterative      impl.pyx:986-1083                    refinement with the FMA Horner model of polyeval.pyx
 //
-// Mapping: one lane per case (no sum is ever split), the reduced matrix and every per-case vector in LDS as [slot][lane]
-// (conflict-free for any per-lane row index: the pivot row of a lane is data-dependent), 64 / 32 / 16 / 8 cases per workgroup
-// depending on the system size so that the image stays under 80-104 KB.  It is a correctness mode: 4-15x the time of the fast kernels
-// (DESIGN.md section 2), chosen per call or per process, never silently.
+// Three mappings of the same operations (no sum is ever split in any of them):
+//   fit_strict_reg_kernel   one lane per case, everything in registers: basic fits of systems up to 10 unknowns, 64-case groups
+//                           without knowns or with exactly F known
+//   fit_strict_rows_kernel  one lane per matrix ROW (a case on 2..64 lanes), neighbours in LDS: the larger systems, sensitivities,
+//                           refinement
+//   fit_strict_kernel       one lane per case with the reduced matrix and every per-case vector in LDS as [slot][lane]: the rest
+//                           (mixed groups, neighbourhoods beyond the LDS, capture of the intermediates)
+// It is a correctness mode: 5-20x the time of the fast kernels, chosen per call or per process, never silently.
 #include <atomic>
 #include <type_traits>
 
@@ -690,19 +694,40 @@ __device__ __forceinline__ void static_for(F&& f) {       // unrolled in the fro
 }
 template <int LPC>
 __device__ __forceinline__ double grp_get(double v, int src) { return __shfl(v, src, LPC); }
+// Lane permutations inside a row of 16 lanes as DPP moves (vector ALU, no LDS pipe)
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// maximum over the group for values that are never NaN (callers map NaN away first)
 template <int LPC>
-__device__ __forceinline__ double grp_max(double v) {       // maximum over the group, never picking a NaN (`o > v` is false for it)
+__device__ __forceinline__ double grp_max(double v) {
+    if constexpr (LPC >= 2) v = fmax(v, dpp_move<0xB1>(v));        // quad_perm [1,0,3,2]
+    if constexpr (LPC >= 4) v = fmax(v, dpp_move<0x4E>(v));        // quad_perm [2,3,0,1]
+    if constexpr (LPC >= 8) v = fmax(v, dpp_move<0x141>(v));       // row_half_mirror: lane i <-> 7 - i of each 8
+    if constexpr (LPC >= 16) v = fmax(v, dpp_move<0x140>(v));      // row_mirror: lane i <-> 15 - i of each 16
 #pragma unroll
-    for (int s = 1; s < LPC; s <<= 1) { const double o = __shfl_xor(v, s, LPC); if (o > v) v = o; }
+    for (int s = 16; s < LPC; s <<= 1) v = fmax(v, __shfl_xor(v, s, LPC));
     return v;
 }
+// c[a] for a per-lane index, registers only: a binary tree of selects on the bits of a.  (A chain of `a == q ? c[q] : r` is
+// turned into an indexed load from a scratch copy of c by the optimizer.)
 template <int N>
-__device__ __forceinline__ double pick(const double (&c)[N], int a) {      // c[a] for a per-lane index, registers only
-    // (written on the bit patterns: a chain of selects on c[q] is turned into an indexed load from a scratch copy of c)
-    long long r = 0;
+__device__ __forceinline__ double pick(const double (&c)[N], int a) {
+    constexpr int P = N <= 1 ? 1 : N <= 2 ? 2 : N <= 4 ? 4 : N <= 8 ? 8 : N <= 16 ? 16 : N <= 32 ? 32 : 64;
+    long long t[P];
 #pragma unroll
-    for (int q = 0; q < N; ++q) r |= (a == q) ? __double_as_longlong(c[q]) : 0ll;
-    return __longlong_as_double(r);
+    for (int q = 0; q < P; ++q) t[q] = __double_as_longlong(c[q < N ? q : N - 1]);
+#pragma unroll
+    for (int w = P / 2, bit = 0; w >= 1; w >>= 1, ++bit) {
+        const bool odd = (a >> bit) & 1;
+#pragma unroll
+        for (int q = 0; q < w; ++q) t[q] = odd ? t[2 * q + 1] : t[2 * q];
+    }
+    return __longlong_as_double(t[0]);
 }
 
 template <int DIM, int ORDER, int LPC>
@@ -906,10 +931,10 @@ __global__ __launch_bounds__(64) void fit_strict_rows_kernel(const KParams p, co
     auto finish = [&](double sum, auto&& fin) __attribute__((always_inline)) -> double {
         double x = rs * sum;
         // knowns move to the right-hand side, term by term (impl.pyx:792-818)
-#pragma unroll 1
-        for (int om = 0; om < NO; ++om) {
+        static_for<0, NO>([&](auto OM) {
+            constexpr int om = decltype(OM)::value;
             const bool kn = (knowns >> om) & 1ll;
-            if (!__any(kn)) continue;
+            if (!__any(kn)) return;
             const double fom = kn ? fin(om) : 0.;
             for (int k = 0; k < nkmax; ++k) {
                 if (kn && k < nk) {
@@ -917,11 +942,11 @@ __global__ __launch_bounds__(64) void fit_strict_rows_kernel(const KParams p, co
 #pragma unroll
                     for (int m = 0; m < DIM; ++m) d[m] = sd[m * KP + k];
                     make_c<DIM, ORDER>(d, c);
-                    const double fwc = fom * sw[k] * pick<NO>(c, om);
+                    const double fwc = fom * sw[k] * c[om];
                     x -= fwc * pick<NO>(c, dof) * rs;
                 }
             }
-        }
+        });
         x = lu_solve(x);
         return x * cs;
     };
@@ -1045,7 +1070,7 @@ static int launch_strict(const KParams& p, const StrictDebug& dbg, hipStream_t s
     // row-per-lane kernel: the larger systems always, the small ones whenever the register kernel does not apply to the call
     // (sensitivities, refinement) — unless the neighbour rows do not fit the LDS or the intermediates are captured
     {
-        constexpr int LPC = NO <= 8 ? 8 : NO <= 16 ? 16 : NO <= 32 ? 32 : 64;
+        constexpr int LPC = NO <= 2 ? 2 : NO <= 4 ? 4 : NO <= 8 ? 8 : NO <= 16 ? 16 : NO <= 32 ? 32 : 64;
         const char* e = getenv("WLSQM_HIP_STRICT_NO_ROWS");
         const int KP = p.max_nk > 0 ? (int)p.max_nk : 1;
         const size_t rl = (size_t)((((3 + DIM) * KP) | 1) * (64 / LPC)) * sizeof(double);
