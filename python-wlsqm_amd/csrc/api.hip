@@ -33,6 +33,7 @@ int launch_fit_tile(int dimension, int order, const KParams& p, long long max_nk
 int launch_fit_wave(int dimension, int order, const KParams& p, hipStream_t stream);
 int launch_fit_moment(int dimension, int order, const KParams& p, long long max_nk, hipStream_t stream, bool* handled);
 int launch_fit_ring(int dimension, int order, const KParams& p, long long max_nk, hipStream_t stream, bool* handled);
+int launch_fit_ring_gather(int dimension, int order, const KParams& p, long long max_nk, hipStream_t stream, bool* handled);
 int launch_fit_tilek(int dimension, int order, const KParams& p, long long max_nk, hipStream_t stream, bool* handled);
 long long preferred_slots(int dimension, int order, long long max_nk);
 int launch_fit_rows(int dimension, int order, const KParams& p, hipStream_t stream, bool* handled);
@@ -174,6 +175,8 @@ int launch_fit(int dimension, int order, const KParams& p_in, long long max_nk, 
     }
     bool handled = false;
     int rc = launch_fit_ring(dimension, order, p, max_nk, stream, &handled);      // one-kernel fit of the 15-unknown systems
+    if (rc != WLSQM_OK || handled) return rc;
+    rc = launch_fit_ring_gather(dimension, order, p, max_nk, stream, &handled);   // the same on index-based input (2D order 4)
     if (rc != WLSQM_OK || handled) return rc;
     rc = launch_fit_moment(dimension, order, p, max_nk, stream, &handled);
     if (rc != WLSQM_OK || handled) return rc;

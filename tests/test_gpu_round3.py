@@ -299,3 +299,43 @@ def test_example_harness_index_based_and_strict(wlsqm, oracle):
     fo = fi0.copy()
     oracle.fit_many(2, xk, fk, nk, S, fo, None, 0, o, kn, w, ntasks=8)
     assert np.array_equal(fi_s.cpu().numpy(), fo)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Kn", [26, 40, 64])
+@pytest.mark.parametrize("pad", [-1, "npoints"])
+def test_index_based_2d_order4_runs_the_one_kernel_ring(wlsqm, oracle, Kn, pad):
+    """index-based 2D order 4 (the reference's harness layout, examples/wlsqm_example.py:103-133) in ONE kernel:
+    the LDS ring filled by per-lane DMA gathers from the point table.  Ragged neighbourhoods with scipy-style padding, point_index,
+    mixed knowns masks, a tail tile: same bits as the dense ring kernel on the gathered rows (it IS the same arithmetic once the
+    ring is filled), parity with the oracle, and the padding never dereferenced."""
+    import torch
+    import synth
+    import wlsqm.hip as whip
+    rng = np.random.default_rng(Kn)
+    npts, n = 6000, 4091                                      # 255 full tiles + a tail tile of 11 cases
+    S = synth.halton(npts, 2); F = synth.field(S)
+    pidx = rng.permutation(npts)[:n].astype(np.int32)
+    hoods = synth.knn(S, Kn, query=pidx).astype(np.int32)
+    nk = rng.integers(17, Kn + 1, n).astype(np.int32); nk[::3] = Kn
+    hp = hoods.copy(); hp[np.arange(Kn)[None, :] >= nk[:, None]] = npts if pad == "npoints" else pad
+    kn = rng.choice(np.array([0, wlsqm.b2_F, wlsqm.b2_F | wlsqm.b2_X2, 1 << 14], np.int64), n)
+    w = rng.choice(np.array([wlsqm.WEIGHT_UNIFORM, wlsqm.WEIGHT_CENTER], np.int32), n)
+    fi0 = rng.uniform(-1, 1, (n, 15)); fi0[:, 0] = F[pidx]
+    fi = _t(fi0)
+    whip.fit_cloud_device(2, 4, _t(S), _t(F), _t(hp), fi, _t(nk), _t(kn), _t(w), point_index=_t(pidx))
+    torch.cuda.synchronize()
+    assert whip.last_kernel() == "tile-solve-gather", whip.last_kernel()
+    got = fi.cpu().numpy()
+    hc = np.where(np.arange(Kn)[None, :] < nk[:, None], hoods, 0).astype(np.int64)
+    xk, fk, xi = S[hc], F[hc], S[pidx]
+    fd = _t(fi0)
+    whip.fit_many_device(2, 4, _t(xk), _t(fk), _t(nk), _t(xi), fd, _t(kn), _t(w))
+    torch.cuda.synchronize()
+    assert whip.last_kernel() == "tile-solve", whip.last_kernel()
+    assert np.array_equal(got.view(np.int64), fd.cpu().numpy().view(np.int64)), "gathered ring != dense ring on the same rows"
+    o = np.full(n, 4, np.int32)
+    ref = fi0.copy()
+    oracle.fit_many(2, xk, fk, nk, xi, ref, None, 0, o, kn, w, ntasks=8)
+    truth = P.truth_fit(2, xk, fk, nk, xi, fi0, o, kn, w)
+    P.assert_parity(got, ref, truth, "index-based ring K = %d" % Kn)

@@ -6,7 +6,7 @@
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
 FILES=("$@")
-if (( ${#FILES[@]} == 0 )); then FILES=(fit_tile.hip fit_ring.hip solve_op.hip fit_chunk.hip fit_strict.hip fit_rows.hip fit_tilek.hip); fi
+if (( ${#FILES[@]} == 0 )); then FILES=(fit_tile.hip fit_ring.hip fit_ring_gather.hip solve_op.hip fit_chunk.hip fit_strict.hip fit_rows.hip fit_tilek.hip); fi
 FILTER="${ISA_FILTER:-.}"
 for f in "${FILES[@]}"; do
   src="$HERE/python-wlsqm_amd/csrc/$f"
