@@ -671,6 +671,55 @@ def emit(full):
     print(json.dumps(compact_line(full, path), separators=(",", ":")), flush=True)
 
 
+def measure_cloud(name, cfg, n, dev, timer, steps, warmup, rank):
+    """One BASELINE shape through the INDEX-BASED device API (wlsqm.hip.fit_cloud_device: point tables S, F + int32 neighbour lists;
+    the kernels gather the rows themselves), points ordered along a Morton curve so that the gathers of a tile stay in L2.
+    Reported with the index-based bytes (never mixed with the dense-layout metric) plus the rate of the gathered rows."""
+    import torch
+    import wlsqm.hip as whip
+    dim, order, nk = cfg["dim"], cfg["order"], cfg["nk"]
+    no = NDOF[dim][order]
+    S, F, hoods = build_problem(cfg, n, rank, device=dev)
+    S_d = torch.from_numpy(np.ascontiguousarray(S)).to(dev)
+    perm = morton_order_device(S_d)
+    inv = torch.empty_like(perm); inv[perm] = torch.arange(n, device=dev, dtype=perm.dtype)
+    S_d = S_d[perm].contiguous()
+    F_d = torch.from_numpy(F).to(dev)[perm].contiguous()
+    h_d = inv[torch.from_numpy(hoods).to(dev)[perm].long()].to(torch.int32).contiguous()
+    del perm, inv
+    nk_d = torch.full((n,), nk, dtype=torch.int32, device=dev)
+    kn_d = torch.full((n,), cfg["knowns"], dtype=torch.int64, device=dev)
+    wm_d = torch.full((n,), cfg["wm"], dtype=torch.int32, device=dev)
+    fi_d = torch.zeros((n, no), dtype=torch.float64, device=dev); fi_d[:, 0] = F_d
+    args = (dim, order, S_d, F_d, h_d, fi_d, nk_d, kn_d, wm_d)
+    dt = timer.run(lambda: whip.fit_cloud_device(*args), steps, warmup)
+    kernel = whip.last_kernel()
+    ms_kernel = whip.time_fit_cloud_device(*args, reps=min(max(steps, 20), 200))
+    B_fit = bytes_per_fit_indexed(dim, order, nk)
+    achieved = B_fit * n / (ms_kernel * 1e-3) / 1e9
+    res = {"workload": "%s index-based: %s; %d local fits per GPU per step from device-resident point tables (Morton order) + int32 "
+                       "neighbour lists" % (name, cfg["desc"], n),
+           "fits_per_gpu": n, "bytes_per_fit": B_fit, "ms_per_step": dt / steps * 1e3, "fits_per_s": n * steps / dt,
+           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                        "traffic": None, "traffic_source": None, "kernel_ms": ms_kernel, "kernel": kernel,
+                        "gathered_bytes_per_fit": 8 * nk * (dim + 1),
+                        "gather_rate_GBps": 8 * nk * (dim + 1) * n / (ms_kernel * 1e-3) / 1e9,
+                        "note": "index-based bytes (4 nk + 8 (dim+1) + 8 no + 20 per fit): not an HBM-bound kernel — the 8 nk (dim+1) "
+                                "bytes per fit of neighbour rows are gathered from the point tables through L2 (gather_rate_GBps)"}}
+    if rank == 0:
+        # the same cases as dense rows through the dense kernel of the shape: the gather ring is the dense ring once it is filled
+        m = min(n, 4096)
+        hh = h_d[:m].long()
+        fa = torch.zeros((m, no), dtype=torch.float64, device=dev); fa[:, 0] = F_d[:m]
+        fb = fa.clone()
+        whip.fit_cloud_device(dim, order, S_d, F_d, h_d[:m], fa, nk_d[:m], kn_d[:m], wm_d[:m])
+        whip.fit_many_device(dim, order, S_d[hh].contiguous(), F_d[hh].contiguous(), nk_d[:m], S_d[:m].contiguous(), fb, kn_d[:m], wm_d[:m])
+        torch.cuda.synchronize()
+        res["parity"] = {"vs_dense_kernel": {"cases": m, "dense_kernel": whip.last_kernel(), "bit_identical": bool(torch.equal(fa, fb)),
+                                             "max_abs_diff": float((fa - fb).abs().max())}}
+    return res, dt
+
+
 def side_configs(a, dev, timer, rank, parity):
     """Every other BASELINE config with the same --steps / --warmup (single GPU).  Each entry carries its own roofline block."""
     import copy
@@ -708,6 +757,9 @@ def side_configs(a, dev, timer, rank, parity):
         line = run_sharded(b, dev, None, rank, 1, timer, parity)
         return {k: line[k] for k in ("config", "steps", "ms_per_step", "value", "roofline", "sharded", "parity") if k in line}
     add("C5-sharded@2M-per-rank", sharded)
+    # index-based input of configs[2]'s shape (the one-kernel gather ring); last, so that the order of the earlier entries is the one
+    # of the earlier rounds' records
+    add("C3-indexed@1M", lambda: measure_cloud("C3", CONFIGS["C3"], 1_000_000, dev, timer, short["steps"], short["warmup"], rank))
     return side
 
 
