@@ -30,6 +30,10 @@
 #include "wlsqm_internal.hpp"
 #include "wlsqm_kernels.hpp"
 
+#ifndef WLSQM_OP_NT
+#define WLSQM_OP_NT 0      // A/B: 1 = non-temporal loads of the fields, 2 = non-temporal stores of the results, 3 = both
+#endif
+
 namespace wlsqm {
 
 constexpr int OP_ROWS = 16;       // rows of the MFMA's A operand (no <= 15 padded); the STORED operator has `no` rows per case, DOF order
@@ -181,7 +185,11 @@ __global__ __launch_bounds__(64 * WPG) void solve_op_mfma_kernel(const OpParams 
                 // pieces beyond the fk row (K not a multiple of 8) replay the row's first pair: their operator columns are zero and
                 // the ragged mask below clears them
                 const int e = 8 * s + 2 * q;
+#if (WLSQM_OP_NT & 1)
+                const od2_ v = __builtin_nontemporal_load(reinterpret_cast<const od2_*>(src + (e < P.K ? e : 0)));
+#else
                 const od2_ v = *reinterpret_cast<const od2_*>(src + (e < P.K ? e : 0));
+#endif
                 B[2 * s] = v.x; B[2 * s + 1] = v.y;
             }
         };
@@ -230,7 +238,11 @@ __global__ __launch_bounds__(64 * WPG) void solve_op_mfma_kernel(const OpParams 
                 const int a = e - row * no;
                 const int f = row / WPG, cs = row - f * WPG;                    // WPG is a power of two
                 if (!((smask[cs] >> a) & 1ull) && !(P.dbg & 1))
+#if (WLSQM_OP_NT & 2)
+                    __builtin_nontemporal_store(out[e + f * (runp - run)], &P.fi[(r0 + f) * P.sfi_r + (j0 + cs) * P.sfi_j + a]);
+#else
                     P.fi[(r0 + f) * P.sfi_r + (j0 + cs) * P.sfi_j + a] = out[e + f * (runp - run)];
+#endif
             };
             if (no <= 8) {
                 const int e0 = (int)threadIdx.x, e1 = e0 + 64 * WPG;

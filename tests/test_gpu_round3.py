@@ -339,3 +339,4 @@ def test_index_based_2d_order4_runs_the_one_kernel_ring(wlsqm, oracle, Kn, pad):
     oracle.fit_many(2, xk, fk, nk, xi, ref, None, 0, o, kn, w, ntasks=8)
     truth = P.truth_fit(2, xk, fk, nk, xi, fi0, o, kn, w)
     P.assert_parity(got, ref, truth, "index-based ring K = %d" % Kn)
+
