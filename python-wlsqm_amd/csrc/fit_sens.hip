@@ -27,6 +27,10 @@
 #include "wlsqm_internal.hpp"
 #include "wlsqm_kernels.hpp"
 
+#ifndef WLSQM_SENS_NT
+#define WLSQM_SENS_NT 1      // non-temporal stores of the sensitivities' 16-byte pieces (written once, never read here): 400k cases of 2D order 4, K = 50: 1.39-1.42 against 1.45-1.46 ms, K = 64: 1.54-1.56 against 1.56-1.60 (profiles/r03i_ab_sens_nt.txt)
+#endif
+
 namespace wlsqm {
 
 bool chunk_inverse_ok(int dimension, int order, const KParams& p, long long K);
@@ -212,7 +216,11 @@ __global__ __launch_bounds__(64) void sens_apply_kernel(const KParams p, const d
 #pragma unroll
                 for (int q0 = 0; q0 < IMG * 16 * NO / 2; q0 += WV) {
                     const int q = q0 + lane;
+#if WLSQM_SENS_NT
+                    if (2 * q + 1 < total) __builtin_nontemporal_store(*reinterpret_cast<const sd2_*>(img + 2 * q), reinterpret_cast<sd2_*>(run + 2 * q));
+#else
                     if (2 * q + 1 < total) *reinterpret_cast<sd2_*>(run + 2 * q) = *reinterpret_cast<const sd2_*>(img + 2 * q);
+#endif
                     else if (2 * q < total) run[2 * q] = img[2 * q];
                 }
             }

@@ -14,6 +14,10 @@
 #include "wlsqm_moments.hpp"
 #include "wlsqm_tile1.hpp"
 
+#ifndef WLSQM_TILEK_SENS_NT
+#define WLSQM_TILEK_SENS_NT 1      // non-temporal stores of the sensitivities' slabs (written once): 1M cases with do_sens, 3D order 2 / 40: 1.62-1.64 against 1.72-1.74 ms; 2D order 2 / 32: 0.61-0.65 against 0.63-0.66 (profiles/r03i_ab_tilek_nt.txt)
+#endif
+
 namespace wlsqm {
 
 constexpr int KW = 64, KSP = 4, KNT = KW * KSP, KROUND = 6;
@@ -401,7 +405,11 @@ __global__ __launch_bounds__(KW, MINW) void fit_tile1_kernel(const KParams p, co
                                     const int cs = q / (E / 2), e = 2 * (q - cs * (E / 2)), k = kbase + e / NO;
                                     if (k < sNk[cs]) {
                                         k1d2_ v; v.x = sS[cs * CS + e]; v.y = sS[cs * CS + e + 1];
+#if WLSQM_TILEK_SENS_NT
+                                        __builtin_nontemporal_store(v, reinterpret_cast<k1d2_*>(out0 + (long long)cs * p.ss_j + (long long)kbase * NO + e));
+#else
                                         *reinterpret_cast<k1d2_*>(out0 + (long long)cs * p.ss_j + (long long)kbase * NO + e) = v;
+#endif
                                     }
                                 }
                             }
@@ -411,7 +419,11 @@ __global__ __launch_bounds__(KW, MINW) void fit_tile1_kernel(const KParams p, co
                             const int q = q0 + lane;
                             if ((TC * E) % KW == 0 || q < TC * E) {
                                 const int cs = q / E, e = q - cs * E, k = kbase + e / NO;       // compile-time divisors
+#if WLSQM_TILEK_SENS_NT
+                                if (k < sNk[cs]) __builtin_nontemporal_store(sS[cs * CS + e], &out0[(long long)cs * p.ss_j + (long long)kbase * NO + e]);
+#else
                                 if (k < sNk[cs]) out0[(long long)cs * p.ss_j + (long long)kbase * NO + e] = sS[cs * CS + e];
+#endif
                             }
                         }
                         }

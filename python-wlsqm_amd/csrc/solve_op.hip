@@ -31,7 +31,7 @@
 #include "wlsqm_kernels.hpp"
 
 #ifndef WLSQM_OP_NT
-#define WLSQM_OP_NT 0      // A/B: 1 = non-temporal loads of the fields, 2 = non-temporal stores of the results, 3 = both
+#define WLSQM_OP_NT 2      // 1 = non-temporal loads of the fields (configs[3]: 16.9 against 14.7 ms), 2 = non-temporal stores of the results (1.0-1.6 % faster in three interleaved pairs, profiles/r03i_ab_c4_nt.txt: kept), 3 = both
 #endif
 
 namespace wlsqm {

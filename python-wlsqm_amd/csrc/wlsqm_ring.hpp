@@ -52,6 +52,21 @@ __device__ __forceinline__ void swap32(double& x, double& y) {
     x = __hiloint2double((int)hi.x, (int)lo.x); y = __hiloint2double((int)hi.y, (int)lo.y);
 }
 
+#ifndef WLSQM_RING_FI_RUN
+#define WLSQM_RING_FI_RUN 1     // 3D branch-free solve: the 64 fi rows leave as one run of non-temporal 16-byte pieces through LDS instead of 8-byte pieces at an 80-byte pitch: configs[4] at 1M, interleaved, 0.3035-0.3086 against 0.3113-0.3159 ms (profiles/r03i_ab_ring_c5.txt)
+#endif
+#ifndef WLSQM_RING_FI_NT
+#define WLSQM_RING_FI_NT 0      // non-temporal for EVERY fi store of the ring: configs[2] unchanged (its rows already leave as a run), configs[4] 0.31 -> 0.46 ms with its 8-byte pieces at an 80-byte pitch — non-temporal pays for whole lines only
+#endif
+template <class T>
+__device__ __forceinline__ void ring_store(T* dst, const T v) {
+#if WLSQM_RING_FI_NT
+    __builtin_nontemporal_store(v, dst);
+#else
+    *dst = v;
+#endif
+}
+
 template <int DIM, int K> struct RingGeom {
     static constexpr int WV = 64, TC = 16, LPC = 4;
     static constexpr int KC = (K + 7) / 8 * 8;              // slots the four shares cover (even share each); slots >= K are masked
@@ -66,6 +81,10 @@ template <int DIM, int K> struct RingGeom {
     static constexpr int RS = (DIM == 2) ? ((2 * KC + 1) / 4) * 4 + 2 : ((KC * DIM + 31) / 32) * 32 + 2;
     static constexpr int SLOT = TC * RS + 2 * WV;            // doubles per ring slot (+ slack: the last row's DMA writes whole 16-B lanes only)
     static constexpr size_t LDS_BYTES = sizeof(double) * 2 * SLOT;
+    // 3D: 64 fi rows of the branch-free solve leave as one contiguous run of 16-byte pieces through a staging area behind the ring
+    // (that solve runs while BOTH ring slots are in use); 35.3 + 5 KB = 39.5 KB: still four workgroups per CU
+    static constexpr bool FI_STAGE = (DIM == 3);
+    static constexpr int FI_STAGE_NO = 10;                   // unknowns of the 3D instantiation (order 2)
     static_assert((K * DIM) % 2 == 0 && K % 2 == 0 && K >= 8, "rows must be multiples of 16 bytes");
     static_assert(RS >= DIM * KC && RS % 2 == 0, "row stride");
 };
@@ -294,10 +313,10 @@ __global__ __launch_bounds__(64, MINW) void fit_ring_kernel(const KParams p, con
                         rd2_* out = reinterpret_cast<rd2_*>(p.fi + jbase * NO);
                         const rd2_* src = reinterpret_cast<const rd2_*>(dead_slot);
 #pragma unroll
-                        for (int q = lane; q < 64 * NO / 2; q += 64) out[q] = src[q];
+                        for (int q = lane; q < 64 * NO / 2; q += 64) ring_store(&out[q], src[q]);
                     } else {
 #pragma unroll
-                        for (int a = 1; a < NO; ++a) fio[a] = r1[a - 1];
+                        for (int a = 1; a < NO; ++a) ring_store(&fio[a], r1[a - 1]);
                     }
                 }
                 havep = false;
@@ -320,7 +339,7 @@ __global__ __launch_bounds__(64, MINW) void fit_ring_kernel(const KParams p, con
             ldlt_solve<NO>(M, rhs);
 #pragma unroll
             for (int a = 0; a < NO; ++a)
-                if (!((knownp >> a) & 1ull)) fio[a] = rhs[a];
+                if (!((knownp >> a) & 1ull)) ring_store(&fio[a], rhs[a]);
         }
         havep = false;
     };
@@ -345,8 +364,27 @@ __global__ __launch_bounds__(64, MINW) void fit_ring_kernel(const KParams p, con
         expand_moments_from<DIM, ORDER>([&](int i) { return entry(i); }, [&](int i) { return entry(NM + i); }, M, rhs);
         ldlt_factor<NO>(M);
         ldlt_solve<NO>(M, rhs);
+#if WLSQM_RING_FI_RUN
+        if constexpr (G::FI_STAGE) {
+            static_assert(!G::FI_STAGE || NO <= G::FI_STAGE_NO, "staging area behind the ring");
+            // the 64 cases are consecutive (four consecutive tiles, all valid): their rows are ONE run of 64 * NO doubles
+            if (p.sfi_j == NO && ((reinterpret_cast<uintptr_t>(p.fi) & 15u) == 0)) {      // wave-uniform
+                double* stg = lds + 2 * G::SLOT;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-        for (int a = 0; a < NO; ++a) fio[a] = rhs[a];
+                for (int a = 0; a < NO; ++a) stg[lane * NO + a] = rhs[a];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                rd2_* out = reinterpret_cast<rd2_*>(p.fi + (jp - lane) * NO);
+                const rd2_* src = reinterpret_cast<const rd2_*>(stg);
+#pragma unroll
+                for (int q = lane; q < 64 * NO / 2; q += 64) __builtin_nontemporal_store(src[q], &out[q]);
+                havep = false;
+                return;
+            }
+        }
+#endif
+#pragma unroll
+        for (int a = 0; a < NO; ++a) ring_store(&fio[a], rhs[a]);
         havep = false;
     };
 #ifndef WLSQM_RING_FUSE_SOLVE
@@ -515,7 +553,7 @@ static int ring_tiles_per_wg() {
 
 template <int DIM, int K, bool GATHER> struct RingLaunchGeom {        // ring + (index-based) the index buffer of the tile ahead
     static constexpr int TC = RingGeom<DIM, K>::TC;
-    static constexpr size_t LDS_BYTES = RingGeom<DIM, K>::LDS_BYTES + (GATHER ? (size_t)TC * K * 4 : 0);
+    static constexpr size_t LDS_BYTES = RingGeom<DIM, K>::LDS_BYTES + (GATHER ? (size_t)TC * K * 4 : 0) + (RingGeom<DIM, K>::FI_STAGE ? (size_t)64 * RingGeom<DIM, K>::FI_STAGE_NO * 8 : 0);
 };
 
 template <int DIM, int ORDER, int K, int UNR, int MINW, bool GATHER = false>

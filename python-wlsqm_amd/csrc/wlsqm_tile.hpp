@@ -54,6 +54,13 @@
 #include "wlsqm_kernels.hpp"
 #include "wlsqm_moments.hpp"
 
+#ifndef WLSQM_TILE_RUN_MIN_NO
+#define WLSQM_TILE_RUN_MIN_NO 6      // A/B: smallest system whose tile stores its fi rows as one run through LDS
+#endif
+#ifndef WLSQM_TILE_FI_NT
+#define WLSQM_TILE_FI_NT 1      // non-temporal stores of the tile's fi run (written once, never read by the kernel): configs[1], interleaved, 0.1523-0.1551 against 0.1550-0.1599 ms (profiles/r03i_ab_tile_nt.txt)
+#endif
+
 namespace wlsqm {
 
 constexpr int WV = 64;            // lanes per wave
@@ -376,7 +383,7 @@ __global__ __launch_bounds__(WV * KSPLIT, MINW) void fit_tile_kernel(const KPara
             // 0.166 ms on a slow box of the pool; without any fi store: -10 %.  Three unknowns (C1: 96 doubles per tile) lose 2 %
             // and keep the direct stores.
             bool run_store = false;
-            if constexpr (KSPLIT == 1 && (TC * NO) % 2 == 0 && NO >= 6) {
+            if constexpr (KSPLIT == 1 && (TC * NO) % 2 == 0 && NO >= WLSQM_TILE_RUN_MIN_NO) {
                 run_store = !no_run_store && nvalid == TC && p.sfi_j == NO && __all(dropped == 0ull && known != FULL) &&
                             ((reinterpret_cast<uintptr_t>(p.fi) & 15u) == 0);
             }
@@ -409,7 +416,7 @@ __global__ __launch_bounds__(WV * KSPLIT, MINW) void fit_tile_kernel(const KPara
                     finish(A, g);
                 }
             }
-            if constexpr (KSPLIT == 1 && (TC * NO) % 2 == 0 && NO >= 6) {
+            if constexpr (KSPLIT == 1 && (TC * NO) % 2 == 0 && NO >= WLSQM_TILE_RUN_MIN_NO) {
                 if (run_store) {
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
@@ -419,7 +426,11 @@ __global__ __launch_bounds__(WV * KSPLIT, MINW) void fit_tile_kernel(const KPara
 #pragma unroll
                     for (int q0 = 0; q0 < TC * NO / 2; q0 += WV) {
                         const int q = q0 + lane;
+#if WLSQM_TILE_FI_NT
+                        if ((TC * NO / 2) % WV == 0 || q < TC * NO / 2) __builtin_nontemporal_store(src[q], &out[q]);
+#else
                         if ((TC * NO / 2) % WV == 0 || q < TC * NO / 2) out[q] = src[q];
+#endif
                     }
                 }
             }

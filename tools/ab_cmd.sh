@@ -1,0 +1,17 @@
+#!/usr/bin/env bash
+# usage (GPU box, repo root): bash tools/ab_cmd.sh UNIT "<command>" "-DFLAG=1" ...   — A/B of compile-time variants of one translation
+# unit (csrc/UNIT.hip) under an arbitrary timing command: runs it on the library as built, then with UNIT.o rebuilt per flag set, then
+# as built again (interleave the flag sets yourself for repeats), and restores the library.
+set -euo pipefail
+UNIT="$1"; CMD="$2"; shift 2
+PKG=python-wlsqm_amd
+cp $PKG/wlsqm/_lib/libwlsqm_hip.so /tmp/lib_orig.so
+echo "== as-built"; bash -c "$CMD"
+for flags in "$@"; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fopenmp -I include -I $PKG/csrc $flags -c $PKG/csrc/$UNIT.hip -o /tmp/unit_var.o
+  objs=(); for o in $PKG/build/*.o; do [[ "$(basename $o)" == "$UNIT.o" ]] && objs+=(/tmp/unit_var.o) || objs+=("$o"); done
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fopenmp -o $PKG/wlsqm/_lib/libwlsqm_hip.so "${objs[@]}"
+  echo "== [$flags]"; bash -c "$CMD"
+done
+cp /tmp/lib_orig.so $PKG/wlsqm/_lib/libwlsqm_hip.so
+echo "== as-built-again"; bash -c "$CMD"

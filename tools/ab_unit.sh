@@ -5,7 +5,7 @@
 set -euo pipefail
 UNIT="$1"; CFG="$2"; shift 2
 PKG=python-wlsqm_amd
-run() { for i in 1 2 3; do python3 bench.py --config "$CFG" --steps 20 --warmup 5 --no-parity --no-cpu-baseline 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$1', d['roofline']['kernel_ms'], d['roofline']['frac'])"; done; }
+run() { for i in 1 2 3; do python3 bench.py --config "$CFG" ${AB_NCASES:+--ncases $AB_NCASES} --steps 20 --warmup 5 --no-parity --no-cpu-baseline 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$1', d['roofline']['kernel_ms'], d['roofline']['frac'])"; done; }
 cp $PKG/wlsqm/_lib/libwlsqm_hip.so /tmp/lib_orig.so
 run "as-built"
 for flags in "$@"; do
