@@ -295,6 +295,10 @@ def measure_fit(name, cfg, n, dev, timer, steps, warmup, rank, parity=True, keep
     if working_set < 256 * 2 ** 20:
         roof["note"] = ("working set %.0f MB fits the 256 MB Infinity Cache: back-to-back launches re-read it on-die, so this is a "
                         "cache-resident rate, not an HBM fraction" % (working_set / 1e6))
+    if name == "C2":
+        # a bare streaming kernel with this kernel's read : write mix (16 : 1) and launch size, measured once (tools/ubench/hbm_mix.hip)
+        roof.update({"bare_stream_same_mix_GBps": [5560.0, 5720.0], "bare_stream_source": "profiles/r03j_ubench_hbm_mix.txt",
+                     "frac_of_bare_stream": achieved / 5720.0})
     if name == "C3":
         fl = flops_per_fit(dim, order, nk, cfg["knowns"])
         tf = fl * n / (ms_kernel * 1e-3) / 1e12
