@@ -60,7 +60,9 @@ __device__ __forceinline__ void swap32(double& x, double& y) {
 #endif
 template <class T>
 __device__ __forceinline__ void ring_store(T* dst, const T v) {
-#if WLSQM_RING_FI_NT
+#if defined(WLSQM_RING_NO_STORE)      // experiment only: what the kernel costs without its results leaving (wrong output)
+    if (reinterpret_cast<uintptr_t>(dst) == 8) *dst = v;
+#elif WLSQM_RING_FI_NT
     __builtin_nontemporal_store(v, dst);
 #else
     *dst = v;
