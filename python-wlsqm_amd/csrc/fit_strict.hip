@@ -32,6 +32,10 @@
 
 #pragma clang fp contract(off)      // the reference is gcc -O2 on x86-64: no contraction; the explicit fma() calls below are polyeval.pyx's own
 
+#ifndef WLSQM_STRICT_ROWS_MINW
+#define WLSQM_STRICT_ROWS_MINW 0      // A/B: waves per SIMD the row-per-lane kernel is compiled for (0: rows_minw below)
+#endif
+
 namespace wlsqm {
 
 namespace strict {
@@ -522,11 +526,19 @@ __device__ __forceinline__ bool fit_strict_group_is_plain(const KParams& p, long
     return __syncthreads_or(mine ? 1 : 0) == 0;
 }
 
+#ifndef WLSQM_STRICT_REG_MINW6
+#define WLSQM_STRICT_REG_MINW6 1      // waves per SIMD the register kernel of the systems up to 6 unknowns is compiled for: registers as needed (C2: 0.74 ms; capped for three / four waves it spills: 0.95 / 1.29; profiles/r03j_ab_strict_minw.txt)
+#endif
+#ifndef WLSQM_STRICT_REG_MINW10
+#define WLSQM_STRICT_REG_MINW10 1     // ... of the 10-unknown systems (C5: 2.00 ms; capped for two waves: 2.79)
+#endif
+__host__ __device__ constexpr int reg_minw(int NO) { return NO <= 6 ? WLSQM_STRICT_REG_MINW6 : WLSQM_STRICT_REG_MINW10; }
+
 // KN1: the groups whose 64 cases all have exactly the function value known (knowns = b?_F = 1, the reference's default mask): the
 // reduced system is DOFs 1 .. NO - 1, again with compile-time indices; the known value moves to the right-hand side term by term
 // in a third pass over the neighbours (it needs the row scales: impl.pyx:815-818 multiplies every term by row_scale[j]).
 template <int DIM, int ORDER, bool KN1>
-__global__ __launch_bounds__(64) void fit_strict_reg_kernel(const KParams p) {
+__global__ __launch_bounds__(64, reg_minw(ndofs(DIM, ORDER))) void fit_strict_reg_kernel(const KParams p) {
     using namespace strict;
     constexpr int NO = ndofs(DIM, ORDER);
     constexpr int N = NO - (KN1 ? 1 : 0), O0 = KN1 ? 1 : 0;      // reduced size; reduced index i is DOF i + O0
@@ -730,8 +742,16 @@ __device__ __forceinline__ double pick(const double (&c)[N], int a) {
     return __longlong_as_double(t[0]);
 }
 
+// Waves per SIMD the row kernel is compiled for.  It is bound by the issue of dependent vector instructions (IEEE divides, selects), so a
+// third / fourth resident wave pays for a few spilled registers: 1M cases, 2D order 4 (F known): 9.5 ms as allocated freely (190
+// VGPRs), 7.97 at three waves (168 + 33 spilled), 8.03 at four; with sensitivities 28.6 / 23.0 / 25.9; 3D order 2 with sensitivities:
+// 9.37 / 9.37 / 8.63 (profiles/r03j_ab_strict_minw.txt).  The 20- and 35-unknown systems keep their registers (242 / 389).
+__host__ __device__ constexpr int rows_minw(int NO) {
+    return WLSQM_STRICT_ROWS_MINW ? WLSQM_STRICT_ROWS_MINW : (NO > 16 ? 1 : NO > 10 ? 3 : 4);
+}
+
 template <int DIM, int ORDER, int LPC>
-__global__ __launch_bounds__(64) void fit_strict_rows_kernel(const KParams p, const int KP) {
+__global__ __launch_bounds__(64, rows_minw(ndofs(DIM, ORDER))) void fit_strict_rows_kernel(const KParams p, const int KP) {
     using namespace strict;
     constexpr int NO = ndofs(DIM, ORDER);
     constexpr int G = 64 / LPC;                       // cases per wave
