@@ -52,6 +52,9 @@ __device__ __forceinline__ void swap32(double& x, double& y) {
     x = __hiloint2double((int)hi.x, (int)lo.x); y = __hiloint2double((int)hi.y, (int)lo.y);
 }
 
+#ifndef WLSQM_RING_IBUF_PAD
+#define WLSQM_RING_IBUF_PAD 4    // ints of padding behind every pair of index rows (0: A/B)
+#endif
 #ifndef WLSQM_RING_FI_RUN
 #define WLSQM_RING_FI_RUN 1     // 3D branch-free solve: the 64 fi rows leave as one run of non-temporal 16-byte pieces through LDS instead of 8-byte pieces at an 80-byte pitch: configs[4] at 1M, interleaved, 0.3035-0.3086 against 0.3113-0.3159 ms (profiles/r03i_ab_ring_c5.txt)
 #endif
@@ -113,7 +116,12 @@ __global__ __launch_bounds__(64, MINW) void fit_ring_kernel(const KParams p, con
     struct Meta { int nk, wm; long long kn; double xi[DIM]; };
     Meta nxt;
     double fnext[KPL];
-    int* const ibuf = reinterpret_cast<int*>(lds + 2 * G::SLOT);          // GATHER: [TC][K] indices of the tile ahead
+    int* const ibuf = reinterpret_cast<int*>(lds + 2 * G::SLOT);          // GATHER: indices of the tile ahead, rows in PAIRS at a pitch of 2 K + 4
+    // (unpadded, the sixteen rows of a 64-slot tile start in the same bank: the lanes' reads of their own shares were 16-way conflicts —
+    // SQ_LDS_BANK_CONFLICT 67 % of the LDS-active cycles of the kernel, profiles/r03k_pmc_new_kernels.txt; a pair of rows is the smallest
+    // unit a 16-byte DMA piece never straddles for every even K)
+    constexpr int IPP = 2 * K + WLSQM_RING_IBUF_PAD;                      // ints per row pair
+    auto irow = [&](int r) { return (r >> 1) * IPP + (r & 1) * K; };      // first int of row r
     int nk_ahead = 0;                                                     // GATHER: nk of this lane's case in the tile whose indices are in ibuf
 
     // GATHER: request the indices of `tile` (lane-linear copy of TC * K int32 into ibuf) and the nk of its cases
@@ -121,13 +129,15 @@ __global__ __launch_bounds__(64, MINW) void fit_ring_kernel(const KParams p, con
         const long long j0 = tile * TC;
         const int nvalid = (p.ncases - j0 < TC) ? (int)(p.ncases - j0) : TC;
         const char* hb = reinterpret_cast<const char*>(p.hoods + j0 * (long long)K);
-        const int bytes = TC * K * 4, lim = nvalid * K * 4 - 16;          // tail tile: replay the last 16 bytes of the last valid row
+        const int lim = nvalid * K * 4 - 16;                              // tail tile: replay the last 16 bytes of the last valid row
+        static_assert(2 * K * 4 <= 1024, "a row pair per DMA instruction");
+        if (lane * 16 < 2 * K * 4) {
 #pragma unroll
-        for (int q = 0; q < (bytes + 1023) / 1024; ++q) {
-            const int off = q * 1024 + lane * 16;
-            if ((q + 1) * 1024 <= bytes || off < bytes)
+            for (int pr = 0; pr < TC / 2; ++pr) {
+                const int off = pr * 2 * K * 4 + lane * 16;
                 __builtin_amdgcn_global_load_lds((ring_glb_ptr_t)(hb + (off < lim ? off : lim)),
-                                                 (ring_lds_ptr_t)(reinterpret_cast<char*>(ibuf) + q * 1024), 16, 0, 0);
+                                                 (ring_lds_ptr_t)(reinterpret_cast<char*>(ibuf) + pr * IPP * 4), 16, 0, 0);
+            }
         }
         const int cc = c < nvalid ? c : nvalid - 1;
         nk_ahead = p.nk[(j0 + cc) * p.snk];
@@ -150,9 +160,9 @@ __global__ __launch_bounds__(64, MINW) void fit_ring_kernel(const KParams p, con
             const int nkl = c < nvalid ? min(nk_ahead, K) : 0;
             int ixr[TC], ixf[KPL];
 #pragma unroll
-            for (int r = 0; r < TC; ++r) ixr[r] = ibuf[r * K + (lane < K ? lane : K - 1)];
+            for (int r = 0; r < TC; ++r) ixr[r] = ibuf[irow(r) + (lane < K ? lane : K - 1)];
 #pragma unroll
-            for (int i = 0; i < KPL; ++i) ixf[i] = ibuf[c * K + ((k0 + i < K) ? k0 + i : K - 1)];   // a padded share replays the last slot (masked in the loop)
+            for (int i = 0; i < KPL; ++i) ixf[i] = ibuf[irow(c) + ((k0 + i < K) ? k0 + i : K - 1)];   // a padded share replays the last slot (masked in the loop)
             __builtin_amdgcn_s_waitcnt(0xc07f);                                   // lgkmcnt(0): the reads have returned
             asm volatile("" ::: "memory");
             const char* Sb = reinterpret_cast<const char*>(p.S);
@@ -555,7 +565,7 @@ static int ring_tiles_per_wg() {
 
 template <int DIM, int K, bool GATHER> struct RingLaunchGeom {        // ring + (index-based) the index buffer of the tile ahead
     static constexpr int TC = RingGeom<DIM, K>::TC;
-    static constexpr size_t LDS_BYTES = RingGeom<DIM, K>::LDS_BYTES + (GATHER ? (size_t)TC * K * 4 : 0) + (RingGeom<DIM, K>::FI_STAGE ? (size_t)64 * RingGeom<DIM, K>::FI_STAGE_NO * 8 : 0);
+    static constexpr size_t LDS_BYTES = RingGeom<DIM, K>::LDS_BYTES + (GATHER ? (size_t)(TC / 2) * (2 * K + WLSQM_RING_IBUF_PAD) * 4 : 0) + (RingGeom<DIM, K>::FI_STAGE ? (size_t)64 * RingGeom<DIM, K>::FI_STAGE_NO * 8 : 0);
 };
 
 template <int DIM, int ORDER, int K, int UNR, int MINW, bool GATHER = false>

@@ -33,8 +33,10 @@ def main():
         kn_d = torch.full((n,), cfg["knowns"], dtype=torch.int64, device=dev)
         fi = torch.zeros((n, no), dtype=torch.float64, device=dev); fi[:, 0] = F_d
         fi2 = fi.clone()
-        ms_d = whip.time_fit_device(dim, order, xk, fk, nk_d, xi, fi, kn_d, wm_d, reps=10); kd = whip.last_kernel()
-        ms_c = whip.time_fit_cloud_device(dim, order, S_d, F_d, h32, fi2, nk_d, kn_d, wm_d, reps=10); kc = whip.last_kernel()
+        whip.time_fit_device(dim, order, xk, fk, nk_d, xi, fi, kn_d, wm_d, reps=5)                  # warm-up
+        ms_d = whip.time_fit_device(dim, order, xk, fk, nk_d, xi, fi, kn_d, wm_d, reps=40); kd = whip.last_kernel()
+        whip.time_fit_cloud_device(dim, order, S_d, F_d, h32, fi2, nk_d, kn_d, wm_d, reps=5)
+        ms_c = whip.time_fit_cloud_device(dim, order, S_d, F_d, h32, fi2, nk_d, kn_d, wm_d, reps=40); kc = whip.last_kernel()
         same = float((fi - fi2).abs().max())
         print("%dD order %d K=%d n=%d: dense %.4f ms (%s), index-based %.4f ms (%s), max |dense - indexed| %.2e" %
               (dim, order, K, n, ms_d, kd, ms_c, kc, same), flush=True)
