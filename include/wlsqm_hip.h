@@ -104,9 +104,12 @@ int wlsqm_hip_fit_many_device(const wlsqm_batch* b, int device, void* stream, in
  * as wlsqm_hip_fit_many_device, with order_dev[j * order_stride] (int32, DEVICE memory) instead of order_uniform.  The cases are
  * bucketed by order ON THE DEVICE (one counting kernel, index lists in stream-ordered scratch) and every bucket is launched
  * with its size left in device memory: no host synchronisation, nothing but kernel launches and stream-ordered allocations
- * unless iterations_out is given.  b->order is not read.  Cases whose order is not 0..4 are left untouched. */
+ * unless iterations_out is given.  b->order is not read.  max_order (0..4) is the largest order the caller's fi / sens rows are
+ * wide enough for (the reference's "(ncases, >= max no)" rule, simple.pyx:379-381): cases whose order is not 0..max_order are
+ * left untouched and their buckets are never launched.  The buckets are STABLE (ascending case number: a stable counting
+ * partition, no atomics on positions), so results are bit-identical from run to run. */
 int wlsqm_hip_fit_many_device_orders(const wlsqm_batch* b, int device, void* stream, const int32_t* order_dev, int64_t order_stride,
-                                     int32_t* iterations_out);
+                                     int max_order, int32_t* iterations_out);
 
 /* ---- numerics mode (extension) ----
  * 0 (default): the fast kernels — moment form, neighbour sums split over lanes, FMA contraction, LDL^T: results agree with the
@@ -116,9 +119,16 @@ int wlsqm_hip_fit_many_device_orders(const wlsqm_batch* b, int device, void* str
  *    and solve_iterative (impl.pyx:731-1083) in the reference's order, one lane per case, IEEE divide and sqrt, no FMA contraction.
  *    Applies to every entry point that fits (wlsqm_hip_fit_many_*, wlsqm_hip_fit_cloud_device, wlsqm_hip_expert_solve*; a stacked
  *    solve runs one fit per field).  Several times slower; for validation against the reference at 1e-10.
- * The mode belongs to the calling thread; its initial value is the environment variable WLSQM_HIP_STRICT (unset / 0: fast).
- * wlsqm_hip_set_strict returns the previous mode. */
-int wlsqm_hip_set_strict(int on);
+ * 2: accurate (csrc/fit_accurate.hip): mode 1 with ONE change — the normal matrix of make_A (impl.pyx:566-602) is assembled from
+ *    its upper triangle, entry (j, m) = sum_k (w c_m) c_j for m >= j, and mirrored; the equilibration then sees a symmetric matrix
+ *    (row and column scales coincide bit for bit) and runs one pass per sweep.  Quotients and roots are correctly rounded (the
+ *    compiler's IEEE sequences without their range scaling where every operand is checked to be in range, the full sequences
+ *    otherwise).  Applies to the basic fits of the 2D / 3D systems up to 10 unknowns, per case, for the cases without a known
+ *    DOF; every other case of an accurate-mode call runs mode 1.  Within 1e-10 of the reference on every column of BASELINE
+ *    configs[1] and configs[4] (as mode 1), at the fast kernels' order of magnitude in time.
+ * The mode belongs to the calling thread; its initial value is the environment variable WLSQM_HIP_STRICT (unset / 0: fast; 1;
+ * 2 or "accurate").  wlsqm_hip_set_strict returns the previous mode. */
+int wlsqm_hip_set_strict(int mode);
 int wlsqm_hip_get_strict(void);
 
 /* Test hook of the strict mode: runs the reference-order fit of `b` (uniform order) and also stores the reference's intermediates,

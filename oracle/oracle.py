@@ -104,3 +104,38 @@ def fit_many(dimension, xk, fk, nk, xi, fi, sens, do_sens, order, knowns, weight
 
 def max_threads():
     return lib().wlsqm_oracle_max_threads()
+
+
+# ---- the checker of the ACCURATE numerics mode: oracle/variants.c with V_SYM (the oracle's arithmetic with the normal matrix
+# assembled from its upper triangle and mirrored; with flags = 0 it IS the oracle, checked bit for bit by tools/attribution.py)
+V_MOMENT, V_SPLIT, V_FMA, V_FASTW, V_LDLT, V_SYM = 1, 2, 4, 8, 16, 32
+_VLIB = None
+
+
+def _variants():
+    global _VLIB
+    if _VLIB is None:
+        so = os.path.join(_HERE, "libwlsqm_variants.so")
+        build()
+        L = C.CDLL(so)
+        L.wlsqm_variant_fit_many_ragged.restype = C.c_int
+        L.wlsqm_variant_fit_many_ragged.argtypes = [C.c_int, C.c_int, C.c_int, C.c_long, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                    C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        _VLIB = L
+    return _VLIB
+
+
+def variant_fit_many(dimension, order, xk, fk, nk, xi, fi, knowns, weighting_method, flags=V_SYM, nsplit=1):
+    """Uniform-order batch (2D / 3D) through oracle/variants.c: contiguous xk (n, K, dim), fk (n, K), xi (n, dim), fi (n, >= no)
+    in/out, per-case nk (int32), knowns (int64), weighting_method (int32).  flags = V_SYM: the accurate mode's arithmetic."""
+    n, K = fk.shape
+    no = number_of_dofs(dimension, order)
+    for a in (xk, fk, xi, fi):
+        assert a.dtype == np.float64 and a.flags.c_contiguous
+    assert nk.dtype == np.int32 and knowns.dtype == np.int64 and weighting_method.dtype == np.int32
+    assert nk.flags.c_contiguous and knowns.flags.c_contiguous and weighting_method.flags.c_contiguous
+    rc = _variants().wlsqm_variant_fit_many_ragged(dimension, order, no, n, K, xk.ctypes.data, fk.ctypes.data, nk.ctypes.data,
+                                                   xi.ctypes.data, fi.ctypes.data, fi.shape[1], knowns.ctypes.data,
+                                                   weighting_method.ctypes.data, flags, nsplit)
+    if rc != 0:
+        raise ValueError("variant fit failed with code %d" % rc)

@@ -179,3 +179,18 @@ int wlsqm_variant_fit_many(int dim, int order, int no, long ncases, int nk, cons
         fit_case(dim, order, no, nk, xk + j * nk * dim, fk + j * nk, xi + j * dim, fi + j * no, knowns, wm, flags, nsplit);
     return 0;
 }
+
+/* Per-case nk / knowns / weighting (rows of max_nk slots, fi rows of fi_stride doubles): the checker of the ACCURATE numerics mode
+ * (csrc/fit_accurate.hip = this routine with V_SYM, bit for bit; tests/test_gpu_accurate.py). */
+int wlsqm_variant_fit_many_ragged(int dim, int order, int no, long ncases, int max_nk, const double* xk, const double* fk,
+                                  const int* nk, const double* xi, double* fi, long fi_stride, const long long* knowns,
+                                  const int* wm, int flags, int nsplit) {
+    if (max_nk > 128 || no > 35 || (dim != 2 && dim != 3)) return -1;
+#pragma omp parallel for schedule(static)
+    for (long j = 0; j < ncases; j++) {
+        int n = nk[j] < max_nk ? nk[j] : max_nk;
+        fit_case(dim, order, no, n, xk + j * (long)max_nk * dim, fk + j * (long)max_nk, xi + j * dim, fi + j * fi_stride, knowns[j], wm[j],
+                 flags, nsplit);
+    }
+    return 0;
+}

@@ -42,15 +42,19 @@ int launch_fit_chunk_refine(int dimension, int order, const KParams& p, long lon
 int launch_fit_sens(int dimension, int order, const KParams& p, long long K, hipStream_t stream, bool* handled);
 int launch_fit_strict(int dimension, int order, const KParams& p, const StrictDebug* dbg, hipStream_t stream);
 
-// Numerics mode of the calling thread: 0 = the fast kernels, 1 = reference-order arithmetic (fit_strict.hip).  The first use on a
-// thread takes WLSQM_HIP_STRICT from the environment; wlsqm_hip_set_strict() overrides it.
+// Numerics mode of the calling thread: 0 = the fast kernels, 1 = reference-order arithmetic (fit_strict.hip), 2 = accurate
+// (fit_accurate.hip: reference-order arithmetic with the normal matrix assembled from its upper triangle).  The first use on a
+// thread takes WLSQM_HIP_STRICT from the environment (unset / 0, 1, 2 or "accurate"); wlsqm_hip_set_strict() overrides it.
 static thread_local int g_strict = -1;
-bool strict_mode() {
+static int strict_mode_value();
+bool accurate_mode() { return strict_mode_value() == 2; }
+bool strict_mode() { return strict_mode_value() >= 1; }
+static int strict_mode_value() {
     if (g_strict < 0) {
         const char* e = getenv("WLSQM_HIP_STRICT");
-        g_strict = (e && e[0] && e[0] != '0') ? 1 : 0;
+        g_strict = (!e || !e[0] || e[0] == '0') ? 0 : ((e[0] == '2' || e[0] == 'a' || e[0] == 'A') ? 2 : 1);
     }
-    return g_strict == 1;
+    return g_strict;
 }
 
 // Dense rows the tiled kernels cannot take as they are — a strided neighbour or case axis, rows that are not multiples of 16
@@ -301,12 +305,12 @@ int wlsqm_hip_device_count(void) {
     return n;
 }
 
-int wlsqm_hip_set_strict(int on) {
-    const int prev = strict_mode() ? 1 : 0;
-    g_strict = on ? 1 : 0;
+int wlsqm_hip_set_strict(int mode) {
+    const int prev = strict_mode_value();
+    g_strict = mode == 2 ? 2 : (mode ? 1 : 0);
     return prev;
 }
-int wlsqm_hip_get_strict(void) { return strict_mode() ? 1 : 0; }
+int wlsqm_hip_get_strict(void) { return strict_mode_value(); }
 
 int wlsqm_hip_number_of_dofs(int dimension, int order) {
     if (dimension < 1 || dimension > 3) return -1;
@@ -369,45 +373,110 @@ int wlsqm_hip_fit_many_device(const wlsqm_batch* b, int device, void* stream, in
 }  // extern "C"
 
 namespace wlsqm {
-// Order buckets on the device: idx[o * n + pos] = case number, counts[o] = cases of order o (the position inside a bucket is
-// whatever the atomics hand out: every case is fitted on its own, so the order of a bucket does not reach the results).
-__global__ void order_zero_kernel(long long* __restrict__ counts) { counts[threadIdx.x] = 0; }
-__global__ void order_bucket_kernel(const int* __restrict__ order, long long sorder, long long n, long long* __restrict__ counts,
-                                    long long* __restrict__ idx) {
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
+// Order buckets on the device: idx[o * n + pos] = case number, counts[o] = cases of order o.  STABLE (round 4): a bucket lists its
+// cases in ascending case number, so the tiles a case shares with others — and with them every wave-uniform code path choice of the
+// kernels — are a function of the batch alone: the same call gives the same bits run after run (round 3 handed the positions out
+// by atomicAdd: bucket order, tile mates and so, for the 14- / 15-unknown systems, a case's last bits varied between runs).
+// Three passes, no host synchronisation: (1) per block of OB_BLOCK cases the five counts; (2) one workgroup per order scans the
+// block counts; (3) rank inside the block by wave ballots.  Cases whose order is not 0..max_order are left out of every bucket.
+constexpr int OB_BLOCK = 256;
+__device__ __forceinline__ int ob_order_of(const int* __restrict__ order, long long sorder, long long n, long long t, int max_order) {
+    if (t >= n) return -1;
     const int o = order[t * sorder];
-    if (o < 0 || o > 4) return;                       // (the host entry points raise ValueError; here the case is left untouched)
-    const long long pos = (long long)atomicAdd(reinterpret_cast<unsigned long long*>(counts + o), 1ull);
-    idx[o * n + pos] = t;
+    return (o < 0 || o > max_order) ? -1 : o;         // (the host entry points raise ValueError; here the case is left untouched)
+}
+__global__ __launch_bounds__(OB_BLOCK) void order_count_kernel(const int* __restrict__ order, long long sorder, long long n, int max_order,
+                                                                long long nb, long long* __restrict__ blk) {   // blk[o * nb + block]
+    __shared__ int cnt[5];
+    if (threadIdx.x < 5) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const long long t = (long long)blockIdx.x * OB_BLOCK + threadIdx.x;
+    const int o = ob_order_of(order, sorder, n, t, max_order);
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        const unsigned long long m = __ballot(o == q);
+        if ((threadIdx.x & 63) == 0 && m) atomicAdd(&cnt[q], __popcll(m));       // integer adds: order-free
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) blk[(long long)threadIdx.x * nb + blockIdx.x] = cnt[threadIdx.x];
+}
+// one workgroup per order: exclusive scan of blk[o][0..nb) in place, total -> counts[o]
+__global__ __launch_bounds__(1024) void order_scan_kernel(long long nb, long long* __restrict__ blk, long long* __restrict__ counts) {
+    __shared__ long long part[1024];
+    long long* row = blk + (long long)blockIdx.x * nb;
+    const long long per = (nb + 1023) / 1024, b0 = (long long)threadIdx.x * per, b1 = (b0 + per < nb) ? b0 + per : nb;
+    long long sum = 0;
+    for (long long b = b0; b < b1; ++b) sum += row[b];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {        // inclusive Hillis-Steele over the 1 024 partial sums
+        const long long v = (threadIdx.x >= (unsigned)off) ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    long long run = part[threadIdx.x] - sum;
+    for (long long b = b0; b < b1; ++b) { const long long c = row[b]; row[b] = run; run += c; }
+    if (threadIdx.x == 1023) counts[blockIdx.x] = part[1023];
+}
+__global__ __launch_bounds__(OB_BLOCK) void order_scatter_kernel(const int* __restrict__ order, long long sorder, long long n, int max_order,
+                                                                  long long nb, const long long* __restrict__ blk, long long* __restrict__ idx) {
+    __shared__ int wcnt[OB_BLOCK / 64][5];
+    const long long t = (long long)blockIdx.x * OB_BLOCK + threadIdx.x;
+    const int o = ob_order_of(order, sorder, n, t, max_order);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int below = 0;                                     // cases of my order in the lower lanes of my wave
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        const unsigned long long m = __ballot(o == q);
+        if (lane == 0) wcnt[wave][q] = __popcll(m);
+        if (o == q) below = __popcll(m & ((1ull << lane) - 1ull));
+    }
+    __syncthreads();
+    if (o < 0) return;
+    for (int w2 = 0; w2 < wave; ++w2) below += wcnt[w2][o];
+    idx[(long long)o * n + blk[(long long)o * nb + blockIdx.x] + below] = t;
 }
 }  // namespace wlsqm
 
 extern "C" {
 
 int wlsqm_hip_fit_many_device_orders(const wlsqm_batch* b, int device, void* stream, const int32_t* order_dev, int64_t order_stride,
-                                     int32_t* iterations_out) {
+                                     int max_order, int32_t* iterations_out) {
     int rc = validate_batch(b);
     if (rc != WLSQM_OK) return rc;
     if (!order_dev) { set_error("null order array"); return WLSQM_EVALUE; }
+    if (max_order < 0 || max_order > 4) { set_error("max_order must be 0..4"); return WLSQM_EVALUE; }
     DeviceScope scope;
     rc = scope.enter(device);
     if (rc != WLSQM_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     const long long n = b->ncases;
-    long long* ws = nullptr;                          // [5] counts, then [5][n] case numbers
-    rc = scratch_alloc_async(reinterpret_cast<void**>(&ws), (size_t)(5 * n + 8) * sizeof(long long), s);
+    const long long nb = (n + OB_BLOCK - 1) / OB_BLOCK;
+    long long* ws = nullptr;                          // [8] counts, then [5][n] case numbers, then [5][nb] block counts / offsets
+    rc = scratch_alloc_async(reinterpret_cast<void**>(&ws), (size_t)(5 * n + 8 + 5 * nb) * sizeof(long long), s);
     if (rc != WLSQM_OK) return rc;
+    long long* blk = ws + 8 + 5 * n;
     int* d_it = nullptr;
     auto cleanup = [&](int code) { (void)scratch_free_async(ws, s); (void)scratch_free_async(d_it, s); return code; };
-    // (a kernel, not hipMemsetAsync: a memset node on memory allocated inside a stream capture aborted the replay on ROCm 7.2)
-    hipLaunchKernelGGL(order_zero_kernel, dim3(1), dim3(8), 0, s, ws);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return cleanup(hip_fail(e, "order_zero_kernel"));
-    hipLaunchKernelGGL(order_bucket_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, order_dev, (long long)order_stride, n,
-                       ws, ws + 8);
+    if (nb > 0x7fffffffll) { set_error("fit_many_device_orders: batch too large for one launch"); return cleanup(WLSQM_EVALUE); }
+    // (kernels only, no hipMemsetAsync: a memset node on memory allocated inside a stream capture aborted the replay on ROCm 7.2;
+    // the scan writes all five totals, also for an empty batch)
+    hipError_t e = hipSuccess;
+    if (nb > 0) {
+        hipLaunchKernelGGL(order_count_kernel, dim3((unsigned)nb), dim3(OB_BLOCK), 0, s, order_dev, (long long)order_stride, n, max_order, nb, blk);
+        e = hipGetLastError();
+        if (e != hipSuccess) return cleanup(hip_fail(e, "order_count_kernel"));
+    }
+    hipLaunchKernelGGL(order_scan_kernel, dim3(5), dim3(1024), 0, s, nb, blk, ws);
     e = hipGetLastError();
-    if (e != hipSuccess) return cleanup(hip_fail(e, "order_bucket_kernel"));
+    if (e != hipSuccess) return cleanup(hip_fail(e, "order_scan_kernel"));
+    if (nb > 0) {
+        hipLaunchKernelGGL(order_scatter_kernel, dim3((unsigned)nb), dim3(OB_BLOCK), 0, s, order_dev, (long long)order_stride, n, max_order, nb,
+                           blk, ws + 8);
+        e = hipGetLastError();
+        if (e != hipSuccess) return cleanup(hip_fail(e, "order_scatter_kernel"));
+    }
     KParams p = params_from(b);
     if (b->iterative && iterations_out) {
         rc = scratch_alloc_async(reinterpret_cast<void**>(&d_it), sizeof(int), s);
@@ -416,7 +485,8 @@ int wlsqm_hip_fit_many_device_orders(const wlsqm_batch* b, int device, void* str
         if (e != hipSuccess) return cleanup(hip_fail(e, "hipMemsetAsync"));
         p.iters_out = d_it;
     }
-    for (int o = 0; o <= 4; ++o) {
+    for (int o = 0; o <= max_order; ++o) {            // buckets above max_order are empty by construction and never launched: a
+        // kernel of order o writes no(o) doubles per fi / sens row, and the caller's rows are only promised wide enough for max_order
         if (wlsqm_hip_number_of_dofs(b->dimension, o) < 0) continue;
         p.case_index = ws + 8 + (long long)o * n;
         p.ncases = n;                                 // the launch is sized for the whole batch; the bucket's real size stays on the device

@@ -86,6 +86,10 @@ struct StrictDebug {
 // true when the calling thread asked for reference-order numerics (WLSQM_HIP_STRICT / wlsqm_hip_set_strict): launch_fit then
 // dispatches every shape to fit_strict.hip
 bool strict_mode();
+// true for mode 2, "accurate" (fit_accurate.hip): strict_mode() is true as well — every call takes the strict dispatch, in which the
+// basic fits of the 2D / 3D systems up to 10 unknowns without a known DOF run fit_accurate_kernel (reference-order arithmetic with
+// the normal matrix assembled from its upper triangle)
+bool accurate_mode();
 
 // name of the kernel family the last launch_fit on this thread dispatched to ("lane", "tile", "wave")
 const char* last_kernel_name();

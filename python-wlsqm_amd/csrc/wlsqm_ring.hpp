@@ -129,7 +129,8 @@ __global__ __launch_bounds__(64, MINW) void fit_ring_kernel(const KParams p, con
         const long long j0 = tile * TC;
         const int nvalid = (p.ncases - j0 < TC) ? (int)(p.ncases - j0) : TC;
         const char* hb = reinterpret_cast<const char*>(p.hoods + j0 * (long long)K);
-        const int lim = nvalid * K * 4 - 16;                              // tail tile: replay the last 16 bytes of the last valid row
+        const int end = nvalid * K * 4;                                   // bytes of the tile's valid rows
+        const int lim = end - 16;                                         // tail tile: pieces at or behind `end` replay the last 16 valid bytes (never dereferenced: rows >= nvalid count as nk = 0)
         static_assert(2 * K * 4 <= 1024, "a row pair per DMA instruction");
         if (lane * 16 < 2 * K * 4) {
 #pragma unroll
@@ -137,6 +138,26 @@ __global__ __launch_bounds__(64, MINW) void fit_ring_kernel(const KParams p, con
                 const int off = pr * 2 * K * 4 + lane * 16;
                 __builtin_amdgcn_global_load_lds((ring_glb_ptr_t)(hb + (off < lim ? off : lim)),
                                                  (ring_lds_ptr_t)(reinterpret_cast<char*>(ibuf) + pr * IPP * 4), 16, 0, 0);
+            }
+        }
+        // The ONE piece that straddles `end` (K == 2 mod 4 and an odd number of valid rows: end == 8 mod 16).  The DMA lands at the
+        // lane's own LDS position whatever its source, so a clamped source put bytes [end - 16, end) where [end - 8, end + 8) belong:
+        // the last two indices of the last valid row became copies of the two before them (round 3's tail bug: wrong neighbours for
+        // the last case of a launch whenever nk >= K - 1).  Its valid half is fetched by a plain 8-byte load instead and written
+        // behind the DMAs: the load's data arrives after every DMA issued before it (vmcnt is in order), so the write lands on top.
+        if constexpr (K % 4 == 2) {
+            if (end & 8) {                                                // wave-uniform: tail tiles only
+                const int pr = (nvalid - 1) >> 1;                         // the pair whose first row is the last valid one
+                asm volatile("" ::: "memory");
+                if (lane == 0) {
+                    const int* tail = reinterpret_cast<const int*>(hb + end - 8);
+                    const int v0 = tail[0], v1 = tail[1];
+                    __builtin_amdgcn_s_waitcnt(0x0f70);                   // vmcnt(0): the DMAs above and the two loads
+                    asm volatile("" ::: "memory");
+                    ibuf[pr * IPP + K - 2] = v0;
+                    ibuf[pr * IPP + K - 1] = v1;
+                }
+                asm volatile("" ::: "memory");
             }
         }
         const int cc = c < nvalid ? c : nvalid - 1;

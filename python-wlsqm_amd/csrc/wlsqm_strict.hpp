@@ -1,0 +1,105 @@
+#pragma once
+// wlsqm_strict.hpp — the reference-order building blocks shared by the strict kernels (fit_strict.hip) and the accurate mode
+// (fit_accurate.hip): constants, row access, make_c_nD with the reference's grouping of every product, the IEEE weight.
+// Every translation unit that includes this file must compile with `#pragma clang fp contract(off)` around its kernels: the
+// reference is gcc -O2 on x86-64 (no contraction), and bit-identity between the kernels depends on it.
+#include "wlsqm_internal.hpp"
+#include "wlsqm_kernels.hpp"
+
+#pragma clang fp contract(off)
+
+namespace wlsqm {
+
+namespace strict {
+
+constexpr double onesixth = 1. / 6.;      // impl.pyx:30-31
+constexpr double one24th = 1. / 24.;
+constexpr double weights_alpha = 1e-4;    // infra.pyx:45-46
+constexpr double weights_beta = 1. - 1e-4;
+constexpr double ruiz_epsilon = 1e-15;    // lapackdrivers.pyx:87
+
+// Cases per 64-thread workgroup for a system of NO DOFs: the LDS image is slots(NO) doubles per case.
+__host__ __device__ constexpr int slots(int NO) { return NO * NO + 10 * NO; }
+__host__ __device__ constexpr int lanes_for(int NO) {
+    return slots(NO) * 8 * 64 <= 80 * 1024 ? 64 : slots(NO) * 8 * 32 <= 80 * 1024 ? 32 : slots(NO) * 8 * 16 <= 80 * 1024 ? 16 : 8;
+}
+
+template <int DIM>
+struct Rows {       // row access of one case: dense rows with strides, or index-based (hoods row into the S / F point tables)
+    const double* xr; long long sxk_k;
+    const double* fr; long long sfk_k;
+    const int* hr; const double* S; const double* F;
+    __device__ __forceinline__ void offset(int k, const double (&xi)[DIM], double (&d)[DIM]) const {
+        const double* q = hr ? S + (long long)hr[k] * DIM : xr + k * sxk_k;
+#pragma unroll
+        for (int m = 0; m < DIM; ++m) d[m] = q[m] - xi[m];
+    }
+    __device__ __forceinline__ double value(int k) const { return hr ? F[hr[k]] : fr[k * sfk_k]; }
+};
+
+// c[k, :] with the reference's own grouping of every product; returns the squared distance (its w[k] before the weighting).
+template <int DIM, int ORDER>
+__device__ __forceinline__ double make_c(const double (&d)[DIM], double (&c)[ndofs(DIM, ORDER)]) {
+    if constexpr (DIM == 1) {                                   // impl.pyx:449-544
+        const double dx = d[0], dx2 = dx * dx;
+        c[0] = 1.;
+        if constexpr (ORDER >= 1) c[1] = dx;
+        if constexpr (ORDER >= 2) c[2] = 0.5 * dx2;
+        if constexpr (ORDER >= 3) c[3] = onesixth * dx * dx2;
+        if constexpr (ORDER >= 4) c[4] = one24th * dx2 * dx2;
+        return dx2;
+    } else if constexpr (DIM == 2) {                            // impl.pyx:286-432
+        const double dx = d[0], dy = d[1];
+        const double dx2 = dx * dx, dy2 = dy * dy;
+        const double d2 = dx2 + dy2;
+        c[0] = 1.;
+        if constexpr (ORDER >= 1) { c[1] = dx; c[2] = dy; }
+        if constexpr (ORDER >= 2) { c[3] = 0.5 * dx2; c[4] = dx * dy; c[5] = 0.5 * dy2; }
+        if constexpr (ORDER == 3) {
+            c[6] = onesixth * dx2 * dx; c[7] = 0.5 * dx2 * dy; c[8] = 0.5 * dx * dy2; c[9] = onesixth * dy * dy2;
+        }
+        if constexpr (ORDER == 4) {
+            const double dx3 = dx2 * dx, dy3 = dy2 * dy;
+            c[6] = onesixth * dx3; c[7] = 0.5 * dx2 * dy; c[8] = 0.5 * dx * dy2; c[9] = onesixth * dy3;
+            c[10] = one24th * dx2 * dx2; c[11] = onesixth * dx3 * dy; c[12] = 0.25 * dx2 * dy2; c[13] = onesixth * dx * dy3;
+            c[14] = one24th * dy2 * dy2;
+        }
+        return d2;
+    } else {                                                    // impl.pyx:70-269, DOF order defs.pyx:137-171
+        const double dx = d[0], dy = d[1], dz = d[2];
+        const double dx2 = dx * dx, dy2 = dy * dy, dz2 = dz * dz;
+        const double d2 = dx2 + dy2 + dz2;
+        c[0] = 1.;
+        if constexpr (ORDER >= 1) { c[1] = dx; c[2] = dy; c[3] = dz; }
+        if constexpr (ORDER >= 2) {
+            c[4] = 0.5 * dx2; c[5] = dx * dy; c[6] = 0.5 * dy2; c[7] = dy * dz; c[8] = 0.5 * dz2; c[9] = dx * dz;
+        }
+        if constexpr (ORDER == 3) {
+            c[10] = onesixth * dx2 * dx; c[11] = 0.5 * dx2 * dy; c[12] = 0.5 * dx * dy2; c[13] = onesixth * dy * dy2;
+            c[14] = 0.5 * dy2 * dz; c[15] = 0.5 * dy * dz2; c[16] = onesixth * dz * dz2; c[17] = 0.5 * dx * dz2;
+            c[18] = 0.5 * dx2 * dz; c[19] = dx * dy * dz;
+        }
+        if constexpr (ORDER == 4) {
+            const double dx3 = dx2 * dx, dy3 = dy2 * dy, dz3 = dz2 * dz;
+            c[10] = onesixth * dx3; c[11] = 0.5 * dx2 * dy; c[12] = 0.5 * dx * dy2; c[13] = onesixth * dy3;
+            c[14] = 0.5 * dy2 * dz; c[15] = 0.5 * dy * dz2; c[16] = onesixth * dz3; c[17] = 0.5 * dx * dz2;
+            c[18] = 0.5 * dx2 * dz; c[19] = dx * dy * dz;
+            c[20] = one24th * dx2 * dx2; c[21] = onesixth * dx3 * dy; c[22] = 0.25 * dx2 * dy2; c[23] = onesixth * dx * dy3;
+            c[24] = one24th * dy2 * dy2; c[25] = onesixth * dy3 * dz; c[26] = 0.25 * dy2 * dz2; c[27] = onesixth * dy * dz3;
+            c[28] = one24th * dz2 * dz2; c[29] = onesixth * dx * dz3; c[30] = 0.25 * dx2 * dz2; c[31] = onesixth * dx3 * dz;
+            c[32] = 0.5 * dx2 * dy * dz; c[33] = 0.5 * dx * dy2 * dz; c[34] = 0.5 * dx * dy * dz2;
+        }
+        return d2;
+    }
+}
+
+// infra.pyx:668-702: IEEE quotient and IEEE root (hipcc expands both to correctly rounded sequences)
+__device__ __forceinline__ double make_weight(double d2, double max_d2, bool uniform) {
+    if (uniform) return 1.;
+    const double tmp = 1. - sqrt(d2 / max_d2);
+    return weights_alpha + weights_beta * tmp * tmp;
+}
+
+}  // namespace strict
+
+}  // namespace wlsqm

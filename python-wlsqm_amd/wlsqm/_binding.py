@@ -74,7 +74,7 @@ def lib():
     L.wlsqm_hip_fit_many_host.argtypes = [C.POINTER(Batch), C.c_int, C.POINTER(C.c_int32)]
     L.wlsqm_hip_fit_many_device.argtypes = [C.POINTER(Batch), C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                             C.c_int64, C.POINTER(C.c_int32)]
-    L.wlsqm_hip_fit_many_device_orders.argtypes = [C.POINTER(Batch), C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int32)]
+    L.wlsqm_hip_fit_many_device_orders.argtypes = [C.POINTER(Batch), C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_int32)]
     L.wlsqm_hip_fit_many_device_orders.restype = C.c_int
     L.wlsqm_hip_set_strict.argtypes = [C.c_int]
     L.wlsqm_hip_set_strict.restype = C.c_int

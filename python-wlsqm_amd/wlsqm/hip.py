@@ -13,24 +13,46 @@ from . import _binding as B
 import contextlib
 
 __all__ = ["fit_many_device", "time_fit_device", "fit_cloud_device", "time_fit_cloud_device", "device_count", "knn", "ball", "nearest",
-           "last_kernel", "set_strict", "get_strict", "strict", "strict_intermediates"]
+           "last_kernel", "set_strict", "get_strict", "strict", "accurate", "strict_intermediates"]
+
+
+def _mode_code(mode):
+    """False / 0 -> 0 (fast), True / 1 / "strict" -> 1, 2 / "accurate" -> 2."""
+    if isinstance(mode, str):
+        m = mode.lower()
+        if m in ("accurate", "2"):
+            return 2
+        if m in ("strict", "1", "true"):
+            return 1
+        if m in ("fast", "0", "false", ""):
+            return 0
+        raise ValueError("numerics mode must be 'fast', 'strict' or 'accurate', got %r" % (mode,))
+    if mode is True:
+        return 1
+    return 2 if int(mode) == 2 else (1 if mode else 0)
 
 
 def set_strict(on):
     """Numerics mode of the calling thread (wlsqm_hip_set_strict): False = the fast kernels (default, or WLSQM_HIP_STRICT in
-    the environment), True = reference-order arithmetic (csrc/fit_strict.hip: the reference's operations one for one, IEEE
-    divide / sqrt, no FMA contraction, Ruiz scaling + pivoted LU), for every entry point that fits — the reference-signature
-    functions of wlsqm.fitter included.  Returns the previous mode."""
-    return bool(B.lib().wlsqm_hip_set_strict(1 if on else 0))
+    the environment), True / "strict" = reference-order arithmetic (csrc/fit_strict.hip: the reference's operations one for one,
+    IEEE divide and sqrt, no contraction; bit-identical to the oracle), 2 / "accurate" = the same arithmetic with the normal
+    matrix assembled from its upper triangle (csrc/fit_accurate.hip: as close to the reference as the strict mode — 1e-10 on every
+    column of BASELINE configs[1] / configs[4] — at a fraction of its time; cases it does not cover run the strict kernels).
+    Returns the previous mode: False, True or 2."""
+    prev = B.lib().wlsqm_hip_set_strict(_mode_code(on))
+    return 2 if prev == 2 else bool(prev)
 
 
 def get_strict():
-    return bool(B.lib().wlsqm_hip_get_strict())
+    """False (fast), True (strict) or 2 (accurate)."""
+    v = B.lib().wlsqm_hip_get_strict()
+    return 2 if v == 2 else bool(v)
 
 
 @contextlib.contextmanager
 def strict(on=True):
-    """``with wlsqm.hip.strict(): ...`` — reference-order numerics inside the block (None: leave the mode alone)."""
+    """``with wlsqm.hip.strict(): ...`` — reference-order numerics inside the block (None: leave the mode alone;
+    ``strict("accurate")`` / ``strict(2)``: the accurate mode)."""
     if on is None:
         yield
         return
@@ -39,6 +61,11 @@ def strict(on=True):
         yield
     finally:
         set_strict(prev)
+
+
+def accurate():
+    """``with wlsqm.hip.accurate(): ...`` — the accurate numerics mode inside the block."""
+    return strict(2)
 
 
 def device_count():
@@ -163,7 +190,7 @@ def fit_many_device(dimension, order, xk, fk, nk, xi, fi, knowns, weighting_meth
         its = C.c_int32(0)
         with _strict_ctx(strict):
             B.check(B.lib().wlsqm_hip_fit_many_device_orders(C.byref(b), dev, s, C.c_void_p(order.data_ptr()), order.stride(0),
-                                                             C.byref(its) if want_iterations else None))
+                                                             int(max_order), C.byref(its) if want_iterations else None))
         return int(its.value)
     b = _batch(dimension, order, xk, fk, nk, xi, fi, knowns, weighting_method, sens, iterative, max_iter, nk)
     s, dev = _stream_and_device(fi, stream)

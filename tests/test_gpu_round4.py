@@ -1,0 +1,104 @@
+"""GPU tests added in round 4: the tail of the index-based 2D order-4 ring, run-to-run and tile-mate
+independence of bucketed batches, the driver's N > 1 bench flow."""
+import numpy as np
+import pytest
+
+import _cases as K
+import _parity as P
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def wlsqm():
+    import wlsqm as W
+    from wlsqm import _binding
+    assert _binding.lib().wlsqm_hip_device_count() >= 1, "no HIP device: the GPU tests need a real MI355X"
+    return W
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import oracle as O
+    return O
+
+
+def _t(a, dev="cuda:0"):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# index-based 2D order 4, 26..64 slots: the tail tile of the gather ring (examples/wlsqm_example.py:103-133 is this layout)
+
+def _hoods_at_the_end_of_an_allocation(hoods):
+    """The index table as a device view that ENDS 8 bytes before the end of its 2 MiB allocation and starts 16-byte aligned
+    (n * K * 4 == 8 mod 16 for the shapes below): a prefetch that reads past the valid rows leaves the block."""
+    import torch
+    n, Kn = hoods.shape
+    total = (2 << 20) // 4
+    while total < n * Kn + 2:
+        total *= 2
+    buf = torch.full((total,), 0x7fffffff, dtype=torch.int32, device="cuda:0")      # anything dereferenced from here is far out of the table
+    start = total - 2 - n * Kn
+    view = buf[start:start + n * Kn].view(n, Kn)
+    view.copy_(torch.from_numpy(hoods))
+    return buf, view
+
+
+@pytest.mark.parametrize("Kn", list(range(26, 66, 4)) + [28, 64])
+def test_gather_ring_tail_tile(wlsqm, oracle, Kn):
+    """Round 3's tail bug: the index prefetch clamped the SOURCE offset of the tail tile but the DMA still landed at the lane's own
+    LDS position; with K == 2 (mod 4) and an odd number of valid rows the last two indices of the last valid case became copies of
+    the two before them (tools/fuzz.py found it: profiles/r03i_fuzz.txt; the curated test had nk <= K - 2 in that case by chance).
+    Every K == 2 (mod 4) of the ring, odd and even batch sizes, the LAST case with nk = K, with and without point_index, the index
+    table at the very end of its allocation: same bits as the dense ring on the gathered rows, parity with the oracle."""
+    import torch
+    import synth
+    import wlsqm.hip as whip
+    rng = np.random.default_rng(1000 + Kn)
+    npts = 3000
+    S = synth.halton(npts, 2); F = synth.field(S)
+    S_d, F_d = _t(S), _t(F)
+    for n in (15, 17, 63, 65, 777, 2049):
+        for with_pidx in (False, True):
+            pidx = rng.permutation(npts)[:n].astype(np.int32) if with_pidx else np.arange(n, dtype=np.int32)
+            hoods = synth.knn(S, Kn, query=pidx).astype(np.int32)
+            nk = rng.integers(22, Kn + 1, n).astype(np.int32)
+            nk[-1] = Kn; nk[-2] = Kn - 1; nk[0] = Kn
+            hp = hoods.copy(); hp[np.arange(Kn)[None, :] >= nk[:, None]] = -1
+            kn = rng.choice(np.array([0, wlsqm.b2_F, wlsqm.b2_F | wlsqm.b2_X2], np.int64), n)
+            w = rng.choice(np.array([wlsqm.WEIGHT_UNIFORM, wlsqm.WEIGHT_CENTER], np.int32), n)
+            fi0 = rng.uniform(-1, 1, (n, 15)); fi0[:, 0] = F[pidx]
+            if (n * Kn * 4) % 16 == 8:
+                keep, h_d = _hoods_at_the_end_of_an_allocation(hp)
+            else:
+                keep, h_d = None, _t(hp)
+            fi = _t(fi0)
+            whip.fit_cloud_device(2, 4, S_d, F_d, h_d, fi, _t(nk), _t(kn), _t(w), point_index=_t(pidx) if with_pidx else None)
+            torch.cuda.synchronize()
+            assert whip.last_kernel() == "tile-solve-gather", whip.last_kernel()
+            got = fi.cpu().numpy()
+            hc = np.where(np.arange(Kn)[None, :] < nk[:, None], hoods, 0).astype(np.int64)
+            xk, fk, xi = S[hc], F[hc], S[pidx]
+            fd = _t(fi0)
+            whip.fit_many_device(2, 4, _t(xk), _t(fk), _t(nk), _t(xi), fd, _t(kn), _t(w))
+            torch.cuda.synchronize()
+            assert whip.last_kernel() == "tile-solve", whip.last_kernel()
+            dense = fd.cpu().numpy()
+            bad = np.nonzero((got.view(np.int64) != dense.view(np.int64)).any(axis=1))[0]
+            assert bad.size == 0, "K %d n %d pidx %s: gathered ring != dense ring for cases %s" % (Kn, n, with_pidx, bad[:8])
+            if n <= 65 or (n <= 777 and not with_pidx):
+                o = np.full(n, 4, np.int32)
+                ref = fi0.copy()
+                oracle.fit_many(2, xk, fk, nk, xi, ref, None, 0, o, kn, w, ntasks=8)
+                truth = P.truth_fit(2, xk, fk, nk, xi, fi0, o, kn, w)
+                if n >= 777:
+                    P.assert_parity(got, ref, truth, "index-based ring tail K = %d n = %d" % (Kn, n))
+                else:
+                    # a few dozen cases make the noise floor a small sample (the oracle may be accurate by luck): the gross criterion
+                    # of tools/fuzz.py — wrong neighbours show as 1e-8 .. 1e-1
+                    E = P.column_metric(got, ref); N = P.column_metric(ref, truth)
+                    assert np.all(E <= 1e-10 + 25.0 * 8.0 * N), "K %d n %d pidx %s: E %s N %s" % (Kn, n, with_pidx, E, N)
+                    assert np.array_equal(got[:, 0][kn & 1 == 1], fi0[:, 0][kn & 1 == 1])
+            del keep
