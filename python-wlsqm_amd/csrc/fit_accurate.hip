@@ -75,6 +75,8 @@ __device__ __forceinline__ double div_by(double a, double b, double r) {   // r 
     return fma(e, r, q);
 }
 struct FastOps {
+    // (no operand of these is ever a NaN on the fast path — the range checks — so v_max_f64 is the reference's `if (q > acc) acc = q`)
+    static __device__ __forceinline__ double maxnum(double acc, double q) { return __builtin_fmax(acc, q); }
     static __device__ __forceinline__ double div(double a, double b) { return div_by(a, b, rcp_refined(b)); }
     static __device__ __forceinline__ double rcp_of(double b) { return rcp_refined(b); }
     static __device__ __forceinline__ double div_r(double a, double b, double r) { return div_by(a, b, r); }
@@ -89,6 +91,7 @@ struct FastOps {
     }
 };
 struct IeeeOps {                                                     // the compiler's sequences: any operand
+    static __device__ __forceinline__ double maxnum(double acc, double q) { return q > acc ? q : acc; }      // NaN q: skipped; NaN acc: kept
     static __device__ __forceinline__ double div(double a, double b) { return a / b; }
     static __device__ __forceinline__ double rcp_of(double) { return 0.; }
     static __device__ __forceinline__ double div_r(double a, double b, double) { return a / b; }
@@ -100,7 +103,17 @@ struct IeeeOps {                                                     // the comp
 // is subnormal, no numerator has a biased exponent <= 53 — the conditions under which v_div_scale / v_div_fixup are the identity
 constexpr double RANGE_LO = 0x1p-200, RANGE_HI = 0x1p200, SCALE_LO = 0x1p-140, SCALE_HI = 0x1p140;
 
-constexpr int CH = 8;                                                // neighbours per staged chunk
+#ifndef WLSQM_ACC_CH
+#define WLSQM_ACC_CH 8
+#endif
+constexpr int CH = WLSQM_ACC_CH;                                     // neighbours per staged chunk
+#ifndef WLSQM_ACC_W1
+#define WLSQM_ACC_W1 2
+#endif
+#ifndef WLSQM_ACC_GRP
+#define WLSQM_ACC_GRP 2
+#endif
+constexpr int GRP = WLSQM_ACC_GRP < CH ? WLSQM_ACC_GRP : CH;                                   // neighbours per straight-line group of the accumulation
 
 template <int N> __host__ __device__ constexpr int utri(int i, int m) { return i * N - i * (i - 1) / 2 + (m - i); }   // i <= m < N
 
@@ -108,232 +121,74 @@ __host__ __device__ constexpr int minw(int NO) { return NO <= 6 ? WLSQM_ACC_MINW
 
 }  // namespace acc
 
-// DENSE: contiguous rows xk[ncases][K][DIM], fk[ncases][K] with 16-byte aligned bases and rows (staged through LDS); otherwise the
-// rows are read per lane through strict::Rows (any strides, index-based input, order buckets) — the same arithmetic, the same bits.
-template <int DIM, int ORDER, bool DENSE>
-__global__ __launch_bounds__(64, acc::minw(ndofs(DIM, ORDER))) void fit_accurate_kernel(const KParams p) {
-    using namespace strict;
-    using namespace acc;
-    constexpr int N = ndofs(DIM, ORDER), NE = N * (N + 1) / 2;
-    constexpr int XPC = CH * DIM * 8 / 16, FPC = CH * 8 / 16;        // 16-byte pieces of one case's chunk: coordinates, values
-    constexpr int XPITCH = CH * DIM + 2, FPITCH = CH + 2;            // doubles per staged row (+ 16 bytes: conflict-free b128 reads)
-    __shared__ __attribute__((aligned(16))) double xs[DENSE ? 64 * XPITCH : 2];
-    __shared__ __attribute__((aligned(16))) double fs[DENSE ? 64 * FPITCH : 2];
 
-    const long long ncases = live_cases(p);
-    const int lane = threadIdx.x;
-    const long long t0 = (long long)blockIdx.x * 64, t = t0 + lane;
-    const bool in_batch = t < ncases;
-    const long long j = in_batch ? (p.case_index ? p.case_index[t] : t) : 0;
-    // a case is taken here iff it has no known DOF (wave-mates do not matter: per case); p.do_sens / p.iterative never reach this kernel
-    const bool active = in_batch && p.knowns[j * p.sknowns] == 0;
-    if (!__any(active)) return;
-    const int K = (int)p.max_nk;
-    const int nk = active ? min(p.nk[j * p.snk], K) : 0;
-    const bool uniform = active ? (p.wm[j * p.swm] == WLSQM_WEIGHT_UNIFORM) : true;
-    double xi[DIM];
-    Rows<DIM> rows{};
-    if constexpr (DENSE) {
+namespace acc {
+
+// range check of the fast equilibration sweeps: every nonzero entry of the matrix in the safe range and no zero row
+template <int N>
+__device__ __forceinline__ bool entries_in_range(const double (&U)[N * (N + 1) / 2]) {
+    bool ok = true;
 #pragma unroll
-        for (int m = 0; m < DIM; ++m) xi[m] = in_batch ? p.xi[j * p.sxi_j + m] : 0.;
-    } else {
-        if (p.hoods) {
-            const long long pj = p.pidx ? p.pidx[j] : j;
+    for (int i = 0; i < N; ++i) {
+        double rowmax = 0.;
 #pragma unroll
-            for (int m = 0; m < DIM; ++m) xi[m] = in_batch ? p.S[pj * DIM + m] : 0.;
-            rows = Rows<DIM>{nullptr, 0, nullptr, 0, p.hoods + j * p.shoods_j, p.S, p.F};
-        } else {
-#pragma unroll
-            for (int m = 0; m < DIM; ++m) xi[m] = in_batch ? p.xi[j * p.sxi_j + m] : 0.;
-            rows = Rows<DIM>{p.xk + j * p.sxk_j, p.sxk_k, p.fk + j * p.sfk_j, p.sfk_k, nullptr, nullptr, nullptr};
+        for (int m = 0; m < N; ++m) {
+            const double a = fabs(U[i <= m ? utri<N>(i, m) : utri<N>(m, i)]);
+            ok = ok && (a == 0. || (a >= RANGE_LO && a <= RANGE_HI));
+            rowmax = a > rowmax ? a : rowmax;
         }
+        ok = ok && rowmax >= RANGE_LO;
     }
+    return ok;
+}
 
-    // ---- one pass over the neighbours of the wave's cases: consume(k, live, d, f) per lane, k ascending.  DENSE: chunks of CH
-    // neighbours through LDS, the next chunk in flight in registers.  MASKED = false: every active lane has nk == K (wave-uniform).
-    const int Q = (K + CH - 1) / CH;
-    const int nvalid = (ncases - t0 < 64) ? (int)(ncases - t0) : 64;
-    d2_ xr[DENSE ? XPC : 1], fr[DENSE ? FPC : 1];
-    auto fetch = [&](int q, bool want_f) {                            // global -> registers, coalesced 16-byte pieces
-        if constexpr (DENSE) {
-            const char* xb = reinterpret_cast<const char*>(p.xk + t0 * (long long)K * DIM) + (size_t)q * (CH * DIM * 8);
-            const int rowb = K * DIM * 8 - q * (CH * DIM * 8);        // bytes of a row from this chunk on
+// rescale_ruiz2001_c (lapackdrivers.pyx:553-623) on the symmetric matrix: DR == DC, DRp == DCp, rs == cs bit for bit, so one
+// pass per sweep.  Returns whether every running scale factor stayed in the safe range of the fast sequences.
+template <int N, class OPS>
+__device__ __forceinline__ bool ruiz_sym(const double (&U)[N * (N + 1) / 2], double (&rs)[N]) {
+    using strict::ruiz_epsilon;
+    double DRp[N];
+    bool in_range = true;
 #pragma unroll
-            for (int i = 0; i < XPC; ++i) {
-                const int pi = i * 64 + lane, cc = pi / XPC, sub = pi - cc * XPC;
-                if (cc < nvalid && sub * 16 < rowb)
-                    xr[i] = *reinterpret_cast<const d2_*>(xb + (size_t)cc * ((size_t)K * DIM * 8) + sub * 16);
-            }
-            if (want_f) {
-                const char* fb = reinterpret_cast<const char*>(p.fk + t0 * (long long)K) + (size_t)q * (CH * 8);
-                const int frow = K * 8 - q * (CH * 8);
+    for (int i = 0; i < N; ++i) { rs[i] = 1.; DRp[i] = 1.; }
+    for (int it = 0; it < 100; ++it) {
+        double DR[N];
 #pragma unroll
-                for (int i = 0; i < FPC; ++i) {
-                    const int pi = i * 64 + lane, cc = pi / FPC, sub = pi - cc * FPC;
-                    if (cc < nvalid && sub * 16 < frow)
-                        fr[i] = *reinterpret_cast<const d2_*>(fb + (size_t)cc * ((size_t)K * 8) + sub * 16);
-                }
+        for (int i = 0; i < N; ++i) DR[i] = 0.;
+#pragma unroll
+        for (int m = 0; m < N; ++m) {
+#pragma unroll
+            for (int i = 0; i <= m; ++i) {
+                const double q = fabs(OPS::div(U[utri<N>(i, m)], DRp[i] * DRp[m]));
+                DR[i] = OPS::maxnum(DR[i], q);
+                if (i != m) DR[m] = OPS::maxnum(DR[m], q);
             }
         }
-    };
-    auto park = [&](bool want_f) {                                    // registers -> LDS rows
-        if constexpr (DENSE) {
-#pragma unroll
-            for (int i = 0; i < XPC; ++i) {
-                const int pi = i * 64 + lane, cc = pi / XPC, sub = pi - cc * XPC;
-                *reinterpret_cast<d2_*>(xs + cc * XPITCH + sub * 2) = xr[i];
-            }
-            if (want_f) {
-#pragma unroll
-                for (int i = 0; i < FPC; ++i) {
-                    const int pi = i * 64 + lane, cc = pi / FPC, sub = pi - cc * FPC;
-                    *reinterpret_cast<d2_*>(fs + cc * FPITCH + sub * 2) = fr[i];
-                }
-            }
-        }
-    };
-    // (the staged passes run back to back: pass P's first chunk is requested under pass P - 1's last)
-    auto run_pass = [&](auto masked_tag, bool want_f, bool prefetched, bool more_passes, bool next_want_f, auto&& consume) {
-        constexpr bool MASKED = decltype(masked_tag)::value;
-        if constexpr (DENSE) {
-            if (!prefetched) fetch(0, want_f);
-            for (int q = 0; q < Q; ++q) {
-                __syncthreads();                                      // the previous chunk has been read by every lane
-                park(want_f);
-                __syncthreads();
-                if (q + 1 < Q) fetch(q + 1, want_f);
-                else if (more_passes) fetch(0, next_want_f);
-                const double* xrow = xs + lane * XPITCH;
-                const double* frow = fs + lane * FPITCH;
-#pragma unroll
-                for (int kk = 0; kk < CH; ++kk) {
-                    const int k = q * CH + kk;
-                    if (k < K) {                                      // wave-uniform
-                        const bool live = MASKED ? (k < nk) : true;
-                        double d[DIM];
-#pragma unroll
-                        for (int m = 0; m < DIM; ++m) { d[m] = xrow[kk * DIM + m] - xi[m]; if (MASKED) d[m] = live ? d[m] : 0.; }
-                        double f = want_f ? frow[kk] : 0.;
-                        if (MASKED) f = live ? f : 0.;
-                        consume(k, live, d, f);
-                    }
-                }
-            }
-        } else {
-            for (int k = 0; k < nk; ++k) {
-                double d[DIM];
-                rows.offset(k, xi, d);
-                consume(k, true, d, want_f ? rows.value(k) : 0.);
-            }
-        }
-    };
-    const bool wave_full = __all(!active || nk == K);
-    auto pass = [&](bool want_f, bool prefetched, bool more_passes, bool next_want_f, auto&& consume) {
-        if (wave_full) run_pass(std::false_type{}, want_f, prefetched, more_passes, next_want_f, consume);
-        else run_pass(std::true_type{}, want_f, prefetched, more_passes, next_want_f, consume);
-    };
-
-    // ---- pass 1 (make_c_nD, first half): the largest squared distance; the smallest too, for the range check of the fast weights
-    double max_d2 = 0., min_d2 = RANGE_HI;
-    pass(false, false, true, true, [&](int, bool live, const double (&d)[DIM], double) {
-        double c[N];
-        const double d2 = make_c<DIM, ORDER>(d, c);
-        if (live) { if (d2 > max_d2) max_d2 = d2; if (!(d2 >= min_d2)) min_d2 = d2; }      // (a NaN distance lands in min_d2)
-    });
-    // fast weights: every squared distance of the case in the safe range (a neighbour AT the centre, a NaN or an empty
-    // neighbourhood fail it and take the IEEE sequences); uniform weighting computes no quotient at all
-    const bool w_ok = !active || uniform || (min_d2 >= RANGE_LO && max_d2 <= RANGE_HI && nk > 0);
-    const bool fast_w = __all(w_ok);
-
-    // ---- pass 2: make_A (upper triangle) and the right-hand side sums of solve (impl.pyx:768-787), k ascending
-    double U[NE], b[N];
-#pragma unroll
-    for (int e = 0; e < NE; ++e) U[e] = 0.;
-#pragma unroll
-    for (int i = 0; i < N; ++i) b[i] = 0.;
-    auto accumulate = [&](auto ops_tag) {
-        using OPS = decltype(ops_tag);
-        const double rmax = OPS::rcp_of(max_d2);
-        pass(true, true, false, false, [&](int, bool live, const double (&d)[DIM], double f) {
-            double c[N];
-            const double d2 = make_c<DIM, ORDER>(d, c);
-            const double tmp = 1. - OPS::sqrt(OPS::div_r(d2, max_d2, rmax));
-            double w = uniform ? 1. : weights_alpha + weights_beta * tmp * tmp;
-            w = live ? w : 0.;
-            const double wf = w * f;
-#pragma unroll
-            for (int om = 0; om < N; ++om) {
-                const double wc = w * c[om];
-#pragma unroll
-                for (int oj = 0; oj <= om; ++oj) U[utri<N>(oj, om)] += wc * c[oj];
-            }
-#pragma unroll
-            for (int oj = 0; oj < N; ++oj) b[oj] += wf * c[oj];
-        });
-    };
-    if (fast_w) accumulate(FastOps{}); else accumulate(IeeeOps{});
-    if (!active) return;                                              // (no barrier below this line)
-
-    // ---- rescale_ruiz2001_c (lapackdrivers.pyx:553-623) on the symmetric matrix: DR == DC, DRp == DCp, rs == cs bit for bit
-    double rs[N], DRp[N];
-    bool r_ok = true;
-    {   // range check of the fast sweeps: every nonzero entry in the safe range and no zero row
+        double acc = 0.;
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            double rowmax = 0.;
-#pragma unroll
-            for (int m = 0; m < N; ++m) {
-                const double a = fabs(U[i <= m ? utri<N>(i, m) : utri<N>(m, i)]);
-                r_ok = r_ok && (a == 0. || (a >= RANGE_LO && a <= RANGE_HI));
-                rowmax = a > rowmax ? a : rowmax;
-            }
-            r_ok = r_ok && rowmax >= RANGE_LO;
+            const double s = OPS::sqrt(DR[i]);
+            DRp[i] *= s; rs[i] = OPS::div(rs[i], s);
+            in_range = in_range && DRp[i] >= SCALE_LO && DRp[i] <= SCALE_HI;      // (a NaN fails it)
+            const double tmp = fabs(1. - s * s);
+            if (i == 0) acc = tmp; else acc = OPS::maxnum(acc, tmp);
         }
+        if (acc < ruiz_epsilon) break;                                // (the column test sees the same numbers)
     }
-    auto ruiz = [&](auto ops_tag) -> bool {
-        using OPS = decltype(ops_tag);
-        double slo = 1., shi = 1.;
-#pragma unroll
-        for (int i = 0; i < N; ++i) { rs[i] = 1.; DRp[i] = 1.; }
-        for (int it = 0; it < 100; ++it) {
-            double DR[N];
-#pragma unroll
-            for (int i = 0; i < N; ++i) DR[i] = 0.;
-#pragma unroll
-            for (int m = 0; m < N; ++m) {
-#pragma unroll
-                for (int i = 0; i <= m; ++i) {
-                    const double q = fabs(OPS::div(U[utri<N>(i, m)], DRp[i] * DRp[m]));
-                    if (q > DR[i]) DR[i] = q;
-                    if (i != m) { if (q > DR[m]) DR[m] = q; }
-                }
-            }
-            double acc = 0.;
-#pragma unroll
-            for (int i = 0; i < N; ++i) {
-                const double s = OPS::sqrt(DR[i]);
-                DRp[i] *= s; rs[i] = OPS::div(rs[i], s);
-                slo = DRp[i] < slo ? DRp[i] : slo; shi = DRp[i] > shi ? DRp[i] : shi;
-                const double tmp = fabs(1. - s * s);
-                if (i == 0) acc = tmp; else if (tmp > acc) acc = tmp;
-            }
-            if (acc < ruiz_epsilon) break;                            // (the column test sees the same numbers)
-        }
-        return slo >= SCALE_LO && shi <= SCALE_HI;
-    };
-    bool fast_done = false;
-    if (__all(r_ok)) { r_ok = ruiz(FastOps{}); fast_done = true; }
-    if (!fast_done || !__all(r_ok)) (void)ruiz(IeeeOps{});           // IEEE sequences for the whole wave: the same bits where both apply
+    return in_range;
+}
 
-    // apply_scaling_c (lapackdrivers.pyx:293-299): A[i][m] *= rs[i] * cs[m] (commutative: the scaled matrix is symmetric too)
+// apply_scaling_c (lapackdrivers.pyx:293-299), dgetrf (unblocked dgetf2 semantics, :1628-1635), solve without knowns
+// (impl.pyx:731-846: b = row_scale * sums, dgetrs('N'), un-scale) and the store of the case's DOFs.  The row exchange is written as
+// selects over the candidate rows; a wave none of whose cases leaves the diagonal pivot in a column skips it.  (The 2 N quotients
+// here are the compiler's IEEE sequences: a pivot may be anything.)
+template <int N>
+__device__ __forceinline__ void lu_solve_store(const double (&U)[N * (N + 1) / 2], const double (&rs)[N], double (&b)[N], double* fio) {
     double A[N][N];
 #pragma unroll
     for (int i = 0; i < N; ++i)
 #pragma unroll
         for (int m = i; m < N; ++m) { const double v = U[utri<N>(i, m)] * (rs[i] * rs[m]); A[i][m] = v; A[m][i] = v; }
-
-    // dgetrf (unblocked dgetf2 semantics).  The row exchange is written as selects over the candidate rows; a wave none of whose
-    // cases leaves the diagonal pivot in this column skips it.
     int ipiv[N];
 #pragma unroll
     for (int c0 = 0; c0 < N; ++c0) {
@@ -361,7 +216,6 @@ __global__ __launch_bounds__(64, acc::minw(ndofs(DIM, ORDER))) void fit_accurate
             for (int i = c0 + 1; i < N; ++i) A[i][m] -= A[i][c0] * u;
         }
     }
-    // solve (impl.pyx:731-846) without knowns: b = row_scale * sums, dgetrs('N'), un-scale
 #pragma unroll
     for (int i = 0; i < N; ++i) b[i] = rs[i] * b[i];
 #pragma unroll
@@ -381,22 +235,386 @@ __global__ __launch_bounds__(64, acc::minw(ndofs(DIM, ORDER))) void fit_accurate
 #pragma unroll
         for (int i = 0; i < c0; ++i) b[i] -= A[i][c0] * b[c0];
     }
-    double* const fio = p.fi + j * p.sfi_j;
 #pragma unroll
     for (int i = 0; i < N; ++i) fio[i] = b[i] * rs[i];
 }
 
+}  // namespace acc
+
+// DENSE: contiguous rows xk[ncases][K][DIM], fk[ncases][K] with 16-byte aligned bases and rows (staged through LDS); otherwise the
+// rows are read per lane through strict::Rows (any strides, index-based input, order buckets) — the same arithmetic, the same bits.
+// Work lists of an accurate-mode launch (device ints, stream-ordered scratch): [0] number of REDO groups, [1] number of LEFTOVER
+// groups, [2 .. 2 + G) the redo groups, [2 + G .. 2 + 2 G) the leftover groups (G = 64-case groups of the launch).
+//   redo:     the speculative kernel could not vouch for a group (its guess of the largest squared distance was wrong, or an
+//             operand left the safe range of the fast sequences): the two-pass kernel fits the group again, from scratch;
+//   leftover: the group holds a case with a known DOF: the strict kernels fit those cases (they stay idle when there are none).
+struct AccLists { int* ws; long long ngroups; };
+
+// One 64-case group.  SPEC (dense rows only): ONE pass over the neighbours.  The weights need the largest squared distance of the
+// case before the first term can be summed, which is what makes the reference (and the two-pass form of this kernel) read every
+// neighbourhood twice — 1.31 GB instead of 0.85 through the fabric per 1M configs[1] cases, and a first pass whose few
+// instructions per neighbour cannot cover its own load latency.  Neighbour lists that come out of a k-nearest-neighbour search
+// are sorted by distance (scipy's cKDTree.query, wlsqm.hip.knn: the reference's examples and every BASELINE config), so the LAST
+// neighbour is the farthest: the pass runs with that guess while it also tracks the true maximum, and the guess is VERIFIED bit for
+// bit afterwards.  A group with a wrong guess (unsorted neighbours: a ball query) or an operand outside the safe range of the fast
+// sequences is written to the redo list and fitted again by the two-pass kernel: speculation, never approximation.
+template <int DIM, int ORDER, bool DENSE, bool SPEC>
+__device__ __forceinline__ void accurate_group(const KParams& p, const long long t0, const AccLists& lists, double* xs, double* fs) {
+    using namespace strict;
+    using namespace acc;
+    static_assert(!SPEC || DENSE, "the speculative single pass stages dense rows");
+    constexpr int N = ndofs(DIM, ORDER), NE = N * (N + 1) / 2;
+    constexpr int XPC = CH * DIM * 8 / 16, FPC = CH * 8 / 16;        // 16-byte pieces of one case's chunk: coordinates, values
+    constexpr int XPITCH = CH * DIM + 2, FPITCH = CH + 2;            // doubles per staged row (+ 16 bytes: conflict-free b128 reads)
+
+    const long long ncases = live_cases(p);
+    const int lane = threadIdx.x;
+    const long long t = t0 + lane;
+    const bool in_batch = t < ncases;
+    const long long j = in_batch ? (p.case_index ? p.case_index[t] : t) : 0;
+    // a case is taken here iff it has no known DOF (wave-mates do not matter: per case); p.do_sens / p.iterative never reach this kernel
+    const long long kn = in_batch ? p.knowns[j * p.sknowns] : 0;
+    const bool active = in_batch && kn == 0;
+    if constexpr (SPEC) {
+        if (__any(in_batch && kn != 0) && lane == 0) lists.ws[2 + lists.ngroups + atomicAdd(lists.ws + 1, 1)] = (int)(t0 >> 6);
+        // the speculative kernel moves whole 64-case groups in whole chunks only (no predicated loads in its loop): the last,
+        // partial group of a launch goes to the two-pass kernel (the launcher sends neighbour counts that are not a multiple of CH there altogether)
+        if (ncases - t0 < 64) {
+            if (__any(active) && lane == 0) lists.ws[2 + atomicAdd(lists.ws, 1)] = (int)(t0 >> 6);
+            return;
+        }
+    }
+    if (!__any(active)) return;
+    const int K = (int)p.max_nk;
+    const int nk = active ? min(p.nk[j * p.snk], K) : 0;
+    const bool uniform = active ? (p.wm[j * p.swm] == WLSQM_WEIGHT_UNIFORM) : true;
+    double xi[DIM];
+    Rows<DIM> rows{};
+    if constexpr (DENSE) {
+#pragma unroll
+        for (int m = 0; m < DIM; ++m) xi[m] = in_batch ? p.xi[j * p.sxi_j + m] : 0.;
+    } else {
+        if (p.hoods) {
+            const long long pj = p.pidx ? p.pidx[j] : j;
+#pragma unroll
+            for (int m = 0; m < DIM; ++m) xi[m] = in_batch ? p.S[pj * DIM + m] : 0.;
+            rows = Rows<DIM>{nullptr, 0, nullptr, 0, p.hoods + j * p.shoods_j, p.S, p.F};
+        } else {
+#pragma unroll
+            for (int m = 0; m < DIM; ++m) xi[m] = in_batch ? p.xi[j * p.sxi_j + m] : 0.;
+            rows = Rows<DIM>{p.xk + j * p.sxk_j, p.sxk_k, p.fk + j * p.sfk_j, p.sfk_k, nullptr, nullptr, nullptr};
+        }
+    }
+
+    // ---- one pass over the neighbours of the wave's cases: consume(k, live, d, f) per lane, k ascending.  DENSE: chunks of CH
+    // neighbours through LDS, the next chunk in flight in registers.  MASKED = false: every active lane has nk == K (wave-uniform).
+    // A load instruction moves the chunks of XCPI (FCPI) whole cases, XPC (FPC) consecutive lanes per case: the lane's global
+    // offset is ONE 32-bit register for every instruction and chunk (the rest of the address is wave-uniform) and its LDS position a
+    // compile-time distance from the first one.
+    const int Q = (K + CH - 1) / CH;
+    const int nvalid = (ncases - t0 < 64) ? (int)(ncases - t0) : 64;
+    constexpr int XCPI = 64 / XPC, XNI = (64 + XCPI - 1) / XCPI;      // 2D: 8 cases x 8 instructions; 3D: 5 x 13 (lanes 60..63 idle)
+    constexpr int FCPI = 64 / FPC, FNI = 64 / FCPI;                   // 16 cases x 4 instructions
+    static_assert(64 % FCPI == 0, "value rows: whole instructions");
+    const int xsub = lane % XPC, xc0 = lane / XPC, fsub = lane % FPC, fc0 = lane / FPC;
+    const unsigned xrowb = (unsigned)K * DIM * 8, frowb = (unsigned)K * 8;
+    const unsigned xg0 = (unsigned)xc0 * xrowb + (unsigned)xsub * 16u, fg0 = (unsigned)fc0 * frowb + (unsigned)fsub * 16u;
+    const bool xlane = lane < XCPI * XPC;
+    d2_ xr[DENSE ? XNI : 1], fr[DENSE ? FNI : 1];
+    // pass 1 (largest squared distance) does a few instructions per neighbour: a chunk does not cover the latency of the next
+    // one's loads.  It keeps W1 chunks in flight instead (their registers are free: the matrix is not live yet).
+    constexpr int W1 = DENSE ? (XNI <= 8 ? WLSQM_ACC_W1 : 2) : 1;
+    d2_ xw[W1][DENSE ? XNI : 1];
+    const char* const xtile = DENSE ? reinterpret_cast<const char*>(p.xk + t0 * (long long)K * DIM) : nullptr;
+    const char* const ftile = DENSE ? reinterpret_cast<const char*>(p.fk + t0 * (long long)K) : nullptr;
+    auto fetch_into = [&](d2_ (&xr)[DENSE ? XNI : 1], int q, bool want_f) {      // global -> registers, coalesced 16-byte pieces
+        if constexpr (DENSE) {
+            const char* xb = xtile + (size_t)q * (CH * DIM * 8);
+            const char* fb = ftile + (size_t)q * (CH * 8);
+            const bool whole = SPEC || (nvalid == 64 && (q + 1) * CH <= K);     // wave-uniform: no case and no piece beyond the data
+            if (whole) {
+#pragma unroll
+                for (int i = 0; i < XNI; ++i)
+                    if (xlane && (i * XCPI + XCPI <= 64 || xc0 + i * XCPI < 64))
+                        xr[i] = *reinterpret_cast<const d2_*>(xb + (size_t)i * XCPI * xrowb + xg0);
+                if (want_f) {
+#pragma unroll
+                    for (int i = 0; i < FNI; ++i) fr[i] = *reinterpret_cast<const d2_*>(fb + (size_t)i * FCPI * frowb + fg0);
+                }
+            } else {
+                const int xleft = (int)xrowb - q * (CH * DIM * 8), fleft = (int)frowb - q * (CH * 8);   // bytes of a row from this chunk on
+#pragma unroll
+                for (int i = 0; i < XNI; ++i)
+                    if (xlane && xc0 + i * XCPI < nvalid && xsub * 16 < xleft)
+                        xr[i] = *reinterpret_cast<const d2_*>(xb + (size_t)i * XCPI * xrowb + xg0);
+                if (want_f) {
+#pragma unroll
+                    for (int i = 0; i < FNI; ++i)
+                        if (fc0 + i * FCPI < nvalid && fsub * 16 < fleft)
+                            fr[i] = *reinterpret_cast<const d2_*>(fb + (size_t)i * FCPI * frowb + fg0);
+                }
+            }
+        }
+    };
+    auto fetch = [&](int q, bool want_f) { fetch_into(xr, q, want_f); };
+    auto park_from = [&](const d2_ (&xr)[DENSE ? XNI : 1], bool want_f) {        // registers -> LDS rows
+        if constexpr (DENSE) {
+            double* xl = xs + xc0 * XPITCH + xsub * 2;
+            double* fl = fs + fc0 * FPITCH + fsub * 2;
+#pragma unroll
+            for (int i = 0; i < XNI; ++i)
+                if (xlane && (i * XCPI + XCPI <= 64 || xc0 + i * XCPI < 64)) *reinterpret_cast<d2_*>(xl + i * XCPI * XPITCH) = xr[i];
+            if (want_f) {
+#pragma unroll
+                for (int i = 0; i < FNI; ++i) *reinterpret_cast<d2_*>(fl + i * FCPI * FPITCH) = fr[i];
+            }
+        }
+    };
+    auto park = [&](bool want_f) { park_from(xr, want_f); };
+    // (the staged passes run back to back: pass P's first chunk is requested under pass P - 1's last)
+    // the neighbours of chunk q, staged in LDS: straight-line code for GRP neighbours at a time (all CH at once: the scheduler hoists
+    // every LDS read and the kernel spills; the group size itself measured flat, profiles/r04b_ab_accurate.txt)
+    auto chunk = [&](auto masked_tag, int q, bool want_f, auto&& consume) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        const double* xrow = xs + lane * XPITCH;
+        const double* frow = fs + lane * FPITCH;
+        if (SPEC || (q + 1) * CH <= K) {
+#pragma nounroll
+            for (int g = 0; g < CH / GRP; ++g) {
+                const double* xg = xrow + g * (GRP * DIM);
+                const double* fg = frow + g * GRP;
+#pragma unroll
+                for (int kk = 0; kk < GRP; ++kk) {
+                    const int k = q * CH + g * GRP + kk;
+                    const bool live = MASKED ? (k < nk) : true;
+                    double d[DIM];
+#pragma unroll
+                    for (int m = 0; m < DIM; ++m) { d[m] = xg[kk * DIM + m] - xi[m]; if (MASKED) d[m] = live ? d[m] : 0.; }
+                    double f = want_f ? fg[kk] : 0.;
+                    if (MASKED) f = live ? f : 0.;
+                    consume(k, live, d, f);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < CH; ++kk) {
+                const int k = q * CH + kk;
+                if (k < K) {                                          // wave-uniform
+                    const bool live = MASKED ? (k < nk) : true;
+                    double d[DIM];
+#pragma unroll
+                    for (int m = 0; m < DIM; ++m) { d[m] = xrow[kk * DIM + m] - xi[m]; if (MASKED) d[m] = live ? d[m] : 0.; }
+                    double f = want_f ? frow[kk] : 0.;
+                    if (MASKED) f = live ? f : 0.;
+                    consume(k, live, d, f);
+                }
+            }
+        }
+    };
+    // (the staged passes run back to back: pass P's first chunk is requested under pass P - 1's last)
+    auto run_pass = [&](auto masked_tag, bool want_f, bool prefetched, bool more_passes, bool next_want_f, auto&& consume) {
+        if constexpr (DENSE) {
+            if (!prefetched) fetch(0, want_f);
+            for (int q = 0; q < Q; ++q) {
+                __syncthreads();                                      // the previous chunk has been read by every lane
+                park(want_f);
+                __syncthreads();
+                if (q + 1 < Q) fetch(q + 1, want_f);
+                else if (more_passes) fetch(0, next_want_f);
+                chunk(masked_tag, q, want_f, consume);
+            }
+        } else {
+            for (int k = 0; k < nk; ++k) {
+                double d[DIM];
+                rows.offset(k, xi, d);
+                consume(k, true, d, want_f ? rows.value(k) : 0.);
+            }
+        }
+    };
+    // the same with W1 chunks in flight (coordinates only: pass 1); the next pass's first chunk is requested under the last window
+    auto run_pass_windowed = [&](auto masked_tag, bool next_want_f, auto&& consume) {
+        if constexpr (DENSE) {
+            for (int q0 = 0; q0 < Q; q0 += W1) {
+#pragma unroll
+                for (int w = 0; w < W1; ++w)
+                    if (q0 + w < Q) fetch_into(xw[w], q0 + w, false);
+                if (q0 + W1 >= Q) fetch(0, next_want_f);
+#pragma unroll
+                for (int w = 0; w < W1; ++w) {
+                    if (q0 + w < Q) {
+                        __syncthreads();
+                        park_from(xw[w], false);
+                        __syncthreads();
+                        chunk(masked_tag, q0 + w, false, consume);
+                    }
+                }
+            }
+        } else {
+            for (int k = 0; k < nk; ++k) {
+                double d[DIM];
+                rows.offset(k, xi, d);
+                consume(k, true, d, 0.);
+            }
+        }
+    };
+    const bool wave_full = __all(!active || nk == K);
+    auto pass = [&](bool want_f, bool prefetched, bool more_passes, bool next_want_f, auto&& consume) {
+        if (wave_full) run_pass(std::false_type{}, want_f, prefetched, more_passes, next_want_f, consume);
+        else run_pass(std::true_type{}, want_f, prefetched, more_passes, next_want_f, consume);
+    };
+    auto pass_windowed = [&](bool next_want_f, auto&& consume) {
+        if (wave_full) run_pass_windowed(std::false_type{}, next_want_f, consume);
+        else run_pass_windowed(std::true_type{}, next_want_f, consume);
+    };
+
+    double U[NE], b[N];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) U[e] = 0.;
+#pragma unroll
+    for (int i = 0; i < N; ++i) b[i] = 0.;
+    if constexpr (SPEC) {
+        // ---- the speculative single pass (see above): guess = squared distance of the last neighbour, same operations as make_c
+        double guess = 0.;
+        if (active && nk > 0) {
+            const double* q = p.xk + j * (long long)K * DIM + (long long)(nk - 1) * DIM;
+            double dg[DIM], cg[N];
+#pragma unroll
+            for (int m = 0; m < DIM; ++m) dg[m] = q[m] - xi[m];
+            guess = make_c<DIM, ORDER>(dg, cg);
+        }
+        fetch(0, true);
+        const double rg = rcp_refined(guess);
+        double max_d2 = 0., min_d2 = RANGE_HI;
+        auto one = [&](int, bool live, const double (&d)[DIM], double f) {
+            double c[N];
+            const double d2 = make_c<DIM, ORDER>(d, c);
+            if (live) { max_d2 = __builtin_fmax(max_d2, d2); min_d2 = __builtin_fmin(min_d2, d2); }
+            const double tmp = 1. - FastOps::sqrt(div_by(d2, guess, rg));
+            double w = uniform ? 1. : weights_alpha + weights_beta * tmp * tmp;
+            w = live ? w : 0.;
+            const double wf = w * f;
+#pragma unroll
+            for (int om = 0; om < N; ++om) {
+                const double wc = w * c[om];
+#pragma unroll
+                for (int oj = 0; oj <= om; ++oj) U[utri<N>(oj, om)] += wc * c[oj];
+            }
+#pragma unroll
+            for (int oj = 0; oj < N; ++oj) b[oj] += wf * c[oj];
+        };
+        pass(true, true, false, false, one);
+        // vouch for the case: the guess WAS the largest squared distance (bit for bit), every squared distance in the safe range
+        // of the fast quotient and root (fmax / fmin drop a NaN distance: the sum test catches it), every matrix entry and every
+        // running scale factor of the equilibration too
+        bool sure = !active || ((uniform || (max_d2 == guess && min_d2 >= RANGE_LO && max_d2 <= RANGE_HI)) && nk > 0 &&
+                                (U[0] - U[0] == 0.) && entries_in_range<N>(U));
+        double rs[N];
+        if (__all(sure)) sure = !active || ruiz_sym<N, FastOps>(U, rs);
+        if (!__all(sure)) {                                           // wave-uniform: the whole group goes to the two-pass kernel
+            if (lane == 0) lists.ws[2 + atomicAdd(lists.ws, 1)] = (int)(t0 >> 6);
+            return;
+        }
+        if (!active) return;
+        lu_solve_store<N>(U, rs, b, p.fi + j * p.sfi_j);
+        return;
+    }
+    // ---- pass 1 (make_c_nD, first half): the largest squared distance; the smallest too, for the range check of the fast weights
+    double max_d2 = 0., min_d2 = RANGE_HI;
+#ifndef WLSQM_ACC_WINDOW
+#define WLSQM_ACC_WINDOW 1
+#endif
+    auto pass1 = [&](auto&& consume) { if (WLSQM_ACC_WINDOW) pass_windowed(true, consume); else pass(false, false, true, true, consume); };
+    pass1([&](int, bool live, const double (&d)[DIM], double) {
+        double c[N];
+        const double d2 = make_c<DIM, ORDER>(d, c);
+        if (live) { if (d2 > max_d2) max_d2 = d2; if (!(d2 >= min_d2)) min_d2 = d2; }      // (a NaN distance lands in min_d2)
+    });
+    // fast weights: every squared distance of the case in the safe range (a neighbour AT the centre, a NaN or an empty
+    // neighbourhood fail it and take the IEEE sequences); uniform weighting computes no quotient at all
+    const bool w_ok = !active || uniform || (min_d2 >= RANGE_LO && max_d2 <= RANGE_HI && nk > 0);
+    const bool fast_w = __all(w_ok);
+
+    // ---- pass 2: make_A (upper triangle) and the right-hand side sums of solve (impl.pyx:768-787), k ascending
+    auto accumulate = [&](auto ops_tag) {
+        using OPS = decltype(ops_tag);
+        const double rmax = OPS::rcp_of(max_d2);
+        pass(true, true, false, false, [&](int, bool live, const double (&d)[DIM], double f) {
+            double c[N];
+            const double d2 = make_c<DIM, ORDER>(d, c);
+            const double tmp = 1. - OPS::sqrt(OPS::div_r(d2, max_d2, rmax));
+            double w = uniform ? 1. : weights_alpha + weights_beta * tmp * tmp;
+            w = live ? w : 0.;
+            const double wf = w * f;
+#pragma unroll
+            for (int om = 0; om < N; ++om) {
+                const double wc = w * c[om];
+#pragma unroll
+                for (int oj = 0; oj <= om; ++oj) U[utri<N>(oj, om)] += wc * c[oj];
+            }
+#pragma unroll
+            for (int oj = 0; oj < N; ++oj) b[oj] += wf * c[oj];
+        });
+    };
+    if (fast_w) accumulate(FastOps{}); else accumulate(IeeeOps{});
+    if (!active) return;                                              // (no barrier below this line)
+
+    // ---- equilibration (fast sequences where every operand is in their safe range, the IEEE sequences for the whole wave
+    // otherwise: the same bits where both apply), scaling, LU, solve
+    double rs[N];
+    bool r_ok = entries_in_range<N>(U), fast_done = false;
+    if (__all(r_ok)) { r_ok = ruiz_sym<N, FastOps>(U, rs); fast_done = true; }
+    if (!fast_done || !__all(r_ok)) (void)ruiz_sym<N, IeeeOps>(U, rs);
+    lu_solve_store<N>(U, rs, b, p.fi + j * p.sfi_j);
+}
+
+template <int DIM, int ORDER, bool DENSE, bool SPEC>
+__global__ __launch_bounds__(64, acc::minw(ndofs(DIM, ORDER))) void fit_accurate_kernel(const KParams p, const AccLists lists) {
+    constexpr int XPITCH = acc::CH * DIM + 2, FPITCH = acc::CH + 2;
+    __shared__ __attribute__((aligned(16))) double xs[DENSE ? 64 * XPITCH : 2];
+    __shared__ __attribute__((aligned(16))) double fs[DENSE ? 64 * FPITCH : 2];
+    accurate_group<DIM, ORDER, DENSE, SPEC>(p, (long long)blockIdx.x * 64, lists, xs, fs);
+}
+
+// the redo groups of a speculative launch: a small grid walks the list (empty in the common case: the kernel is a few idle waves)
 template <int DIM, int ORDER>
-static int launch_accurate(const KParams& p, hipStream_t stream) {
+__global__ __launch_bounds__(64, acc::minw(ndofs(DIM, ORDER))) void fit_accurate_redo_kernel(const KParams p, const AccLists lists) {
+    constexpr int XPITCH = acc::CH * DIM + 2, FPITCH = acc::CH + 2;
+    __shared__ __attribute__((aligned(16))) double xs[64 * XPITCH];
+    __shared__ __attribute__((aligned(16))) double fs[64 * FPITCH];
+    const int n = lists.ws[0];
+    for (int g = blockIdx.x; g < n; g += gridDim.x) {
+        accurate_group<DIM, ORDER, true, false>(p, (long long)lists.ws[2 + g] * 64, lists, xs, fs);
+        __syncthreads();                                              // the staging buffers are reused by the next group
+    }
+}
+
+__global__ void acc_lists_zero_kernel(int* ws) { if (threadIdx.x < 2) ws[threadIdx.x] = 0; }
+
+template <int DIM, int ORDER>
+static int launch_accurate(const KParams& p, hipStream_t stream, int** lists_out) {
+    *lists_out = nullptr;
     const long long groups = (p.ncases + 63) / 64;
     if (groups <= 0) return WLSQM_OK;
-    if (groups > 0x7fffffffLL) { set_error("too many cases for one launch"); return WLSQM_EVALUE; }
+    if (groups > 0x3fffffffLL) { set_error("too many cases for one launch"); return WLSQM_EVALUE; }
     const long long K = p.max_nk;
     const bool dense = !p.hoods && !p.case_index && p.xk && p.fk && K >= 2 && K % 2 == 0 && p.sxk_k == DIM && p.sxk_j == K * DIM &&
                        p.sfk_k == 1 && p.sfk_j == K && ((reinterpret_cast<uintptr_t>(p.xk) | reinterpret_cast<uintptr_t>(p.fk)) & 15u) == 0 &&
                        !getenv("WLSQM_HIP_ACCURATE_NO_STAGE");
-    if (dense) hipLaunchKernelGGL((fit_accurate_kernel<DIM, ORDER, true>), dim3((unsigned)groups), dim3(64), 0, stream, p);
-    else hipLaunchKernelGGL((fit_accurate_kernel<DIM, ORDER, false>), dim3((unsigned)groups), dim3(64), 0, stream, p);
+    const char* nospec = getenv("WLSQM_HIP_ACCURATE_NO_SPEC");        // A/B and tests: the two-pass kernel for every group
+    AccLists lists{nullptr, groups};
+    if (dense && K % acc::CH == 0 && !(nospec && nospec[0] == '1')) {
+        int rc = scratch_alloc_async(reinterpret_cast<void**>(&lists.ws), (size_t)(2 + 2 * groups) * sizeof(int), stream);
+        if (rc != WLSQM_OK) return rc;
+        *lists_out = lists.ws;                                        // (freed by the caller behind the strict kernels, which read the leftover list)
+        hipLaunchKernelGGL(acc_lists_zero_kernel, dim3(1), dim3(64), 0, stream, lists.ws);
+        hipLaunchKernelGGL((fit_accurate_kernel<DIM, ORDER, true, true>), dim3((unsigned)groups), dim3(64), 0, stream, p, lists);
+        const unsigned redo_grid = (unsigned)(groups < 2048 ? groups : 2048);
+        hipLaunchKernelGGL((fit_accurate_redo_kernel<DIM, ORDER>), dim3(redo_grid), dim3(64), 0, stream, p, lists);
+    } else if (dense) {
+        hipLaunchKernelGGL((fit_accurate_kernel<DIM, ORDER, true, false>), dim3((unsigned)groups), dim3(64), 0, stream, p, lists);
+    } else {
+        hipLaunchKernelGGL((fit_accurate_kernel<DIM, ORDER, false, false>), dim3((unsigned)groups), dim3(64), 0, stream, p, lists);
+    }
     WLSQM_HIP_CHECK(hipGetLastError());
     return WLSQM_OK;
 }
@@ -404,10 +622,11 @@ static int launch_accurate(const KParams& p, hipStream_t stream) {
 // Accurate mode, basic fits of the 2D / 3D systems up to 10 unknowns: every case WITHOUT a known DOF is fitted here (the strict
 // kernels, launched behind this one by launch_fit_strict, leave exactly those cases alone).  *handled = false: the shape has no
 // accurate kernel (1D, more than 10 unknowns) and the strict kernels take every case.
-int launch_fit_accurate(int dimension, int order, const KParams& p, hipStream_t stream, bool* handled) {
+int launch_fit_accurate(int dimension, int order, const KParams& p, hipStream_t stream, bool* handled, int** lists_out) {
     *handled = false;
+    *lists_out = nullptr;
     if (p.do_sens || p.iterative) return WLSQM_OK;
-#define CASE(D, O) if (dimension == D && order == O) { *handled = true; return launch_accurate<D, O>(p, stream); }
+#define CASE(D, O) if (dimension == D && order == O) { *handled = true; return launch_accurate<D, O>(p, stream, lists_out); }
     CASE(2, 0) CASE(2, 1) CASE(2, 2) CASE(2, 3)
     CASE(3, 0) CASE(3, 1) CASE(3, 2)
 #undef CASE

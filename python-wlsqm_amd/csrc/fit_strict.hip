@@ -139,8 +139,11 @@ __device__ __forceinline__ double taylor(const double (&d)[DIM], const FI& f) {
 __device__ __forceinline__ bool fit_strict_group_is_plain(const KParams& p, long long t, long long ncases, long long want = 0);
 
 template <int DIM, int ORDER>
-__global__ __launch_bounds__(64) void fit_strict_kernel(const KParams p, const StrictDebug dbg, const int skip_plain_groups) {
+__global__ __launch_bounds__(64) void fit_strict_kernel(const KParams p, const StrictDebug dbg, const int skip_plain_groups,
+                                                        const int* __restrict__ leftover_groups) {
     using namespace strict;
+    // accurate mode behind the speculative kernel: it counted the 64-case groups that hold a case with a known DOF; none: nothing to do
+    if (leftover_groups && *leftover_groups == 0) return;
     constexpr int NO = ndofs(DIM, ORDER);
     constexpr int LPW = lanes_for(NO);
     extern __shared__ double smem[];
@@ -453,8 +456,9 @@ __host__ __device__ constexpr int reg_minw(int NO) { return NO <= 6 ? WLSQM_STRI
 // reduced system is DOFs 1 .. NO - 1, again with compile-time indices; the known value moves to the right-hand side term by term
 // in a third pass over the neighbours (it needs the row scales: impl.pyx:815-818 multiplies every term by row_scale[j]).
 template <int DIM, int ORDER, bool KN1>
-__global__ __launch_bounds__(64, reg_minw(ndofs(DIM, ORDER))) void fit_strict_reg_kernel(const KParams p) {
+__global__ __launch_bounds__(64, reg_minw(ndofs(DIM, ORDER))) void fit_strict_reg_kernel(const KParams p, const int* __restrict__ leftover_groups) {
     using namespace strict;
+    if (leftover_groups && *leftover_groups == 0) return;            // (see fit_strict_kernel)
     constexpr int NO = ndofs(DIM, ORDER);
     constexpr int N = NO - (KN1 ? 1 : 0), O0 = KN1 ? 1 : 0;      // reduced size; reduced index i is DOF i + O0
     const long long ncases = live_cases(p);
@@ -984,7 +988,7 @@ __global__ __launch_bounds__(64, rows_minw(ndofs(DIM, ORDER))) void fit_strict_r
 }
 
 template <int DIM, int ORDER>
-static int launch_strict(const KParams& p, const StrictDebug& dbg, hipStream_t stream, const bool accurate_taken) {
+static int launch_strict(const KParams& p, const StrictDebug& dbg, hipStream_t stream, const bool accurate_taken, const int* leftover_groups) {
     constexpr int NO = ndofs(DIM, ORDER);
     constexpr int LPW = strict::lanes_for(NO);
     constexpr size_t lds = (size_t)strict::slots(NO) * LPW * sizeof(double);
@@ -1034,34 +1038,36 @@ static int launch_strict(const KParams& p, const StrictDebug& dbg, hipStream_t s
         if (split || accurate_taken) {
             const long long groups = (p.ncases + 63) / 64;
             if (!accurate_taken) {
-                hipLaunchKernelGGL((fit_strict_reg_kernel<DIM, ORDER, false>), dim3((unsigned)groups), dim3(64), 0, stream, p);
+                hipLaunchKernelGGL((fit_strict_reg_kernel<DIM, ORDER, false>), dim3((unsigned)groups), dim3(64), 0, stream, p, (const int*)nullptr);
                 WLSQM_HIP_CHECK(hipGetLastError());
             }
             if constexpr (NO >= 2) {
                 if (split) {
-                    hipLaunchKernelGGL((fit_strict_reg_kernel<DIM, ORDER, true>), dim3((unsigned)groups), dim3(64), 0, stream, p);
+                    hipLaunchKernelGGL((fit_strict_reg_kernel<DIM, ORDER, true>), dim3((unsigned)groups), dim3(64), 0, stream, p, leftover_groups);
                     WLSQM_HIP_CHECK(hipGetLastError());
                 }
             }
         }
     }
     hipLaunchKernelGGL((fit_strict_kernel<DIM, ORDER>), dim3((unsigned)blocks), dim3(64), lds, stream, p, dbg,
-                       accurate_taken ? 2 : (split ? 1 : 0));
+                       accurate_taken ? 2 : (split ? 1 : 0), leftover_groups);
     WLSQM_HIP_CHECK(hipGetLastError());
     note_kernel(accurate_taken ? "accurate" : "strict");
     return WLSQM_OK;
 }
 
-int launch_fit_accurate(int dimension, int order, const KParams& p, hipStream_t stream, bool* handled);      // fit_accurate.hip
+int launch_fit_accurate(int dimension, int order, const KParams& p, hipStream_t stream, bool* handled, int** lists_out);      // fit_accurate.hip
 
 int launch_fit_strict(int dimension, int order, const KParams& p, const StrictDebug* dbg_in, hipStream_t stream) {
     const StrictDebug dbg = dbg_in ? *dbg_in : StrictDebug{};
     bool accurate_taken = false;
+    int* lists = nullptr;                             // work lists of the speculative accurate kernel ([1] = leftover groups), or null
     if (accurate_mode() && !dbg_in) {
-        const int rc = launch_fit_accurate(dimension, order, p, stream, &accurate_taken);
-        if (rc != WLSQM_OK) return rc;
+        const int rc = launch_fit_accurate(dimension, order, p, stream, &accurate_taken, &lists);
+        if (rc != WLSQM_OK) { (void)scratch_free_async(lists, stream); return rc; }
     }
-#define CASE(D, O) if (dimension == D && order == O) return launch_strict<D, O>(p, dbg, stream, accurate_taken);
+    auto done = [&](int rc) { const int rf = scratch_free_async(lists, stream); return rc != WLSQM_OK ? rc : rf; };
+#define CASE(D, O) if (dimension == D && order == O) return done(launch_strict<D, O>(p, dbg, stream, accurate_taken, lists ? lists + 1 : nullptr));
     CASE(1, 0) CASE(1, 1) CASE(1, 2) CASE(1, 3) CASE(1, 4)
     CASE(2, 0) CASE(2, 1) CASE(2, 2) CASE(2, 3) CASE(2, 4)
     CASE(3, 0) CASE(3, 1) CASE(3, 2) CASE(3, 3) CASE(3, 4)

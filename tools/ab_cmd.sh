@@ -5,13 +5,16 @@
 set -euo pipefail
 UNIT="$1"; CMD="$2"; shift 2
 PKG=python-wlsqm_amd
-cp $PKG/wlsqm/_lib/libwlsqm_hip.so /tmp/lib_orig.so
+ORIG="$(mktemp /tmp/lib_orig_XXXXXX.so)"; VAR="$(mktemp /tmp/unit_var_XXXXXX.o)"
+cp $PKG/wlsqm/_lib/libwlsqm_hip.so "$ORIG"
+# whatever happens below (a failing compile, link or timing command under set -e): the library as built comes back
+trap 'cp "$ORIG" $PKG/wlsqm/_lib/libwlsqm_hip.so; rm -f "$ORIG" "$VAR"' EXIT
 echo "== as-built"; bash -c "$CMD"
 for flags in "$@"; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fopenmp -I include -I $PKG/csrc $flags -c $PKG/csrc/$UNIT.hip -o /tmp/unit_var.o
-  objs=(); for o in $PKG/build/*.o; do [[ "$(basename $o)" == "$UNIT.o" ]] && objs+=(/tmp/unit_var.o) || objs+=("$o"); done
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fopenmp -I include -I $PKG/csrc $flags -c $PKG/csrc/$UNIT.hip -o $VAR
+  objs=(); for o in $PKG/build/*.o; do [[ "$(basename $o)" == "$UNIT.o" ]] && objs+=("$VAR") || objs+=("$o"); done
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fopenmp -o $PKG/wlsqm/_lib/libwlsqm_hip.so "${objs[@]}"
   echo "== [$flags]"; bash -c "$CMD"
 done
-cp /tmp/lib_orig.so $PKG/wlsqm/_lib/libwlsqm_hip.so
+cp "$ORIG" $PKG/wlsqm/_lib/libwlsqm_hip.so
 echo "== as-built-again"; bash -c "$CMD"

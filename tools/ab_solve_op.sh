@@ -4,13 +4,16 @@
 set -euo pipefail
 PKG=python-wlsqm_amd
 run() { python3 bench.py --config C4 --steps 10 --warmup 3 --no-parity 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$1', d['roofline']['kernel_ms'], d['roofline']['frac'])"; }
-cp $PKG/wlsqm/_lib/libwlsqm_hip.so /tmp/lib_orig.so
+ORIG="$(mktemp /tmp/lib_orig_XXXXXX.so)"; VAR="$(mktemp /tmp/unit_var_XXXXXX.o)"
+cp $PKG/wlsqm/_lib/libwlsqm_hip.so "$ORIG"
+# whatever happens below (a failing compile, link or timing command under set -e): the library as built comes back
+trap 'cp "$ORIG" $PKG/wlsqm/_lib/libwlsqm_hip.so; rm -f "$ORIG" "$VAR"' EXIT
 run "as-built"
 for flags in "$@"; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fopenmp -I include -I $PKG/csrc $flags -c $PKG/csrc/solve_op.hip -o /tmp/solve_op_var.o
-  objs=(); for o in $PKG/build/*.o; do [[ "$(basename $o)" == "solve_op.o" ]] && objs+=(/tmp/solve_op_var.o) || objs+=("$o"); done
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fopenmp -I include -I $PKG/csrc $flags -c $PKG/csrc/solve_op.hip -o "$VAR"
+  objs=(); for o in $PKG/build/*.o; do [[ "$(basename $o)" == "solve_op.o" ]] && objs+=("$VAR") || objs+=("$o"); done
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fopenmp -o $PKG/wlsqm/_lib/libwlsqm_hip.so "${objs[@]}"
   run "[$flags]"
 done
-cp /tmp/lib_orig.so $PKG/wlsqm/_lib/libwlsqm_hip.so
+cp "$ORIG" $PKG/wlsqm/_lib/libwlsqm_hip.so
 run "as-built-again"
