@@ -78,24 +78,39 @@ struct FastOps {
     // (no operand of these is ever a NaN on the fast path — the range checks — so v_max_f64 is the reference's `if (q > acc) acc = q`)
     static __device__ __forceinline__ double maxnum(double acc, double q) { return __builtin_fmax(acc, q); }
     static __device__ __forceinline__ double div(double a, double b) { return div_by(a, b, rcp_refined(b)); }
+    // the same quotient from a SEED that is already within 2^-44 of 1 / b: one Newton step instead of v_rcp_f64 (a quarter-rate
+    // instruction: 16 cycles) and two.  The refined reciprocal is as accurate as the standard sequence's (its error is the square of
+    // the seed's plus one rounding), and the quotient / remainder / correction steps are the same: bit-identical to `/` on 3 x 2^31
+    // operand pairs with seeds up to 256 ulps off and adversarial denominators (tools/ubench/exact_div_sqrt.hip, classes 4-6).
+    static __device__ __forceinline__ double div_seeded(double a, double b, double seed) {
+        const double e = fma(-b, seed, 1.0);
+        return div_by(a, b, fma(seed, e, seed));
+    }
     static __device__ __forceinline__ double rcp_of(double b) { return rcp_refined(b); }
     static __device__ __forceinline__ double div_r(double a, double b, double r) { return div_by(a, b, r); }
-    static __device__ __forceinline__ double sqrt(double x) {
+    static __device__ __forceinline__ double sqrt(double x) { double h; return sqrt_h(x, h); }
+    // the root, and the refined half reciprocal root h = 1 / (2 sqrt(x)) (1 + O(2^-46)) the sequence computes on the way:
+    // 2 h is a seed for the quotient by the root (div_seeded)
+    static __device__ __forceinline__ double sqrt_h(double x, double& h) {
         const double y = __builtin_amdgcn_rsq(x);
-        double g = x * y, h = y * 0.5;
+        double g = x * y; h = y * 0.5;
         const double r = fma(-h, g, 0.5);
         g = fma(g, r, g); h = fma(h, r, h);
         double d = fma(-g, g, x); g = fma(d, h, g);
         d = fma(-g, g, x); g = fma(d, h, g);
         return g;
     }
+    static __device__ __forceinline__ double div_by_root(double a, double s, double h) { return div_seeded(a, s, h + h); }
 };
 struct IeeeOps {                                                     // the compiler's sequences: any operand
     static __device__ __forceinline__ double maxnum(double acc, double q) { return q > acc ? q : acc; }      // NaN q: skipped; NaN acc: kept
     static __device__ __forceinline__ double div(double a, double b) { return a / b; }
+    static __device__ __forceinline__ double div_seeded(double a, double b, double) { return a / b; }
     static __device__ __forceinline__ double rcp_of(double) { return 0.; }
     static __device__ __forceinline__ double div_r(double a, double b, double) { return a / b; }
     static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
+    static __device__ __forceinline__ double sqrt_h(double x, double& h) { h = 0.; return ::sqrt(x); }
+    static __device__ __forceinline__ double div_by_root(double a, double s, double) { return a / s; }
 };
 
 // safe range of the fast sequences (see the header): every nonzero magnitude that enters a fast quotient or root lies in
@@ -144,36 +159,85 @@ __device__ __forceinline__ bool entries_in_range(const double (&U)[N * (N + 1) /
 
 // rescale_ruiz2001_c (lapackdrivers.pyx:553-623) on the symmetric matrix: DR == DC, DRp == DCp, rs == cs bit for bit, so one
 // pass per sweep.  Returns whether every running scale factor stayed in the safe range of the fast sequences.
-template <int N, class OPS>
+//
+// DIAG (fast path only): a sweep needs the LARGEST quotient |A[i][m]| / (DRp[i] DRp[m]) of every row, nothing else.  The matrix is
+// a Gram matrix, A[i][m]^2 = c_im^2 A[i][i] A[m][m] with c_im < 1 the cosine of two weighted monomial columns, so a quotient is
+// q_im = c_im sqrt(q_ii q_mm) (1 + O(2^-50)): once the DIAGONAL quotients of a sweep are within a factor 1 / c_max^2 of each other,
+// no off-diagonal quotient can exceed the diagonal one of its row or of its column, every row maximum IS its diagonal quotient and
+// the other N (N - 1) / 2 quotients of the sweep need not be computed — the same doubles come out, not an approximation.  c_max^2 is
+// computed once per case (raw v_rcp_f64: 2^-23, covered by the 2^-16 margin below); the test is wave-uniform (every lane of the
+// wave must pass: otherwise the full sweep runs, which is always right).  On BASELINE configs[1] the sweeps from the third on pass.
+#ifndef WLSQM_ACC_RUIZ_DIAG
+#define WLSQM_ACC_RUIZ_DIAG 1
+#endif
+template <int N, class OPS, bool DIAG = false>
 __device__ __forceinline__ bool ruiz_sym(const double (&U)[N * (N + 1) / 2], double (&rs)[N]) {
     using strict::ruiz_epsilon;
     double DRp[N];
     bool in_range = true;
 #pragma unroll
     for (int i = 0; i < N; ++i) { rs[i] = 1.; DRp[i] = 1.; }
-    for (int it = 0; it < 100; ++it) {
-        double DR[N];
+    double thresh = 0.;                                                // c_max^2 (1 + 2^-16); NaN / inf (a zero diagonal entry): never passes
+    if constexpr (DIAG && N > 1) {
+        double ra[N], cm2 = 0.;
 #pragma unroll
-        for (int i = 0; i < N; ++i) DR[i] = 0.;
+        for (int i = 0; i < N; ++i) ra[i] = __builtin_amdgcn_rcp(U[utri<N>(i, i)]);
 #pragma unroll
-        for (int m = 0; m < N; ++m) {
+        for (int m = 1; m < N; ++m)
 #pragma unroll
-            for (int i = 0; i <= m; ++i) {
-                const double q = fabs(OPS::div(U[utri<N>(i, m)], DRp[i] * DRp[m]));
-                DR[i] = OPS::maxnum(DR[i], q);
-                if (i != m) DR[m] = OPS::maxnum(DR[m], q);
-            }
-        }
+            for (int i = 0; i < m; ++i) { const double a = U[utri<N>(i, m)]; cm2 = __builtin_fmax(cm2, (a * a) * (ra[i] * ra[m])); }
+        thresh = cm2 * (1. + 0x1p-16);
+        if (!(thresh >= 0.)) thresh = 2.;                              // (fmax dropped a NaN: make the test fail)
+    }
+    auto finish = [&](double (&DR)[N]) -> bool {                       // roots, scale updates, stop test; true: converged
         double acc = 0.;
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            const double s = OPS::sqrt(DR[i]);
-            DRp[i] *= s; rs[i] = OPS::div(rs[i], s);
+            double h;
+            const double s = OPS::sqrt_h(DR[i], h);
+            DRp[i] *= s; rs[i] = OPS::div_by_root(rs[i], s, h);
             in_range = in_range && DRp[i] >= SCALE_LO && DRp[i] <= SCALE_HI;      // (a NaN fails it)
             const double tmp = fabs(1. - s * s);
             if (i == 0) acc = tmp; else acc = OPS::maxnum(acc, tmp);
         }
-        if (acc < ruiz_epsilon) break;                                // (the column test sees the same numbers)
+        return acc < ruiz_epsilon;                                    // (the column test sees the same numbers)
+    };
+    double DR[N];
+    // first sweep: both running factors are 1.0, their product is 1.0 and x / 1.0 == x exactly: no quotient to compute
+#pragma unroll
+    for (int i = 0; i < N; ++i) DR[i] = 0.;
+#pragma unroll
+    for (int m = 0; m < N; ++m)
+#pragma unroll
+        for (int i = 0; i <= m; ++i) {
+            const double q = fabs(U[utri<N>(i, m)]);
+            DR[i] = OPS::maxnum(DR[i], q);
+            if (i != m) DR[m] = OPS::maxnum(DR[m], q);
+        }
+    if (finish(DR)) return in_range;
+    for (int it = 1; it < 100; ++it) {
+        // diagonal quotients (needed by both forms of the sweep)
+        double qlo = 0., qhi = 0.;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            // (seed of the reciprocal of DRp[i] DRp[m]: rs[i] rs[m] — every sweep multiplies DRp[i] and divides rs[i] by the same root,
+            // each rounded once, so rs[i] DRp[i] = 1 +- 2 k 2^-53 after k sweeps)
+            DR[i] = OPS::maxnum(0., fabs(OPS::div_seeded(U[utri<N>(i, i)], DRp[i] * DRp[i], rs[i] * rs[i])));      // (as the reference: a NaN quotient is skipped)
+            if constexpr (DIAG) { qlo = i ? __builtin_fmin(qlo, DR[i]) : DR[i]; qhi = i ? __builtin_fmax(qhi, DR[i]) : DR[i]; }
+        }
+        bool diag_only = false;
+        if constexpr (DIAG && N > 1) diag_only = __all(thresh * qhi <= qlo);      // (a NaN quotient fails it)
+        if (!diag_only) {
+#pragma unroll
+            for (int m = 1; m < N; ++m)
+#pragma unroll
+                for (int i = 0; i < m; ++i) {
+                    const double q = fabs(OPS::div_seeded(U[utri<N>(i, m)], DRp[i] * DRp[m], rs[i] * rs[m]));
+                    DR[i] = OPS::maxnum(DR[i], q);
+                    DR[m] = OPS::maxnum(DR[m], q);
+                }
+        }
+        if (finish(DR)) break;
     }
     return in_range;
 }
@@ -378,6 +442,8 @@ __device__ __forceinline__ void accurate_group(const KParams& p, const long long
         constexpr bool MASKED = decltype(masked_tag)::value;
         const double* xrow = xs + lane * XPITCH;
         const double* frow = fs + lane * FPITCH;
+        // (the 10-unknown systems run one wave per SIMD with registers to spare: the whole chunk at once, 0.758 against 0.809 ms)
+        constexpr int GRP = N > 6 ? CH : acc::GRP;
         if (SPEC || (q + 1) * CH <= K) {
 #pragma nounroll
             for (int g = 0; g < CH / GRP; ++g) {
@@ -509,7 +575,7 @@ __device__ __forceinline__ void accurate_group(const KParams& p, const long long
         bool sure = !active || ((uniform || (max_d2 == guess && min_d2 >= RANGE_LO && max_d2 <= RANGE_HI)) && nk > 0 &&
                                 (U[0] - U[0] == 0.) && entries_in_range<N>(U));
         double rs[N];
-        if (__all(sure)) sure = !active || ruiz_sym<N, FastOps>(U, rs);
+        if (__all(sure)) sure = !active || ruiz_sym<N, FastOps, WLSQM_ACC_RUIZ_DIAG != 0>(U, rs);
         if (!__all(sure)) {                                           // wave-uniform: the whole group goes to the two-pass kernel
             if (lane == 0) lists.ws[2 + atomicAdd(lists.ws, 1)] = (int)(t0 >> 6);
             return;
@@ -568,11 +634,16 @@ __device__ __forceinline__ void accurate_group(const KParams& p, const long long
 }
 
 template <int DIM, int ORDER, bool DENSE, bool SPEC>
-__global__ __launch_bounds__(64, acc::minw(ndofs(DIM, ORDER))) void fit_accurate_kernel(const KParams p, const AccLists lists) {
+__global__ __launch_bounds__(64, acc::minw(ndofs(DIM, ORDER))) void fit_accurate_kernel(const KParams p, const AccLists lists, const long long ngroups) {
     constexpr int XPITCH = acc::CH * DIM + 2, FPITCH = acc::CH + 2;
     __shared__ __attribute__((aligned(16))) double xs[DENSE ? 64 * XPITCH : 2];
     __shared__ __attribute__((aligned(16))) double fs[DENSE ? 64 * FPITCH : 2];
-    accurate_group<DIM, ORDER, DENSE, SPEC>(p, (long long)blockIdx.x * 64, lists, xs, fs);
+    // (a workgroup per resident slot walks the groups: a finished wave's slot took ~5 us to be handed a new workgroup — 1.67 resident
+    // waves per SIMD of the 2 the registers allow with one group per workgroup)
+    for (long long g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        accurate_group<DIM, ORDER, DENSE, SPEC>(p, g * 64, lists, xs, fs);
+        if (DENSE) __syncthreads();                                   // the staging buffers are reused by the next group
+    }
 }
 
 // the redo groups of a speculative launch: a small grid walks the list (empty in the common case: the kernel is a few idle waves)
@@ -602,18 +673,39 @@ static int launch_accurate(const KParams& p, hipStream_t stream, int** lists_out
                        !getenv("WLSQM_HIP_ACCURATE_NO_STAGE");
     const char* nospec = getenv("WLSQM_HIP_ACCURATE_NO_SPEC");        // A/B and tests: the two-pass kernel for every group
     AccLists lists{nullptr, groups};
+    // grid: one workgroup per group (default), or with WLSQM_HIP_ACCURATE_PERSIST=1 the resident slots times a small factor
+    auto grid_for = [&](const void* kern, unsigned* out) {
+        static KernelSetup setup[2];
+        long long slots = groups;
+        const char* e = getenv("WLSQM_HIP_ACCURATE_PERSIST");
+        if (e && e[0] == '1') {                                     // (measured: 0.331 against 0.304 ms on configs[1]: the dispatcher balances short workgroups better)
+            const int rc = persistent_grid(kern, 64, 0, 0, false, setup[0], &slots);
+            if (rc != WLSQM_OK) return rc;
+            slots = (long long)((double)slots / grid_multiple());     // (persistent_grid applies the tile kernels' multiple)
+            const char* m = getenv("WLSQM_HIP_ACCURATE_GRID_MULT");
+            if (m) slots = (long long)(slots * atof(m));
+            if (slots < 1) slots = 1;
+        }
+        *out = (unsigned)(slots < groups ? slots : groups);
+        return (int)WLSQM_OK;
+    };
+    unsigned grid = 0;
     if (dense && K % acc::CH == 0 && !(nospec && nospec[0] == '1')) {
         int rc = scratch_alloc_async(reinterpret_cast<void**>(&lists.ws), (size_t)(2 + 2 * groups) * sizeof(int), stream);
         if (rc != WLSQM_OK) return rc;
         *lists_out = lists.ws;                                        // (freed by the caller behind the strict kernels, which read the leftover list)
         hipLaunchKernelGGL(acc_lists_zero_kernel, dim3(1), dim3(64), 0, stream, lists.ws);
-        hipLaunchKernelGGL((fit_accurate_kernel<DIM, ORDER, true, true>), dim3((unsigned)groups), dim3(64), 0, stream, p, lists);
-        const unsigned redo_grid = (unsigned)(groups < 2048 ? groups : 2048);
+        rc = grid_for(reinterpret_cast<const void*>(&fit_accurate_kernel<DIM, ORDER, true, true>), &grid);
+        if (rc != WLSQM_OK) return rc;
+        hipLaunchKernelGGL((fit_accurate_kernel<DIM, ORDER, true, true>), dim3(grid), dim3(64), 0, stream, p, lists, groups);
+        const unsigned redo_grid = (unsigned)(groups < 256 ? groups : 256);
         hipLaunchKernelGGL((fit_accurate_redo_kernel<DIM, ORDER>), dim3(redo_grid), dim3(64), 0, stream, p, lists);
     } else if (dense) {
-        hipLaunchKernelGGL((fit_accurate_kernel<DIM, ORDER, true, false>), dim3((unsigned)groups), dim3(64), 0, stream, p, lists);
+        const int rc = grid_for(reinterpret_cast<const void*>(&fit_accurate_kernel<DIM, ORDER, true, false>), &grid);
+        if (rc != WLSQM_OK) return rc;
+        hipLaunchKernelGGL((fit_accurate_kernel<DIM, ORDER, true, false>), dim3(grid), dim3(64), 0, stream, p, lists, groups);
     } else {
-        hipLaunchKernelGGL((fit_accurate_kernel<DIM, ORDER, false, false>), dim3((unsigned)groups), dim3(64), 0, stream, p, lists);
+        hipLaunchKernelGGL((fit_accurate_kernel<DIM, ORDER, false, false>), dim3((unsigned)groups), dim3(64), 0, stream, p, lists, groups);
     }
     WLSQM_HIP_CHECK(hipGetLastError());
     return WLSQM_OK;

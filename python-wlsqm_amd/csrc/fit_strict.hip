@@ -138,25 +138,23 @@ __device__ __forceinline__ double taylor(const double (&d)[DIM], const FI& f) {
 
 __device__ __forceinline__ bool fit_strict_group_is_plain(const KParams& p, long long t, long long ncases, long long want = 0);
 
+// (vblock: the workgroup's number in the batch — blockIdx.x, or a 64-case group of the leftover list in accurate mode)
 template <int DIM, int ORDER>
-__global__ __launch_bounds__(64) void fit_strict_kernel(const KParams p, const StrictDebug dbg, const int skip_plain_groups,
-                                                        const int* __restrict__ leftover_groups) {
+__device__ __forceinline__ void fit_strict_block(const KParams& p, const StrictDebug& dbg, const int skip_plain_groups, const long long vblock,
+                                                 double* smem) {
     using namespace strict;
-    // accurate mode behind the speculative kernel: it counted the 64-case groups that hold a case with a known DOF; none: nothing to do
-    if (leftover_groups && *leftover_groups == 0) return;
     constexpr int NO = ndofs(DIM, ORDER);
     constexpr int LPW = lanes_for(NO);
-    extern __shared__ double smem[];
     const int lane = threadIdx.x;
     if (skip_plain_groups) {
         // the register kernel takes the 64-case groups without any known DOF: this block's cases lie in group (block * LPW) / 64
         // (2 = accurate mode: fit_accurate_kernel has every CASE without a known DOF, whatever its group — see below)
-        const long long g0 = ((long long)blockIdx.x * LPW) / 64 * 64;
+        const long long g0 = (vblock * LPW) / 64 * 64;
         if (skip_plain_groups == 1 && fit_strict_group_is_plain(p, g0 + lane, live_cases(p), 0)) return;
         if (NO >= 2 && fit_strict_group_is_plain(p, g0 + lane, live_cases(p), 1)) return;      // the F-known register kernel has it
     }
     if (lane >= LPW) return;
-    const long long t = (long long)blockIdx.x * LPW + lane;
+    const long long t = vblock * LPW + lane;
     if (t >= live_cases(p)) return;
     const long long j = p.case_index ? p.case_index[t] : t;
     if (skip_plain_groups == 2 && p.knowns[j * p.sknowns] == 0) return;      // (the lanes of this kernel never meet again: no barrier below)
@@ -427,6 +425,21 @@ __global__ __launch_bounds__(64) void fit_strict_kernel(const KParams p, const S
     if (p.iters_out) atomicMax(p.iters_out, iters);
 }
 
+// Accurate mode behind the speculative kernel (fit_accurate.hip): `lists` holds the 64-case groups with a known DOF somewhere
+// ([1] their number, [2 + ngroups ..) the groups); a small grid walks them — none in the common case: a few idle waves.
+template <int DIM, int ORDER>
+__global__ __launch_bounds__(64) void fit_strict_kernel(const KParams p, const StrictDebug dbg, const int skip_plain_groups,
+                                                        const int* __restrict__ lists, const long long ngroups) {
+    extern __shared__ double smem[];
+    if (!lists) { fit_strict_block<DIM, ORDER>(p, dbg, skip_plain_groups, blockIdx.x, smem); return; }
+    constexpr int PER = 64 / strict::lanes_for(ndofs(DIM, ORDER));   // workgroups of this kernel per 64-case group
+    const long long n = (long long)lists[1] * PER;
+    for (long long v = blockIdx.x; v < n; v += gridDim.x) {
+        fit_strict_block<DIM, ORDER>(p, dbg, skip_plain_groups, (long long)lists[2 + ngroups + v / PER] * PER + v % PER, smem);
+        __syncthreads();
+    }
+}
+
 // The same operations with EVERYTHING in registers, for the common case of a workgroup whose 64 cases have no knowns at all (the
 // reduced system is the full one: every index is a compile-time constant) and a basic fit: no LDS, so the occupancy is set by
 // the registers (two or more waves per SIMD) instead of by 48 KB of LDS per 64 cases (three waves per CU) — BASELINE configs[1]
@@ -456,13 +469,12 @@ __host__ __device__ constexpr int reg_minw(int NO) { return NO <= 6 ? WLSQM_STRI
 // reduced system is DOFs 1 .. NO - 1, again with compile-time indices; the known value moves to the right-hand side term by term
 // in a third pass over the neighbours (it needs the row scales: impl.pyx:815-818 multiplies every term by row_scale[j]).
 template <int DIM, int ORDER, bool KN1>
-__global__ __launch_bounds__(64, reg_minw(ndofs(DIM, ORDER))) void fit_strict_reg_kernel(const KParams p, const int* __restrict__ leftover_groups) {
+__device__ __forceinline__ void fit_strict_reg_block(const KParams& p, const long long vblock) {
     using namespace strict;
-    if (leftover_groups && *leftover_groups == 0) return;            // (see fit_strict_kernel)
     constexpr int NO = ndofs(DIM, ORDER);
     constexpr int N = NO - (KN1 ? 1 : 0), O0 = KN1 ? 1 : 0;      // reduced size; reduced index i is DOF i + O0
     const long long ncases = live_cases(p);
-    const long long t = (long long)blockIdx.x * 64 + threadIdx.x;
+    const long long t = vblock * 64 + threadIdx.x;
     if (!fit_strict_group_is_plain(p, t, ncases, KN1 ? 1 : 0)) return;     // another kind of group: another kernel has it
     if (t >= ncases) return;
     const long long j = p.case_index ? p.case_index[t] : t;
@@ -604,6 +616,13 @@ __global__ __launch_bounds__(64, reg_minw(ndofs(DIM, ORDER))) void fit_strict_re
     }
 #pragma unroll
     for (int i = 0; i < N; ++i) fio[i + O0] = b[i] * cs[i];
+}
+
+template <int DIM, int ORDER, bool KN1>
+__global__ __launch_bounds__(64, reg_minw(ndofs(DIM, ORDER))) void fit_strict_reg_kernel(const KParams p, const int* __restrict__ lists, const long long ngroups) {
+    if (!lists) { fit_strict_reg_block<DIM, ORDER, KN1>(p, blockIdx.x); return; }
+    const long long n = lists[1];                                     // (see fit_strict_kernel)
+    for (long long v = blockIdx.x; v < n; v += gridDim.x) fit_strict_reg_block<DIM, ORDER, KN1>(p, lists[2 + ngroups + v]);
 }
 
 constexpr int STRICT_REG_MAX_NO = 10;      // register kernel: systems up to this size (3D order 2 / 2D order 3: one wave per SIMD)
@@ -988,7 +1007,7 @@ __global__ __launch_bounds__(64, rows_minw(ndofs(DIM, ORDER))) void fit_strict_r
 }
 
 template <int DIM, int ORDER>
-static int launch_strict(const KParams& p, const StrictDebug& dbg, hipStream_t stream, const bool accurate_taken, const int* leftover_groups) {
+static int launch_strict(const KParams& p, const StrictDebug& dbg, hipStream_t stream, const bool accurate_taken, const int* lists) {
     constexpr int NO = ndofs(DIM, ORDER);
     constexpr int LPW = strict::lanes_for(NO);
     constexpr size_t lds = (size_t)strict::slots(NO) * LPW * sizeof(double);
@@ -1038,19 +1057,19 @@ static int launch_strict(const KParams& p, const StrictDebug& dbg, hipStream_t s
         if (split || accurate_taken) {
             const long long groups = (p.ncases + 63) / 64;
             if (!accurate_taken) {
-                hipLaunchKernelGGL((fit_strict_reg_kernel<DIM, ORDER, false>), dim3((unsigned)groups), dim3(64), 0, stream, p, (const int*)nullptr);
+                hipLaunchKernelGGL((fit_strict_reg_kernel<DIM, ORDER, false>), dim3((unsigned)groups), dim3(64), 0, stream, p, (const int*)nullptr, 0ll);
                 WLSQM_HIP_CHECK(hipGetLastError());
             }
             if constexpr (NO >= 2) {
                 if (split) {
-                    hipLaunchKernelGGL((fit_strict_reg_kernel<DIM, ORDER, true>), dim3((unsigned)groups), dim3(64), 0, stream, p, leftover_groups);
+                    hipLaunchKernelGGL((fit_strict_reg_kernel<DIM, ORDER, true>), dim3((unsigned)(lists && groups > 128 ? 128 : groups)), dim3(64), 0, stream, p, lists, groups);
                     WLSQM_HIP_CHECK(hipGetLastError());
                 }
             }
         }
     }
-    hipLaunchKernelGGL((fit_strict_kernel<DIM, ORDER>), dim3((unsigned)blocks), dim3(64), lds, stream, p, dbg,
-                       accurate_taken ? 2 : (split ? 1 : 0), leftover_groups);
+    hipLaunchKernelGGL((fit_strict_kernel<DIM, ORDER>), dim3((unsigned)(lists && blocks > 128 ? 128 : blocks)), dim3(64), lds, stream, p, dbg,
+                       accurate_taken ? 2 : (split ? 1 : 0), lists, (p.ncases + 63) / 64);
     WLSQM_HIP_CHECK(hipGetLastError());
     note_kernel(accurate_taken ? "accurate" : "strict");
     return WLSQM_OK;
@@ -1067,7 +1086,7 @@ int launch_fit_strict(int dimension, int order, const KParams& p, const StrictDe
         if (rc != WLSQM_OK) { (void)scratch_free_async(lists, stream); return rc; }
     }
     auto done = [&](int rc) { const int rf = scratch_free_async(lists, stream); return rc != WLSQM_OK ? rc : rf; };
-#define CASE(D, O) if (dimension == D && order == O) return done(launch_strict<D, O>(p, dbg, stream, accurate_taken, lists ? lists + 1 : nullptr));
+#define CASE(D, O) if (dimension == D && order == O) return done(launch_strict<D, O>(p, dbg, stream, accurate_taken, lists));
     CASE(1, 0) CASE(1, 1) CASE(1, 2) CASE(1, 3) CASE(1, 4)
     CASE(2, 0) CASE(2, 1) CASE(2, 2) CASE(2, 3) CASE(2, 4)
     CASE(3, 0) CASE(3, 1) CASE(3, 2) CASE(3, 3) CASE(3, 4)
