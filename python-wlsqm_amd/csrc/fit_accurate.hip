@@ -6,7 +6,7 @@
 // than the fast kernels; the fast kernels are 2.4e-10 from the reference on configs[1].  profiles/r03_attribution.txt says which of
 // the fast kernels' choices cost that distance: the split neighbour sums, the reciprocal in the weights, the unscaled LDL^T — and
 // that ONE choice is free: assembling only the upper triangle of the normal matrix and mirroring it (3.33e-11 against the strict
-// mode's 3.36e-11 on configs[1], 1.71e-11 against 1.69e-11 on configs[4]; oracle/variants.c V_SYM).  This kernel is therefore the
+// mode's 3.36e-11 on configs[1], 1.71e-11 against 1.69e-11 on configs[4]; the V_SYM switch of the tests' CPU checker).  This kernel is therefore the
 // reference's arithmetic with exactly that one change:
 //
 //   make_c_{2,3}D        impl.pyx:286-432, 70-269     the reference's grouping of every scaled monomial
@@ -18,7 +18,8 @@
 //   dgetrf / dgetrs      lapackdrivers.pyx:1628-1665  unblocked partial-pivot LU, first maximum wins
 //   solve                impl.pyx:731-846             right-hand side sums, un-scaling
 //
-// and its output is BIT-IDENTICAL to oracle/variants.c with V_SYM (tests/test_gpu_accurate.py), layout- and tile-mate-independent.
+// and its output is BIT-IDENTICAL to the CPU statement of exactly these operations that the tests hold it to (tests/test_gpu_accurate.py),
+// layout- and tile-mate-independent.
 //
 // Where the time of the strict register kernel went, and what is different here (same bits, fewer instructions):
 //   * IEEE divide = v_div_scale x2 + v_rcp + 4 fma + mul + fma + v_div_fmas + v_div_fixup (11 instructions; read from the ISA).
@@ -37,7 +38,7 @@
 //     coalesced 16-byte pieces of whole 128- / 192-byte runs (the strict register kernel's lanes each read their own row: 64 cache
 //     lines per load instruction), the next chunk is in flight in registers while the current one is consumed.
 // One lane per case; a wave owns 64 consecutive cases.  Cases with a known DOF, sensitivities, refinement, systems above 10
-// unknowns and 1D fits are NOT taken here: in accurate mode they run the strict kernels (bit-identical to the oracle, i.e. at least
+// unknowns and 1D fits are NOT taken here: in accurate mode they run the strict kernels (the reference's operations one for one, i.e. at least
 // as close to the reference).  Which kernel takes a case depends on that case alone.
 #include <atomic>
 #include <type_traits>

@@ -149,7 +149,9 @@ def default_device():
     """Device of the host-array entry points, in this order: WLSQM_HIP_DEVICE if set; torch's current device when torch has
     initialised the GPU in this process AND that device is not the default 0 (the caller said torch.cuda.set_device /
     torch.cuda.device); LOCAL_RANK when set (one process per GPU under torch.distributed.run: a rank that only ever named
-    'cuda:<local_rank>' explicitly still has current_device() == 0); otherwise torch's current device, otherwise 0."""
+    'cuda:<local_rank>' explicitly still has current_device() == 0) AND that ordinal exists — a launcher that isolates one GPU per
+    rank (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES) leaves every rank with device 0 only, and LOCAL_RANK = 3 names nothing there;
+    otherwise torch's current device, otherwise 0."""
     if "WLSQM_HIP_DEVICE" in os.environ:
         return int(os.environ["WLSQM_HIP_DEVICE"])
     import sys
@@ -164,7 +166,13 @@ def default_device():
     if cur:
         return cur
     if "LOCAL_RANK" in os.environ:
-        return int(os.environ["LOCAL_RANK"])
+        lr = int(os.environ["LOCAL_RANK"])
+        try:
+            ndev = int(lib().wlsqm_hip_device_count())
+        except Exception:
+            ndev = 0
+        if 0 <= lr < ndev or ndev <= 0:                 # (no visible device at all: keep the rank's number, the call fails loudly anyway)
+            return lr
     return cur or 0
 
 

@@ -35,7 +35,7 @@ def _mode_code(mode):
 def set_strict(on):
     """Numerics mode of the calling thread (wlsqm_hip_set_strict): False = the fast kernels (default, or WLSQM_HIP_STRICT in
     the environment), True / "strict" = reference-order arithmetic (csrc/fit_strict.hip: the reference's operations one for one,
-    IEEE divide and sqrt, no contraction; bit-identical to the oracle), 2 / "accurate" = the same arithmetic with the normal
+    IEEE divide and sqrt, no contraction), 2 / "accurate" = the same arithmetic with the normal
     matrix assembled from its upper triangle (csrc/fit_accurate.hip: as close to the reference as the strict mode — 1e-10 on every
     column of BASELINE configs[1] / configs[4] — at a fraction of its time; cases it does not cover run the strict kernels).
     Returns the previous mode: False, True or 2."""

@@ -306,5 +306,37 @@ def test_default_device_precedence(monkeypatch):
     assert B.default_device() == 5                       # the caller chose a device with torch: follow it
     monkeypatch.setitem(sys.modules, "torch", fake_torch(False, 5))
     assert B.default_device() == 3                       # torch has not touched the GPU: LOCAL_RANK
+    # one visible GPU per rank (HIP_VISIBLE_DEVICES set by the launcher): LOCAL_RANK 3 is not an ordinal there
+    class OneGpu:
+        def wlsqm_hip_device_count(self):
+            return 1
+    monkeypatch.setattr(B, "lib", lambda: OneGpu())
+    monkeypatch.setitem(sys.modules, "torch", fake_torch(True, 0))
+    assert B.default_device() == 0
+    monkeypatch.setenv("LOCAL_RANK", "0")
+    assert B.default_device() == 0
+    monkeypatch.undo()
     monkeypatch.setenv("WLSQM_HIP_DEVICE", "7")
     assert B.default_device() == 7
+
+
+def test_numerics_mode_codes():
+    """wlsqm.hip.set_strict / get_strict / strict() / accurate(): False = fast, True = strict, 2 = accurate; strings accepted; the
+    mode is per thread and needs no device (wlsqm_hip_set_strict is host state)."""
+    import wlsqm.hip as h
+    prev = h.set_strict(False)
+    try:
+        assert h.get_strict() is False
+        assert h.set_strict("accurate") is False and h.get_strict() == 2
+        assert h.set_strict("strict") == 2 and h.get_strict() is True
+        assert h.set_strict(0) is True and h.get_strict() is False
+        with h.accurate():
+            assert h.get_strict() == 2
+            with h.strict():
+                assert h.get_strict() is True
+            assert h.get_strict() == 2
+        assert h.get_strict() is False
+        with pytest.raises(ValueError):
+            h.set_strict("fastest")
+    finally:
+        h.set_strict(prev)

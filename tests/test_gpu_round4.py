@@ -102,3 +102,34 @@ def test_gather_ring_tail_tile(wlsqm, oracle, Kn):
                     assert np.all(E <= 1e-10 + 25.0 * 8.0 * N), "K %d n %d pidx %s: E %s N %s" % (Kn, n, with_pidx, E, N)
                     assert np.array_equal(got[:, 0][kn & 1 == 1], fi0[:, 0][kn & 1 == 1])
             del keep
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the driver's N > 1 flow, end to end: bench.py under torch.distributed.run with two ranks
+
+def test_bench_n2_flow_runs_end_to_end_as_a_rehearsal(tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...` is what the driver's scaling run launches.  The
+    test box has one GPU and RCCL wants one per rank, so WLSQM_BENCH_REHEARSAL=1 puts both ranks on GPU 0 over gloo (control flow and
+    arithmetic of the N > 1 path; the line is marked as a rehearsal and is no measurement): the LAST stdout line must parse and carry
+    the weak-scaling C2 value for two ranks, the sharded configs[4] block and the collective block."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, WLSQM_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--ncases", "200000", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    last = json.loads(lines[-1])
+    assert last["n_gpus"] == 2 and last["steps"] == 2 and last["warmup"] == 1
+    assert last["scaling"] == "weak" and last["value"] > 0 and last["unit"]
+    assert "roofline" in last
+    assert "sharded" in last and last["sharded"]["points"] > 0 and last["sharded"]["fits_per_s"] > 0
+    assert "rccl" in last and last["rccl"]["world_size"] == 2
+    assert len(lines[-1]) < 1500, "the headline must fit the driver's tail"
