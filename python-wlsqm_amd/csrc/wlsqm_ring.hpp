@@ -296,12 +296,18 @@ __global__ __launch_bounds__(64, MINW) void fit_ring_kernel(const KParams p, con
         // Every case of the wave has exactly the function value known (knowns = b?_F, the reference's default and BASELINE
         // configs[2]): the (NO - 1) x (NO - 1) system is expanded and factored directly — 105 + 14 instead of 120 + 15 entries for 15
         // DOFs, which is what lets the matrix stay in the architectural registers (the full system overflows them by a few entries
-        // and the compiler then shuttles ~1 400 values per solve through the accumulation registers).  Same operations on the same
-        // numbers as the generic path below (its first elimination step is the identity row): bit-identical results.
+        // and the compiler then shuttles ~1 400 values per solve through the accumulation registers).  The same linear system as the
+        // generic path's (whose first elimination step is the identity row), not the same roundings: see `mine1`.
+        // Which of the two forms a case gets depends on ITS mask alone (round 4): a case with exactly F known takes the reduced system
+        // also when other cases of its wave do not — the two forms round differently (3e-9 relative on the 14 x 14 systems: different
+        // instantiations of the factorisation, contracted differently), and a case's bits must not depend on its wave-mates
+        // (tools/check_tile_mates.py).  A mixed wave runs both forms one after the other; a uniform wave one, as before.
+        const bool mine1 = NO >= 3 && havep && knownp == 1ull && droppedp == 0ull;
         if constexpr (NO >= 3) {
-            if (__all(!havep || (knownp == 1ull && droppedp == 0ull))) {
-                const bool all_have = __all(havep);              // (asked outside the divergent region below: every lane votes)
-                if (havep) {
+            const bool all1 = __all(!havep || mine1);            // (asked outside the divergent region below: every lane votes)
+            const bool all_have = __all(havep);
+            {
+                if (mine1) {
                     constexpr int N1 = NO - 1, NE1 = N1 * (N1 + 1) / 2;
                     double* fio = p.fi + jp * p.sfi_j;
                     const double v0 = fio[0];
@@ -335,7 +341,7 @@ __global__ __launch_bounds__(64, MINW) void fit_ring_kernel(const KParams p, con
                     // (infra.pyx:780-795 copies all `no` doubles back).  Separate 8-byte stores at a 120-byte pitch with the
                     // known DOF left out made every row a partial-sector write: 200 instead of 120 MB written and 150 MB of
                     // extra sector fetches per 1M cases (profiles/r02c_C3_pmc_summary.json).
-                    const bool whole_rows = dead_slot != nullptr && p.sfi_j == NO && all_have && ((reinterpret_cast<uintptr_t>(p.fi) & 15u) == 0);
+                    const bool whole_rows = dead_slot != nullptr && p.sfi_j == NO && all_have && all1 && ((reinterpret_cast<uintptr_t>(p.fi) & 15u) == 0);      // (wave-uniform; true only when no lane is outside this branch)
                     if (whole_rows) {
                         double* mine = dead_slot + lane * NO;
                         mine[0] = v0;
@@ -352,11 +358,9 @@ __global__ __launch_bounds__(64, MINW) void fit_ring_kernel(const KParams p, con
                         for (int a = 1; a < NO; ++a) ring_store(&fio[a], r1[a - 1]);
                     }
                 }
-                havep = false;
-                return;
             }
         }
-        if (havep && knownp != FULL) {
+        if (havep && !mine1 && knownp != FULL) {
             double* fio = p.fi + jp * p.sfi_j;
             double M[NE], rhs[NO];
             // (nu in graded order is the right-hand-side moment of DOF order for every (dimension, order) here: mom_index == DOF index

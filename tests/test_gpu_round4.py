@@ -133,3 +133,44 @@ def test_bench_n2_flow_runs_end_to_end_as_a_rehearsal(tmp_path):
     assert "sharded" in last and last["sharded"]["points"] > 0 and last["sharded"]["fits_per_s"] > 0
     assert "rccl" in last and last["rccl"]["world_size"] == 2
     assert len(lines[-1]) < 1500, "the headline must fit the driver's tail"
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# a case's bits depend on that case alone
+
+@pytest.mark.parametrize("dim,order,Kn", [(2, 4, 64), (2, 4, 40), (3, 2, 40), (2, 2, 32), (2, 3, 30)])
+def test_a_cases_bits_do_not_depend_on_its_batch_mates(wlsqm, dim, order, Kn):
+    """Fast mode, mixed knowns masks: (1) the batch permuted, (2) the same launch again, (3) per-case orders through the device
+    order tensor twice (stable buckets: round 3 handed bucket positions out by atomicAdd), (4) the cases with exactly F known once in
+    waves where EVERY case has F known (the ring kernels then solve the reduced system) and once among cases without knowns — the two
+    forms of that solve round differently, so since round 4 a case takes the reduced form by its own mask, whatever its wave holds.
+    Every case must come out with the same bits each time."""
+    import torch
+    import wlsqm.hip as whip
+    rng = np.random.default_rng(17 * dim + order)
+    n = 4096
+    no = K.NDOF[dim][order]
+    xi = rng.uniform(0, 1, (n, dim)); xk = xi[:, None, :] + 0.05 * rng.uniform(-1, 1, (n, Kn, dim))
+    fk = np.sin(3 * xk[..., 0]) * np.cos(2 * xk[..., -1])
+    nk = np.full(n, Kn, np.int32); wm = np.full(n, 2, np.int32)
+    fi0 = rng.uniform(-1, 1, (n, no)); fi0[:, 0] = np.sin(3 * xi[:, 0]) * np.cos(2 * xi[:, -1])
+
+    def run(kn, perm=None, orders=None):
+        perm = np.arange(n) if perm is None else perm
+        fi = _t(fi0[perm])
+        o = order if orders is None else _t(orders[perm])
+        whip.fit_many_device(dim, o, _t(xk[perm]), _t(fk[perm]), _t(nk[perm]), _t(xi[perm]), fi, _t(kn[perm]), _t(wm[perm]), max_order=order)
+        torch.cuda.synchronize()
+        out = np.empty_like(fi0); out[perm] = fi.cpu().numpy()
+        return out.view(np.int64)
+
+    kn = rng.choice(np.array([0, 1, 1, 1, 5 if no > 2 else 1], np.int64), n)
+    a = run(kn)
+    assert np.array_equal(a, run(kn)), "the same launch twice"
+    assert np.array_equal(a, run(kn, rng.permutation(n))), "permuted batch"
+    orders = rng.choice(np.array([max(order - 1, 0), order], np.int32), n)
+    assert np.array_equal(run(kn, orders=orders), run(kn, orders=orders)), "order buckets, two runs"
+    all1 = np.ones(n, np.int64)
+    mixed = all1.copy(); mixed[::7] = 0
+    same = mixed == 1
+    assert np.array_equal(run(all1)[same], run(mixed)[same]), "F-known cases: all-F-known waves vs mixed waves"
