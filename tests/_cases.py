@@ -81,3 +81,25 @@ def config_dense(name):
     return dict(g=g, dim=dim, order=order, nkv=nk, n=n, no=no, xk=xk, fk=fk, xi=xi, fi0=fi0, conds=g["conds"],
                 order_a=np.full(n, order, np.int32), knowns_a=np.full(n, int(g["knowns"]), np.int64),
                 wm_a=np.full(n, int(g["wm"]), np.int32), nk_a=np.full(n, nk, np.int32))
+
+
+def config_c4():
+    """BASELINE configs[3] in the reference's calling pattern (tests/golden/config_C4_1M.npz: one ExpertSolver.prepare on the
+    geometry of config_C2_1M, one solve() per time level with fk_t = F_t[hoods]): the rebuilt geometry, the stacked fields
+    fk (nlevels, n, nk), the start values fi0 (nlevels, n, 6) and the reference's outputs."""
+    import hashlib
+    g = golden("config_C4_1M.npz")
+    dim, nk, n, L = int(g["dim"]), int(g["nk"]), int(g["ncases"]), int(g["nlevels"])
+    hoods, cases = g["hoods"].astype(np.int64), g["cases"]
+    xk = synth.halton_at(hoods, dim); xi = synth.halton_at(cases, dim)
+    fk = np.stack([synth.field(xk.reshape(-1, dim), float(t)).reshape(n, nk) for t in range(L)])
+    fi0 = np.zeros((L, n, 6))
+    for t in range(L):
+        fi0[t, :, 0] = synth.field(xi, float(t))
+    h = hashlib.sha256()
+    for a in (xk, fk, xi):
+        h.update(np.ascontiguousarray(a).tobytes())
+    assert np.array_equal(np.frombuffer(h.digest(), dtype=np.uint8), g["digest"]), "rebuilt inputs of config_C4_1M differ"
+    return dict(g=g, dim=dim, order=int(g["order"]), nkv=nk, n=n, nlevels=L, xk=xk, xi=xi, fk=fk, fi0=fi0, fi_ref=g["fi"],
+                order_a=np.full(n, int(g["order"]), np.int32), knowns_a=np.zeros(n, np.int64),
+                wm_a=np.full(n, int(g["wm"]), np.int32), nk_a=np.full(n, nk, np.int32))

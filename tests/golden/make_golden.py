@@ -350,6 +350,38 @@ DENSE = {   # name -> (dim, order, nk, wm, knowns, npoints)
 }
 
 
+def gen_c4_timelevels(outdir, npoints=1_000_000, every=977, ncases=1024, nlevels=4):
+    """BASELINE.json configs[3] ("prepare once + 256 RHS solves") in the reference's own calling pattern (expert.pyx:309-426 prepare,
+    :467-655 solve; tests/test_expert.py:92-117 re-solves one prepared geometry with new data): ONE ExpertSolver.prepare on the
+    geometry of config_C2_1M (2D order 2, 32 neighbours, all DOFs unknown, every 977th case of the 1M-point cloud), then one
+    solve() per time level t with fk_t = F_t[hoods], F_t = sin(pi x + 0.01 t) cos(pi y) (synth.field(S, t): SURVEY section 8d).
+    The GPU's stacked solve (ExpertSolver.solve_many: the matrix-core kernel) is held to these outputs."""
+    import wlsqm
+    dim, order, nk = 2, 2, 32
+    S = synth.halton(npoints, dim)
+    cases = np.arange(ncases, dtype=np.int64) * every
+    hoods = synth.knn(S, nk, query=cases).astype(np.int64)
+    xk = S[hoods]; xi = S[cases].copy()
+    assert np.array_equal(xk, synth.halton_at(hoods, dim)) and np.array_equal(xi, synth.halton_at(cases, dim))
+    o = np.full(ncases, order, np.int32); kn = np.zeros(ncases, np.int64)
+    w = np.full(ncases, wlsqm.WEIGHT_CENTER, np.int32); nka = np.full(ncases, nk, np.int32)
+    solver = wlsqm.ExpertSolver(dimension=dim, nk=nka, order=o, knowns=kn, weighting_method=w,
+                                algorithm=wlsqm.ALGO_BASIC, do_sens=False, ntasks=8, debug=False)
+    solver.prepare(xi=xi, xk=xk)
+    fis, fks = [], []
+    for t in range(nlevels):
+        Ft = synth.field(S, float(t))
+        fk = Ft[hoods]
+        assert np.array_equal(fk, synth.field(xk.reshape(-1, dim), float(t)).reshape(ncases, nk))
+        fi = np.zeros((ncases, 6)); fi[:, 0] = Ft[cases]
+        solver.solve(fk=fk, fi=fi)
+        fis.append(fi); fks.append(fk)
+    np.savez_compressed(os.path.join(outdir, "config_C4_1M.npz"), dim=dim, order=order, nk=nk, wm=int(wlsqm.WEIGHT_CENTER), knowns=0,
+                        npoints=npoints, ncases=ncases, every=every, nlevels=nlevels, cases=cases, hoods=hoods.astype(np.int32),
+                        fi=np.stack(fis), digest=input_digest(xk, np.stack(fks), xi))
+    print("config_C4_1M: one prepare, %d time levels, %d cases of a %d-point cloud" % (nlevels, ncases, npoints))
+
+
 def gen_edge(outdir):
     """Edge cases the reference's own tests pin (tests/test_edge_cases.py, test_stencil.py) + a few it does not."""
     import wlsqm
@@ -474,6 +506,9 @@ def main():
     if a.only == "testmany2d":
         gen_testmany2d(a.out)
         return
+    if a.only == "c4":
+        gen_c4_timelevels(a.out)
+        return
     if a.only == "dense":
         for name, (dim, order, nk, wm, kn, npts) in DENSE.items():
             gen_config_dense(name, dim, order, nk, wm, kn, npts, a.out)
@@ -492,6 +527,7 @@ def main():
     gen_testmany2d(a.out)
     for name, (dim, order, nk, wm, kn, npts) in DENSE.items():
         gen_config_dense(name, dim, order, nk, wm, kn, npts, a.out)
+    gen_c4_timelevels(a.out)
 
 
 if __name__ == "__main__":

@@ -174,3 +174,47 @@ def test_a_cases_bits_do_not_depend_on_its_batch_mates(wlsqm, dim, order, Kn):
     mixed = all1.copy(); mixed[::7] = 0
     same = mixed == 1
     assert np.array_equal(run(all1)[same], run(mixed)[same]), "F-known cases: all-F-known waves vs mixed waves"
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[3] against the REFERENCE: prepare once, several solves on new data
+
+@pytest.mark.parametrize("path", ["op", "fused", "strict", "accurate"])
+def test_prepare_once_time_levels_vs_reference_golden(wlsqm, path, monkeypatch):
+    """tests/golden/config_C4_1M.npz holds what the real reference returns for ONE ExpertSolver.prepare and four solve() calls with
+    fk_t = F_t[hoods] (expert.pyx:309-426, 467-655; the pattern of tests/test_expert.py:92-117) on the geometry of the headline
+    config at full density.  The GPU's ExpertSolver on the same inputs: the stacked solve through the matrix-core operator kernel
+    (`op`: what bench.py's configs[3] line runs), one fused fit per level (`fused`), and the strict / accurate numerics modes —
+    the last two within 1e-10 of the reference on every column, the fast ones within the noise-floor criterion of tests/_parity.py."""
+    import torch
+    import wlsqm.hip as whip
+    c = K.config_c4()
+    L, n = c["nlevels"], c["n"]
+    s = wlsqm.ExpertSolver(dimension=2, nk=c["nk_a"], order=c["order_a"], knowns=c["knowns_a"], weighting_method=c["wm_a"],
+                           algorithm=wlsqm.ALGO_BASIC, do_sens=False)
+    mode = {"strict": True, "accurate": 2}.get(path, False)
+    with whip.strict(mode):
+        s.prepare(xi=c["xi"], xk=c["xk"])
+        if path == "fused":
+            got = c["fi0"].copy()
+            for t in range(L):
+                s.solve(fk=c["fk"][t], fi=got[t])
+        else:
+            if path == "op":
+                monkeypatch.setenv("WLSQM_HIP_SOLVE_MANY", "op")
+            got_d = _t(c["fi0"])
+            s.solve_many_device(_t(c["fk"]), got_d)
+            torch.cuda.synchronize()
+            if path == "op":
+                assert whip.last_kernel() == "solve-op-mfma", whip.last_kernel()
+            got = got_d.cpu().numpy()
+    s.close()
+    for t in range(L):
+        if path in ("strict", "accurate"):
+            # (the strict mode IS the oracle, which is 2.7e-11 .. 5.5e-11 from the reference on these four levels — LAPACK's internal
+            # summation order; the accurate mode 2.7e-11 .. 5.6e-11)
+            E = P.column_metric(got[t], c["fi_ref"][t])
+            assert np.all(E <= 1e-10), (path, t, E)
+        else:
+            truth = P.truth_fit(2, c["xk"], c["fk"][t], c["nk_a"], c["xi"], c["fi0"][t], c["order_a"], c["knowns_a"], c["wm_a"])
+            P.assert_parity(got[t], c["fi_ref"][t], truth, "configs[3] pattern, %s path, level %d" % (path, t))

@@ -214,3 +214,17 @@ def test_accurate_mode_statement_against_the_reference_goldens(name):
     O.variant_fit_many(*args, fi_s, c["knowns_a"], c["wm_a"], flags=O.V_SYM)
     E = P.column_metric(fi_s, c["g"]["fi"])
     assert np.all(E <= 0.5e-10), E
+
+
+def test_oracle_on_the_prepare_once_time_levels_of_configs3():
+    """tests/golden/config_C4_1M.npz: the reference's ExpertSolver prepared once and solved for four time levels (BASELINE
+    configs[3]'s pattern, expert.pyx:309-655).  The oracle, one fit per level, agrees to LAPACK's rounding (column metric 1e-10)."""
+    import _cases as K
+    import _parity as P
+    from oracle import oracle as O
+    c = K.config_c4()
+    for t in range(c["nlevels"]):
+        fi = c["fi0"][t].copy()
+        O.fit_many(2, c["xk"], c["fk"][t], c["nk_a"], c["xi"], fi, None, 0, c["order_a"], c["knowns_a"], c["wm_a"], ntasks=8)
+        E = P.column_metric(fi, c["fi_ref"][t])
+        assert np.all(E <= 1e-10), (t, E)

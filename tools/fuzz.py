@@ -15,7 +15,7 @@ import _parity as P
 NDOF = {1: [1, 2, 3, 4, 5], 2: [1, 3, 6, 10, 15], 3: [1, 4, 10, 20, 35]}
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-t0 = time.time(); trials = 0; worst = 0.0; sens_worst = 0.0; sens_trials = 0; acc_desc = []; ratios = []; acc = []; cloud_trials = 0; expert_trials = 0; stacked_trials = 0; strided_trials = 0; strict_trials = 0; order_trials = 0; t_progress = time.time()
+t0 = time.time(); trials = 0; worst = 0.0; sens_worst = 0.0; sens_trials = 0; acc_desc = []; ratios = []; acc = []; cloud_trials = 0; expert_trials = 0; stacked_trials = 0; strided_trials = 0; strict_trials = 0; accurate_trials = 0; order_trials = 0; t_progress = time.time()
 dev = torch.device("cuda", 0)
 while time.time() - t0 < budget:
     dim = int(rng.integers(1, 4)); mixed = rng.random() < 0.25
@@ -132,6 +132,26 @@ while time.time() - t0 < budget:
         if mode == "iter":
             assert it_s == it_o, desc + ": STRICT iteration count %d vs oracle %d" % (it_s, it_o)
         strict_trials += 1
+    if mode == "basic" and dim >= 2 and K <= 128 and rng.random() < 0.35:
+        # the same call in the ACCURATE numerics mode (csrc/fit_accurate.hip): per order bucket, the cases WITHOUT a known DOF of the
+        # systems up to 10 unknowns must carry the bits of oracle/variants.c with V_SYM, every other case the oracle's (strict kernels)
+        fi_a = fi0.copy()
+        with whip.accurate():
+            f(xk_a, fk, nk, xi_a, fi_a, None, 0, orders, knowns, wm, **kw)
+        want = fi_o.copy()
+        for o in np.unique(orders):
+            no_o = NDOF[dim][int(o)]
+            sel = np.nonzero((orders == o) & (knowns == 0))[0]
+            if no_o > 10 or sel.size == 0:
+                continue
+            sub = np.ascontiguousarray(fi0[sel][:, :no_o])
+            oracle.variant_fit_many(dim, int(o), np.ascontiguousarray(xk_a[sel]), np.ascontiguousarray(fk[sel]), np.ascontiguousarray(nk[sel]),
+                                    np.ascontiguousarray(xi_a[sel]), sub, np.ascontiguousarray(knowns[sel]), np.ascontiguousarray(wm[sel]),
+                                    flags=oracle.V_SYM)
+            want[sel, :no_o] = sub
+        assert np.array_equal(fi_a, want, equal_nan=True), desc + ": ACCURATE mode differs from its CPU statement (%d of %d doubles)" % (
+            int((fi_a != want).sum()), fi_a.size)
+        accurate_trials += 1
     if mixed and rng.random() < 0.6:
         # per-case orders as a DEVICE tensor (wlsqm_hip_fit_many_device_orders: bucketed on the device, no host sync)
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -191,7 +211,7 @@ while time.time() - t0 < budget:
 ratios.sort(reverse=True)
 print("fuzz: sensitivities of %d batches compared with the oracle's: largest per-case relative difference among well-conditioned cases %.1e" % (sens_trials, sens_worst))
 over = [r for r in ratios if r[0] > 1.0]
-print("fuzz: %d batches also in STRICT mode (bit-identical to the oracle), %d mixed-order batches also with a device order tensor" % (strict_trials, order_trials))
+print("fuzz: %d batches also in STRICT mode (bit-identical to the oracle), %d also in ACCURATE mode (bit-identical to variants.c V_SYM / the oracle, per case), %d mixed-order batches also with a device order tensor" % (strict_trials, accurate_trials, order_trials))
 print("fuzz: %d random batches (%d of them also index-based, %d also from strided device views, %d also through ExpertSolver, %d of those with a stacked solve; %d order buckets) in %.0f s; largest column metric vs oracle %.2e; buckets over the 1e-10 + 8 N criterion: %d"
       % (trials, cloud_trials, strided_trials, expert_trials, stacked_trials, len(ratios), time.time() - t0, worst, len(over)))
 for r, _, d in ratios[:8]:
