@@ -9,6 +9,7 @@
 // MOM: accumulate the distinct moments (wlsqm_moments.hpp) instead of the matrix entries; wave 0 expands them.
 #include <cstdlib>
 
+#include <cstdio>
 #include "wlsqm_internal.hpp"
 #include "wlsqm_kernels.hpp"
 #include "wlsqm_moments.hpp"
@@ -451,6 +452,7 @@ __global__ __launch_bounds__(KW, MINW) void fit_tile1_kernel(const KParams p, co
             // ---- iterative refinement: every sweep re-evaluates the model at the neighbours, solves for a correction
             // from the residual and stops when the residual's max-norm repeats exactly (impl.pyx:1037-1057)
             int iters = 0;
+            bool unfinished = false;
             if (p.iterative) {
                 double fi[NO];
 #pragma unroll
@@ -458,9 +460,23 @@ __global__ __launch_bounds__(KW, MINW) void fit_tile1_kernel(const KParams p, co
 #pragma unroll
                 for (int a = 0; a < NO; ++a) if ((dropped >> a) & 1ull) fi[a] = fio[a];   // Case_set_fi copies all `no`
                 double prev_norm = -1.0;
+                // a later ROUND of the refinement (KParams::it_first): the iterate so far is in fi, the last residual norm in it_state
+                const int i_first = p.it_stop > 0 ? p.it_first : 0, i_stop = p.it_stop > 0 ? min(p.it_stop, p.max_iter) : p.max_iter;
+                if (i_first > 0) {
+#pragma unroll
+                    for (int a = 0; a < NO; ++a) fi[a] = fio[a];
+                    prev_norm = p.it_state[jc];
+                }
                 bool running = true, broke = false;
                 int i = 0;
-                for (i = 0; i < p.max_iter; ++i) {
+                // the weights of this lane's neighbours do not change from sweep to sweep (a quotient, a root): kept
+                double wv[FMAX];
+#pragma unroll
+                for (int kk = 0; kk < FMAX; ++kk) {
+                    wv[kk] = 0.0;
+                    if (kk < G.KPL) { double cc0[NO], w0; const bool live0 = neighbour(kk, cc0, w0); wv[kk] = live0 ? w0 : 0.0; }
+                }
+                for (i = i_first; i < i_stop; ++i) {
                     if (!__any(running)) break;
                     double norm = 0.0, r[NO];
 #pragma unroll
@@ -468,8 +484,17 @@ __global__ __launch_bounds__(KW, MINW) void fit_tile1_kernel(const KParams p, co
 #pragma unroll
                     for (int kk = 0; kk < FMAX; ++kk) {
                         if (kk < G.KPL) {
-                            double cc[NO], w;
-                            const bool live = neighbour(kk, cc, w);
+                            double cc[NO];
+                            const int k = k0 + kk;
+                            const bool live = k < nkc;
+                            {
+                                const int kc = live ? k : 0;
+                                double d[DIM];
+#pragma unroll
+                                for (int m = 0; m < DIM; ++m) d[m] = xr[kc * DIM + m] - xi[m];
+                                (void)monomials<DIM, ORDER>(d, cc);
+                            }
+                            const double w = wv[kk];
                             double model = fi[0];
 #pragma unroll
                             for (int a = 1; a < NO; ++a) model += cc[a] * fi[a];
@@ -503,17 +528,26 @@ __global__ __launch_bounds__(KW, MINW) void fit_tile1_kernel(const KParams p, co
                 if (!broke) iters = p.max_iter > 0 ? p.max_iter : 1;   // for/else, impl.pyx:1080-1081
 #pragma unroll
                 for (int a = 0; a < NO; ++a) sol[a] = fi[a];
+                // the round is over and this case is still running: the next round carries on from the iterate stored below
+                unfinished = running && !broke && i_stop < p.max_iter;
+                if (unfinished && store && h == 0 && p.cont_list) {
+                    const unsigned long long slot = atomicAdd(reinterpret_cast<unsigned long long*>(p.cont_count), 1ull);
+                    p.cont_list[slot] = jc;
+                    p.it_state[jc] = prev_norm;
+                }
             }
             if (store && h == 0) {
 #pragma unroll
                 for (int a = 0; a < NO; ++a)
                     if (!((known >> a) & 1ull)) fio[a] = sol[a];
-                if (p.iterative && p.iters_out) atomicMax(p.iters_out, iters);
+                if (p.iterative && p.iters_out && !unfinished) atomicMax(p.iters_out, iters);
             }
         }
         __syncthreads();   // the next tile overwrites LDS
     }
 }
+
+__global__ void tile1_rounds_zero_kernel(long long* ws) { ws[threadIdx.x] = 0; }
 
 static int rup(int v, int m, int r) { return v + ((r - v % m) % m + m) % m; }
 
@@ -559,6 +593,50 @@ static int launch_tile1(const KParams& p, long long K, hipStream_t stream, bool*
     int rc = persistent_grid(reinterpret_cast<const void*>(kern), KW, lds_bytes, 0, false, setup, &grid);
     if (rc != WLSQM_OK) return rc;
     if (grid > ntiles) grid = ntiles;
+    if constexpr (EXTRAS) {
+        // Refinement in ROUNDS (KParams::it_first): sweeps [0, 3) for every case, [3, 6) for the cases still running, the rest for
+        // those that still are — each round a launch over the previous round's survivor list, sized on the device (no host
+        // synchronisation); bit-identical to the single launch (a case's arithmetic involves its own lanes only; tools/time_rounds.py).
+        // OFF by default (WLSQM_HIP_REFINE_ROUNDS=1 turns it on): measured SLOWER, 1.75 against 0.88 ms per 1M configs[1] cases and
+        // 3.33 against 2.34 ms on configs[4].  The oracle's stop test fires after 3.1 / 3.4 sweeps on average there (1 024 cases at 1M
+        // density: 33 / 507 / 233 / 110 / 45 / 27 / 16 / 7 / 4 / 42 cases for 1 .. 10), which is what made the rounds look worthwhile
+        // — but the test is exact equality of two consecutive residual max-norms, and in THIS kernel's arithmetic (moment form, FMA
+        // contraction, LDL^T) the iterates keep moving in their last bits for longer: 67-76 % of the cases are still running after
+        // sweep 3 and 24-38 % after sweep 6 (WLSQM_HIP_REFINE_DEBUG=1), and a later round has to rebuild the factor of its cases
+        // (configs[4]: 1.0 ms of the kernel's 1.45 ms for fit + 3 sweeps).  The divergence inside a tile is therefore small on the
+        // GPU; what the refinement lines cost is the sweeps themselves.
+        const bool rounds = p.iterative && !p.do_sens && p.it_stop == 0 && p.max_iter >= 5 && p.ncases >= 4096 && (e && e[0] == '1');
+        if (rounds) {
+            const long long n = p.ncases;
+            long long* ws = nullptr;                  // [8] counters, [n] list A, [n] list B, [n] residual norms
+            rc = scratch_alloc_async(reinterpret_cast<void**>(&ws), (size_t)(3 * n + 8) * sizeof(long long), stream);
+            if (rc != WLSQM_OK) return rc;
+            hipLaunchKernelGGL(tile1_rounds_zero_kernel, dim3(1), dim3(8), 0, stream, ws);
+            const int r1 = 3, r2 = p.max_iter > 7 ? 6 : p.max_iter;
+            KParams q = p;
+            q.it_first = 0; q.it_stop = r1; q.cont_list = ws + 8; q.cont_count = ws; q.it_state = reinterpret_cast<double*>(ws + 8 + 2 * n);
+            hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(KW), lds_bytes, stream, q, ntiles, G);
+            q.case_index = ws + 8; q.ncases_dev = ws; q.ncases = n;
+            q.it_first = r1; q.it_stop = r2; q.cont_list = ws + 8 + n; q.cont_count = ws + 1;
+            hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(KW), lds_bytes, stream, q, ntiles, G);
+            if (r2 < p.max_iter) {
+                q.case_index = ws + 8 + n; q.ncases_dev = ws + 1;
+                q.it_first = r2; q.it_stop = p.max_iter; q.cont_list = nullptr; q.cont_count = nullptr;
+                hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(KW), lds_bytes, stream, q, ntiles, G);
+            }
+            hipError_t le = hipGetLastError();
+            if (getenv("WLSQM_HIP_REFINE_DEBUG")) {           // survivors of the first two rounds (synchronises: diagnostics only)
+                long long c[2] = {0, 0};
+                (void)hipMemcpyAsync(c, ws, sizeof(c), hipMemcpyDeviceToHost, stream);
+                (void)hipStreamSynchronize(stream);
+                fprintf(stderr, "refinement rounds: %lld cases, %lld still running after sweep %d, %lld after sweep %d\n", n, c[0], r1, c[1], r2);
+            }
+            const int rf = scratch_free_async(ws, stream);
+            if (le != hipSuccess) return hip_fail(le, "fit_tile1_kernel (refinement rounds)");
+            note_kernel("tile1-extras");
+            return rf;
+        }
+    }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(KW), lds_bytes, stream, p, ntiles, G);
     WLSQM_HIP_CHECK(hipGetLastError());
     note_kernel(EXTRAS ? "tile1-extras" : "tile1");

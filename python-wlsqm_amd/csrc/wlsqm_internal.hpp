@@ -42,6 +42,14 @@ struct KParams {
     // Two-kernel moment path (fit_moment.hip): the tile kernel parks the reduced moments of case j at
     // ws[e * ws_stride + j] (structure of arrays) and the solve kernel picks them up.
     double* ws;        long long ws_stride;
+    // Refinement in ROUNDS (fit_tilek.hip, the one-wave tile kernel with extras; round 4).  The reference's stop test (impl.pyx:1057)
+    // fires after 3.1 sweeps on average on BASELINE configs[1] but a 16-case tile holds a case that runs 8 of them: a round does the
+    // sweeps [it_first, it_stop) for its cases, writes the cases that are still running to `cont_list` (their number to
+    // `cont_count`, their last residual norm to it_state[case]) and the next round — a launch over that list — carries on from the
+    // iterate in fi.  it_stop == 0: no rounds (the whole loop in one launch, as before).
+    int it_first = 0, it_stop = 0;
+    long long* cont_list = nullptr; long long* cont_count = nullptr;
+    double* it_state = nullptr;
 };
 
 // Cases a launch really has (see KParams::ncases_dev).
