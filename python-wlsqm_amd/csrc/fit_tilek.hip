@@ -605,6 +605,7 @@ static int launch_tile1(const KParams& p, long long K, hipStream_t stream, bool*
         // sweep 3 and 24-38 % after sweep 6 (WLSQM_HIP_REFINE_DEBUG=1), and a later round has to rebuild the factor of its cases
         // (configs[4]: 1.0 ms of the kernel's 1.45 ms for fit + 3 sweeps).  The divergence inside a tile is therefore small on the
         // GPU; what the refinement lines cost is the sweeps themselves.
+        const char* e = getenv("WLSQM_HIP_REFINE_ROUNDS");
         const bool rounds = p.iterative && !p.do_sens && p.it_stop == 0 && p.max_iter >= 5 && p.ncases >= 4096 && (e && e[0] == '1');
         if (rounds) {
             const long long n = p.ncases;
