@@ -121,8 +121,13 @@ static int fit_through_dense_scratch(int dimension, int order, const KParams& p,
         return rc;
     }
     int* nkc = reinterpret_cast<int*>(ws + nx + nf + ni);
-    for (long long j0 = 0; j0 < p.ncases && rc == WLSQM_OK; j0 += ns) {
-        const long long n = std::min(ns, p.ncases - j0);
+    // (slices of a batch must all take the same kernel family, or fast-mode bits would depend on WLSQM_HIP_REPACK_MB and on
+    // ncases modulo the slice size: a tail shorter than 256 cases — the threshold below which the dispatcher prefers the lane
+    // kernel to a repack — is cut from the last two slices' sum in two halves instead)
+    for (long long j0 = 0; j0 < p.ncases && rc == WLSQM_OK;) {
+        long long n = std::min(ns, p.ncases - j0);
+        const long long rest = p.ncases - j0 - n;
+        if (rest > 0 && rest < 256 && n > 512) n -= 256;           // leave the next (last) slice at least 256 cases
         const KParams src = slice_cases(p, j0, n);
         const long long threads = n * Kp;
         if (gather)
@@ -142,6 +147,7 @@ static int fit_through_dense_scratch(int dimension, int order, const KParams& p,
             q.xi = ws + nx + nf; q.sxi_j = dimension;
         }
         rc = launch_fit(dimension, order, q, Kp, stream);          // contiguous now: takes the tiled kernels
+        j0 += n;
     }
     const int rc2 = scratch_free_async(ws, stream);
     *done = true;

@@ -62,63 +62,6 @@ namespace acc {
 
 typedef double d2_ __attribute__((ext_vector_type(2)));
 
-// ---- correctly rounded quotient and root for in-range operands: the instruction sequences hipcc emits for `/` and sqrt()
-// (LLVM AMDGPU LowerFDIV64 / lowerFSQRTF64) without the range scaling and the special-case fix-up
-__device__ __forceinline__ double rcp_refined(double b) {          // v_rcp_f64 + two Newton steps
-    double r = __builtin_amdgcn_rcp(b);
-    double e = fma(-b, r, 1.0); r = fma(r, e, r);
-    e = fma(-b, r, 1.0); r = fma(r, e, r);
-    return r;
-}
-__device__ __forceinline__ double div_by(double a, double b, double r) {   // r = rcp_refined(b)
-    const double q = a * r;
-    const double e = fma(-b, q, a);
-    return fma(e, r, q);
-}
-struct FastOps {
-    // (no operand of these is ever a NaN on the fast path — the range checks — so v_max_f64 is the reference's `if (q > acc) acc = q`)
-    static __device__ __forceinline__ double maxnum(double acc, double q) { return __builtin_fmax(acc, q); }
-    static __device__ __forceinline__ double div(double a, double b) { return div_by(a, b, rcp_refined(b)); }
-    // the same quotient from a SEED that is already within 2^-44 of 1 / b: one Newton step instead of v_rcp_f64 (a quarter-rate
-    // instruction: 16 cycles) and two.  The refined reciprocal is as accurate as the standard sequence's (its error is the square of
-    // the seed's plus one rounding), and the quotient / remainder / correction steps are the same: bit-identical to `/` on 3 x 2^31
-    // operand pairs with seeds up to 256 ulps off and adversarial denominators (tools/ubench/exact_div_sqrt.hip, classes 4-6).
-    static __device__ __forceinline__ double div_seeded(double a, double b, double seed) {
-        const double e = fma(-b, seed, 1.0);
-        return div_by(a, b, fma(seed, e, seed));
-    }
-    static __device__ __forceinline__ double rcp_of(double b) { return rcp_refined(b); }
-    static __device__ __forceinline__ double div_r(double a, double b, double r) { return div_by(a, b, r); }
-    static __device__ __forceinline__ double sqrt(double x) { double h; return sqrt_h(x, h); }
-    // the root, and the refined half reciprocal root h = 1 / (2 sqrt(x)) (1 + O(2^-46)) the sequence computes on the way:
-    // 2 h is a seed for the quotient by the root (div_seeded)
-    static __device__ __forceinline__ double sqrt_h(double x, double& h) {
-        const double y = __builtin_amdgcn_rsq(x);
-        double g = x * y; h = y * 0.5;
-        const double r = fma(-h, g, 0.5);
-        g = fma(g, r, g); h = fma(h, r, h);
-        double d = fma(-g, g, x); g = fma(d, h, g);
-        d = fma(-g, g, x); g = fma(d, h, g);
-        return g;
-    }
-    static __device__ __forceinline__ double div_by_root(double a, double s, double h) { return div_seeded(a, s, h + h); }
-};
-struct IeeeOps {                                                     // the compiler's sequences: any operand
-    static __device__ __forceinline__ double maxnum(double acc, double q) { return q > acc ? q : acc; }      // NaN q: skipped; NaN acc: kept
-    static __device__ __forceinline__ double div(double a, double b) { return a / b; }
-    static __device__ __forceinline__ double div_seeded(double a, double b, double) { return a / b; }
-    static __device__ __forceinline__ double rcp_of(double) { return 0.; }
-    static __device__ __forceinline__ double div_r(double a, double b, double) { return a / b; }
-    static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
-    static __device__ __forceinline__ double sqrt_h(double x, double& h) { h = 0.; return ::sqrt(x); }
-    static __device__ __forceinline__ double div_by_root(double a, double s, double) { return a / s; }
-};
-
-// safe range of the fast sequences (see the header): every nonzero magnitude that enters a fast quotient or root lies in
-// [2^-200, 2^200] and every running scale factor in [2^-140, 2^140]: exponent differences stay below 768, no operand or result
-// is subnormal, no numerator has a biased exponent <= 53 — the conditions under which v_div_scale / v_div_fixup are the identity
-constexpr double RANGE_LO = 0x1p-200, RANGE_HI = 0x1p200, SCALE_LO = 0x1p-140, SCALE_HI = 0x1p140;
-
 #ifndef WLSQM_ACC_CH
 #define WLSQM_ACC_CH 8
 #endif

@@ -298,15 +298,18 @@ static int launch_chunk(const KParams& p, long long K, hipStream_t stream) {
     const long long ntiles = (p.ncases + 15) / 16;
     static KernelSetup setup;
     auto kern = fit_chunk_kernel<DIM, ORDER, MINW, INV, ITER>;
-    long long grid = 0;
-    int rc = persistent_grid(reinterpret_cast<const void*>(kern), 64, 0, 0, true, setup, &grid);
-    if (rc != WLSQM_OK) return rc;
-    if (grid > ntiles) grid = ntiles;
     // refinement: the tile's xk and fk rows stay in LDS between the sweeps when four such waves still fit one CU
     const size_t cache_bytes = (size_t)16 * (((K * DIM) | 1) + (K | 1)) * sizeof(double);
     const size_t fixed_bytes = (size_t)(16 * (32 * DIM + 2) + 2) * sizeof(double);
     const bool cache_x = ITER && 4 * (cache_bytes + fixed_bytes + 256) <= 160 * 1024;
     const size_t dyn = cache_x ? cache_bytes : 0;
+    // (the grid is sized for the workgroups that can really be resident WITH this launch's dynamic LDS: ADVICE r3 — it was asked for
+    // with 0 bytes, i.e. for more workgroups than co-reside when the refinement caches its rows; the occupancy depends on K then, so
+    // it is not memoised)
+    long long grid = 0;
+    int rc = persistent_grid(reinterpret_cast<const void*>(kern), 64, dyn, 0, dyn == 0, setup, &grid);
+    if (rc != WLSQM_OK) return rc;
+    if (grid > ntiles) grid = ntiles;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), dyn, stream, p, ntiles, (int)K, cache_x);
     WLSQM_HIP_CHECK(hipGetLastError());
     note_kernel(ITER ? "chunk-refine" : INV ? "chunk-inverse" : "chunk");

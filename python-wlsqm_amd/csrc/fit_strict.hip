@@ -492,65 +492,106 @@ __device__ __forceinline__ void fit_strict_reg_block(const KParams& p, const lon
         for (int m = 0; m < DIM; ++m) xi[m] = p.xi[j * p.sxi_j + m];
         rows = Rows<DIM>{p.xk + j * p.sxk_j, p.sxk_k, p.fk + j * p.sfk_j, p.sfk_k, nullptr, nullptr, nullptr};
     }
-    double max_d2 = 0.;
+    // Round 4: the quotients and roots of the weights and of the equilibration run the compiler's IEEE sequences WITHOUT their range
+    // scaling and special-case fix-up (acc::FastOps, wlsqm_strict.hpp: the same operations, the same bits; seeded reciprocals in the
+    // equilibration) when every operand of the wave's cases is in their safe range — checked here —, and the full sequences otherwise.
+    double max_d2 = 0., min_d2 = acc::RANGE_HI;
     for (int k = 0; k < nk; ++k) {
         double d[DIM], c[NO];
         rows.offset(k, xi, d);
         const double d2 = make_c<DIM, ORDER>(d, c);
         if (d2 > max_d2) max_d2 = d2;
+        if (!(d2 >= min_d2)) min_d2 = d2;                        // (a NaN distance lands here and fails the range test)
     }
+    const bool fast_w = __all(uniform || (nk > 0 && min_d2 >= acc::RANGE_LO && max_d2 <= acc::RANGE_HI));
     // make_A (impl.pyx:566-602) and the right-hand side sums of solve (impl.pyx:768-787): each its own sum over k ascending
     double A[N][N], b[N];                                        // A[row][col]
 #pragma unroll
     for (int i = 0; i < N; ++i) { b[i] = 0.;
 #pragma unroll
         for (int m = 0; m < N; ++m) A[i][m] = 0.; }
-    for (int k = 0; k < nk; ++k) {
-        double d[DIM], c[NO];
-        rows.offset(k, xi, d);
-        const double d2 = make_c<DIM, ORDER>(d, c);
-        const double w = make_weight(d2, max_d2, uniform);
-        const double wf = w * rows.value(k);
+    auto weight_of = [&](auto ops_tag, double d2, double rmax) {
+        using OPS = decltype(ops_tag);
+        if (uniform) return 1.;
+        const double tmp = 1. - OPS::sqrt(OPS::div_r(d2, max_d2, rmax));
+        return weights_alpha + weights_beta * tmp * tmp;
+    };
+    auto assemble = [&](auto ops_tag) {
+        const double rmax = decltype(ops_tag)::rcp_of(max_d2);
+        for (int k = 0; k < nk; ++k) {
+            double d[DIM], c[NO];
+            rows.offset(k, xi, d);
+            const double d2 = make_c<DIM, ORDER>(d, c);
+            const double w = weight_of(ops_tag, d2, rmax);
+            const double wf = w * rows.value(k);
 #pragma unroll
-        for (int om = 0; om < N; ++om) {
-            const double wc = w * c[om + O0];
+            for (int om = 0; om < N; ++om) {
+                const double wc = w * c[om + O0];
 #pragma unroll
-            for (int oj = 0; oj < N; ++oj) A[oj][om] += wc * c[oj + O0];
+                for (int oj = 0; oj < N; ++oj) A[oj][om] += wc * c[oj + O0];
+            }
+#pragma unroll
+            for (int oj = 0; oj < N; ++oj) b[oj] += wf * c[oj + O0];
         }
-#pragma unroll
-        for (int oj = 0; oj < N; ++oj) b[oj] += wf * c[oj + O0];
-    }
+    };
+    if (fast_w) assemble(acc::FastOps{}); else assemble(acc::IeeeOps{});
     // rescale_ruiz2001_c (lapackdrivers.pyx:553-623)
-    double rs[N], cs[N], DRp[N], DCp[N], DR[N], DC[N];
+    double rs[N], cs[N];
+    auto ruiz = [&](auto ops_tag) -> bool {                       // returns: every running scale factor stayed in the safe range
+        using OPS = decltype(ops_tag);
+        double DRp[N], DCp[N], DR[N], DC[N];
+        bool in_range = true;
 #pragma unroll
-    for (int i = 0; i < N; ++i) { rs[i] = 1.; cs[i] = 1.; DRp[i] = 1.; DCp[i] = 1.; }
-    for (int it = 0; it < 100; ++it) {
+        for (int i = 0; i < N; ++i) { rs[i] = 1.; cs[i] = 1.; DRp[i] = 1.; DCp[i] = 1.; }
+        for (int it = 0; it < 100; ++it) {
 #pragma unroll
-        for (int i = 0; i < N; ++i) { DR[i] = 0.; DC[i] = 0.; }
+            for (int i = 0; i < N; ++i) { DR[i] = 0.; DC[i] = 0.; }
 #pragma unroll
-        for (int m = 0; m < N; ++m) {
+            for (int m = 0; m < N; ++m) {
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    // (fast path: rs[i] cs[m] is within 2^-48 of the reciprocal of DRp[i] DCp[m] — every sweep multiplies the one
+                    // and divides the other by the same root —, the seed of the quotient's reciprocal; first sweep: 1 x 1)
+                    const double q = fabs(OPS::div_seeded(A[i][m], DRp[i] * DCp[m], rs[i] * cs[m]));
+                    DC[m] = OPS::maxnum(DC[m], q);
+                    DR[i] = OPS::maxnum(DR[i], q);
+                }
+            }
 #pragma unroll
             for (int i = 0; i < N; ++i) {
-                const double q = fabs(A[i][m] / (DRp[i] * DCp[m]));
-                if (q > DC[m]) DC[m] = q;
-                if (q > DR[i]) DR[i] = q;
+                double hr, hc;
+                DR[i] = OPS::sqrt_h(DR[i], hr); DC[i] = OPS::sqrt_h(DC[i], hc);
+                DRp[i] *= DR[i]; rs[i] = OPS::div_by_root(rs[i], DR[i], hr);
+                DCp[i] *= DC[i]; cs[i] = OPS::div_by_root(cs[i], DC[i], hc);
+                in_range = in_range && DRp[i] >= acc::SCALE_LO && DRp[i] <= acc::SCALE_HI && DCp[i] >= acc::SCALE_LO && DCp[i] <= acc::SCALE_HI;
+            }
+            double accm = fabs(1. - DR[0] * DR[0]);
+#pragma unroll
+            for (int i = 1; i < N; ++i) { const double tmp = fabs(1. - DR[i] * DR[i]); if (tmp > accm) accm = tmp; }
+            if (accm < ruiz_epsilon) {
+                accm = fabs(1. - DC[0] * DC[0]);
+#pragma unroll
+                for (int i = 1; i < N; ++i) { const double tmp = fabs(1. - DC[i] * DC[i]); if (tmp > accm) accm = tmp; }
+                if (accm < ruiz_epsilon) break;
             }
         }
+        return in_range;
+    };
+    {
+        bool r_ok = true, fast_done = false;                      // every nonzero entry in the safe range and no zero row or column
 #pragma unroll
-        for (int i = 0; i < N; ++i) { DR[i] = sqrt(DR[i]); DC[i] = sqrt(DC[i]); }
+        for (int i = 0; i < N; ++i) {
+            double rowmax = 0., colmax = 0.;
 #pragma unroll
-        for (int i = 0; i < N; ++i) { DRp[i] *= DR[i]; rs[i] /= DR[i]; }
-#pragma unroll
-        for (int i = 0; i < N; ++i) { DCp[i] *= DC[i]; cs[i] /= DC[i]; }
-        double acc = fabs(1. - DR[0] * DR[0]);
-#pragma unroll
-        for (int i = 1; i < N; ++i) { const double tmp = fabs(1. - DR[i] * DR[i]); if (tmp > acc) acc = tmp; }
-        if (acc < ruiz_epsilon) {
-            acc = fabs(1. - DC[0] * DC[0]);
-#pragma unroll
-            for (int i = 1; i < N; ++i) { const double tmp = fabs(1. - DC[i] * DC[i]); if (tmp > acc) acc = tmp; }
-            if (acc < ruiz_epsilon) break;
+            for (int m = 0; m < N; ++m) {
+                const double a = fabs(A[i][m]), t2 = fabs(A[m][i]);
+                r_ok = r_ok && (a == 0. || (a >= acc::RANGE_LO && a <= acc::RANGE_HI));
+                rowmax = a > rowmax ? a : rowmax; colmax = t2 > colmax ? t2 : colmax;
+            }
+            r_ok = r_ok && rowmax >= acc::RANGE_LO && colmax >= acc::RANGE_LO;
         }
+        if (__all(r_ok)) { r_ok = ruiz(acc::FastOps{}); fast_done = true; }
+        if (!fast_done || !__all(r_ok)) (void)ruiz(acc::IeeeOps{});
     }
 #pragma unroll
     for (int m = 0; m < N; ++m)
@@ -589,11 +630,12 @@ __device__ __forceinline__ void fit_strict_reg_block(const KParams& p, const lon
     if constexpr (KN1) {
         // the known function value moves to the right-hand side, term by term into b[j] (impl.pyx:792-818)
         const double f0 = fio[0];
+        const double rmax3 = fast_w ? acc::rcp_refined(max_d2) : 0.;
         for (int k = 0; k < nk; ++k) {
             double d[DIM], c[NO];
             rows.offset(k, xi, d);
             const double d2 = make_c<DIM, ORDER>(d, c);
-            const double w = make_weight(d2, max_d2, uniform);
+            const double w = fast_w ? weight_of(acc::FastOps{}, d2, rmax3) : weight_of(acc::IeeeOps{}, d2, 0.);
             const double fwc = f0 * w * c[0];
 #pragma unroll
             for (int i = 0; i < N; ++i) b[i] -= fwc * c[i + O0] * rs[i];

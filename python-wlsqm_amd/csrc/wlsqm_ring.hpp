@@ -112,6 +112,16 @@ __global__ __launch_bounds__(64, MINW) void fit_ring_kernel(const KParams p, con
     extern __shared__ __attribute__((aligned(16))) double lds[];          // [2][SLOT]
 
     const int lane = threadIdx.x, c = lane % TC, h = lane / TC, k0 = h * KPL;
+    // 3D: the four lanes of a case take INTERLEAVED neighbours (k = 4 kk + h) instead of contiguous quarters.  A point is three
+    // doubles and a quarter 3 KPL = 30 of them: with contiguous quarters the ds_read_b64 of lanes (c, h) and (c, h + 1) — same 32-lane
+    // group, addresses c RS + 30 h + ... with RS == 2 (mod 32) — land on the same bank pair for every c (both offsets are even in
+    // 8-byte units: re-pitching the rows cannot separate them), a 2-way conflict on every coordinate read: SQ_LDS_BANK_CONFLICT 0.46
+    // of the LDS-active cycles of configs[4] since round 2.  Interleaved, the offsets are 2 c + 3 h: 32 different bank pairs.
+#ifndef WLSQM_RING_INTERLEAVE3D
+#define WLSQM_RING_INTERLEAVE3D 1
+#endif
+    constexpr bool ILV = (DIM == 3) && (WLSQM_RING_INTERLEAVE3D != 0) && (G::KC == K) && !GATHER;
+    auto slot_of = [&](int kk) { return ILV ? G::LPC * kk + h : k0 + kk; };      // neighbour slot of this lane's kk-th term
 
     struct Meta { int nk, wm; long long kn; double xi[DIM]; };
     Meta nxt;
@@ -256,6 +266,11 @@ __global__ __launch_bounds__(64, MINW) void fit_ring_kernel(const KParams p, con
 #pragma unroll
         for (int m = 0; m < DIM; ++m) nxt.xi[m] = p.xi[jc * p.sxi_j + m];
         const char* fbase = reinterpret_cast<const char*>(p.fk + j0 * (long long)K);
+        if constexpr (ILV) {
+#pragma unroll
+            for (int i = 0; i < KPL; ++i)
+                fnext[i] = *reinterpret_cast<const double*>(fbase + (unsigned)(cc * K + h) * 8u + (unsigned)(i * G::LPC) * 8u);
+        } else {
 #pragma unroll
         for (int i = 0; i < KPL / 2; ++i) {
             // a padded share's slots beyond the row replay the row's last pair (masked in the loop)
@@ -263,6 +278,7 @@ __global__ __launch_bounds__(64, MINW) void fit_ring_kernel(const KParams p, con
             const unsigned foff = (unsigned)(cc * K + kq) * 8u;
             const rd2_ v = *reinterpret_cast<const rd2_*>(fbase + foff);
             fnext[2 * i] = v.x; fnext[2 * i + 1] = v.y;
+        }
         }
     };
 
@@ -453,7 +469,7 @@ __global__ __launch_bounds__(64, MINW) void fit_ring_kernel(const KParams p, con
         double f[KPL];
 #pragma unroll
         for (int i = 0; i < KPL; ++i) f[i] = fnext[i];
-        const double* row = lds + (it & 1) * G::SLOT + c * RS + k0 * DIM;       // this lane's share of its case's row
+        const double* row = lds + (it & 1) * G::SLOT + c * RS + (ILV ? h : k0) * DIM;       // this lane's share of its case's row
         if (tile + 1 < tend) prefetch(tile + 1, (it + 1) & 1, tile + 2 < tend);
         // DELAY: the solve of the previous four tiles runs HERE, behind the prefetch, so that its fi stores are acknowledged
         // while this tile accumulates instead of at the next barrier (vmcnt counts the stores too); no ring slot is dead at
@@ -476,7 +492,7 @@ __global__ __launch_bounds__(64, MINW) void fit_ring_kernel(const KParams p, con
                 d[0] = xy.x - xi[0]; d[1] = xy.y - xi[1];
             } else {
 #pragma unroll
-                for (int m = 0; m < DIM; ++m) d[m] = row[kk * DIM + m] - xi[m];
+                for (int m = 0; m < DIM; ++m) d[m] = row[(ILV ? G::LPC * kk : kk) * DIM + m] - xi[m];
             }
         };
         auto sqdist = [&](const double (&d)[DIM]) {    // one rounding sequence for every code path (see above)
@@ -502,7 +518,7 @@ __global__ __launch_bounds__(64, MINW) void fit_ring_kernel(const KParams p, con
                 double d[DIM];
                 offset(kk, d);
                 double d2 = sqdist(d);
-                d2 = (k0 + kk < nkc) ? d2 : 0.0;
+                d2 = (slot_of(kk) < nkc) ? d2 : 0.0;
                 max_d2 = d2 > max_d2 ? d2 : max_d2;
             }
         }
@@ -531,7 +547,7 @@ __global__ __launch_bounds__(64, MINW) void fit_ring_kernel(const KParams p, con
             for (int kk = 0; kk < KPL; ++kk) neighbour(kk, true);
         } else {
 #pragma unroll
-            for (int kk = 0; kk < KPL; ++kk) neighbour(kk, k0 + kk < nkc);
+            for (int kk = 0; kk < KPL; ++kk) neighbour(kk, slot_of(kk) < nkc);
         }
         // reduce-scatter over the four lanes of a case.  V = (mu, nu), 60 entries.  Step 1 (rows of 16 lanes: h <-> h ^ 1) on the
         // pairs (e, e + 30): even rows keep the sums of the first half, odd rows of the second; step 2 (halves of the wave:
