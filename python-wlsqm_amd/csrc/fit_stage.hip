@@ -1,0 +1,300 @@
+// fit_stage.hip — ONE LANE PER CASE fast fit on dense contiguous rows (round 4): the tile / ring kernels' arithmetic (moment form,
+// FMA, rsq-seeded weights, unpivoted LDL^T on the masked full system: wlsqm_kernels.hpp / wlsqm_moments.hpp) without their
+// cross-lane machinery.
+//
+// Reference path (file:line in /root/reference): make_c_nD impl.pyx:286-432 / 70-269, Case_make_weights infra.pyx:668-702, make_A
+// impl.pyx:566-602, solve with knowns elimination impl.pyx:731-846, dgetrf / dgetrs lapackdrivers.pyx:1628-1665.
+//
+// Why.  The ring kernels (wlsqm_ring.hpp) give a case to FOUR lanes: 16 (10) neighbours each, then a reduce-scatter of the partial
+// moments over the four lanes, the quarters of four tiles parked in (accumulation) registers, a 4 x 4 transposition so that the wave
+// can solve 64 different cases at once.  Counted from the ISA (profiles/isa_r03.txt): BASELINE configs[2] executes
+// 2 584 vector instructions per 16-case tile = 10 336 per 64 cases, of which the reduce-scatter, the parking and the transposition
+// (388 of its 690 instructions are v_accvgpr moves) and the per-tile prologues are about a fifth — work that exists only because a
+// case is spread over lanes.  With one lane per case nothing is reduced, parked or transposed: 64 neighbours x (81 moment operations +
+// the weight) + one solve per lane.  What kept that mapping slow before (fit_lane_kernel: 8.5 % of the HBM peak) was its memory side —
+// every lane reading its own row, 64 cache lines per load instruction — and that is what the accurate mode's staging (fit_accurate.hip)
+// solved: the rows of a wave's 64 consecutive cases travel through LDS in chunks of 8 neighbours, global loads are coalesced 16-byte
+// pieces of whole 128- / 192-byte runs, the next chunk is in flight in registers while the current one is consumed.
+//
+// The weights need the largest squared distance before the first moment can be summed (a second pass over the rows, for which there
+// is no room in LDS at 64 cases per wave).  As in the accurate mode the pass is SPECULATIVE: neighbour lists out of a k-nearest-
+// neighbour search are sorted by distance (scipy's cKDTree.query, wlsqm.hip.knn: the reference's examples and every BASELINE config),
+// so it runs with the last neighbour's squared distance as the maximum while it tracks the true one, and the guess is verified bit for
+// bit; a wave with a wrong guess (unsorted neighbours) repeats the pass with the true maxima — same bits either way.
+//
+// One sum per moment over k ascending in ONE lane: of the fast kernels this one is the closest to the reference's summation order
+// (profiles/r03_attribution.txt: the lane-split sums are the largest single contribution to the fast kernels' distance from it).
+#include <atomic>
+#include <type_traits>
+
+#include "wlsqm_internal.hpp"
+#include "wlsqm_kernels.hpp"
+#include "wlsqm_moments.hpp"
+
+#ifndef WLSQM_STAGE_GRP
+#define WLSQM_STAGE_GRP 4           // neighbours the scheduler may interleave in the moment pass (with WLSQM_STAGE_SCHED_BARRIER)
+#endif
+#ifndef WLSQM_STAGE_SCHED_BARRIER
+#define WLSQM_STAGE_SCHED_BARRIER 0
+#endif
+
+namespace wlsqm {
+
+namespace stage {
+typedef double d2_ __attribute__((ext_vector_type(2)));
+constexpr int CH = 8;               // neighbours per staged chunk
+}
+
+#ifndef WLSQM_STAGE_MINW10
+#define WLSQM_STAGE_MINW10 1        // waves per SIMD the systems up to 10 unknowns are compiled for
+#endif
+template <int DIM, int ORDER>
+__global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER) <= 10 ? WLSQM_STAGE_MINW10 : 1)) void fit_stage_kernel(const KParams p) {
+    using namespace stage;
+    constexpr int NO = ndofs(DIM, ORDER), NE = NO * (NO + 1) / 2, NM = mom_count<DIM>(2 * ORDER);
+    static_assert(mom_count<DIM>(ORDER) == NO, "one right-hand-side moment per DOF");
+    constexpr int XPC = CH * DIM * 8 / 16, FPC = CH * 8 / 16;        // 16-byte pieces of one case's chunk: coordinates, values
+    constexpr int XPITCH = CH * DIM + 2, FPITCH = CH + 2;            // doubles per staged row (+ 16 bytes: conflict-free b128 reads)
+    constexpr int XCPI = 64 / XPC, XNI = (64 + XCPI - 1) / XCPI;      // whole cases per load instruction; instructions per chunk
+    constexpr int FCPI = 64 / FPC, FNI = 64 / FCPI;
+    // neighbours the scheduler may interleave: the 6-unknown systems run two waves per SIMD and fit their 256 registers only with
+    // two at a time (no scratch; four: 44 B, eight: 76 B); the larger systems own their SIMD and take the whole chunk
+    constexpr bool SCHED_BARRIER = WLSQM_STAGE_SCHED_BARRIER || NO <= 6;
+    constexpr int GRP = WLSQM_STAGE_SCHED_BARRIER ? (WLSQM_STAGE_GRP < CH ? WLSQM_STAGE_GRP : CH) : (NO <= 6 ? 2 : CH);
+    // the staging rows; behind them (reusing the same bytes after the last chunk) the 64 result rows of the wave
+    constexpr int STAGE_D = 64 * XPITCH + 64 * FPITCH, OUT_D = 64 * NO;
+    __shared__ __attribute__((aligned(16))) double lds[STAGE_D > OUT_D ? STAGE_D : OUT_D];
+    double* const xs = lds;
+    double* const fs = lds + 64 * XPITCH;
+
+    const int lane = threadIdx.x;
+    const long long t0 = (long long)blockIdx.x * 64, t = t0 + lane;
+    const int nvalid = (p.ncases - t0 < 64) ? (int)(p.ncases - t0) : 64;      // wave-uniform
+    const bool valid = lane < nvalid;
+    const long long j = valid ? t : t0 + nvalid - 1;                          // tail lanes replay the last case (never stored)
+    const int K = (int)p.max_nk;
+    const int nkc = min(p.nk[j * p.snk], K);
+    const bool uniform = (p.wm[j * p.swm] == WLSQM_WEIGHT_UNIFORM);
+    unsigned long long known, dropped;
+    effective_mask<NO>(p.knowns[j * p.sknowns], known, dropped);
+    double xi[DIM];
+#pragma unroll
+    for (int m = 0; m < DIM; ++m) xi[m] = p.xi[j * p.sxi_j + m];
+
+    auto sqdist = [&](const double (&d)[DIM]) {       // one rounding sequence for the guess and for the pass: they are compared for equality
+        double d2 = d[0] * d[0];
+#pragma unroll
+        for (int m = 1; m < DIM; ++m) d2 = fma(d[m], d[m], d2);
+        return d2;
+    };
+    // the guess: the last neighbour is the farthest (see the header)
+    double guess = 0.0;
+    if (nkc > 0) {
+        const double* q = p.xk + j * (long long)K * DIM + (long long)(nkc - 1) * DIM;
+        double dg[DIM];
+#pragma unroll
+        for (int m = 0; m < DIM; ++m) dg[m] = q[m] - xi[m];
+        guess = sqdist(dg);
+    }
+
+    // ---- staging: a load instruction moves the chunks of XCPI (FCPI) whole cases, XPC (FPC) consecutive lanes per case
+    const int Q = (K + CH - 1) / CH;                                  // (a last partial chunk: its pieces beyond the row replay the row's last one; masked)
+    const int xsub = lane % XPC, xc0 = lane / XPC, fsub = lane % FPC, fc0 = lane / FPC;
+    const unsigned xrowb = (unsigned)K * DIM * 8, frowb = (unsigned)K * 8;
+    const bool xlane = lane < XCPI * XPC;
+    const char* const xtile = reinterpret_cast<const char*>(p.xk + t0 * (long long)K * DIM);
+    const char* const ftile = reinterpret_cast<const char*>(p.fk + t0 * (long long)K);
+    d2_ xr[XNI], fr[FNI];
+    auto fetch = [&](int q) {
+        unsigned xo = (unsigned)q * (CH * DIM * 8) + (unsigned)xsub * 16u, fo = (unsigned)q * (CH * 8) + (unsigned)fsub * 16u;
+        xo = xo < xrowb ? xo : xrowb - 16u; fo = fo < frowb ? fo : frowb - 16u;      // (rows are multiples of 16 bytes: K even)
+        const char* xb = xtile + xo;
+        const char* fb = ftile + fo;
+#pragma unroll
+        for (int i = 0; i < XNI; ++i) {
+            int cc = xc0 + i * XCPI;
+            cc = cc < nvalid ? cc : nvalid - 1;                       // tail group / idle lanes of the last instruction: replay a valid row
+            if (xlane) xr[i] = *reinterpret_cast<const d2_*>(xb + (size_t)(unsigned)cc * xrowb);
+        }
+#pragma unroll
+        for (int i = 0; i < FNI; ++i) {
+            int cc = fc0 + i * FCPI;
+            cc = cc < nvalid ? cc : nvalid - 1;
+            fr[i] = *reinterpret_cast<const d2_*>(fb + (size_t)(unsigned)cc * frowb);
+        }
+    };
+    auto park = [&]() {
+        double* xl = xs + xc0 * XPITCH + xsub * 2;
+        double* fl = fs + fc0 * FPITCH + fsub * 2;
+#pragma unroll
+        for (int i = 0; i < XNI; ++i)
+            if (xlane && (i * XCPI + XCPI <= 64 || xc0 + i * XCPI < 64)) *reinterpret_cast<d2_*>(xl + i * XCPI * XPITCH) = xr[i];
+#pragma unroll
+        for (int i = 0; i < FNI; ++i) *reinterpret_cast<d2_*>(fl + i * FCPI * FPITCH) = fr[i];
+    };
+
+    double mu[NM], nu[NO];
+    double max_d2 = 0.0;
+    // One pass over the neighbours.  MAXONLY: only the largest squared distance is computed; otherwise the moments, with `maxv` as the
+    // largest squared distance of the lane's case.  MASKED (some case of the group is ragged, or K is not a multiple of CH) is decided
+    // ONCE per pass: with the choice inside the chunk loop the two variants' 60 accumulators met in different registers and every
+    // iteration paid ~50 copies per 4 neighbours at the join (first version: 179 instructions per neighbour).  warm: chunk 0 is
+    // already parked and chunk 1 in flight (the prologue below).
+    auto pass_impl = [&](auto masked_tag, auto maxonly_tag, const double maxv, const bool warm) __attribute__((always_inline)) {
+        constexpr bool MASKED = decltype(masked_tag)::value, MAXONLY = decltype(maxonly_tag)::value;
+        if constexpr (!MAXONLY) {
+#pragma unroll
+            for (int e = 0; e < NM; ++e) mu[e] = 0.0;
+#pragma unroll
+            for (int a = 0; a < NO; ++a) nu[a] = 0.0;
+        }
+        max_d2 = 0.0;
+        const double inv_max = MAXONLY ? 0.0 : inverse_max(maxv);
+        const double* xrow = xs + lane * XPITCH;
+        const double* frow = fs + lane * FPITCH;
+        if (!warm) fetch(0);
+        for (int q = 0; q < Q; ++q) {
+            if (!(warm && q == 0)) {
+                __syncthreads();                                      // the previous chunk has been read by every lane
+                park();
+                __syncthreads();
+                if (q + 1 < Q) fetch(q + 1);
+            }
+#pragma unroll
+            for (int g = 0; g < CH / GRP; ++g) {
+#pragma unroll
+                for (int kk = 0; kk < GRP; ++kk) {
+                    const int ks = g * GRP + kk;
+                    const bool live = MASKED ? (q * CH + ks < nkc) : true;
+                    double d[DIM];
+#pragma unroll
+                    for (int m = 0; m < DIM; ++m) { d[m] = xrow[ks * DIM + m] - xi[m]; if (MASKED) d[m] = live ? d[m] : 0.0; }
+                    const double d2 = sqdist(d);
+                    max_d2 = d2 > max_d2 ? d2 : max_d2;               // (a masked slot contributes 0)
+                    if constexpr (!MAXONLY) {
+                        double w = weight(d2, inv_max, uniform);
+                        double f = frow[ks];
+                        if (MASKED) { w = live ? w : 0.0; f = live ? f : 0.0; }
+                        accumulate_moments_best<DIM, ORDER>(mu, nu, d, w, f);
+                    }
+                }
+                if constexpr (SCHED_BARRIER) __builtin_amdgcn_sched_barrier(0);      // GRP neighbours in flight at a time
+            }
+        }
+    };
+    const bool full = (K % CH == 0) && __all(nkc >= K);               // wave-uniform: no ragged case in this group, whole chunks
+    auto moments = [&](const double maxv, const bool warm) __attribute__((always_inline)) {
+        if (full) pass_impl(std::false_type{}, std::false_type{}, maxv, warm); else pass_impl(std::true_type{}, std::false_type{}, maxv, warm);
+    };
+    // ---- prologue: chunk 0 parked, chunk 1 requested; is this group's input SORTED by distance?  The speculation below pays only
+    // then (a wrong guess costs a whole second pass: 1.9x): the squared distances of the first chunk must be non-decreasing in every
+    // lane — by chance for unsorted neighbours with probability 1 / 8! per case.  Unsorted input (a ball query) takes the plain two
+    // passes instead: the largest squared distance first (a few instructions per neighbour), then the moments.
+    fetch(0);
+    __syncthreads();
+    park();
+    __syncthreads();
+    if (Q > 1) fetch(1);
+    bool mono = true;
+    {
+        const double* xrow = xs + lane * XPITCH;
+        double prev = 0.0;
+#pragma unroll
+        for (int ks = 0; ks < CH; ++ks) {
+            double d[DIM];
+#pragma unroll
+            for (int m = 0; m < DIM; ++m) d[m] = xrow[ks * DIM + m] - xi[m];
+            const double d2 = sqdist(d);
+            if (ks < nkc) { mono = mono && d2 >= prev; prev = d2; }
+        }
+    }
+    if (__all(uniform || mono)) {
+        moments(guess, true);
+        // the guess must have been the largest squared distance, bit for bit (uniform weighting does not use it); otherwise the wave
+        // repeats the pass with the true maxima — lanes whose guess was right get the same bits again
+        if (!__all(uniform || max_d2 == guess)) moments(max_d2, false);
+    } else {
+        if (full) pass_impl(std::false_type{}, std::true_type{}, 0.0, true); else pass_impl(std::true_type{}, std::true_type{}, 0.0, true);
+        moments(max_d2, false);
+    }
+
+    // ---- one solve per lane: masked full system, unpivoted LDL^T
+    constexpr unsigned long long FULL = (1ull << NO) - 1ull;
+    double* const fio = p.fi + j * p.sfi_j;
+    double M[NE], rhs[NO];
+    expand_moments<DIM, ORDER>(mu, nu, M, rhs);
+    if (known) {
+        double val[NO];
+#pragma unroll
+        for (int a = 0; a < NO; ++a) val[a] = (((known & ~dropped) >> a) & 1ull) ? fio[a] : 0.0;
+        eliminate_knowns<NO>(M, rhs, known, val);
+#pragma unroll
+        for (int a = 0; a < NO; ++a) if (((known & ~dropped) >> a) & 1ull) rhs[a] = val[a];      // (for the whole-row store below: its own bits)
+    }
+    ldlt_factor<NO>(M);
+    {
+        double sol[NO];
+#pragma unroll
+        for (int a = 0; a < NO; ++a) sol[a] = ((known >> a) & 1ull) ? 0.0 : rhs[a];
+        ldlt_solve<NO>(M, sol);
+#pragma unroll
+        for (int a = 0; a < NO; ++a) if (!((known >> a) & 1ull)) rhs[a] = sol[a];
+    }
+    // ---- results.  A full group with contiguous fi rows and no dropped DOF: the wave's 64 rows are ONE run of 64 NO doubles; they go
+    // through LDS and leave as whole 16-byte pieces, known DOFs re-written with their own bits (what the reference's Case_get_fi
+    // does too, infra.pyx:780-795) — separate 8-byte stores at a row pitch are partial-sector writes.
+    const bool whole = nvalid == 64 && p.sfi_j == NO && ((reinterpret_cast<uintptr_t>(p.fi) & 15u) == 0) && (64 * NO) % 2 == 0 &&
+                       __all(dropped == 0ull && known != FULL);
+    if (whole) {
+        __syncthreads();                                              // the last chunk has been read
+#pragma unroll
+        for (int a = 0; a < NO; ++a) lds[lane * NO + a] = rhs[a];
+        __syncthreads();
+        d2_* out = reinterpret_cast<d2_*>(p.fi + t0 * NO);
+        const d2_* src = reinterpret_cast<const d2_*>(lds);
+#pragma unroll
+        for (int q = lane; q < 64 * NO / 2; q += 64) __builtin_nontemporal_store(src[q], &out[q]);
+    } else if (valid && known != FULL) {
+#pragma unroll
+        for (int a = 0; a < NO; ++a)
+            if (!((known >> a) & 1ull)) fio[a] = rhs[a];
+    }
+}
+
+template <int DIM, int ORDER>
+static int launch_stage(const KParams& p, hipStream_t stream) {
+    const long long groups = (p.ncases + 63) / 64;
+    if (groups <= 0) return WLSQM_OK;
+    if (groups > 0x7fffffffLL) { set_error("fit_stage: batch too large for one launch"); return WLSQM_EVALUE; }
+    hipLaunchKernelGGL((fit_stage_kernel<DIM, ORDER>), dim3((unsigned)groups), dim3(64), 0, stream, p);
+    WLSQM_HIP_CHECK(hipGetLastError());
+    note_kernel("stage");
+    return WLSQM_OK;
+}
+
+// Basic fits of dense contiguous batches with an even neighbour count, for the shapes listed below;
+// everything else keeps its kernels.  WLSQM_HIP_STAGE=0 disables it, =all sends every covered shape here (A/B).
+int launch_fit_stage(int dimension, int order, const KParams& p, long long K, hipStream_t stream, bool* handled) {
+    *handled = false;
+    const char* e = getenv("WLSQM_HIP_STAGE");
+    if (e && e[0] == '0') return WLSQM_OK;
+    const char* off = getenv("WLSQM_HIP_DISABLE_TILE");
+    if (off && off[0] == '1') return WLSQM_OK;
+    if (p.do_sens || p.iterative || p.hoods || p.case_index || !p.xk || !p.fk) return WLSQM_OK;
+    if (K < 8 || K % 2 != 0 || K > 0x3fffffff) return WLSQM_OK;
+    if (p.sxk_k != dimension || p.sxk_j != K * dimension || p.sfk_k != 1 || p.sfk_j != K) return WLSQM_OK;
+    if ((reinterpret_cast<uintptr_t>(p.xk) | reinterpret_cast<uintptr_t>(p.fk)) & 15u) return WLSQM_OK;
+    const bool all = e && e[0] == 'a';
+#define SCASE(D, O, COND) if (dimension == D && order == O && (all || (COND))) { *handled = true; return launch_stage<D, O>(p, stream); }
+    // (tools/sweep_stage.py, profiles/r04l_sweep_stage.txt: 400k cases, against the fixed-K tile / ring / moment kernels, neighbour
+    // counts 8 .. 128: 2D order 4 1.05-2.3x, 3D order 2 1.05-1.9x, 2D order 3 0.98-1.56x, 2D order 2 0.94-0.99x up to 24 neighbours
+    // and 0.95-1.41x from 32 on)
+    SCASE(2, 4, true)
+    SCASE(3, 2, true)
+    SCASE(2, 3, true)
+    SCASE(2, 2, K >= 32)
+#undef SCASE
+    return WLSQM_OK;
+}
+
+}  // namespace wlsqm

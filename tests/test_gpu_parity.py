@@ -277,7 +277,9 @@ def test_every_even_neighbourhood_size_has_a_fixed_shape(wlsqm, dim, order, K, m
     # (ragged nk stays clear of the nearly determined systems, whose rounding noise differs between any two summation orders
     # by more than the parity bar; those are the business of test_tile_path_equals_lane_path and tools/fuzz.py)
     # (3D order 2 with 40 slots, the BASELINE configs[4] shape, takes the ring kernel of csrc/fit_ring.hip)
-    _tile_vs_lane(wlsqm, dim, order, K, 16 * 9 + 5 + K, monkeypatch, expect="tile-solve" if (dim, order, K) == (3, 2, 40) else "tile", spare=6)
+    # (round 4: the one-lane-per-case staged kernel, csrc/fit_stage.hip, takes 2D order 3 and 3D order 2 at every even K >= 8 and
+    # 2D order 2 from 32 neighbours on; the fixed-K tile kernels keep the rest)
+    _tile_vs_lane(wlsqm, dim, order, K, 16 * 9 + 5 + K, monkeypatch, expect=_fast_kernel(dim, order, K, "tile"), spare=6)
 
 
 @pytest.mark.parametrize("K", list(range(22, 102, 2)))
@@ -286,7 +288,8 @@ def test_every_even_neighbourhood_size_2d_order4_takes_the_moment_kernels(wlsqm,
     multiple of 4 slots), so no host batch is padded by more than one slot and device batches of any even K avoid the generic
     kernel."""
     # 26 <= K <= 72: the one-kernel fit (csrc/fit_ring.hip); the other sizes: tile pass + moment_solve_kernel
-    _tile_vs_lane(wlsqm, 2, 4, K, 32 * 5 + 7 + K, monkeypatch, expect="tile-solve" if 26 <= K <= 72 else "moment", spare=8)
+    # (round 4: dense 2D order 4 at every even K is ONE launch of the staged kernel, csrc/fit_stage.hip — K = 66..100 included)
+    _tile_vs_lane(wlsqm, 2, 4, K, 32 * 5 + 7 + K, monkeypatch, expect="stage", spare=8)
 
 
 @pytest.mark.parametrize("dim,order", [(2, 1), (2, 2), (2, 3), (3, 1), (3, 2)])
@@ -294,7 +297,14 @@ def test_every_even_neighbourhood_size_2d_order4_takes_the_moment_kernels(wlsqm,
 def test_large_neighbourhoods_have_fixed_shapes_too(wlsqm, dim, order, K, monkeypatch):
     """64 < K <= 128 (e.g. the 124 neighbours of a 5 x 5 x 5 block): two waves x four lanes per case on a 16-case tile, shares
     padded to a multiple of 16 slots, instead of the generic lane-per-case kernel these sizes used to take."""
-    _tile_vs_lane(wlsqm, dim, order, K, 16 * 5 + 3 + K % 7, monkeypatch, expect="tile", spare=6)
+    _tile_vs_lane(wlsqm, dim, order, K, 16 * 5 + 3 + K % 7, monkeypatch, expect=_fast_kernel(dim, order, K, "tile"), spare=6)
+
+
+def _fast_kernel(dim, order, K, otherwise):
+    """Which kernel family the dispatcher picks for a dense contiguous basic fit (csrc/api.hip launch_fit, csrc/fit_stage.hip)."""
+    if K >= 8 and K % 2 == 0 and ((dim, order) in ((2, 3), (2, 4), (3, 2)) or ((dim, order) == (2, 2) and K >= 32)):
+        return "stage"
+    return otherwise
 
 
 def _tile_vs_lane(wlsqm, dim, order, K, ncases, monkeypatch, expect=None, spare=2):
@@ -1314,7 +1324,7 @@ def test_index_based_input_has_a_fixed_shape_for_every_even_K(wlsqm, dim, order,
     whip.fit_cloud_device(dim, order, S_d, F_d, h_d, fi_b, nk_d, kn_d, wm_d, point_index=p_d)
     assert whip.last_kernel() == "tile-gather"
     whip.fit_many_device(dim, order, xk_d, fk_d, nk_d, xi_d, fi_a, kn_d, wm_d)
-    assert whip.last_kernel() in ("tile", "tile-solve")
+    assert whip.last_kernel() in ("tile", "tile-solve", "stage")
     torch.cuda.synchronize()
     truth = P.truth_fit(dim, xk_d.cpu().numpy(), fk_d.cpu().numpy(), nk, xi_d.cpu().numpy(), fi0, np.full(n, order, np.int32), kn, wm)
     from oracle import oracle as O

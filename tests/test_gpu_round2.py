@@ -39,7 +39,7 @@ def _t(a, dev="cuda:0"):
 # ----------------------------------------------------------------------------------------------------------------------
 # parity at the headline density, against the REFERENCE (simple.pyx:379-421 output captured in tests/golden/config_*_1M.npz)
 
-FAST_KERNELS = {"C2_1M": ("tile",), "C3_1M": ("tile-solve",), "C5_1M": ("tile-solve",), "C5_16M": ("tile-solve",)}
+FAST_KERNELS = {"C2_1M": ("tile", "stage"), "C3_1M": ("tile-solve", "stage"), "C5_1M": ("tile-solve", "stage"), "C5_16M": ("tile-solve", "stage")}
 
 
 @pytest.mark.parametrize("name", K.DENSE)
@@ -346,7 +346,7 @@ def test_hip_kernels_under_world_size_2(wlsqm, tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     res = json.load(open(str(out) + ".json"))
     assert res["dense_bit_identical"] and res["cloud_bit_identical"] and res["halo_bit_identical"], res
-    assert res["kernel_dense"] == "tile" and res["world"] == 2
+    assert res["kernel_dense"] in ("tile", "stage") and res["world"] == 2
     assert res["halo_kernel"] == "tile-gather" and 0 < res["halo_shape_rank0"][0] < 30011 // 2, res
 
 
@@ -367,9 +367,12 @@ def _assert_vs_oracle_floor(cand, fo, truth, n):
 @pytest.mark.parametrize("n,ragged,kn", [(300, False, 0), (277, True, 0b1000010001), (37, True, 1), (64, False, 0), (1, False, 0), (17, True, 0)])
 def test_ring_fit_3d_order2(wlsqm, oracle, n, ragged, kn, monkeypatch):
     """The same kernel template on the 3D order-2 / 40-slot shape of BASELINE configs[4] (45 moments padded to four quarters of 12):
-    against the oracle and against the one-wave tile kernel it replaces (WLSQM_TILE_VARIANT=1)."""
+    against the oracle and against the one-wave tile kernel it replaces (WLSQM_TILE_VARIANT=1).  (Round 4: dense input of this
+    shape takes the staged kernel by default, csrc/fit_stage.hip; WLSQM_HIP_STAGE=0 keeps the ring kernels under test — the
+    index-based ring shares their code.)"""
     import torch
     import synth
+    monkeypatch.setenv("WLSQM_HIP_STAGE", "0")
     import wlsqm.hip as whip
     Kn = 40
     rng = np.random.default_rng(n)
@@ -403,13 +406,15 @@ def test_ring_fit_3d_order2(wlsqm, oracle, n, ragged, kn, monkeypatch):
 
 @pytest.mark.parametrize("Kn", [26, 40, 50, 64])
 @pytest.mark.parametrize("n,ragged,kn", [(300, False, 1), (277, True, 0), (37, True, 0b101), (64, False, 0), (1, False, 1), (17, True, 1)])
-def test_ring_fit_vs_oracle_and_two_kernel_path(wlsqm, oracle, Kn, n, ragged, kn):
+def test_ring_fit_vs_oracle_and_two_kernel_path(wlsqm, oracle, Kn, n, ragged, kn, monkeypatch):
     """Every shape of run the ring kernel has: full groups of four tiles, a partial last tile, a partial solve group, one
     case; ragged nk (masked slots, padded shares when K is not a multiple of 8), both weightings, knowns masks.  Compared
-    with the oracle under the usual bound, with the two-kernel moment path it replaces, and knowns must stay bit-identical."""
+    with the oracle under the usual bound, with the two-kernel moment path it replaces, and knowns must stay bit-identical.
+    (WLSQM_HIP_STAGE=0: see test_ring_fit_3d_order2.)"""
     import torch
     import synth
     import wlsqm.hip as whip
+    monkeypatch.setenv("WLSQM_HIP_STAGE", "0")
     rng = np.random.default_rng(100 * Kn + n)
     S = synth.halton(6000, 2, skip=1); F = synth.field(S)
     hoods = synth.knn(S, Kn, workers=4)[:n]
@@ -544,9 +549,10 @@ def test_any_neighbourhood_size_runs_a_tiled_kernel(wlsqm, oracle, dim, order, K
     fi_d = _t(fi0)
     whip.fit_many_device(dim, order, _t(xk_a), _t(fk), _t(nk), _t(xi_a), fi_d, _t(kn), _t(wm))
     torch.cuda.synchronize()
-    assert whip.last_kernel() in ("chunk", "tile", "tilek", "moment"), whip.last_kernel()
+    assert whip.last_kernel() in ("chunk", "tile", "tilek", "moment", "stage"), whip.last_kernel()
     if Kn > 128:
-        assert whip.last_kernel() == "chunk"
+        # (odd K is repacked to an even row first; round 4: the staged kernel takes these shapes at any even K)
+        assert whip.last_kernel() == ("stage" if (dim, order) in ((2, 2), (2, 3), (2, 4), (3, 2)) else "chunk")
     fo = fi0.copy()
     oracle.fit_many(dim, xk_a, fk, nk, xi_a, fo, None, 0, orders, kn, wm)
     truth = P.truth_fit(dim, xk_a, fk, nk, xi_a, fi0, orders, kn, wm)
@@ -738,13 +744,17 @@ def test_sensitivities_path_in_slices(wlsqm, dim, order, Kn, n, monkeypatch):
 # ----------------------------------------------------------------------------------------------------------------------
 # the round-2 paths inside a HIP graph
 
-def test_round2_paths_capture_into_a_hip_graph(wlsqm):
+@pytest.mark.parametrize("staged", [False, True])
+def test_round2_paths_capture_into_a_hip_graph(wlsqm, staged, monkeypatch):
     """The one-kernel 2D order-4 fit (LDS-DMA ring), the stacked solve on the stored operator (built by an earlier call), the
     device-side repack of strided rows and the chunked any-K kernel only enqueue work (the repack's scratch comes from the
-    stream-ordered pool): captured once, nothing runs during the capture, replays are bit-identical to eager calls."""
+    stream-ordered pool): captured once, nothing runs during the capture, replays are bit-identical to eager calls.  staged: the
+    same three calls with round 4's staged kernel in the dispatch (its default)."""
     import torch
     import synth
     import wlsqm.hip as whip
+    if not staged:
+        monkeypatch.setenv("WLSQM_HIP_STAGE", "0")
     dev = torch.device("cuda", 0)
     n = 3000
     S = synth.halton(n, 2); S_d = torch.from_numpy(S).to(dev)
@@ -762,7 +772,7 @@ def test_round2_paths_capture_into_a_hip_graph(wlsqm):
                 torch.ones(n, dtype=torch.int64, device=dev), torch.full((n,), 2, dtype=torch.int32, device=dev))
         whip.fit_many_device(*args)                                  # warm-up outside the capture
         cases.append((name, args, whip.last_kernel()))
-    assert [c[2] for c in cases] == ["tile-solve", "tile", "chunk"], [c[2] for c in cases]
+    assert [c[2] for c in cases] == (["stage", "stage", "stage"] if staged else ["tile-solve", "tile", "chunk"]), [c[2] for c in cases]
     K2 = 32
     h2 = whip.knn(S_d, K2).long()
     solver = wlsqm.ExpertSolver(dimension=2, nk=np.full(n, K2, np.int32), order=np.full(n, 2, np.int32),

@@ -1,5 +1,7 @@
 """GPU tests added in round 3 (beside test_gpu_strict.py and test_gpu_rccl.py): the repack / gather scratch in bounded slices
 (ADVICE r2), the logical neighbour count behind a repack, per-case order tensors on the device-resident API."""
+import os
+
 import numpy as np
 import pytest
 
@@ -330,8 +332,12 @@ def test_index_based_2d_order4_runs_the_one_kernel_ring(wlsqm, oracle, Kn, pad):
     hc = np.where(np.arange(Kn)[None, :] < nk[:, None], hoods, 0).astype(np.int64)
     xk, fk, xi = S[hc], F[hc], S[pidx]
     fd = _t(fi0)
-    whip.fit_many_device(2, 4, _t(xk), _t(fk), _t(nk), _t(xi), fd, _t(kn), _t(w))
-    torch.cuda.synchronize()
+    os.environ["WLSQM_HIP_STAGE"] = "0"                      # the dense RING (round 4: dense input takes the staged kernel by default)
+    try:
+        whip.fit_many_device(2, 4, _t(xk), _t(fk), _t(nk), _t(xi), fd, _t(kn), _t(w))
+        torch.cuda.synchronize()
+    finally:
+        os.environ.pop("WLSQM_HIP_STAGE", None)
     assert whip.last_kernel() == "tile-solve", whip.last_kernel()
     assert np.array_equal(got.view(np.int64), fd.cpu().numpy().view(np.int64)), "gathered ring != dense ring on the same rows"
     o = np.full(n, 4, np.int32)
