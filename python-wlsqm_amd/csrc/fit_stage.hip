@@ -87,9 +87,15 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER)
         for (int m = 1; m < DIM; ++m) d2 = fma(d[m], d[m], d2);
         return d2;
     };
-    // the guess: the last neighbour is the farthest (see the header)
+    // the guess: the last neighbour is the farthest (see the header).  The chunks are processed LAST CHUNK FIRST (neighbours in
+    // descending k: a fixed order per case, so results do not depend on the route), so that the guess comes out of the first staged
+    // chunk: a separate load of the last neighbour at the start fetched a whole line per case that the staging fetched AGAIN four
+    // to eight chunks later (954 instead of 800 MB read per 1M configs[1] cases, 1 530 instead of 1 321 MB on configs[4]:
+    // profiles/r04m_*_pmc_summary.json).  Only a ragged case whose last neighbour lies in an earlier chunk loads it directly.
+    const int Q = (K + CH - 1) / CH;                                  // (a last partial chunk: its pieces beyond the row replay the row's last one; masked)
     double guess = 0.0;
-    if (nkc > 0) {
+    const bool guess_staged = nkc > (Q - 1) * CH;                     // the last neighbour sits in the chunk that is staged first
+    if (nkc > 0 && !guess_staged) {
         const double* q = p.xk + j * (long long)K * DIM + (long long)(nkc - 1) * DIM;
         double dg[DIM];
 #pragma unroll
@@ -98,7 +104,6 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER)
     }
 
     // ---- staging: a load instruction moves the chunks of XCPI (FCPI) whole cases, XPC (FPC) consecutive lanes per case
-    const int Q = (K + CH - 1) / CH;                                  // (a last partial chunk: its pieces beyond the row replay the row's last one; masked)
     const int xsub = lane % XPC, xc0 = lane / XPC, fsub = lane % FPC, fc0 = lane / FPC;
     const unsigned xrowb = (unsigned)K * DIM * 8, frowb = (unsigned)K * 8;
     const bool xlane = lane < XCPI * XPC;
@@ -139,7 +144,7 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER)
     // largest squared distance of the lane's case.  MASKED (some case of the group is ragged, or K is not a multiple of CH) is decided
     // ONCE per pass: with the choice inside the chunk loop the two variants' 60 accumulators met in different registers and every
     // iteration paid ~50 copies per 4 neighbours at the join (first version: 179 instructions per neighbour).  warm: chunk 0 is
-    // already parked and chunk 1 in flight (the prologue below).
+    // Q - 1 is already parked and chunk Q - 2 in flight (the prologue below).
     auto pass_impl = [&](auto masked_tag, auto maxonly_tag, const double maxv, const bool warm) __attribute__((always_inline)) {
         constexpr bool MASKED = decltype(masked_tag)::value, MAXONLY = decltype(maxonly_tag)::value;
         if constexpr (!MAXONLY) {
@@ -152,18 +157,18 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER)
         const double inv_max = MAXONLY ? 0.0 : inverse_max(maxv);
         const double* xrow = xs + lane * XPITCH;
         const double* frow = fs + lane * FPITCH;
-        if (!warm) fetch(0);
-        for (int q = 0; q < Q; ++q) {
-            if (!(warm && q == 0)) {
+        if (!warm) fetch(Q - 1);
+        for (int q = Q - 1; q >= 0; --q) {
+            if (!(warm && q == Q - 1)) {
                 __syncthreads();                                      // the previous chunk has been read by every lane
                 park();
                 __syncthreads();
-                if (q + 1 < Q) fetch(q + 1);
+                if (q > 0) fetch(q - 1);
             }
 #pragma unroll
-            for (int g = 0; g < CH / GRP; ++g) {
+            for (int g = CH / GRP - 1; g >= 0; --g) {
 #pragma unroll
-                for (int kk = 0; kk < GRP; ++kk) {
+                for (int kk = GRP - 1; kk >= 0; --kk) {
                     const int ks = g * GRP + kk;
                     const bool live = MASKED ? (q * CH + ks < nkc) : true;
                     double d[DIM];
@@ -186,15 +191,15 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER)
     auto moments = [&](const double maxv, const bool warm) __attribute__((always_inline)) {
         if (full) pass_impl(std::false_type{}, std::false_type{}, maxv, warm); else pass_impl(std::true_type{}, std::false_type{}, maxv, warm);
     };
-    // ---- prologue: chunk 0 parked, chunk 1 requested; is this group's input SORTED by distance?  The speculation below pays only
-    // then (a wrong guess costs a whole second pass: 1.9x): the squared distances of the first chunk must be non-decreasing in every
+    // ---- prologue: the LAST chunk parked, the one before it requested; is this group's input SORTED by distance?  The speculation below pays only
+    // then (a wrong guess costs a whole second pass: 1.9x): the squared distances of that chunk must be non-decreasing in every
     // lane — by chance for unsorted neighbours with probability 1 / 8! per case.  Unsorted input (a ball query) takes the plain two
     // passes instead: the largest squared distance first (a few instructions per neighbour), then the moments.
-    fetch(0);
+    fetch(Q - 1);
     __syncthreads();
     park();
     __syncthreads();
-    if (Q > 1) fetch(1);
+    if (Q > 1) fetch(Q - 2);
     bool mono = true;
     {
         const double* xrow = xs + lane * XPITCH;
@@ -205,8 +210,9 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER)
 #pragma unroll
             for (int m = 0; m < DIM; ++m) d[m] = xrow[ks * DIM + m] - xi[m];
             const double d2 = sqdist(d);
-            if (ks < nkc) { mono = mono && d2 >= prev; prev = d2; }
+            if ((Q - 1) * CH + ks < nkc) { mono = mono && d2 >= prev; prev = d2; }
         }
+        if (guess_staged) guess = prev;                               // the squared distance of neighbour nkc - 1
     }
     if (__all(uniform || mono)) {
         moments(guess, true);
