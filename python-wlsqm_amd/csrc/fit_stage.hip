@@ -109,8 +109,14 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER)
     const bool xlane = lane < XCPI * XPC;
     const char* const xtile = reinterpret_cast<const char*>(p.xk + t0 * (long long)K * DIM);
     const char* const ftile = reinterpret_cast<const char*>(p.fk + t0 * (long long)K);
-    d2_ xr[XNI], fr[FNI];
-    auto fetch = [&](int q) {
+    // DEEP: TWO chunks in flight (two register sets, chunk c in set (Q - 1 - c) & 1): the systems that own their SIMD have the
+    // registers, and a lone wave has nobody to cover the gap between the landing of a chunk and the request for the next
+#ifndef WLSQM_STAGE_DEEP
+#define WLSQM_STAGE_DEEP 0      // (measured: the second register set spills — 512 registers + 108 B — and configs[2] runs 0.475 instead of 0.432 ms)
+#endif
+    constexpr bool DEEP = (WLSQM_STAGE_DEEP != 0) && NO > 10;
+    d2_ xr[XNI], fr[FNI], xr2[DEEP ? XNI : 1], fr2[DEEP ? FNI : 1];
+    auto fetch_into = [&](d2_ (&xr)[XNI], d2_ (&fr)[FNI], int q) __attribute__((always_inline)) {
         unsigned xo = (unsigned)q * (CH * DIM * 8) + (unsigned)xsub * 16u, fo = (unsigned)q * (CH * 8) + (unsigned)fsub * 16u;
         xo = xo < xrowb ? xo : xrowb - 16u; fo = fo < frowb ? fo : frowb - 16u;      // (rows are multiples of 16 bytes: K even)
         const char* xb = xtile + xo;
@@ -128,7 +134,8 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER)
             fr[i] = *reinterpret_cast<const d2_*>(fb + (size_t)(unsigned)cc * frowb);
         }
     };
-    auto park = [&]() {
+    auto fetch = [&](int q) __attribute__((always_inline)) { fetch_into(xr, fr, q); };
+    auto park_from = [&](const d2_ (&xr)[XNI], const d2_ (&fr)[FNI]) __attribute__((always_inline)) {
         double* xl = xs + xc0 * XPITCH + xsub * 2;
         double* fl = fs + fc0 * FPITCH + fsub * 2;
 #pragma unroll
@@ -137,6 +144,7 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER)
 #pragma unroll
         for (int i = 0; i < FNI; ++i) *reinterpret_cast<d2_*>(fl + i * FCPI * FPITCH) = fr[i];
     };
+    auto park = [&]() __attribute__((always_inline)) { park_from(xr, fr); };
 
     double mu[NM], nu[NO];
     double max_d2 = 0.0;
@@ -157,14 +165,7 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER)
         const double inv_max = MAXONLY ? 0.0 : inverse_max(maxv);
         const double* xrow = xs + lane * XPITCH;
         const double* frow = fs + lane * FPITCH;
-        if (!warm) fetch(Q - 1);
-        for (int q = Q - 1; q >= 0; --q) {
-            if (!(warm && q == Q - 1)) {
-                __syncthreads();                                      // the previous chunk has been read by every lane
-                park();
-                __syncthreads();
-                if (q > 0) fetch(q - 1);
-            }
+        auto chunk = [&](const int q) __attribute__((always_inline)) {
 #pragma unroll
             for (int g = CH / GRP - 1; g >= 0; --g) {
 #pragma unroll
@@ -185,6 +186,37 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER)
                 }
                 if constexpr (SCHED_BARRIER) __builtin_amdgcn_sched_barrier(0);      // GRP neighbours in flight at a time
             }
+        };
+        if constexpr (DEEP) {
+            // (warm: chunk Q - 1 parked, chunks Q - 2 (second set) and Q - 3 (first set) in flight)
+            if (!warm) { fetch_into(xr, fr, Q - 1); if (Q > 1) fetch_into(xr2, fr2, Q - 2); }
+            for (int c = Q - 1; c >= 0; c -= 2) {
+                if (!(warm && c == Q - 1)) {
+                    __syncthreads();
+                    park_from(xr, fr);
+                    __syncthreads();
+                    if (c >= 2) fetch_into(xr, fr, c - 2);
+                }
+                chunk(c);
+                if (c >= 1) {
+                    __syncthreads();
+                    park_from(xr2, fr2);
+                    __syncthreads();
+                    if (c >= 3) fetch_into(xr2, fr2, c - 3);
+                    chunk(c - 1);
+                }
+            }
+        } else {
+            if (!warm) fetch(Q - 1);
+            for (int q = Q - 1; q >= 0; --q) {
+                if (!(warm && q == Q - 1)) {
+                    __syncthreads();                                  // the previous chunk has been read by every lane
+                    park();
+                    __syncthreads();
+                    if (q > 0) fetch(q - 1);
+                }
+                chunk(q);
+            }
         }
     };
     const bool full = (K % CH == 0) && __all(nkc >= K);               // wave-uniform: no ragged case in this group, whole chunks
@@ -199,7 +231,8 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER)
     __syncthreads();
     park();
     __syncthreads();
-    if (Q > 1) fetch(Q - 2);
+    if constexpr (DEEP) { if (Q > 1) fetch_into(xr2, fr2, Q - 2); if (Q > 2) fetch_into(xr, fr, Q - 3); }
+    else { if (Q > 1) fetch(Q - 2); }
     bool mono = true;
     {
         const double* xrow = xs + lane * XPITCH;
