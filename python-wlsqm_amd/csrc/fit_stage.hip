@@ -22,7 +22,8 @@
 // so it runs with the last neighbour's squared distance as the maximum while it tracks the true one, and the guess is verified bit for
 // bit; a wave with a wrong guess (unsorted neighbours) repeats the pass with the true maxima — same bits either way.
 //
-// One sum per moment over k ascending in ONE lane: of the fast kernels this one is the closest to the reference's summation order
+// One sum per moment over k (descending: the chunks are staged last-first, see the kernel) in ONE lane: of the fast kernels this one is
+// the closest to the reference's summation
 // (profiles/r03_attribution.txt: the lane-split sums are the largest single contribution to the fast kernels' distance from it).
 #include <atomic>
 #include <type_traits>
@@ -260,18 +261,59 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER)
     // ---- one solve per lane: masked full system, unpivoted LDL^T
     constexpr unsigned long long FULL = (1ull << NO) - 1ull;
     double* const fio = p.fi + j * p.sfi_j;
-    double M[NE], rhs[NO];
-    expand_moments<DIM, ORDER>(mu, nu, M, rhs);
-    if (known) {
-        double val[NO];
+    double rhs[NO];
+    // A case with exactly the function value known (knowns = b?_F: the reference's default mask and BASELINE configs[2]) solves the
+    // (NO - 1) x (NO - 1) system directly: 105 + 14 instead of 120 + 15 entries to expand, factor and substitute for 15 DOFs.  Chosen
+    // by the case's own mask (a mixed wave runs both forms), so a case's bits do not depend on its wave-mates.
+    // (only for the 15-unknown systems: the smaller ones gain nothing and their register allocation suffered — 2D order 3 went from
+    // 330 registers to 512 + 704 B of scratch with the second form compiled in)
+    constexpr bool REDUCED = NO >= 15;
+    const bool mine1 = REDUCED && known == 1ull && dropped == 0ull;
+    if constexpr (REDUCED) {
+        if (mine1) {
+            constexpr int N1 = NO - 1, NE1 = N1 * (N1 + 1) / 2;
+            const double v0 = fio[0];
+            double M1[NE1], r1[N1];
 #pragma unroll
-        for (int a = 0; a < NO; ++a) val[a] = (((known & ~dropped) >> a) & 1ull) ? fio[a] : 0.0;
-        eliminate_knowns<NO>(M, rhs, known, val);
+            for (int a = 1; a < NO; ++a) {
+                const int pa = Mono<DIM>::P[a], qa = Mono<DIM>::Q[a], ra = Mono<DIM>::R[a];
+                r1[a - 1] = nu[mom_index<DIM>(pa, qa, ra)] * (mom_inv_fact(pa) * mom_inv_fact(qa) * mom_inv_fact(ra));
+            }
 #pragma unroll
-        for (int a = 0; a < NO; ++a) if (((known & ~dropped) >> a) & 1ull) rhs[a] = val[a];      // (for the whole-row store below: its own bits)
+            for (int i = 0; i < NM; ++i) {
+                const double m = mu[i];
+#pragma unroll
+                for (int a = 1; a < NO; ++a) {
+                    const int pa = Mono<DIM>::P[a], qa = Mono<DIM>::Q[a], ra = Mono<DIM>::R[a];
+                    const double fa = mom_inv_fact(pa) * mom_inv_fact(qa) * mom_inv_fact(ra);
+                    if (mom_index<DIM>(pa, qa, ra) == i) r1[a - 1] = fma(-(m * (1.0 * fa)), v0, r1[a - 1]);      // M[0, a] * fi[0] (impl.pyx:815-818)
+#pragma unroll
+                    for (int b = a; b < NO; ++b) {
+                        const int pb = Mono<DIM>::P[b], qb = Mono<DIM>::Q[b], rb = Mono<DIM>::R[b];
+                        const double fb = mom_inv_fact(pb) * mom_inv_fact(qb) * mom_inv_fact(rb);
+                        if (mom_index<DIM>(pa + pb, qa + qb, ra + rb) == i) M1[tri<N1>(a - 1, b - 1)] = m * (fa * fb);
+                    }
+                }
+            }
+            ldlt_factor<N1>(M1);
+            ldlt_solve<N1>(M1, r1);
+            rhs[0] = v0;                                              // (for the whole-row store below: its own bits)
+#pragma unroll
+            for (int a = 1; a < NO; ++a) rhs[a] = r1[a - 1];
+        }
     }
-    ldlt_factor<NO>(M);
-    {
+    if (!mine1) {
+        double M[NE];
+        expand_moments<DIM, ORDER>(mu, nu, M, rhs);
+        if (known) {
+            double val[NO];
+#pragma unroll
+            for (int a = 0; a < NO; ++a) val[a] = (((known & ~dropped) >> a) & 1ull) ? fio[a] : 0.0;
+            eliminate_knowns<NO>(M, rhs, known, val);
+#pragma unroll
+            for (int a = 0; a < NO; ++a) if (((known & ~dropped) >> a) & 1ull) rhs[a] = val[a];      // (for the whole-row store below: its own bits)
+        }
+        ldlt_factor<NO>(M);
         double sol[NO];
 #pragma unroll
         for (int a = 0; a < NO; ++a) sol[a] = ((known >> a) & 1ull) ? 0.0 : rhs[a];
@@ -320,7 +362,7 @@ int launch_fit_stage(int dimension, int order, const KParams& p, long long K, hi
     const char* off = getenv("WLSQM_HIP_DISABLE_TILE");
     if (off && off[0] == '1') return WLSQM_OK;
     if (p.do_sens || p.iterative || p.hoods || p.case_index || !p.xk || !p.fk) return WLSQM_OK;
-    if (K < 8 || K % 2 != 0 || K > 0x3fffffff) return WLSQM_OK;
+    if (K < 8 || K % 2 != 0 || K > 65536) return WLSQM_OK;          // (row bytes and the tile's offsets are 32-bit)
     if (p.sxk_k != dimension || p.sxk_j != K * dimension || p.sfk_k != 1 || p.sfk_j != K) return WLSQM_OK;
     if ((reinterpret_cast<uintptr_t>(p.xk) | reinterpret_cast<uintptr_t>(p.fk)) & 15u) return WLSQM_OK;
     const bool all = e && e[0] == 'a';
