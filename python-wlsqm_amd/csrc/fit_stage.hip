@@ -115,7 +115,7 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER)
 #ifndef WLSQM_STAGE_DEEP
 #define WLSQM_STAGE_DEEP 0      // (measured: the second register set spills — 512 registers + 108 B — and configs[2] runs 0.475 instead of 0.432 ms)
 #endif
-    constexpr bool DEEP = (WLSQM_STAGE_DEEP != 0) && NO > 10;
+    constexpr bool DEEP = (WLSQM_STAGE_DEEP != 0) && (WLSQM_STAGE_DEEP == 2 ? (NO > 6 && NO <= 10) : NO > 10);
     d2_ xr[XNI], fr[FNI], xr2[DEEP ? XNI : 1], fr2[DEEP ? FNI : 1];
     auto fetch_into = [&](d2_ (&xr)[XNI], d2_ (&fr)[FNI], int q) __attribute__((always_inline)) {
         unsigned xo = (unsigned)q * (CH * DIM * 8) + (unsigned)xsub * 16u, fo = (unsigned)q * (CH * 8) + (unsigned)fsub * 16u;

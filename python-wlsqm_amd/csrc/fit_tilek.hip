@@ -598,7 +598,7 @@ static int launch_tile1(const KParams& p, long long K, hipStream_t stream, bool*
         // those that still are — each round a launch over the previous round's survivor list, sized on the device (no host
         // synchronisation); bit-identical to the single launch (a case's arithmetic involves its own lanes only; tools/time_rounds.py).
         // OFF by default (WLSQM_HIP_REFINE_ROUNDS=1 turns it on): measured SLOWER, 1.75 against 0.88 ms per 1M configs[1] cases and
-        // 3.33 against 2.34 ms on configs[4].  The oracle's stop test fires after 3.1 / 3.4 sweeps on average there (1 024 cases at 1M
+        // 3.33 against 2.34 ms on configs[4].  The reference-order arithmetic's stop test fires after 3.1 / 3.4 sweeps on average there (1 024 cases at 1M
         // density: 33 / 507 / 233 / 110 / 45 / 27 / 16 / 7 / 4 / 42 cases for 1 .. 10), which is what made the rounds look worthwhile
         // — but the test is exact equality of two consecutive residual max-norms, and in THIS kernel's arithmetic (moment form, FMA
         // contraction, LDL^T) the iterates keep moving in their last bits for longer: 67-76 % of the cases are still running after
