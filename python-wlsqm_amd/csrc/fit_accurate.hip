@@ -422,7 +422,8 @@ __device__ __forceinline__ void accurate_group(const KParams& p, const long long
         }
     };
     // (the staged passes run back to back: pass P's first chunk is requested under pass P - 1's last)
-    auto run_pass = [&](auto masked_tag, bool want_f, bool prefetched, bool more_passes, bool next_want_f, auto&& consume) {
+    // give_up(): wave-uniform, asked after every chunk — the speculative pass leaves as soon as its guess is refuted
+    auto run_pass = [&](auto masked_tag, bool want_f, bool prefetched, bool more_passes, bool next_want_f, auto&& consume, auto&& give_up) {
         if constexpr (DENSE) {
             if (!prefetched) fetch(0, want_f);
             for (int q = 0; q < Q; ++q) {
@@ -432,6 +433,7 @@ __device__ __forceinline__ void accurate_group(const KParams& p, const long long
                 if (q + 1 < Q) fetch(q + 1, want_f);
                 else if (more_passes) fetch(0, next_want_f);
                 chunk(masked_tag, q, want_f, consume);
+                if (give_up()) break;
             }
         } else {
             for (int k = 0; k < nk; ++k) {
@@ -468,9 +470,12 @@ __device__ __forceinline__ void accurate_group(const KParams& p, const long long
         }
     };
     const bool wave_full = __all(!active || nk == K);
+    auto pass_until = [&](bool want_f, bool prefetched, bool more_passes, bool next_want_f, auto&& consume, auto&& give_up) {
+        if (wave_full) run_pass(std::false_type{}, want_f, prefetched, more_passes, next_want_f, consume, give_up);
+        else run_pass(std::true_type{}, want_f, prefetched, more_passes, next_want_f, consume, give_up);
+    };
     auto pass = [&](bool want_f, bool prefetched, bool more_passes, bool next_want_f, auto&& consume) {
-        if (wave_full) run_pass(std::false_type{}, want_f, prefetched, more_passes, next_want_f, consume);
-        else run_pass(std::true_type{}, want_f, prefetched, more_passes, next_want_f, consume);
+        pass_until(want_f, prefetched, more_passes, next_want_f, consume, [] { return false; });
     };
     auto pass_windowed = [&](bool next_want_f, auto&& consume) {
         if (wave_full) run_pass_windowed(std::false_type{}, next_want_f, consume);
@@ -512,7 +517,12 @@ __device__ __forceinline__ void accurate_group(const KParams& p, const long long
 #pragma unroll
             for (int oj = 0; oj < N; ++oj) b[oj] += wf * c[oj];
         };
-        pass(true, true, false, false, one);
+        // (unsorted neighbours — a ball query — refute the guess within the first chunk: the group leaves for the two-pass kernel
+        // there instead of finishing a pass whose sums are thrown away)
+#ifndef WLSQM_ACC_EARLY_OUT
+#define WLSQM_ACC_EARLY_OUT 1
+#endif
+        pass_until(true, true, false, false, one, [&] { return WLSQM_ACC_EARLY_OUT && __any(!uniform && max_d2 > guess); });
         // vouch for the case: the guess WAS the largest squared distance (bit for bit), every squared distance in the safe range
         // of the fast quotient and root (fmax / fmin drop a NaN distance: the sum test catches it), every matrix entry and every
         // running scale factor of the equilibration too
@@ -590,7 +600,7 @@ __global__ __launch_bounds__(64, acc::minw(ndofs(DIM, ORDER))) void fit_accurate
     }
 }
 
-// the redo groups of a speculative launch: a small grid walks the list (empty in the common case: the kernel is a few idle waves)
+// the redo groups of a speculative launch: a grid of the resident waves walks the list (empty in the common case: idle waves)
 template <int DIM, int ORDER>
 __global__ __launch_bounds__(64, acc::minw(ndofs(DIM, ORDER))) void fit_accurate_redo_kernel(const KParams p, const AccLists lists) {
     constexpr int XPITCH = acc::CH * DIM + 2, FPITCH = acc::CH + 2;
@@ -642,7 +652,10 @@ static int launch_accurate(const KParams& p, hipStream_t stream, int** lists_out
         rc = grid_for(reinterpret_cast<const void*>(&fit_accurate_kernel<DIM, ORDER, true, true>), &grid);
         if (rc != WLSQM_OK) return rc;
         hipLaunchKernelGGL((fit_accurate_kernel<DIM, ORDER, true, true>), dim3(grid), dim3(64), 0, stream, p, lists, groups);
-        const unsigned redo_grid = (unsigned)(groups < 256 ? groups : 256);
+        // the redo grid fills the chip when every group comes back (unsorted neighbours: with 256 workgroups 1M configs[1] cases took
+        // 1.72 ms, profiles/r04s_ab_early_out.txt) and is a few microseconds of idle waves when none does
+        const long long resident = 1024LL * acc::minw(ndofs(DIM, ORDER));
+        const unsigned redo_grid = (unsigned)(groups < resident ? groups : resident);
         hipLaunchKernelGGL((fit_accurate_redo_kernel<DIM, ORDER>), dim3(redo_grid), dim3(64), 0, stream, p, lists);
     } else if (dense) {
         const int rc = grid_for(reinterpret_cast<const void*>(&fit_accurate_kernel<DIM, ORDER, true, false>), &grid);

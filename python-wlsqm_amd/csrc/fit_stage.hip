@@ -46,6 +46,12 @@ typedef double d2_ __attribute__((ext_vector_type(2)));
 constexpr int CH = 8;               // neighbours per staged chunk
 }
 
+#ifndef WLSQM_STAGE_GRP20
+#define WLSQM_STAGE_GRP20 1         // ... of the 20-unknown systems (104 accumulators: 208 of the 256 registers an instruction can name)
+#endif
+#ifndef WLSQM_STAGE_LDS_ROWS
+#define WLSQM_STAGE_LDS_ROWS 4      // rows of a 20 x 20 normal matrix kept in LDS during the solve (74 of its 210 entries: 37 KB per wave)
+#endif
 #ifndef WLSQM_STAGE_MINW10
 #define WLSQM_STAGE_MINW10 1        // waves per SIMD the systems up to 10 unknowns are compiled for
 #endif
@@ -60,11 +66,14 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER)
     constexpr int FCPI = 64 / FPC, FNI = 64 / FCPI;
     // neighbours the scheduler may interleave: the 6-unknown systems run two waves per SIMD and fit their 256 registers only with
     // two at a time (no scratch; four: 44 B, eight: 76 B); the larger systems own their SIMD and take the whole chunk
-    constexpr bool SCHED_BARRIER = WLSQM_STAGE_SCHED_BARRIER || NO <= 6;
-    constexpr int GRP = WLSQM_STAGE_SCHED_BARRIER ? (WLSQM_STAGE_GRP < CH ? WLSQM_STAGE_GRP : CH) : (NO <= 6 ? 2 : CH);
+    constexpr bool SCHED_BARRIER = WLSQM_STAGE_SCHED_BARRIER || NO <= 6 || NO >= 20;
+    constexpr int GRP = WLSQM_STAGE_SCHED_BARRIER ? (WLSQM_STAGE_GRP < CH ? WLSQM_STAGE_GRP : CH) : (NO <= 6 ? 2 : NO >= 20 ? WLSQM_STAGE_GRP20 : CH);
     // the staging rows; behind them (reusing the same bytes after the last chunk) the 64 result rows of the wave
+    // (and, for the 20-unknown systems, the top R0 rows of every lane's normal matrix during the solve: see below)
+    constexpr int R0 = NO == 20 ? WLSQM_STAGE_LDS_ROWS : 0, TOP_D = 64 * tri<NO>(R0, R0);
     constexpr int STAGE_D = 64 * XPITCH + 64 * FPITCH, OUT_D = 64 * NO;
-    __shared__ __attribute__((aligned(16))) double lds[STAGE_D > OUT_D ? STAGE_D : OUT_D];
+    constexpr int LDS_D = (STAGE_D > OUT_D ? STAGE_D : OUT_D) > TOP_D ? (STAGE_D > OUT_D ? STAGE_D : OUT_D) : TOP_D;
+    __shared__ __attribute__((aligned(16))) double lds[LDS_D];
     double* const xs = lds;
     double* const fs = lds + 64 * XPITCH;
 
@@ -267,7 +276,7 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER)
     // by the case's own mask (a mixed wave runs both forms), so a case's bits do not depend on its wave-mates.
     // (only for the 15-unknown systems: the smaller ones gain nothing and their register allocation suffered — 2D order 3 went from
     // 330 registers to 512 + 704 B of scratch with the second form compiled in)
-    constexpr bool REDUCED = NO >= 15;
+    constexpr bool REDUCED = NO == 15;
     const bool mine1 = REDUCED && known == 1ull && dropped == 0ull;
     if constexpr (REDUCED) {
         if (mine1) {
@@ -302,7 +311,111 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER)
             for (int a = 1; a < NO; ++a) rhs[a] = r1[a - 1];
         }
     }
-    if (!mine1) {
+    if constexpr (R0 > 0) {
+        // ---- 20 unknowns: 210 + 20 entries are 460 registers, more than a lane has next to anything else, and a lone wave per
+        // SIMD waits out every scratch access in full (all in registers: 2.3 KB of scratch per lane and 1.96 ms per 200k cases, half
+        // the speed of the wave-per-case kernel this replaces).  The top R0 rows of the matrix — the ones the elimination is done
+        // with first — live in LDS instead, entry e of lane l at lds[64 e + l] (conflict-free), where the staging rows were; the
+        // trailing (NO - R0) x (NO - R0) block and the right-hand side stay in registers as for the smaller systems.
+        constexpr int N2 = NO - R0, NE2 = N2 * (N2 + 1) / 2;
+        __syncthreads();                                              // the last chunk has been read
+        double* const L = lds + lane;
+        double R[NE2];
+        auto at = [&](int a, int b) __attribute__((always_inline)) -> double {          // a <= b
+            return a < R0 ? L[tri<NO>(a, b) * 64] : R[tri<N2>(a - R0, b - R0)];
+        };
+        auto put = [&](int a, int b, double v) __attribute__((always_inline)) {
+            if (a < R0) L[tri<NO>(a, b) * 64] = v; else R[tri<N2>(a - R0, b - R0)] = v;
+        };
+        // (entry by entry: the moment-by-moment form of expand_moments is 84 x 20 x 20 iterations here, beyond what the compiler
+        // unrolls — the moments would be indexed at run time and live in scratch)
+#pragma unroll
+        for (int a = 0; a < NO; ++a) {
+            const int pa = Mono<DIM>::P[a], qa = Mono<DIM>::Q[a], ra = Mono<DIM>::R[a];
+            const double fa = mom_inv_fact(pa) * mom_inv_fact(qa) * mom_inv_fact(ra);
+#pragma unroll
+            for (int b = a; b < NO; ++b) {
+                const int pb = Mono<DIM>::P[b], qb = Mono<DIM>::Q[b], rb = Mono<DIM>::R[b];
+                const double fb = mom_inv_fact(pb) * mom_inv_fact(qb) * mom_inv_fact(rb);
+                put(a, b, mu[mom_index<DIM>(pa + pb, qa + qb, ra + rb)] * (fa * fb));
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < NO; ++a) {
+            const int pa = Mono<DIM>::P[a], qa = Mono<DIM>::Q[a], ra = Mono<DIM>::R[a];
+            rhs[a] = nu[mom_index<DIM>(pa, qa, ra)] * (mom_inv_fact(pa) * mom_inv_fact(qa) * mom_inv_fact(ra));
+        }
+        if (known) {                                                  // knowns elimination + masking to identity (eliminate_knowns)
+#pragma unroll
+            for (int om = 0; om < NO; ++om) {
+                if ((known >> om) & 1ull) {
+                    const double v = (((known & ~dropped) >> om) & 1ull) ? fio[om] : 0.0;
+#pragma unroll
+                    for (int a = 0; a < NO; ++a)
+                        if (a != om) rhs[a] = fma(-(a < om ? at(a, om) : at(om, a)), v, rhs[a]);
+                }
+            }
+#pragma unroll
+            for (int om = 0; om < NO; ++om) {
+                if ((known >> om) & 1ull) {
+#pragma unroll
+                    for (int a = 0; a < NO; ++a)
+                        if (a != om) { if (a < om) put(a, om, 0.0); else put(om, a, 0.0); }
+                    put(om, om, 1.0);
+                    rhs[om] = 0.0;
+                }
+            }
+        }
+        // LDL^T, right-looking: the LDS rows first (pivot row into registers, trailing updates in LDS or registers), then the
+        // register block with the routine of the smaller systems
+#pragma unroll
+        for (int j = 0; j < R0; ++j) {
+            double pr[NO], t[NO];
+#pragma unroll
+            for (int m = j; m < NO; ++m) pr[m] = L[tri<NO>(j, m) * 64];
+            const double inv = recip(pr[j]);
+#pragma unroll
+            for (int i = j + 1; i < NO; ++i) t[i] = pr[i] * inv;
+#pragma unroll
+            for (int i = j + 1; i < NO; ++i) {
+#pragma unroll
+                for (int m = i; m < NO; ++m) put(i, m, fma(-t[i], pr[m], at(i, m)));
+            }
+#pragma unroll
+            for (int i = j + 1; i < NO; ++i) L[tri<NO>(j, i) * 64] = t[i];
+            L[tri<NO>(j, j) * 64] = inv;
+        }
+        ldlt_factor<N2>(R);
+        // substitution: forward through the LDS rows, both directions in the register block, backward through the LDS rows
+        double sol[NO];
+#pragma unroll
+        for (int a = 0; a < NO; ++a) sol[a] = ((known >> a) & 1ull) ? 0.0 : rhs[a];
+#pragma unroll
+        for (int j = 0; j < R0; ++j) {
+#pragma unroll
+            for (int i = j + 1; i < NO; ++i) sol[i] = fma(-L[tri<NO>(j, i) * 64], sol[j], sol[i]);
+        }
+        {
+            double s2[N2];
+#pragma unroll
+            for (int a = 0; a < N2; ++a) s2[a] = sol[R0 + a];
+            ldlt_solve<N2>(R, s2);
+#pragma unroll
+            for (int a = 0; a < N2; ++a) sol[R0 + a] = s2[a];
+        }
+#pragma unroll
+        for (int j = R0 - 1; j >= 0; --j) {
+            double v = sol[j] * L[tri<NO>(j, j) * 64];
+#pragma unroll
+            for (int i = j + 1; i < NO; ++i) v = fma(-L[tri<NO>(j, i) * 64], sol[i], v);
+            sol[j] = v;
+        }
+#pragma unroll
+        for (int a = 0; a < NO; ++a) {
+            if (!((known >> a) & 1ull)) rhs[a] = sol[a];
+            else if (((known & ~dropped) >> a) & 1ull) rhs[a] = fio[a];                     // (for the whole-row store below: its own bits)
+        }
+    } else if (!mine1) {
         double M[NE];
         expand_moments<DIM, ORDER>(mu, nu, M, rhs);
         if (known) {
@@ -374,6 +487,7 @@ int launch_fit_stage(int dimension, int order, const KParams& p, long long K, hi
     SCASE(3, 2, true)
     SCASE(2, 3, true)
     SCASE(2, 2, K >= 32)
+    SCASE(3, 3, true)
 #undef SCASE
     return WLSQM_OK;
 }

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""Fast / accurate / strict kernel times on BASELINE shapes (ms per launch, HIP events): python tools/time_accurate.py [ncases] [configs]
-One line per (config, mode): ms, fraction of the 8 TB/s HBM peak from the algorithmic bytes, kernel family."""
+"""Fast / accurate / strict kernel times on BASELINE shapes (ms per launch, HIP events): python tools/time_accurate.py [ncases] [configs] [shuffle]
+("shuffle": the neighbours of every case in random order, as a ball query delivers them.)  One line per (config, mode): ms, fraction of the 8 TB/s HBM peak from the algorithmic bytes, kernel family."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -14,11 +14,15 @@ BYTES = {"C2": 852, "C5": 1404, "C3": 1700, "C1": 180}
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
     names = sys.argv[2].split(",") if len(sys.argv) > 2 else ["C2", "C5"]
+    shuffle = len(sys.argv) > 3 and sys.argv[3] == "shuffle"
     dev = torch.device("cuda", 0)
     for name in names:
         cfg = bench.CONFIGS[name]
         dim, order, nk = cfg["dim"], cfg["order"], cfg["nk"]
         S, F, hoods = bench.build_problem(cfg, n, 0)
+        if shuffle:
+            rng = np.random.default_rng(5)
+            hoods = rng.permuted(hoods, axis=1)
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
         S_d, F_d, h_d = t(S), t(F), t(hoods.astype(np.int64))
         xk = S_d[h_d].contiguous(); fk = F_d[h_d].contiguous(); xi = S_d.clone()

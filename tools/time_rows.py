@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time the basic fit of the 3D order-3 / order-4 systems (20 / 35 unknowns: csrc/fit_rows.hip) on device-resident dense input.
-usage: python tools/time_rows.py [ncases] [K]"""
+usage: python tools/time_rows.py [ncases] [K] [sorted]   ("sorted": neighbours by ascending distance, as a k-nearest-neighbour search delivers them)"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,10 +10,14 @@ import wlsqm.hip as whip
 dev = torch.device("cuda", 0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+by_distance = len(sys.argv) > 3 and sys.argv[3] == "sorted"
 for order, no in ((3, 20), (4, 35)):
     g = torch.Generator(device=dev); g.manual_seed(1)
     xi = torch.rand((n, 3), dtype=torch.float64, device=dev, generator=g)
     xk = (xi[:, None, :] + 0.05 * (2 * torch.rand((n, K, 3), dtype=torch.float64, device=dev, generator=g) - 1)).contiguous()
+    if by_distance:
+        idx = ((xk - xi[:, None, :]) ** 2).sum(-1).argsort(dim=1)
+        xk = torch.gather(xk, 1, idx[..., None].expand(-1, -1, 3)).contiguous()
     fk = (torch.sin(3 * xk[..., 0]) * torch.cos(2 * xk[..., 1]) * torch.exp(xk[..., 2])).contiguous()
     nk = torch.full((n,), K, dtype=torch.int32, device=dev); kn = torch.zeros(n, dtype=torch.int64, device=dev)
     wm = torch.full((n,), 2, dtype=torch.int32, device=dev)
