@@ -47,7 +47,10 @@ constexpr int CH = 8;               // neighbours per staged chunk
 }
 
 #ifndef WLSQM_STAGE_GRP20
-#define WLSQM_STAGE_GRP20 1         // ... of the 20-unknown systems (104 accumulators: 208 of the 256 registers an instruction can name)
+#define WLSQM_STAGE_GRP20 8         // ... of the 20-unknown systems (1 / 2 / 4 / 8: 0.608 / 0.594 / 0.594 / 0.569 ms per 1M cases of 32 neighbours, profiles/r04t_ab_stage33.txt)
+#endif
+#ifndef WLSQM_STAGE_SOLVE_BARRIERS
+#define WLSQM_STAGE_SOLVE_BARRIERS 1
 #endif
 #ifndef WLSQM_STAGE_LDS_ROWS
 #define WLSQM_STAGE_LDS_ROWS 4      // rows of a 20 x 20 normal matrix kept in LDS during the solve (74 of its 210 entries: 37 KB per wave)
@@ -191,7 +194,11 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER)
                         double w = weight(d2, inv_max, uniform);
                         double f = frow[ks];
                         if (MASKED) { w = live ? w : 0.0; f = live ? f : 0.0; }
-                        accumulate_moments_best<DIM, ORDER>(mu, nu, d, w, f);
+#ifndef WLSQM_STAGE_OUTER3D
+#define WLSQM_STAGE_OUTER3D 1
+#endif
+                        if constexpr (DIM == 3 && ORDER >= 3 && WLSQM_STAGE_OUTER3D) accumulate_moments_outer3d<ORDER>(mu, nu, d, w, f);
+                        else accumulate_moments_best<DIM, ORDER>(mu, nu, d, w, f);
                     }
                 }
                 if constexpr (SCHED_BARRIER) __builtin_amdgcn_sched_barrier(0);      // GRP neighbours in flight at a time
@@ -327,81 +334,97 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER)
         auto put = [&](int a, int b, double v) __attribute__((always_inline)) {
             if (a < R0) L[tri<NO>(a, b) * 64] = v; else R[tri<N2>(a - R0, b - R0)] = v;
         };
-        // (entry by entry: the moment-by-moment form of expand_moments is 84 x 20 x 20 iterations here, beyond what the compiler
-        // unrolls — the moments would be indexed at run time and live in scratch)
+        // Entry (a, b), a <= b, of the masked full system straight from the moments (by entry: the moment-by-moment form of
+        // expand_moments is 84 x 20 x 20 iterations here, beyond what the compiler unrolls — the moments would be indexed at run time
+        // and live in scratch).  The matrix is never materialised before the elimination: step 0 of the factorisation takes its
+        // operands from here, so the 84 moments die while the 136 register entries are born (both at once do not fit the lane).
+        const unsigned k32 = (unsigned)known, t32 = (unsigned)(known & ~dropped);        // (20 bits)
+        const bool any_known = __any(k32 != 0u);                      // wave-uniform: the common wave has no known DOF at all
+        auto raw = [&](int a, int b) __attribute__((always_inline)) -> double {
+            const int pa = Mono<DIM>::P[a], qa = Mono<DIM>::Q[a], ra = Mono<DIM>::R[a];
+            const int pb = Mono<DIM>::P[b], qb = Mono<DIM>::Q[b], rb = Mono<DIM>::R[b];
+            const double fa = mom_inv_fact(pa) * mom_inv_fact(qa) * mom_inv_fact(ra), fb = mom_inv_fact(pb) * mom_inv_fact(qb) * mom_inv_fact(rb);
+            return mu[mom_index<DIM>(pa + pb, qa + qb, ra + rb)] * (fa * fb);
+        };
+        auto entry = [&](int a, int b) __attribute__((always_inline)) -> double {       // masked to identity in the known DOFs
+            const double m = raw(a, b);
+            if (!any_known) return m;
+            return a == b ? (((k32 >> a) & 1u) ? 1.0 : m) : ((((k32 >> a) | (k32 >> b)) & 1u) ? 0.0 : m);
+        };
+        double sol[NO];
 #pragma unroll
         for (int a = 0; a < NO; ++a) {
             const int pa = Mono<DIM>::P[a], qa = Mono<DIM>::Q[a], ra = Mono<DIM>::R[a];
-            const double fa = mom_inv_fact(pa) * mom_inv_fact(qa) * mom_inv_fact(ra);
-#pragma unroll
-            for (int b = a; b < NO; ++b) {
-                const int pb = Mono<DIM>::P[b], qb = Mono<DIM>::Q[b], rb = Mono<DIM>::R[b];
-                const double fb = mom_inv_fact(pb) * mom_inv_fact(qb) * mom_inv_fact(rb);
-                put(a, b, mu[mom_index<DIM>(pa + pb, qa + qb, ra + rb)] * (fa * fb));
-            }
+            sol[a] = nu[mom_index<DIM>(pa, qa, ra)] * (mom_inv_fact(pa) * mom_inv_fact(qa) * mom_inv_fact(ra));
         }
-#pragma unroll
-        for (int a = 0; a < NO; ++a) {
-            const int pa = Mono<DIM>::P[a], qa = Mono<DIM>::Q[a], ra = Mono<DIM>::R[a];
-            rhs[a] = nu[mom_index<DIM>(pa, qa, ra)] * (mom_inv_fact(pa) * mom_inv_fact(qa) * mom_inv_fact(ra));
-        }
-        if (known) {                                                  // knowns elimination + masking to identity (eliminate_knowns)
+        // knowns elimination (eliminate_knowns), branch-free per lane behind the wave-uniform test: the value of an unknown DOF
+        // enters as 0.0 (fma(-m, 0, s) = s exactly), so a case's bits do not depend on its wave-mates' masks
+        if (any_known) {
 #pragma unroll
             for (int om = 0; om < NO; ++om) {
-                if ((known >> om) & 1ull) {
-                    const double v = (((known & ~dropped) >> om) & 1ull) ? fio[om] : 0.0;
+                const double v = ((t32 >> om) & 1u) ? fio[om] : 0.0;
 #pragma unroll
-                    for (int a = 0; a < NO; ++a)
-                        if (a != om) rhs[a] = fma(-(a < om ? at(a, om) : at(om, a)), v, rhs[a]);
-                }
+                for (int a = 0; a < NO; ++a)
+                    if (a != om) sol[a] = fma(-(a < om ? raw(a, om) : raw(om, a)), v, sol[a]);
             }
 #pragma unroll
-            for (int om = 0; om < NO; ++om) {
-                if ((known >> om) & 1ull) {
-#pragma unroll
-                    for (int a = 0; a < NO; ++a)
-                        if (a != om) { if (a < om) put(a, om, 0.0); else put(om, a, 0.0); }
-                    put(om, om, 1.0);
-                    rhs[om] = 0.0;
-                }
-            }
+            for (int a = 0; a < NO; ++a) sol[a] = ((k32 >> a) & 1u) ? 0.0 : sol[a];
         }
-        // LDL^T, right-looking: the LDS rows first (pivot row into registers, trailing updates in LDS or registers), then the
+        // LDL^T, right-looking: the LDS rows first (pivot row in registers, trailing updates into LDS or registers), then the
         // register block with the routine of the smaller systems
 #pragma unroll
         for (int j = 0; j < R0; ++j) {
             double pr[NO], t[NO];
 #pragma unroll
-            for (int m = j; m < NO; ++m) pr[m] = L[tri<NO>(j, m) * 64];
+            for (int m = j; m < NO; ++m) pr[m] = j == 0 ? entry(0, m) : L[tri<NO>(j, m) * 64];
             const double inv = recip(pr[j]);
 #pragma unroll
             for (int i = j + 1; i < NO; ++i) t[i] = pr[i] * inv;
 #pragma unroll
             for (int i = j + 1; i < NO; ++i) {
 #pragma unroll
-                for (int m = i; m < NO; ++m) put(i, m, fma(-t[i], pr[m], at(i, m)));
+                for (int m = i; m < NO; ++m) put(i, m, fma(-t[i], pr[m], j == 0 ? entry(i, m) : at(i, m)));
             }
 #pragma unroll
             for (int i = j + 1; i < NO; ++i) L[tri<NO>(j, i) * 64] = t[i];
             L[tri<NO>(j, j) * 64] = inv;
+            if (WLSQM_STAGE_SOLVE_BARRIERS) __builtin_amdgcn_sched_barrier(0);
         }
-        ldlt_factor<N2>(R);
-        // substitution: forward through the LDS rows, both directions in the register block, backward through the LDS rows
-        double sol[NO];
+        // (ldlt_factor<N2>, one elimination step at a time: steps interleaved by the scheduler keep more of the matrix in flight
+        // than the lane has registers for)
 #pragma unroll
-        for (int a = 0; a < NO; ++a) sol[a] = ((known >> a) & 1ull) ? 0.0 : rhs[a];
+        for (int j = 0; j < N2; ++j) {
+            const double inv = recip(R[tri<N2>(j, j)]);
+#pragma unroll
+            for (int i = j + 1; i < N2; ++i) {
+                const double t = R[tri<N2>(j, i)] * inv;
+#pragma unroll
+                for (int m = i; m < N2; ++m) R[tri<N2>(i, m)] -= t * R[tri<N2>(j, m)];
+                R[tri<N2>(j, i)] = t;
+            }
+            R[tri<N2>(j, j)] = inv;
+            if (WLSQM_STAGE_SOLVE_BARRIERS) __builtin_amdgcn_sched_barrier(0);
+        }
+        // substitution: forward through the LDS rows, both directions in the register block, backward through the LDS rows
 #pragma unroll
         for (int j = 0; j < R0; ++j) {
 #pragma unroll
             for (int i = j + 1; i < NO; ++i) sol[i] = fma(-L[tri<NO>(j, i) * 64], sol[j], sol[i]);
         }
-        {
-            double s2[N2];
+        if (WLSQM_STAGE_SOLVE_BARRIERS) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int a = 0; a < N2; ++a) s2[a] = sol[R0 + a];
-            ldlt_solve<N2>(R, s2);
+        for (int j = 0; j < N2; ++j) {
 #pragma unroll
-            for (int a = 0; a < N2; ++a) sol[R0 + a] = s2[a];
+            for (int i = j + 1; i < N2; ++i) sol[R0 + i] -= R[tri<N2>(j, i)] * sol[R0 + j];
+            if (WLSQM_STAGE_SOLVE_BARRIERS) __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int j = N2 - 1; j >= 0; --j) {
+            double v = sol[R0 + j] * R[tri<N2>(j, j)];
+#pragma unroll
+            for (int i = j + 1; i < N2; ++i) v -= R[tri<N2>(j, i)] * sol[R0 + i];
+            sol[R0 + j] = v;
+            if (WLSQM_STAGE_SOLVE_BARRIERS) __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int j = R0 - 1; j >= 0; --j) {
@@ -410,11 +433,12 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER)
             for (int i = j + 1; i < NO; ++i) v = fma(-L[tri<NO>(j, i) * 64], sol[i], v);
             sol[j] = v;
         }
+        if (any_known) {                                              // (for the whole-row store below: a known DOF's own bits)
 #pragma unroll
-        for (int a = 0; a < NO; ++a) {
-            if (!((known >> a) & 1ull)) rhs[a] = sol[a];
-            else if (((known & ~dropped) >> a) & 1ull) rhs[a] = fio[a];                     // (for the whole-row store below: its own bits)
+            for (int a = 0; a < NO; ++a) if ((t32 >> a) & 1u) sol[a] = fio[a];
         }
+#pragma unroll
+        for (int a = 0; a < NO; ++a) rhs[a] = sol[a];
     } else if (!mine1) {
         double M[NE];
         expand_moments<DIM, ORDER>(mu, nu, M, rhs);

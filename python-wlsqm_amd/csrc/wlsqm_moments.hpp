@@ -100,7 +100,40 @@ __device__ __forceinline__ void accumulate_moments_outer2d(double (&mu)[mom_coun
     }
 }
 
-// The cheaper of the two forms for (DIM, ORDER).
+// 3D, order 3 and up: powers of x and y once per neighbour, then for every (q, r) the product yz = (w z^r) y^q and ONE fma per moment,
+// mu(p,q,r) += x^p yz.  Order 3: 37 multiplies + 10 for the right-hand side + 104 accumulations = 151 operations and 14 live
+// temporaries, against 203 instructions (25 of them copies) and 56 temporaries of the chain form — with the 104 accumulators of the
+// 20-unknown systems (208 of the 256 registers an instruction can name) the temporaries decide whether accumulators travel through
+// the accumulation file inside the neighbour loop.
+template <int ORDER>
+__device__ __forceinline__ void accumulate_moments_outer3d(double (&mu)[mom_count<3>(2 * ORDER)], double (&nu)[mom_count<3>(ORDER)],
+                                                           const double (&d)[3], double w, double f) {
+    constexpr int D = 2 * ORDER;
+    double X[D + 1], Y[D + 1];
+    X[1] = d[0]; Y[1] = d[1];
+#pragma unroll
+    for (int p = 2; p <= D; ++p) { X[p] = X[p - 1] * d[0]; Y[p] = Y[p - 1] * d[1]; }
+    double zw = w;
+#pragma unroll
+    for (int r = 0; r <= D; ++r) {
+        if (r > 0) zw *= d[2];
+#pragma unroll
+        for (int q = 0; q + r <= D; ++q) {
+            const double yz = q > 0 ? zw * Y[q] : zw;
+            mu[mom_index<3>(0, q, r)] += yz;
+#pragma unroll
+            for (int p = 1; p + q + r <= D; ++p) mu[mom_index<3>(p, q, r)] = fma(X[p], yz, mu[mom_index<3>(p, q, r)]);
+            if (q + r <= ORDER) {
+                const double yzf = yz * f;
+                nu[mom_index<3>(0, q, r)] += yzf;
+#pragma unroll
+                for (int p = 1; p + q + r <= ORDER; ++p) nu[mom_index<3>(p, q, r)] = fma(X[p], yzf, nu[mom_index<3>(p, q, r)]);
+            }
+        }
+    }
+}
+
+// The cheaper of the two forms for (DIM, ORDER) (the 3D outer form is the staged kernel's: csrc/fit_stage.hip).
 template <int DIM, int ORDER>
 __device__ __forceinline__ void accumulate_moments_best(double (&mu)[mom_count<DIM>(2 * ORDER)], double (&nu)[mom_count<DIM>(ORDER)],
                                                         const double (&d)[DIM], double w, double f) {
