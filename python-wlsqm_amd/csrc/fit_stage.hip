@@ -58,7 +58,10 @@ constexpr int CH = 8;               // neighbours per staged chunk
 #ifndef WLSQM_STAGE_MINW10
 #define WLSQM_STAGE_MINW10 1        // waves per SIMD the systems up to 10 unknowns are compiled for
 #endif
-template <int DIM, int ORDER>
+// PART = 0: the whole fit.  PART = 1 / 2 (3D order 4, 35 unknowns): the kernel stops after the moment pass and leaves HALF of the case's
+// 165 + 35 moments (wlsqm_moments.hpp: stage_part) at p.ws — entry e of case t at ws[((t / 64) 200 + e) 64 + t % 64] — for the
+// four-lanes-per-case solve of csrc/fit_quad.hip; all 200 accumulators at once are 400 registers, more than an instruction can name.
+template <int DIM, int ORDER, int PART = 0>
 __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER) <= 10 ? WLSQM_STAGE_MINW10 : 1)) void fit_stage_kernel(const KParams p) {
     using namespace stage;
     constexpr int NO = ndofs(DIM, ORDER), NE = NO * (NO + 1) / 2, NM = mom_count<DIM>(2 * ORDER);
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER)
 #ifndef WLSQM_STAGE_OUTER3D
 #define WLSQM_STAGE_OUTER3D 1
 #endif
-                        if constexpr (DIM == 3 && ORDER >= 3 && WLSQM_STAGE_OUTER3D) accumulate_moments_outer3d<ORDER>(mu, nu, d, w, f);
+                        if constexpr (DIM == 3 && ORDER >= 3 && WLSQM_STAGE_OUTER3D) accumulate_moments_outer3d<ORDER, PART>(mu, nu, d, w, f);
                         else accumulate_moments_best<DIM, ORDER>(mu, nu, d, w, f);
                     }
                 }
@@ -274,6 +277,24 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER)
         moments(max_d2, false);
     }
 
+    if constexpr (PART != 0) {
+        // ---- this half of the moments to the workspace: 512 contiguous bytes per entry (tail lanes store their replayed case too: the
+        // solve reads whole 16-case runs)
+        double* const out = p.ws + (long long)blockIdx.x * (200 * 64) + lane;
+#pragma unroll
+        for (int r = 0; r <= 2 * ORDER; ++r) {
+            if (stage_part(r) != PART) continue;
+#pragma unroll
+            for (int q = 0; q + r <= 2 * ORDER; ++q) {
+#pragma unroll
+                for (int pp = 0; pp + q + r <= 2 * ORDER; ++pp) {
+                    __builtin_nontemporal_store(mu[mom_index<3>(pp, q, r)], out + mom_index<3>(pp, q, r) * 64);
+                    if (pp + q + r <= ORDER) __builtin_nontemporal_store(nu[mom_index<3>(pp, q, r)], out + (NM + mom_index<3>(pp, q, r)) * 64);
+                }
+            }
+        }
+        return;
+    } else {
     // ---- one solve per lane: masked full system, unpivoted LDL^T
     constexpr unsigned long long FULL = (1ull << NO) - 1ull;
     double* const fio = p.fi + j * p.sfi_j;
@@ -477,6 +498,7 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER)
         for (int a = 0; a < NO; ++a)
             if (!((known >> a) & 1ull)) fio[a] = rhs[a];
     }
+    }   // PART == 0
 }
 
 template <int DIM, int ORDER>
@@ -487,6 +509,31 @@ static int launch_stage(const KParams& p, hipStream_t stream) {
     hipLaunchKernelGGL((fit_stage_kernel<DIM, ORDER>), dim3((unsigned)groups), dim3(64), 0, stream, p);
     WLSQM_HIP_CHECK(hipGetLastError());
     note_kernel("stage");
+    return WLSQM_OK;
+}
+
+int launch_quad_solve(const KParams& p, hipStream_t stream);          // fit_quad.hip
+
+// 3D order 4: two moment launches (half of the 200 sums each) and the four-lanes-per-case solve, in slices that bound the workspace
+// (1 600 bytes per case, stream-ordered) at 1.7 GB.
+static int launch_stage34(const KParams& p, hipStream_t stream) {
+    const long long SLICE = 1LL << 20;
+    for (long long j0 = 0; j0 < p.ncases; j0 += SLICE) {
+        KParams q = slice_cases(p, j0, p.ncases - j0 < SLICE ? p.ncases - j0 : SLICE);
+        const long long groups = (q.ncases + 63) / 64;
+        double* ws = nullptr;
+        int rc = scratch_alloc_async(reinterpret_cast<void**>(&ws), (size_t)groups * 200 * 64 * sizeof(double), stream);
+        if (rc != WLSQM_OK) return rc;
+        q.ws = ws; q.ws_stride = 0;
+        hipLaunchKernelGGL((fit_stage_kernel<3, 4, 1>), dim3((unsigned)groups), dim3(64), 0, stream, q);
+        hipLaunchKernelGGL((fit_stage_kernel<3, 4, 2>), dim3((unsigned)groups), dim3(64), 0, stream, q);
+        rc = launch_quad_solve(q, stream);
+        const int rc2 = scratch_free_async(ws, stream);
+        if (rc != WLSQM_OK) return rc;
+        if (rc2 != WLSQM_OK) return rc2;
+        WLSQM_HIP_CHECK(hipGetLastError());
+    }
+    note_kernel("quad");
     return WLSQM_OK;
 }
 
@@ -512,6 +559,7 @@ int launch_fit_stage(int dimension, int order, const KParams& p, long long K, hi
     SCASE(2, 3, true)
     SCASE(2, 2, K >= 32)
     SCASE(3, 3, true)
+    if (dimension == 3 && order == 4) { *handled = true; return launch_stage34(p, stream); }
 #undef SCASE
     return WLSQM_OK;
 }

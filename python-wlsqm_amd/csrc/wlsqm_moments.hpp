@@ -105,7 +105,10 @@ __device__ __forceinline__ void accumulate_moments_outer2d(double (&mu)[mom_coun
 // temporaries, against 203 instructions (25 of them copies) and 56 temporaries of the chain form — with the 104 accumulators of the
 // 20-unknown systems (208 of the 256 registers an instruction can name) the temporaries decide whether accumulators travel through
 // the accumulation file inside the neighbour loop.
-template <int ORDER>
+// PART = 1 / 2: only the moments whose z power r has stage_part(r) == PART (the two halves of the 165 + 35 sums of 3D order 4, 104 and
+// 96 accumulators: fit_stage_kernel<3,4,PART>).
+__host__ __device__ constexpr int stage_part(int r) { return (r == 0 || r == 2 || r >= 6) ? 1 : 2; }
+template <int ORDER, int PART = 0>
 __device__ __forceinline__ void accumulate_moments_outer3d(double (&mu)[mom_count<3>(2 * ORDER)], double (&nu)[mom_count<3>(ORDER)],
                                                            const double (&d)[3], double w, double f) {
     constexpr int D = 2 * ORDER;
@@ -117,6 +120,7 @@ __device__ __forceinline__ void accumulate_moments_outer3d(double (&mu)[mom_coun
 #pragma unroll
     for (int r = 0; r <= D; ++r) {
         if (r > 0) zw *= d[2];
+        if (PART != 0 && stage_part(r) != PART) continue;
 #pragma unroll
         for (int q = 0; q + r <= D; ++q) {
             const double yz = q > 0 ? zw * Y[q] : zw;
