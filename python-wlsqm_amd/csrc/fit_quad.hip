@@ -77,7 +77,10 @@ __global__ __launch_bounds__(64, 1) void quad_solve_kernel(const KParams p) {
     // lane's rows (68 of the 180 doubles: entry e of lane t at lds[64 e + t]) — the rows that are finished first and then only read
     // again by the back substitution.  All 180 in registers were 360 of the lane's 512 and the compiler put 120 doubles of them in
     // scratch (0.83 ms per 200k cases: a lone wave waits out every scratch access).
-    constexpr int LROWS = 2, NL = off(LROWS);
+#ifndef WLSQM_QUAD_LROWS
+#define WLSQM_QUAD_LROWS 2
+#endif
+    constexpr int LROWS = WLSQM_QUAD_LROWS, NL = off(LROWS);
     __shared__ __attribute__((aligned(16))) double mom[(16 * PITCH > 64 * NL) ? 16 * PITCH : 64 * NL];
     __shared__ unsigned int s_idx32[NP * NP / 4];
     const int lane = threadIdx.x, l = lane & 3, c = lane >> 2;
@@ -133,26 +136,38 @@ __global__ __launch_bounds__(64, 1) void quad_solve_kernel(const KParams p) {
     // look-ups of a lane ran one after the other, each waiting out the LDS latency twice)
     auto build = [&](auto masked_tag) __attribute__((always_inline)) {
         constexpr bool MASKED = decltype(masked_tag)::value;
-#pragma unroll
-        for (int s = 0; s < SLOTS; ++s) {
+        // Every entry is two dependent LDS reads (table word, then the moment).  Left to itself the compiler — short of registers
+        // with the rows filling up — issued them one at a time: 171 x 2 LDS round trips per lane, about 40 % of the kernel.  So in
+        // batches, separated by scheduling barriers: the table words of a slot, then eight moments at a time, then their products.
+        static_for<0, SLOTS>([&](auto s_) __attribute__((always_inline)) {
+            constexpr int s = decltype(s_)::value;
             const int i = 4 * s + l;
             const bool bi = (known >> i) & 1ull;                       // (bit 35 is never set: effective_mask keeps NO bits)
-#pragma unroll
-            for (int g = s; g < SLOTS; ++g) {
-                const unsigned int w = s_idx32[i * (NP / 4) + g];      // table entries of columns 4 g .. 4 g + 3 of row i
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int m = 4 * g + k;
-                    if (m >= NO) continue;                             // (column 35 of the stored row is the right-hand side)
-                    double v = mc[(w >> (8 * k)) & 0xffu] * (fa[s] * fact_of(m));
-                    if (MASKED) {
-                        const bool bm = (known >> m) & 1ull;
-                        v = (bi || bm) ? ((i == m) ? 1.0 : 0.0) : v;
+            unsigned int w[SLOTS];
+            static_for<s, SLOTS>([&](auto g_) __attribute__((always_inline)) { w[decltype(g_)::value] = s_idx32[i * (NP / 4) + decltype(g_)::value]; });
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<0, (SLOTS - s + 1) / 2>([&](auto h_) __attribute__((always_inline)) {
+                constexpr int g0 = s + 2 * decltype(h_)::value;        // column groups g0 and g0 + 1
+                double v[8];
+                static_for<0, 8>([&](auto e_) __attribute__((always_inline)) {
+                    constexpr int e = decltype(e_)::value, g = g0 + e / 4, k = e % 4;
+                    if constexpr (g < SLOTS && 4 * g + k < NO) v[e] = mc[(w[g] >> (8 * k)) & 0xffu];
+                });
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<0, 8>([&](auto e_) __attribute__((always_inline)) {
+                    constexpr int e = decltype(e_)::value, g = g0 + e / 4, k = e % 4, m = 4 * g + k;
+                    if constexpr (g < SLOTS && m < NO) {               // (column 35 of the stored row is the right-hand side)
+                        double x = v[e] * (fa[s] * fact_of(m));
+                        if (MASKED) {
+                            const bool bm = (known >> m) & 1ull;
+                            x = (bi || bm) ? ((i == m) ? 1.0 : 0.0) : x;
+                        }
+                        R[off(s) + 4 * (g - s) + k] = x;
                     }
-                    R[off(s) + 4 * (g - s) + k] = v;
-                }
-            }
-        }
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        });
     };
     if (any_known) build(std::true_type{}); else build(std::false_type{});
 
