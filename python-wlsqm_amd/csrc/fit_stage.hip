@@ -61,7 +61,11 @@ constexpr int CH = 8;               // neighbours per staged chunk
 // PART = 0: the whole fit.  PART = 1 / 2 (3D order 4, 35 unknowns): the kernel stops after the moment pass and leaves HALF of the case's
 // 165 + 35 moments (wlsqm_moments.hpp: stage_part) at p.ws — entry e of case t at ws[((t / 64) 200 + e) 64 + t % 64] — for the
 // four-lanes-per-case solve of csrc/fit_quad.hip; all 200 accumulators at once are 400 registers, more than an instruction can name.
-template <int DIM, int ORDER, int PART = 0>
+// GATHER: index-based input (p.hoods: the neighbours of case j are rows hoods[j, k] of the point table p.S / p.F).  A lane gathers ITS
+// case's neighbours, so the data arrives in the lane that consumes it: no LDS staging — the next chunk's eight points are in flight in
+// registers while the current ones are consumed.  Everything behind the fetch is the dense kernel's code (same bits as the dense
+// kernel on the gathered rows).
+template <int DIM, int ORDER, int PART = 0, bool GATHER = false>
 __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER) <= 10 ? WLSQM_STAGE_MINW10 : 1)) void fit_stage_kernel(const KParams p) {
     using namespace stage;
     constexpr int NO = ndofs(DIM, ORDER), NE = NO * (NO + 1) / 2, NM = mom_count<DIM>(2 * ORDER);
@@ -94,8 +98,10 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER)
     unsigned long long known, dropped;
     effective_mask<NO>(p.knowns[j * p.sknowns], known, dropped);
     double xi[DIM];
+    const long long pj = GATHER ? (p.pidx ? (long long)p.pidx[j] : j) : 0;      // the case's own point (also the stand-in for padding slots)
+    const int* const hrow = GATHER ? p.hoods + j * p.shoods_j : nullptr;
 #pragma unroll
-    for (int m = 0; m < DIM; ++m) xi[m] = p.xi[j * p.sxi_j + m];
+    for (int m = 0; m < DIM; ++m) xi[m] = GATHER ? p.S[pj * DIM + m] : p.xi[j * p.sxi_j + m];
 
     auto sqdist = [&](const double (&d)[DIM]) {       // one rounding sequence for the guess and for the pass: they are compared for equality
         double d2 = d[0] * d[0];
@@ -112,7 +118,7 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER)
     double guess = 0.0;
     const bool guess_staged = nkc > (Q - 1) * CH;                     // the last neighbour sits in the chunk that is staged first
     if (nkc > 0 && !guess_staged) {
-        const double* q = p.xk + j * (long long)K * DIM + (long long)(nkc - 1) * DIM;
+        const double* q = GATHER ? p.S + (long long)hrow[nkc - 1] * DIM : p.xk + j * (long long)K * DIM + (long long)(nkc - 1) * DIM;
         double dg[DIM];
 #pragma unroll
         for (int m = 0; m < DIM; ++m) dg[m] = q[m] - xi[m];
@@ -123,8 +129,11 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER)
     const int xsub = lane % XPC, xc0 = lane / XPC, fsub = lane % FPC, fc0 = lane / FPC;
     const unsigned xrowb = (unsigned)K * DIM * 8, frowb = (unsigned)K * 8;
     const bool xlane = lane < XCPI * XPC;
-    const char* const xtile = reinterpret_cast<const char*>(p.xk + t0 * (long long)K * DIM);
-    const char* const ftile = reinterpret_cast<const char*>(p.fk + t0 * (long long)K);
+    const char* const xtile = GATHER ? nullptr : reinterpret_cast<const char*>(p.xk + t0 * (long long)K * DIM);
+    const char* const ftile = GATHER ? nullptr : reinterpret_cast<const char*>(p.fk + t0 * (long long)K);
+    // GATHER: the chunk in flight (nx, nf) and the chunk being consumed (cx, cf)
+    double nx[GATHER ? CH : 1][DIM], nf[GATHER ? CH : 1], cx[GATHER ? CH : 1][DIM], cf[GATHER ? CH : 1];
+    const bool rows16 = GATHER && ((reinterpret_cast<uintptr_t>(p.hoods) & 15u) == 0) && (p.shoods_j % 4 == 0);      // wave-uniform
     // DEEP: TWO chunks in flight (two register sets, chunk c in set (Q - 1 - c) & 1): the systems that own their SIMD have the
     // registers, and a lone wave has nobody to cover the gap between the landing of a chunk and the request for the next
 #ifndef WLSQM_STAGE_DEEP
@@ -150,7 +159,28 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER)
             fr[i] = *reinterpret_cast<const d2_*>(fb + (size_t)(unsigned)cc * frowb);
         }
     };
-    auto fetch = [&](int q) __attribute__((always_inline)) { fetch_into(xr, fr, q); };
+    auto gather = [&](int q) __attribute__((always_inline)) {
+        if constexpr (GATHER) {
+            int idx[CH];
+            if (rows16 && (q + 1) * CH <= K) {                        // whole chunk, 16-byte aligned index rows: two loads
+                typedef int i4_ __attribute__((ext_vector_type(4)));
+                const i4_ a = *reinterpret_cast<const i4_*>(hrow + q * CH), b = *reinterpret_cast<const i4_*>(hrow + q * CH + 4);
+                idx[0] = a.x; idx[1] = a.y; idx[2] = a.z; idx[3] = a.w; idx[4] = b.x; idx[5] = b.y; idx[6] = b.z; idx[7] = b.w;
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < CH; ++ks) { const int k = q * CH + ks; idx[ks] = hrow[k < K ? k : K - 1]; }
+            }
+#pragma unroll
+            for (int ks = 0; ks < CH; ++ks) {
+                // a slot beyond the case's neighbours holds anything (padding): never dereferenced, the case's own point stands in
+                const long long pk = (q * CH + ks < nkc) ? (long long)idx[ks] : pj;
+#pragma unroll
+                for (int m = 0; m < DIM; ++m) nx[ks][m] = p.S[pk * DIM + m];
+                nf[ks] = p.F[pk];
+            }
+        }
+    };
+    auto fetch = [&](int q) __attribute__((always_inline)) { if constexpr (GATHER) gather(q); else fetch_into(xr, fr, q); };
     auto park_from = [&](const d2_ (&xr)[XNI], const d2_ (&fr)[FNI]) __attribute__((always_inline)) {
         double* xl = xs + xc0 * XPITCH + xsub * 2;
         double* fl = fs + fc0 * FPITCH + fsub * 2;
@@ -160,7 +190,16 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER)
 #pragma unroll
         for (int i = 0; i < FNI; ++i) *reinterpret_cast<d2_*>(fl + i * FCPI * FPITCH) = fr[i];
     };
-    auto park = [&]() __attribute__((always_inline)) { park_from(xr, fr); };
+    auto park = [&]() __attribute__((always_inline)) {
+        if constexpr (GATHER) {
+#pragma unroll
+            for (int ks = 0; ks < CH; ++ks) {
+#pragma unroll
+                for (int m = 0; m < DIM; ++m) cx[ks][m] = nx[ks][m];
+                cf[ks] = nf[ks];
+            }
+        } else park_from(xr, fr);
+    };
 
     double mu[NM], nu[NO];
     double max_d2 = 0.0;
@@ -190,12 +229,12 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER)
                     const bool live = MASKED ? (q * CH + ks < nkc) : true;
                     double d[DIM];
 #pragma unroll
-                    for (int m = 0; m < DIM; ++m) { d[m] = xrow[ks * DIM + m] - xi[m]; if (MASKED) d[m] = live ? d[m] : 0.0; }
+                    for (int m = 0; m < DIM; ++m) { d[m] = (GATHER ? cx[ks][m] : xrow[ks * DIM + m]) - xi[m]; if (MASKED) d[m] = live ? d[m] : 0.0; }
                     const double d2 = sqdist(d);
                     max_d2 = d2 > max_d2 ? d2 : max_d2;               // (a masked slot contributes 0)
                     if constexpr (!MAXONLY) {
                         double w = weight(d2, inv_max, uniform);
-                        double f = frow[ks];
+                        double f = GATHER ? cf[ks] : frow[ks];
                         if (MASKED) { w = live ? w : 0.0; f = live ? f : 0.0; }
 #ifndef WLSQM_STAGE_OUTER3D
 #define WLSQM_STAGE_OUTER3D 1
@@ -261,7 +300,7 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER)
         for (int ks = 0; ks < CH; ++ks) {
             double d[DIM];
 #pragma unroll
-            for (int m = 0; m < DIM; ++m) d[m] = xrow[ks * DIM + m] - xi[m];
+            for (int m = 0; m < DIM; ++m) d[m] = (GATHER ? cx[ks][m] : xrow[ks * DIM + m]) - xi[m];
             const double d2 = sqdist(d);
             if ((Q - 1) * CH + ks < nkc) { mono = mono && d2 >= prev; prev = d2; }
         }
@@ -501,14 +540,14 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER)
     }   // PART == 0
 }
 
-template <int DIM, int ORDER>
+template <int DIM, int ORDER, bool GATHER = false>
 static int launch_stage(const KParams& p, hipStream_t stream) {
     const long long groups = (p.ncases + 63) / 64;
     if (groups <= 0) return WLSQM_OK;
     if (groups > 0x7fffffffLL) { set_error("fit_stage: batch too large for one launch"); return WLSQM_EVALUE; }
-    hipLaunchKernelGGL((fit_stage_kernel<DIM, ORDER>), dim3((unsigned)groups), dim3(64), 0, stream, p);
+    hipLaunchKernelGGL((fit_stage_kernel<DIM, ORDER, 0, GATHER>), dim3((unsigned)groups), dim3(64), 0, stream, p);
     WLSQM_HIP_CHECK(hipGetLastError());
-    note_kernel("stage");
+    note_kernel(GATHER ? "stage-gather" : "stage");
     return WLSQM_OK;
 }
 
@@ -516,6 +555,7 @@ int launch_quad_solve(const KParams& p, hipStream_t stream);          // fit_qua
 
 // 3D order 4: two moment launches (half of the 200 sums each) and the four-lanes-per-case solve, in slices that bound the workspace
 // (1 600 bytes per case, stream-ordered) at 1.7 GB.
+template <bool GATHER = false>
 static int launch_stage34(const KParams& p, hipStream_t stream) {
     const long long SLICE = 1LL << 20;
     for (long long j0 = 0; j0 < p.ncases; j0 += SLICE) {
@@ -525,15 +565,15 @@ static int launch_stage34(const KParams& p, hipStream_t stream) {
         int rc = scratch_alloc_async(reinterpret_cast<void**>(&ws), (size_t)groups * 200 * 64 * sizeof(double), stream);
         if (rc != WLSQM_OK) return rc;
         q.ws = ws; q.ws_stride = 0;
-        hipLaunchKernelGGL((fit_stage_kernel<3, 4, 1>), dim3((unsigned)groups), dim3(64), 0, stream, q);
-        hipLaunchKernelGGL((fit_stage_kernel<3, 4, 2>), dim3((unsigned)groups), dim3(64), 0, stream, q);
+        hipLaunchKernelGGL((fit_stage_kernel<3, 4, 1, GATHER>), dim3((unsigned)groups), dim3(64), 0, stream, q);
+        hipLaunchKernelGGL((fit_stage_kernel<3, 4, 2, GATHER>), dim3((unsigned)groups), dim3(64), 0, stream, q);
         rc = launch_quad_solve(q, stream);
         const int rc2 = scratch_free_async(ws, stream);
         if (rc != WLSQM_OK) return rc;
         if (rc2 != WLSQM_OK) return rc2;
         WLSQM_HIP_CHECK(hipGetLastError());
     }
-    note_kernel("quad");
+    note_kernel(GATHER ? "quad-gather" : "quad");
     return WLSQM_OK;
 }
 
@@ -545,7 +585,30 @@ int launch_fit_stage(int dimension, int order, const KParams& p, long long K, hi
     if (e && e[0] == '0') return WLSQM_OK;
     const char* off = getenv("WLSQM_HIP_DISABLE_TILE");
     if (off && off[0] == '1') return WLSQM_OK;
-    if (p.do_sens || p.iterative || p.hoods || p.case_index || !p.xk || !p.fk) return WLSQM_OK;
+    if (p.do_sens || p.iterative || p.case_index) return WLSQM_OK;
+    if (p.hoods) {
+        // index-based input: the gathering form (WLSQM_HIP_STAGE_GATHER=0 disables it, =all sends every covered shape here: A/B).
+        // tools/time_cloud.py, 1M cases, points in Morton order / in Halton order (every gather a miss), against the gathering tile /
+        // ring / wave-per-case kernels: 2D order 4 at 64 neighbours 0.42 / 0.44 against 0.57 / 0.69 ms, 3D order 2 at 40 0.28 / 0.40
+        // against 0.37 / 0.41, 2D order 2 at 24 0.094 / 0.124 against 0.124 / 0.132, 2D order 3 at 30 0.21 / 0.21 against 0.24 / 0.26,
+        // 3D order 3 at 40 (400k) 0.30 against 1.62, 3D order 4 1.18 against 4.13 (profiles/r04y_stage_gather.txt)
+        const char* g = getenv("WLSQM_HIP_STAGE_GATHER");
+        if ((g && g[0] == '0') || !p.S || !p.F || K < 8 || K > 65536) return WLSQM_OK;
+        const bool gall = g && g[0] == 'a';
+#define GCASE(D, O, COND) if (dimension == D && order == O && (gall || (COND))) { *handled = true; return launch_stage<D, O, true>(p, stream); }
+        GCASE(3, 3, true)
+        if (dimension == 3 && order == 4) { *handled = true; return launch_stage34<true>(p, stream); }
+        // (the small systems at small neighbour counts keep the gathering tile kernels where those measured faster: 2D order 2 at
+        // 12 / 20 / 28 neighbours 0.113 / 0.135 / 0.162 against 0.079 / 0.110 / 0.147 ms, 2D order 3 at 20 / 28 0.170 / 0.205 against
+        // 0.145 / 0.187, 3D order 2 at 20 0.188 against 0.179 — the partial first chunk costs more than it carries)
+        GCASE(2, 4, true)
+        GCASE(3, 2, K >= 24)
+        GCASE(2, 3, K >= 30)
+        GCASE(2, 2, K >= 32 || K % 8 == 0)
+#undef GCASE
+        return WLSQM_OK;
+    }
+    if (!p.xk || !p.fk) return WLSQM_OK;
     if (K < 8 || K % 2 != 0 || K > 65536) return WLSQM_OK;          // (row bytes and the tile's offsets are 32-bit)
     if (p.sxk_k != dimension || p.sxk_j != K * dimension || p.sfk_k != 1 || p.sfk_j != K) return WLSQM_OK;
     if ((reinterpret_cast<uintptr_t>(p.xk) | reinterpret_cast<uintptr_t>(p.fk)) & 15u) return WLSQM_OK;
@@ -559,7 +622,7 @@ int launch_fit_stage(int dimension, int order, const KParams& p, long long K, hi
     SCASE(2, 3, true)
     SCASE(2, 2, K >= 32)
     SCASE(3, 3, true)
-    if (dimension == 3 && order == 4) { *handled = true; return launch_stage34(p, stream); }
+    if (dimension == 3 && order == 4) { *handled = true; return launch_stage34<false>(p, stream); }
 #undef SCASE
     return WLSQM_OK;
 }

@@ -1293,7 +1293,7 @@ def test_continuous_interpolation_ball_search_on_the_device(wlsqm, dim):
 @pytest.mark.gpu
 @pytest.mark.parametrize("dim,order,K", [(d, o, k) for d, o in ((2, 1), (2, 2), (2, 3), (3, 1), (3, 2)) for k in range(6, 66, 2)] +
                          [(d, o, k) for d, o in ((2, 1), (2, 2), (2, 3), (3, 1), (3, 2)) for k in range(66, 130, 2)])
-def test_index_based_input_has_a_fixed_shape_for_every_even_K(wlsqm, dim, order, K):
+def test_index_based_input_has_a_fixed_shape_for_every_even_K(wlsqm, dim, order, K, monkeypatch):
     """Index-based ("cloud") input, 2D orders 1-3 and 3D orders 1-2: every even K up to 128 runs a fixed-K
     instantiation of the gathering tile kernel (8-byte index chunks where K is not a multiple of 4, shares padded to a multiple of 4 slots),
     and agrees with the dense path on the same neighbourhoods to rounding: subset of the points as cases, ragged nk, knowns,
@@ -1301,6 +1301,7 @@ def test_index_based_input_has_a_fixed_shape_for_every_even_K(wlsqm, dim, order,
     import torch
     import synth
     import wlsqm.hip as whip
+    monkeypatch.setenv("WLSQM_HIP_STAGE_GATHER", "0")        # (round 4: orders >= 2 take the gathering staged kernel by default: tests/test_gpu_round4.py)
     no = K_.NDOF[dim][order]
     if K < no + 2:
         pytest.skip("fewer neighbours than unknowns + 2")

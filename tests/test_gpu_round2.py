@@ -347,7 +347,7 @@ def test_hip_kernels_under_world_size_2(wlsqm, tmp_path):
     res = json.load(open(str(out) + ".json"))
     assert res["dense_bit_identical"] and res["cloud_bit_identical"] and res["halo_bit_identical"], res
     assert res["kernel_dense"] in ("tile", "stage") and res["world"] == 2
-    assert res["halo_kernel"] == "tile-gather" and 0 < res["halo_shape_rank0"][0] < 30011 // 2, res
+    assert res["halo_kernel"] in ("tile-gather", "stage-gather") and 0 < res["halo_shape_rank0"][0] < 30011 // 2, res
 
 
 # ----------------------------------------------------------------------------------------------------------------------

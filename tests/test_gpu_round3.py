@@ -306,7 +306,7 @@ def test_example_harness_index_based_and_strict(wlsqm, oracle):
 @pytest.mark.gpu
 @pytest.mark.parametrize("Kn", [26, 40, 64])
 @pytest.mark.parametrize("pad", [-1, "npoints"])
-def test_index_based_2d_order4_runs_the_one_kernel_ring(wlsqm, oracle, Kn, pad):
+def test_index_based_2d_order4_runs_the_one_kernel_ring(wlsqm, oracle, Kn, pad, monkeypatch):
     """index-based 2D order 4 (the reference's harness layout, examples/wlsqm_example.py:103-133) in ONE kernel:
     the LDS ring filled by per-lane DMA gathers from the point table.  Ragged neighbourhoods with scipy-style padding, point_index,
     mixed knowns masks, a tail tile: same bits as the dense ring kernel on the gathered rows (it IS the same arithmetic once the
@@ -314,6 +314,7 @@ def test_index_based_2d_order4_runs_the_one_kernel_ring(wlsqm, oracle, Kn, pad):
     import torch
     import synth
     import wlsqm.hip as whip
+    monkeypatch.setenv("WLSQM_HIP_STAGE_GATHER", "0")        # (round 4: index-based input takes the gathering staged kernel by default)
     rng = np.random.default_rng(Kn)
     npts, n = 6000, 4091                                      # 255 full tiles + a tail tile of 11 cases
     S = synth.halton(npts, 2); F = synth.field(S)

@@ -49,7 +49,7 @@ def _hoods_at_the_end_of_an_allocation(hoods):
 
 
 @pytest.mark.parametrize("Kn", list(range(26, 66, 4)) + [28, 64])
-def test_gather_ring_tail_tile(wlsqm, oracle, Kn):
+def test_gather_ring_tail_tile(wlsqm, oracle, Kn, monkeypatch):
     """Round 3's tail bug: the index prefetch clamped the SOURCE offset of the tail tile but the DMA still landed at the lane's own
     LDS position; with K == 2 (mod 4) and an odd number of valid rows the last two indices of the last valid case became copies of
     the two before them (tools/fuzz.py found it: profiles/r03i_fuzz.txt; the curated test had nk <= K - 2 in that case by chance).
@@ -58,6 +58,7 @@ def test_gather_ring_tail_tile(wlsqm, oracle, Kn):
     import torch
     import synth
     import wlsqm.hip as whip
+    monkeypatch.setenv("WLSQM_HIP_STAGE_GATHER", "0")        # the gather RING (index-based input takes the gathering staged kernel by default)
     rng = np.random.default_rng(1000 + Kn)
     npts = 3000
     S = synth.halton(npts, 2); F = synth.field(S)
@@ -293,3 +294,61 @@ def test_staged_kernel(wlsqm, oracle, dim, order, Kn, n, neighbours, monkeypatch
         # expressible per case; instead: the ring / tile kernels' route-independence — run to run
         _, _, again = run(o)
         assert np.array_equal(got.view(np.int64), again.view(np.int64))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the gathering form of the staged kernel: index-based input (csrc/fit_stage.hip, GATHER)
+
+@pytest.mark.parametrize("dim,order,Kn", [(2, 4, 64), (2, 4, 50), (2, 4, 26), (2, 4, 17), (3, 2, 40), (3, 2, 26), (2, 3, 30), (2, 3, 37), (2, 2, 24),
+                                          (2, 2, 33), (3, 3, 64), (3, 3, 42), (3, 4, 64), (3, 4, 50)])
+@pytest.mark.parametrize("n", [1, 65, 1000])
+@pytest.mark.parametrize("pad", [-1, "npoints", "shuffled"])
+def test_staged_gather_kernel(wlsqm, oracle, dim, order, Kn, n, pad):
+    """Index-based input of the shapes the staged kernel covers: a lane gathers its own case's neighbours (no LDS staging), everything
+    behind the fetch is the dense staged kernel.  Ragged neighbourhoods with scipy-style padding (-1 or npoints: never dereferenced),
+    point_index, knowns masks incl. stray high bits, both weightings, neighbour counts that are not multiples of the 8-neighbour
+    chunk or of 4 (index rows that are not 16-byte aligned), k-nearest-neighbour order and shuffled order (the speculation about the
+    largest distance refuted): same BITS as the dense staged kernel on the gathered rows, parity with the oracle, known DOFs untouched."""
+    import torch
+    import synth
+    import wlsqm.hip as whip
+    rng = np.random.default_rng(7 * Kn + n + dim)
+    no = K.NDOF[dim][order]
+    npts = 5000
+    S = synth.halton(npts, dim); F = synth.field(S)
+    pidx = rng.permutation(npts)[:n].astype(np.int32)
+    hoods = synth.knn(S, Kn, query=pidx).astype(np.int32)
+    # (ragged nk stays clear of the nearly determined systems: tests/test_gpu_parity.py::_tile_vs_lane)
+    nk = rng.integers(min(Kn, max(no + (15 if no >= 35 else 10), Kn // 3)), Kn + 1, n).astype(np.int32); nk[::3] = Kn
+    if pad == "shuffled":
+        for j in range(n):
+            hoods[j, :nk[j]] = rng.permutation(hoods[j, :nk[j]])
+    hp = hoods.copy()
+    hp[np.arange(Kn)[None, :] >= nk[:, None]] = npts if pad == "npoints" else -1
+    kn = rng.choice(np.array([0, 0, 1, 1 | (1 << (no - 1)), (1 << no) - 1, 1 << (no + 2)], np.int64), n)
+    wm = rng.choice(np.array([wlsqm.WEIGHT_UNIFORM, wlsqm.WEIGHT_CENTER], np.int32), n)
+    fi0 = rng.uniform(-1, 1, (n, no)); fi0[:, 0] = F[pidx]
+    fi = _t(fi0)
+    whip.fit_cloud_device(dim, order, _t(S), _t(F), _t(hp), fi, _t(nk), _t(kn), _t(wm), point_index=_t(pidx))
+    torch.cuda.synchronize()
+    assert whip.last_kernel() == ("quad-gather" if (dim, order) == (3, 4) else "stage-gather"), whip.last_kernel()
+    got = fi.cpu().numpy()
+    hc = np.where(np.arange(Kn)[None, :] < nk[:, None], hoods, 0).astype(np.int64)
+    xk, fk, xi = S[hc], F[hc], S[pidx]
+    known_true = np.array([[(int(k) >> a) & 1 for a in range(no)] for k in kn], bool)
+    assert np.array_equal(got[known_true], fi0[known_true]), "a known DOF was modified"
+    if Kn % 2 == 0:
+        fd = _t(fi0)
+        whip.fit_many_device(dim, order, _t(xk), _t(fk), _t(nk), _t(xi), fd, _t(kn), _t(wm))
+        torch.cuda.synchronize()
+        if whip.last_kernel() in ("stage", "quad"):              # (2D order 2 below 32 neighbours: the dense path keeps its tile kernel)
+            assert np.array_equal(got.view(np.int64), fd.cpu().numpy().view(np.int64)), "index-based and dense staged kernels differ"
+    orders = np.full(n, order, np.int32)
+    ref = fi0.copy()
+    oracle.fit_many(dim, xk, fk, nk, xi, ref, None, 0, orders, kn, wm, ntasks=8)
+    truth = P.truth_fit(dim, xk, fk, nk, xi, fi0, orders, kn, wm)
+    if n >= 64:
+        P.assert_parity(got, ref, truth, "gathering staged kernel, padding %s" % pad)
+    else:
+        E = P.column_metric(got, ref); N = P.column_metric(ref, truth)
+        assert np.all(E <= 1e-10 + 25.0 * 8.0 * N), (E, N)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Index-based (S, F, hoods) against dense (xk, fk) input of the same fits, ms per launch (HIP events), points in Morton order
 (TIME_CLOUD_MORTON=0: Halton order, every gather a cache miss):
-python tools/time_cloud.py [ncases]   — 2D order 4 at K = 32 / 48 / 64 (F known, C3's mask) and 3D order 2 at K = 40."""
+python tools/time_cloud.py [ncases] [dim.order.K,...]   — default: 2D order 4 at K = 32 / 48 / 64 (F known, C3's mask) and 3D order 2 at K = 40."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -14,9 +14,15 @@ from wlsqm.hip import _ndofs
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
     dev = torch.device("cuda", 0)
-    shapes = [("C3", 32), ("C3", 48), ("C3", 64), ("C5", 40)]
-    for name, K in shapes:
+    shapes = [("C3", 32, None), ("C3", 48, None), ("C3", 64, None), ("C5", 40, None)]
+    if len(sys.argv) > 2:                                     # "dim.order.K,..." e.g. 3.3.40,3.4.64,2.2.24
+        shapes = []
+        for tok in sys.argv[2].split(","):
+            d, o, K = (int(x) for x in tok.split("."))
+            shapes.append(("C5" if d == 3 else "C3" if o == 4 else "C2", K, o))
+    for name, K, order_override in shapes:
         cfg = dict(bench.CONFIGS[name]); cfg["nk"] = K
+        if order_override is not None: cfg["order"] = order_override
         dim, order = cfg["dim"], cfg["order"]
         S, F, hoods = bench.build_problem(cfg, n, 0)
         if os.environ.get("TIME_CLOUD_MORTON", "1") == "1":      # points along a space-filling curve: the gathers of a tile hit L2
