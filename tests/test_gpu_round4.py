@@ -347,7 +347,7 @@ def test_staged_gather_kernel(wlsqm, oracle, dim, order, Kn, n, pad):
     ref = fi0.copy()
     oracle.fit_many(dim, xk, fk, nk, xi, ref, None, 0, orders, kn, wm, ntasks=8)
     truth = P.truth_fit(dim, xk, fk, nk, xi, fi0, orders, kn, wm)
-    if n >= 64:
+    if n >= 500:                                                 # (the max-over-cases statistics of assert_parity want a sample: 65 cases of 35 unknowns on 50 neighbours are not one)
         P.assert_parity(got, ref, truth, "gathering staged kernel, padding %s" % pad)
     else:
         E = P.column_metric(got, ref); N = P.column_metric(ref, truth)
