@@ -751,7 +751,7 @@ def measure_cloud(name, cfg, n, dev, timer, steps, warmup, rank):
                         "note": "index-based bytes (4 nk + 8 (dim+1) + 8 no + 20 per fit): not an HBM-bound kernel — the 8 nk (dim+1) "
                                 "bytes per fit of neighbour rows are gathered from the point tables through L2 (gather_rate_GBps)"}}
     if rank == 0:
-        # the same cases as dense rows through the dense kernel of the shape: the gather ring is the dense ring once it is filled
+        # the same cases as dense rows through the dense kernel of the shape: the gathering kernel is the dense one behind its fetch
         m = min(n, 4096)
         hh = h_d[:m].long()
         fa = torch.zeros((m, no), dtype=torch.float64, device=dev); fa[:, 0] = F_d[:m]
@@ -801,7 +801,7 @@ def side_configs(a, dev, timer, rank, parity):
         line = run_sharded(b, dev, None, rank, 1, timer, parity)
         return {k: line[k] for k in ("config", "steps", "ms_per_step", "value", "roofline", "sharded", "parity") if k in line}
     add("C5-sharded@2M-per-rank", sharded)
-    # index-based input of configs[2]'s shape (the one-kernel gather ring); last, so that the order of the earlier entries is the one
+    # index-based input of configs[2]'s shape (the gathering form of the staged kernel); last, so that the order of the earlier entries is the one
     # of the earlier rounds' records
     add("C3-indexed@1M", lambda: measure_cloud("C3", CONFIGS["C3"], 1_000_000, dev, timer, short["steps"], short["warmup"], rank))
     return side
