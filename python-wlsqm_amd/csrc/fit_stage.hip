@@ -69,6 +69,10 @@ template <int DIM, int ORDER, int PART = 0, bool GATHER = false>
 __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER) <= 10 ? WLSQM_STAGE_MINW10 : 1)) void fit_stage_kernel(const KParams p) {
     using namespace stage;
     constexpr int NO = ndofs(DIM, ORDER), NE = NO * (NO + 1) / 2, NM = mom_count<DIM>(2 * ORDER);
+#ifndef WLSQM_STAGE_CH10
+#define WLSQM_STAGE_CH10 8          // neighbours per staged chunk of the systems with 7 .. 10 unknowns (A/B: with 4 and two waves per SIMD the loops still spill — configs[4] 0.74-0.87 against 0.32 ms; 4 at one wave: 0.338: profiles/r04z_ab_c5_two_waves.txt)
+#endif
+    constexpr int CH = (NO > 6 && NO <= 10) ? WLSQM_STAGE_CH10 : stage::CH;
     static_assert(mom_count<DIM>(ORDER) == NO, "one right-hand-side moment per DOF");
     constexpr int XPC = CH * DIM * 8 / 16, FPC = CH * 8 / 16;        // 16-byte pieces of one case's chunk: coordinates, values
     constexpr int XPITCH = CH * DIM + 2, FPITCH = CH + 2;            // doubles per staged row (+ 16 bytes: conflict-free b128 reads)
@@ -162,10 +166,12 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER)
     auto gather = [&](int q) __attribute__((always_inline)) {
         if constexpr (GATHER) {
             int idx[CH];
-            if (rows16 && (q + 1) * CH <= K) {                        // whole chunk, 16-byte aligned index rows: two loads
+            if (CH == 8 && rows16 && (q + 1) * CH <= K) {             // whole chunk, 16-byte aligned index rows: two loads
                 typedef int i4_ __attribute__((ext_vector_type(4)));
                 const i4_ a = *reinterpret_cast<const i4_*>(hrow + q * CH), b = *reinterpret_cast<const i4_*>(hrow + q * CH + 4);
-                idx[0] = a.x; idx[1] = a.y; idx[2] = a.z; idx[3] = a.w; idx[4] = b.x; idx[5] = b.y; idx[6] = b.z; idx[7] = b.w;
+                const int both[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+                for (int ks = 0; ks < CH; ++ks) idx[ks] = both[ks < 8 ? ks : 7];
             } else {
 #pragma unroll
                 for (int ks = 0; ks < CH; ++ks) { const int k = q * CH + ks; idx[ks] = hrow[k < K ? k : K - 1]; }
@@ -239,7 +245,10 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER)
 #ifndef WLSQM_STAGE_OUTER3D
 #define WLSQM_STAGE_OUTER3D 1
 #endif
-                        if constexpr (DIM == 3 && ORDER >= 3 && WLSQM_STAGE_OUTER3D) accumulate_moments_outer3d<ORDER, PART>(mu, nu, d, w, f);
+#ifndef WLSQM_STAGE_OUTER3D_FROM
+#define WLSQM_STAGE_OUTER3D_FROM 3
+#endif
+                        if constexpr (DIM == 3 && ORDER >= WLSQM_STAGE_OUTER3D_FROM && WLSQM_STAGE_OUTER3D) accumulate_moments_outer3d<ORDER, PART>(mu, nu, d, w, f);
                         else accumulate_moments_best<DIM, ORDER>(mu, nu, d, w, f);
                     }
                 }
@@ -557,7 +566,11 @@ int launch_quad_solve(const KParams& p, hipStream_t stream);          // fit_qua
 // (1 600 bytes per case, stream-ordered) at 1.7 GB.
 template <bool GATHER = false>
 static int launch_stage34(const KParams& p, hipStream_t stream) {
-    const long long SLICE = 1LL << 20;
+    long long SLICE = 1LL << 20;
+    if (const char* e = getenv("WLSQM_HIP_QUAD_SLICE")) {             // (tests: small slices; whole 64-case groups)
+        const long long v = atoll(e);
+        if (v >= 64) SLICE = v / 64 * 64;
+    }
     for (long long j0 = 0; j0 < p.ncases; j0 += SLICE) {
         KParams q = slice_cases(p, j0, p.ncases - j0 < SLICE ? p.ncases - j0 : SLICE);
         const long long groups = (q.ncases + 63) / 64;

@@ -352,3 +352,33 @@ def test_staged_gather_kernel(wlsqm, oracle, dim, order, Kn, n, pad):
     else:
         E = P.column_metric(got, ref); N = P.column_metric(ref, truth)
         assert np.all(E <= 1e-10 + 25.0 * 8.0 * N), (E, N)
+
+
+def test_3d_order4_slices_give_the_same_bits(wlsqm, monkeypatch):
+    """3D order 4 runs in slices that bound the moment workspace (1M cases by default); a sliced launch must reproduce the unsliced one
+    bit for bit — dense and index-based input, a batch that is not a multiple of the slice or of the 64-case groups."""
+    import torch
+    import synth
+    import wlsqm.hip as whip
+    rng = np.random.default_rng(5)
+    n, Kn, npts = 3000 + 37, 48, 6000
+    S = synth.halton(npts, 3); F = synth.field(S)
+    pidx = rng.permutation(npts)[:n].astype(np.int32)
+    hoods = synth.knn(S, Kn, query=pidx).astype(np.int32)
+    nk = np.full(n, Kn, np.int32); kn = rng.choice(np.array([0, 1], np.int64), n); wm = np.full(n, wlsqm.WEIGHT_CENTER, np.int32)
+    fi0 = np.zeros((n, 35)); fi0[:, 0] = F[pidx]
+    hl = hoods.astype(np.int64)
+    args_d = (_t(S[hl]), _t(F[hl]), _t(nk), _t(S[pidx]))
+
+    def both():
+        fa, fb = _t(fi0), _t(fi0)
+        whip.fit_many_device(3, 4, *args_d, fa, _t(kn), _t(wm)); assert whip.last_kernel() == "quad"
+        whip.fit_cloud_device(3, 4, _t(S), _t(F), _t(hoods), fb, _t(nk), _t(kn), _t(wm), point_index=_t(pidx)); assert whip.last_kernel() == "quad-gather"
+        torch.cuda.synchronize()
+        return fa.cpu().numpy(), fb.cpu().numpy()
+    a0, b0 = both()
+    monkeypatch.setenv("WLSQM_HIP_QUAD_SLICE", "1024")
+    a1, b1 = both()
+    assert np.array_equal(a0.view(np.int64), a1.view(np.int64)) and np.array_equal(b0.view(np.int64), b1.view(np.int64))
+    assert np.array_equal(a0.view(np.int64), b0.view(np.int64))
+    assert np.isfinite(a0).all()
