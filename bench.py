@@ -635,7 +635,7 @@ def _sig(x, nd=4):
         return x
 
 
-COMPACT_LIMIT = 1500        # bytes: the driver keeps a 2 KB tail of stdout and parses its last line
+COMPACT_LIMIT = 1750        # bytes: the driver keeps a 2 KB tail of stdout and parses its last line
 
 
 def compact_line(full, full_path=None):
@@ -693,7 +693,10 @@ def compact_line(full, full_path=None):
     for k, v in optional:
         out[k] = v
     drop = [k for k, _ in optional][::-1]
-    while len(json.dumps(out, separators=(",", ":"))) > COMPACT_LIMIT and drop:
+    size = lambda: len(json.dumps(out, separators=(",", ":")))
+    while size() > COMPACT_LIMIT and isinstance(out.get("configs_summary"), dict) and len(out["configs_summary"]) > 6:
+        out["configs_summary"].popitem()                              # the newest side lines go first; the BASELINE configs lead the dict
+    while size() > COMPACT_LIMIT and drop:
         out.pop(drop.pop(0), None)
     return out
 
@@ -804,7 +807,34 @@ def side_configs(a, dev, timer, rank, parity):
     # index-based input of configs[2]'s shape (the gathering form of the staged kernel); last, so that the order of the earlier entries is the one
     # of the earlier rounds' records
     add("C3-indexed@1M", lambda: measure_cloud("C3", CONFIGS["C3"], 1_000_000, dev, timer, short["steps"], short["warmup"], rank))
+    # 3D orders 3 and 4 (20 / 35 unknowns; round 4: the staged kernel with LDS rows / moments + the four-lanes-per-case solve), with a
+    # sample of the batch checked against the CPU port as in the sharded line (no reference golden at these shapes)
+    for key, order, cn in (("3Do3@1M", 3, 1_000_000), ("3Do4@400k", 4, 400_000)):
+        cfg = dict(CONFIGS["C5"], order=order, desc="3D order-%d, Halton, 40 neighbours, WEIGHT_CENTER, all DOFs unknown" % order)
+        add(key, lambda key=key, cfg=cfg, cn=cn: measure_extra_shape(key, cfg, cn, dev, timer, short["steps"], short["warmup"], rank, parity))
     return side
+
+
+def measure_extra_shape(name, cfg, n, dev, timer, steps, warmup, rank, parity):
+    """measure_fit for a shape outside BASELINE's configs; the first 1 024 cases of the batch against the CPU port (checker only)."""
+    res, dt = measure_fit(name, cfg, n, dev, timer, steps, warmup, rank, False, keep=True)
+    t = res.pop("_tensors")
+    if parity and rank == 0:
+        from oracle import oracle
+        m = 1024
+        dim, order, no = cfg["dim"], cfg["order"], NDOF[cfg["dim"]][cfg["order"]]
+        xk, fk, xi = (t[k][:m].cpu().numpy() for k in ("xk", "fk", "xi"))
+        got = t["fi"][:m].cpu().numpy()
+        ref = np.zeros((m, no)); ref[:, 0] = t["F"][:m]
+        oracle.fit_many(dim, xk, fk, np.full(m, cfg["nk"], np.int32), xi, ref, None, 0, np.full(m, order, np.int32),
+                        np.full(m, cfg["knowns"], np.int64), np.full(m, cfg["wm"], np.int32), ntasks=8)
+        scale = np.abs(ref).max(axis=0)
+        E = np.abs(got - ref).max(axis=0) / np.where(scale > 0, scale, 1.0)
+        res["parity"] = {"vs_oracle": {"cases": m, "E_max": float(E.max()), "columns": int(no), "columns_le_1e-8": int((E <= 1e-8).sum()),
+                                       "note": "column metric max_j |fi - fi_oracle| / max_j |fi_oracle| on the first 1 024 cases; fast mode "
+                                               "(moment form, unpivoted LDL^T) against the port's Ruiz-scaled pivoted LU"}}
+    del t
+    return res, dt
 
 
 def main():
