@@ -42,6 +42,7 @@ int launch_fit_chunk_refine(int dimension, int order, const KParams& p, long lon
 int launch_fit_sens(int dimension, int order, const KParams& p, long long K, hipStream_t stream, bool* handled);
 int launch_fit_strict(int dimension, int order, const KParams& p, const StrictDebug* dbg, hipStream_t stream);
 int launch_fit_stage(int dimension, int order, const KParams& p, long long K, hipStream_t stream, bool* handled);
+int launch_fit_stage_refine(int dimension, int order, const KParams& p, long long K, hipStream_t stream, bool* handled);
 
 // Numerics mode of the calling thread: 0 = the fast kernels, 1 = reference-order arithmetic (fit_strict.hip), 2 = accurate
 // (fit_accurate.hip: reference-order arithmetic with the normal matrix assembled from its upper triangle).  The first use on a
@@ -186,6 +187,8 @@ int launch_fit(int dimension, int order, const KParams& p_in, long long max_nk, 
     }
     bool handled = false;
     int rc = launch_fit_stage(dimension, order, p, max_nk, stream, &handled);     // one lane per case, rows staged through LDS (round 4)
+    if (rc != WLSQM_OK || handled) return rc;
+    rc = launch_fit_stage_refine(dimension, order, p, max_nk, stream, &handled);  // the same mapping with the refinement sweeps (fit_stage_iter.hip)
     if (rc != WLSQM_OK || handled) return rc;
     rc = launch_fit_ring(dimension, order, p, max_nk, stream, &handled);          // one-kernel fit of the 15-unknown systems
     if (rc != WLSQM_OK || handled) return rc;

@@ -1,0 +1,444 @@
+// fit_stage_iter.hip — fit + ITERATIVE REFINEMENT with ONE LANE PER CASE (round 4): solve_iterative of the reference
+// (impl.pyx:986-1083: fit, then sweeps of  residual at the neighbours -> correction with the same factor -> stop when two successive
+// residual norms are equal, impl.pyx:1057) on the mapping of fit_stage.hip.
+//
+// Reference path (file:line in /root/reference): make_c_nD impl.pyx:286-432 / 70-269, Case_make_weights infra.pyx:668-702, make_A
+// impl.pyx:566-602, solve with knowns elimination impl.pyx:731-846, the Taylor evaluation of the model polyeval.pyx:82-951,
+// solve_iterative impl.pyx:986-1083 (return value: for / else, :1080-1081).
+//
+// Why.  The refinement kernels so far gave a case to FOUR lanes of a 16-case tile (fit_tilek.hip, fit_chunk.hip ITER): every lane of
+// a case repeats the case's substitution, a sweep ends in a butterfly over the four lanes, the neighbours of a lane come in runs
+// of two with a 15-deep dependent chain each for a lone wave per SIMD, and the fit in front of the sweeps is the slow chunked one
+// (0.62 ms per 400k configs[2] cases against the staged kernel's 0.16).  With one lane per case there is one substitution per case and
+// sweep, nothing to reduce, and GRP independent neighbours in flight per lane.  The factor (up to 120 entries) stays in the lane's
+// registers between the sweeps.
+//
+// Where the rows are during the sweeps (the kernel reads them max_iter + 1 times):
+//   RESIDENT   the wave's 64 rows fit LDS three times per CU (64 (K (DIM + 1) + 4) 8 bytes <= 53 KB: configs[1], 32 neighbours): they are
+//              staged ONCE, whole, and every pass — largest distance, moments, sweeps — reads LDS; no speculation needed.
+//   otherwise  every pass re-stages the rows in 8-neighbour chunks exactly as fit_stage.hip does (the chunks of a wave are 50-100 KB
+//              that were read a few microseconds ago: they come back from L2 / the Infinity Cache, not from HBM).  The moment pass is
+//              speculative as there (largest squared distance = the last neighbour's, verified bit for bit, repeated otherwise).
+// One sum per moment / per right-hand-side entry over k DESCENDING in one lane (the order of fit_stage.hip): the fit in front of
+// the sweeps has the bits of the staged kernel's generic solve.
+#include <atomic>
+#include <type_traits>
+
+#include "wlsqm_internal.hpp"
+#include "wlsqm_kernels.hpp"
+#include "wlsqm_moments.hpp"
+
+#ifndef WLSQM_SITER_GRP
+#define WLSQM_SITER_GRP 4           // neighbours of a lane in flight in the moment pass and in a sweep
+#endif
+
+namespace wlsqm {
+
+namespace siter {
+typedef double d2_ __attribute__((ext_vector_type(2)));
+constexpr int CH = 8;               // neighbours per staged chunk
+__host__ __device__ constexpr int sens_group(int no) { return no <= 6 ? 4 : 2; }       // neighbours per sens tile: at most 16 pieces of 16 bytes per case
+__host__ __device__ constexpr int pitch2(int doubles) {               // row pitch in 16-byte units: odd, so that 16 lanes' b128 reads hit 16 different slots
+    const int h = (doubles + 1) / 2;
+    return (h % 2) ? h : h + 1;
+}
+}
+
+// SENS: the sensitivities d fi[a] / d fk[k] as well (impl.pyx:776-778, 821-846: one substitution per neighbour with the kept factor),
+// in one more pass over the rows between the fit and the sweeps.  A lane's G x NO results per group of G neighbours are G NO
+// consecutive doubles of ITS case's sens block: they leave through an LDS tile, one case per store instruction (G NO 8 contiguous
+// bytes), instead of 64 lanes storing 8 bytes each at a pitch of K NO 8 bytes.
+template <int DIM, int ORDER, bool RESIDENT, bool SENS>
+__global__ __launch_bounds__(64, (!RESIDENT && !SENS && ndofs(DIM, ORDER) <= 6) ? 2 : 1) void fit_stage_refine_kernel(const KParams p, const int XP2r, const int FP2r) {
+    using namespace siter;
+    constexpr int NO = ndofs(DIM, ORDER), NE = NO * (NO + 1) / 2, NM = mom_count<DIM>(2 * ORDER);
+    constexpr int SG = sens_group(NO), SR = SG * NO / 2, TP2 = pitch2(SG * NO);      // neighbours per sens tile; 16-byte pieces of a case's tile; tile pitch
+    constexpr int TILE2 = SENS ? 64 * TP2 : 0;
+    constexpr int XPC = CH * DIM * 8 / 16, FPC = CH * 8 / 16;        // 16-byte pieces of one case's chunk: coordinates, values
+    constexpr int XCPI = 64 / XPC, XNI = (64 + XCPI - 1) / XCPI;      // whole cases per load instruction; instructions per chunk
+    constexpr int FCPI = 64 / FPC, FNI = 64 / FCPI;
+    constexpr int GRP = WLSQM_SITER_GRP < CH ? WLSQM_SITER_GRP : CH;
+    constexpr int XP2s = pitch2(CH * DIM), FP2s = pitch2(CH);         // chunk staging pitches (not RESIDENT)
+    constexpr int STAGE2 = 64 * XP2s + 64 * FP2s, OUT2 = 64 * NO / 2;
+    constexpr int ROWS2s = STAGE2 > OUT2 ? STAGE2 : OUT2;
+    __shared__ __attribute__((aligned(16))) d2_ lds_s[RESIDENT ? 1 : ROWS2s + TILE2];
+    extern __shared__ __attribute__((aligned(16))) d2_ lds_d[];
+    d2_* const lds = RESIDENT ? lds_d : lds_s;
+    const int XP2 = RESIDENT ? XP2r : XP2s, FP2 = RESIDENT ? FP2r : FP2s;
+    d2_* const xs = lds;
+    d2_* const fs = lds + 64 * XP2;
+    d2_* const tile2 = lds + (RESIDENT ? 64 * (XP2 + FP2) : ROWS2s);      // (SENS) behind the rows
+
+    const int lane = threadIdx.x;
+    const long long t0 = (long long)blockIdx.x * 64, t = t0 + lane;
+    const int nvalid = (p.ncases - t0 < 64) ? (int)(p.ncases - t0) : 64;      // wave-uniform
+    const bool valid = lane < nvalid;
+    const long long j = valid ? t : t0 + nvalid - 1;                          // tail lanes replay the last case (never stored)
+    const int K = (int)p.max_nk;
+    const int nkc = min(p.nk[j * p.snk], K);
+    const bool uniform = (p.wm[j * p.swm] == WLSQM_WEIGHT_UNIFORM);
+    unsigned long long known, dropped;
+    effective_mask<NO>(p.knowns[j * p.sknowns], known, dropped);
+    double xi[DIM];
+#pragma unroll
+    for (int m = 0; m < DIM; ++m) xi[m] = p.xi[j * p.sxi_j + m];
+    const int Q = (K + CH - 1) / CH;
+
+    auto sqdist = [&](const double (&d)[DIM]) {
+        double d2 = d[0] * d[0];
+#pragma unroll
+        for (int m = 1; m < DIM; ++m) d2 = fma(d[m], d[m], d2);
+        return d2;
+    };
+
+    // ---- staging (fit_stage.hip): a load instruction moves the chunks of XCPI (FCPI) whole cases, XPC (FPC) consecutive lanes per case
+    const int xsub = lane % XPC, xc0 = lane / XPC, fsub = lane % FPC, fc0 = lane / FPC;
+    const unsigned xrowb = (unsigned)K * DIM * 8, frowb = (unsigned)K * 8;
+    const bool xlane = lane < XCPI * XPC;
+    const char* const xtile = reinterpret_cast<const char*>(p.xk + t0 * (long long)K * DIM);
+    const char* const ftile = reinterpret_cast<const char*>(p.fk + t0 * (long long)K);
+    d2_ xr[XNI], fr[FNI];
+    auto fetch = [&](int q) __attribute__((always_inline)) {
+        unsigned xo = (unsigned)q * (CH * DIM * 8) + (unsigned)xsub * 16u, fo = (unsigned)q * (CH * 8) + (unsigned)fsub * 16u;
+        xo = xo < xrowb ? xo : xrowb - 16u; fo = fo < frowb ? fo : frowb - 16u;      // (rows are multiples of 16 bytes: K even)
+        const char* xb = xtile + xo;
+        const char* fb = ftile + fo;
+#pragma unroll
+        for (int i = 0; i < XNI; ++i) {
+            int cc = xc0 + i * XCPI;
+            cc = cc < nvalid ? cc : nvalid - 1;                       // tail group / idle lanes of the last instruction: replay a valid row
+            if (xlane) xr[i] = *reinterpret_cast<const d2_*>(xb + (size_t)(unsigned)cc * xrowb);
+        }
+#pragma unroll
+        for (int i = 0; i < FNI; ++i) {
+            int cc = fc0 + i * FCPI;
+            cc = cc < nvalid ? cc : nvalid - 1;
+            fr[i] = *reinterpret_cast<const d2_*>(fb + (size_t)(unsigned)cc * frowb);
+        }
+    };
+    auto park = [&](int q) __attribute__((always_inline)) {           // RESIDENT: chunk q at its place in the whole row
+        d2_* xl = xs + xc0 * XP2 + xsub + (RESIDENT ? q * (CH * DIM / 2) : 0);
+        d2_* fl = fs + fc0 * FP2 + fsub + (RESIDENT ? q * (CH / 2) : 0);
+#pragma unroll
+        for (int i = 0; i < XNI; ++i)
+            if (xlane && (i * XCPI + XCPI <= 64 || xc0 + i * XCPI < 64)) xl[i * XCPI * XP2] = xr[i];
+#pragma unroll
+        for (int i = 0; i < FNI; ++i) fl[i * FCPI * FP2] = fr[i];
+    };
+    const d2_* const xrow = xs + lane * XP2;
+    const d2_* const frow = fs + lane * FP2;
+
+    // One pass over the neighbours, chunks LAST FIRST (descending k, the order of fit_stage.hip).  body(d, f, live, k) per neighbour,
+    // after_group(k0) behind every group of GRP neighbours k0 .. k0 + GRP - 1.
+    // Not RESIDENT: the chunks travel through the staging rows; warm: chunk Q - 1 is parked and chunk Q - 2 in flight.
+    // RESIDENT and !fill: everything is in LDS.  RESIDENT and fill: the first pass, which parks the chunks at their places.
+    auto for_neighbours = [&](auto masked_tag, auto grp_tag, auto body, auto after_group, const bool fill, const bool warm) __attribute__((always_inline)) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        constexpr int GRP = decltype(grp_tag)::value;                 // neighbours of a lane in flight
+        const bool staged = !RESIDENT || fill;
+        if (staged && !warm) fetch(Q - 1);
+        for (int q = Q - 1; q >= 0; --q) {
+            if (staged && !(warm && q == Q - 1)) {
+                if (!RESIDENT) __syncthreads();                       // the previous chunk has been read by every lane
+                park(q);
+                __syncthreads();
+                if (q > 0) fetch(q - 1);
+            }
+            const d2_* xq = xrow + (RESIDENT ? q * (CH * DIM / 2) : 0);
+            const d2_* fq = frow + (RESIDENT ? q * (CH / 2) : 0);
+#pragma unroll
+            for (int g = CH / GRP - 1; g >= 0; --g) {
+                double xv[GRP * DIM], fv[GRP];
+                static_assert(GRP % 2 == 0 || (GRP == 1 && DIM == 2), "whole 16-byte pieces per group");
+#pragma unroll
+                for (int i = 0; i < GRP * DIM / 2; ++i) { const d2_ v = xq[g * (GRP * DIM / 2) + i]; xv[2 * i] = v.x; xv[2 * i + 1] = v.y; }
+                if constexpr (GRP == 1) { const d2_ v = fq[g / 2]; fv[0] = (g & 1) ? v.y : v.x; }
+#pragma unroll
+                for (int i = 0; i < GRP / 2; ++i) { const d2_ v = fq[g * (GRP / 2) + i]; fv[2 * i] = v.x; fv[2 * i + 1] = v.y; }
+#pragma unroll
+                for (int kk = GRP - 1; kk >= 0; --kk) {
+                    const int ks = g * GRP + kk;
+                    const bool live = MASKED ? (q * CH + ks < nkc) : true;
+                    double d[DIM];
+#pragma unroll
+                    for (int m = 0; m < DIM; ++m) { d[m] = xv[kk * DIM + m] - xi[m]; if (MASKED) d[m] = live ? d[m] : 0.0; }
+                    body(d, MASKED ? (live ? fv[kk] : 0.0) : fv[kk], live, q * CH + ks);
+                }
+                __builtin_amdgcn_sched_barrier(0);                    // GRP neighbours in flight at a time
+                after_group(q * CH + g * GRP);
+            }
+        }
+    };
+    const bool full = (K % CH == 0) && __all(nkc >= K);               // wave-uniform: no ragged case in this group, whole chunks
+    auto no_hook = [](int) __attribute__((always_inline)) {};
+    auto pass = [&](auto body, const bool fill, const bool warm) __attribute__((always_inline)) {
+        if (full) for_neighbours(std::false_type{}, std::integral_constant<int, GRP>{}, body, no_hook, fill, warm);
+        else for_neighbours(std::true_type{}, std::integral_constant<int, GRP>{}, body, no_hook, fill, warm);
+    };
+
+    // ---- the fit: largest squared distance, moments
+    double mu[NM], nu[NO];
+    double max_d2 = 0.0, inv_max = 0.0;
+    auto max_body = [&](const double (&d)[DIM], double, bool, int) __attribute__((always_inline)) {
+        const double d2 = sqdist(d);
+        max_d2 = d2 > max_d2 ? d2 : max_d2;                           // (a masked slot contributes 0)
+    };
+    auto mom_body = [&](const double (&d)[DIM], double f, bool live, int) __attribute__((always_inline)) {
+        const double d2 = sqdist(d);
+        max_d2 = d2 > max_d2 ? d2 : max_d2;
+        double w = weight(d2, inv_max, uniform);
+        w = live ? w : 0.0;
+        accumulate_moments_best<DIM, ORDER>(mu, nu, d, w, f);
+    };
+    auto moments = [&](const double maxv) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < NM; ++e) mu[e] = 0.0;
+#pragma unroll
+        for (int a = 0; a < NO; ++a) nu[a] = 0.0;
+        max_d2 = 0.0;
+        inv_max = inverse_max(maxv);
+        pass(mom_body, false, false);
+    };
+    if constexpr (RESIDENT) {
+        pass(max_body, true, false);
+        moments(max_d2);
+    } else {
+        // speculative (fit_stage.hip): the last neighbour is the farthest for sorted neighbour lists; verified bit for bit
+        double guess = 0.0;
+        if (nkc > 0) {
+            const double* q = p.xk + j * (long long)K * DIM + (long long)(nkc - 1) * DIM;
+            double dg[DIM];
+#pragma unroll
+            for (int m = 0; m < DIM; ++m) dg[m] = q[m] - xi[m];
+            guess = sqdist(dg);
+        }
+        moments(guess);
+        if (!__all(uniform || max_d2 == guess)) moments(max_d2);
+    }
+
+    // ---- solve: masked full system, unpivoted LDL^T; the factor stays
+    constexpr unsigned long long FULL = (1ull << NO) - 1ull;
+    double* const fio = p.fi + j * p.sfi_j;
+    double M[NE], fi[NO];
+    {
+        double g[NO], val[NO];
+        expand_moments<DIM, ORDER>(mu, nu, M, g);
+#pragma unroll
+        for (int a = 0; a < NO; ++a) val[a] = (((known & ~dropped) >> a) & 1ull) ? fio[a] : 0.0;
+        eliminate_knowns<NO>(M, g, known, val);
+        ldlt_factor<NO>(M);
+        ldlt_solve<NO>(M, g);
+#pragma unroll
+        for (int a = 0; a < NO; ++a) fi[a] = ((known >> a) & 1ull) ? (((dropped >> a) & 1ull) ? fio[a] : val[a]) : g[a];
+    }
+
+    // ---- sensitivities (impl.pyx:776-778, 821-823, 831-846): sens[k, a] = d fi[a] / d fk[k] for k < nk; NaN in the columns of the
+    // true knowns; a dropped DOF's column, the rows from nk on and the cases with every DOF known are not written (fit_lane.hip)
+    if constexpr (SENS) {
+        static_assert(SR <= 16 && (SG * NO) % 2 == 0 && CH % SG == 0, "a case's tile is at most 16 pieces of 16 bytes");
+        const int lim = (valid && known != FULL) ? nkc : 0;           // rows of this lane's case that are written
+        // Cooperative stores (wave-uniform): rows of NO contiguous doubles, 16-byte aligned case blocks, no dropped DOF in the wave.
+        // The SG x NO results of a lane go to its row of the LDS tile; then SIXTEEN lanes store one case's SG NO 8 contiguous bytes,
+        // four cases per instruction.  Otherwise every lane stores its own 8-byte results (any strides).
+        const bool coop = p.ss_k == NO && (p.ss_j % 2) == 0 && ((reinterpret_cast<uintptr_t>(p.sens) & 15u) == 0) && __all(dropped == 0ull);
+        const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+        double* const trow = reinterpret_cast<double*>(tile2 + lane * TP2);
+        double* const srow = p.sens + j * p.ss_j;
+        auto sens_body = [&](const double (&d)[DIM], double, bool, int k) __attribute__((always_inline)) {
+            double cc[NO], sv[NO];
+            const double d2 = monomials<DIM, ORDER>(d, cc);
+            const double w = weight(d2, inv_max, uniform);
+#pragma unroll
+            for (int a = 0; a < NO; ++a) sv[a] = ((known >> a) & 1ull) ? 0.0 : ((a == 0) ? w : w * cc[a]);
+            ldlt_solve<NO>(M, sv);
+            if (coop) {
+#pragma unroll
+                for (int a = 0; a < NO; ++a) trow[(k % SG) * NO + a] = ((known >> a) & 1ull) ? qnan : sv[a];
+            } else if (k < lim) {
+#pragma unroll
+                for (int a = 0; a < NO; ++a) {
+                    if (!((known >> a) & 1ull)) srow[k * p.ss_k + a] = sv[a];
+                    else if (!((dropped >> a) & 1ull)) srow[k * p.ss_k + a] = qnan;
+                }
+            }
+        };
+        const int sc = lane / 16, e2 = lane % 16;                     // this lane's case of an instruction's four, its piece of the case's tile
+        const int r0 = (2 * e2) / NO, r1 = (2 * e2 + 1) / NO;         // tile rows of the piece's two doubles
+        const unsigned voff = (unsigned)sc * (unsigned)(p.ss_j * 8) + (unsigned)e2 * 16u;
+        // (the 15-unknown systems take one neighbour at a time: two of them — 60 registers beside the 240 of the factor — spilled 350)
+        constexpr int SGRP = NO >= 15 ? 1 : SG;
+        auto flush = [&](const int k0) __attribute__((always_inline)) {
+            if (!coop || (k0 % SG) != 0) return;
+            __syncthreads();                                          // the tile is written
+            const bool allrows = __all(lim >= k0 + SG || !valid);
+            char* const base = reinterpret_cast<char*>(p.sens + t0 * p.ss_j + (long long)k0 * NO);
+#pragma unroll 4
+            for (int i = 0; i < 16; ++i) {
+                const int c = 4 * i + sc;
+                const d2_ v = tile2[c * TP2 + e2];
+                char* const dst = base + (size_t)i * 4u * (size_t)(p.ss_j * 8) + voff;
+                bool ok0 = e2 < SR && c < nvalid, ok1 = ok0;
+                if (!allrows) {
+                    const int n_ok = __shfl(lim, c, 64) - k0;         // rows of this tile that case c writes
+                    ok0 = ok0 && r0 < n_ok; ok1 = ok1 && r1 < n_ok;
+                }
+                // (plain stores instead measured mixed: 2D order 2 / 3 / 4, 3D order 2: 0.355 / 0.571 / 3.13 / 0.694 against 0.305 / 0.654 / 2.72 / 0.842 ms)
+                if (ok1) __builtin_nontemporal_store(v, reinterpret_cast<d2_*>(dst));
+                else if (ok0) __builtin_nontemporal_store(v.x, reinterpret_cast<double*>(dst));
+            }
+            __syncthreads();                                          // the tile is read
+        };
+        if (p.sens) {
+            if (full) for_neighbours(std::false_type{}, std::integral_constant<int, SGRP>{}, sens_body, flush, false, false);
+            else for_neighbours(std::true_type{}, std::integral_constant<int, SGRP>{}, sens_body, flush, false, false);
+        }
+    }
+
+    // ---- sweeps (impl.pyx:1016-1081)
+    bool done = !(valid && known != FULL);
+    bool broke = false;
+    int it_case = 0;
+    double prev_norm = -1.0;
+    for (int it = 0; it < (p.iterative ? p.max_iter : 0); ++it) {
+        if (__ballot(!done) == 0ull) break;                           // every case of the wave has stopped
+        double norm = 0.0, r[NO];
+#pragma unroll
+        for (int a = 0; a < NO; ++a) r[a] = 0.0;
+        auto sweep_body = [&](const double (&d)[DIM], double f, bool live, int) __attribute__((always_inline)) {
+            double cc[NO];
+            const double d2 = monomials<DIM, ORDER>(d, cc);
+            double w = weight(d2, inv_max, uniform);
+            w = live ? w : 0.0;
+            double model = fi[0];                                     // taylor_*D (polyeval.pyx): sum_a c[a] fi[a]
+#pragma unroll
+            for (int a = 1; a < NO; ++a) model = fma(cc[a], fi[a], model);
+            const double res = live ? f - model : 0.0;
+            const double ar = fabs(res);
+            norm = ar > norm ? ar : norm;                             // impl.pyx:1037-1041
+            const double wr = w * res;
+#pragma unroll
+            for (int a = 0; a < NO; ++a) r[a] = fma(wr, (a == 0) ? 1.0 : cc[a], r[a]);
+        };
+        pass(sweep_body, false, false);
+        if (!done) {
+            if (norm == prev_norm) { broke = true; done = true; it_case = it; }      // impl.pyx:1057
+            else {
+                prev_norm = norm;
+#pragma unroll
+                for (int a = 0; a < NO; ++a) if ((known >> a) & 1ull) r[a] = 0.0;    // knowns of the correction are 0
+                ldlt_solve<NO>(M, r);
+#pragma unroll
+                for (int a = 0; a < NO; ++a) if (!((known >> a) & 1ull)) fi[a] += r[a];
+            }
+        }
+    }
+    if (p.iterative && p.iters_out) {
+        int iters = (valid && known != FULL) ? (broke ? it_case : (p.max_iter > 0 ? p.max_iter : 1)) : 0;      // for / else, impl.pyx:1080-1081
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_xor(iters, off, 64); iters = o > iters ? o : iters; }
+        if (lane == 0 && iters > 0) atomicMax(p.iters_out, iters);
+    }
+
+    // ---- results (fit_stage.hip): a full group with contiguous fi rows leaves as ONE run of 64 NO doubles through LDS
+    const bool whole = nvalid == 64 && p.sfi_j == NO && ((reinterpret_cast<uintptr_t>(p.fi) & 15u) == 0) && (64 * NO) % 2 == 0 &&
+                       __all(dropped == 0ull && known != FULL);
+    if (whole) {
+        __syncthreads();                                              // the last pass has been read
+        double* const o = reinterpret_cast<double*>(lds);
+#pragma unroll
+        for (int a = 0; a < NO; ++a) o[lane * NO + a] = fi[a];        // (known DOFs: their own bits, Case_get_fi infra.pyx:780-795)
+        __syncthreads();
+        d2_* out = reinterpret_cast<d2_*>(p.fi + t0 * NO);
+#pragma unroll
+        for (int q = lane; q < 64 * NO / 2; q += 64) __builtin_nontemporal_store(lds[q], &out[q]);
+    } else if (valid && known != FULL) {
+#pragma unroll
+        for (int a = 0; a < NO; ++a)
+            if (!((known >> a) & 1ull)) fio[a] = fi[a];
+    }
+}
+
+template <int DIM, int ORDER>
+static int launch_stage_refine(const KParams& p, long long K, hipStream_t stream) {
+    using namespace siter;
+    const long long groups = (p.ncases + 63) / 64;
+    if (groups <= 0) return WLSQM_OK;
+    if (groups > 0x7fffffffLL) { set_error("fit_stage_refine: batch too large for one launch"); return WLSQM_EVALUE; }
+    if (p.do_sens) {
+        // (the rows are re-staged per pass: with the sens tile beside them whole rows would leave two waves per CU)
+        hipLaunchKernelGGL((fit_stage_refine_kernel<DIM, ORDER, false, true>), dim3((unsigned)groups), dim3(64), 0, stream, p, 0, 0);
+        WLSQM_HIP_CHECK(hipGetLastError());
+        note_kernel(p.iterative ? "stage-sens-refine" : "stage-sens");
+        return WLSQM_OK;
+    }
+    // whole rows in LDS when three waves per CU still fit (WLSQM_HIP_REFINE_RESIDENT_KB overrides the bound; 0: never)
+    const int Q = (int)((K + CH - 1) / CH);
+    const int XP2 = pitch2(Q * CH * DIM), FP2 = pitch2(Q * CH);
+    const size_t bytes = (size_t)64 * (XP2 + FP2) * 16;
+    size_t bound = 53 * 1024;
+    if (const char* e = getenv("WLSQM_HIP_REFINE_RESIDENT_KB")) bound = (size_t)atol(e) * 1024;
+    if (bound > 160 * 1024) bound = 160 * 1024;
+    if (bytes <= bound && bytes >= (size_t)64 * ndofs(DIM, ORDER) * 8) {
+        auto kern = fit_stage_refine_kernel<DIM, ORDER, true, false>;
+        static std::atomic<unsigned> optin{0};                        // per device, once: more than 64 KB of dynamic LDS
+        int dev = 0;
+        WLSQM_HIP_CHECK(hipGetDevice(&dev));
+        if (bytes > 64 * 1024 && dev >= 0 && dev < 32 && !((optin.load() >> dev) & 1u)) {
+            WLSQM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            optin.fetch_or(1u << dev);
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3(64), bytes, stream, p, XP2, FP2);
+        WLSQM_HIP_CHECK(hipGetLastError());
+        note_kernel("stage-refine-resident");
+        return WLSQM_OK;
+    }
+    hipLaunchKernelGGL((fit_stage_refine_kernel<DIM, ORDER, false, false>), dim3((unsigned)groups), dim3(64), 0, stream, p, 0, 0);
+    WLSQM_HIP_CHECK(hipGetLastError());
+    note_kernel("stage-refine");
+    return WLSQM_OK;
+}
+
+// Fits with refinement of dense contiguous batches with an even neighbour count (2D orders 2-4, 3D order 2); everything else keeps its
+// kernels.  WLSQM_HIP_STAGE_REFINE=0 disables it, =all sends every covered shape here (A/B).
+//
+// The SENS form (sensitivities, with or without refinement) is built, tested (tests/test_gpu_round4.py) and OFF: it only runs with
+// WLSQM_HIP_STAGE_SENS=all.  Measured (tools/time_sens.py, 400k cases, profiles/r04zb_time_sens.txt) against tile1-extras / the
+// inverse + MFMA path: 2D order 2 at 32 neighbours 0.305 against 0.249 ms, 2D order 3 at 30 0.654 against 0.519, 2D order 4 at 64
+// 2.72 against 1.43, 3D order 2 at 40 0.842 against 0.658; with refinement in the same launch (200k cases) 0.43 / 0.63 / 2.23 / 0.86
+// against 0.24 / 0.50 / 2.26 (lane) / 0.62.  One substitution per neighbour and lane is NO^2 dependent multiply-adds through a factor
+// that lives half in the accumulation registers (2D order 4: 37 of its 120 entries in scratch as well), and a lane's results must
+// cross the wave through LDS before they can leave as contiguous runs; the matrix cores do the same NO x NO by NO x K product on
+// the inverse at 2 147 GB/s of sens rows.
+//
+// Refinement alone (tools/time_refine.py, 400k cases, max_iter 10, against tile1-extras / chunk-refine / refine-apply;
+// profiles/r04zb_time_refine.txt): 2D order 4 at 26 / 40 / 64 / 100 neighbours 0.78 / 1.01 / 1.40 / 2.17 against 1.56 / 2.11 / 2.15 /
+// 4.01 ms, 3D order 2 at 20 / 40 / 124 0.51 / 0.88 / 2.92 against 0.56 / 0.94 / 5.00, 2D order 3 at 80 1.24 against 1.61 — but 2D
+// order 3 at 30 0.62 against 0.54 and 2D order 2 at 16 / 32 / 64 0.19 / 0.43 / 1.08 against 0.17 / 0.31 / 0.75: a 64-case wave sweeps
+// until its LAST case stops and re-reads its rows per sweep where the 16-case tiles of those kernels keep them in LDS at two waves per
+// SIMD.  The fit in front of the sweeps is 2-3x faster here, so the small systems come here for few sweeps only (the crossover:
+// max_iter 2 for 2D order 2, 7 for 2D order 3 below 40 neighbours).
+int launch_fit_stage_refine(int dimension, int order, const KParams& p, long long K, hipStream_t stream, bool* handled) {
+    *handled = false;
+    const char* off = getenv("WLSQM_HIP_DISABLE_TILE");
+    if (off && off[0] == '1') return WLSQM_OK;
+    if (!(p.iterative || p.do_sens) || p.case_index || p.hoods || p.it_stop != 0) return WLSQM_OK;
+    if (p.do_sens && !p.sens) return WLSQM_OK;
+    const char* e = getenv(p.do_sens ? "WLSQM_HIP_STAGE_SENS" : "WLSQM_HIP_STAGE_REFINE");
+    if (e && e[0] == '0') return WLSQM_OK;
+    const bool all = e && e[0] == 'a';
+    if (p.do_sens && !all) return WLSQM_OK;                           // (measured slower than the kernels these calls have: see above)
+    if (!p.xk || !p.fk || !p.xi) return WLSQM_OK;
+    if (K < 8 || K % 2 != 0 || K > 65536) return WLSQM_OK;          // (row bytes and the tile's offsets are 32-bit)
+    if (p.sxk_k != dimension || p.sxk_j != K * dimension || p.sfk_k != 1 || p.sfk_j != K) return WLSQM_OK;
+    if ((reinterpret_cast<uintptr_t>(p.xk) | reinterpret_cast<uintptr_t>(p.fk)) & 15u) return WLSQM_OK;
+    if (p.do_sens && (p.ss_j * 8 * 4 > 0x7fffffffLL)) return WLSQM_OK;            // (32-bit offsets inside a store instruction's four cases)
+#define RCASE(D, O, COND) if (dimension == D && order == O && (all || (COND))) { *handled = true; return launch_stage_refine<D, O>(p, K, stream); }
+    RCASE(2, 2, p.max_iter <= 2)
+    RCASE(2, 3, K >= 40 || p.max_iter <= 7)
+    RCASE(2, 4, true)
+    RCASE(3, 2, true)
+#undef RCASE
+    return WLSQM_OK;
+}
+
+}  // namespace wlsqm

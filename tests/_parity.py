@@ -118,7 +118,10 @@ def assert_parity(cand, ref, truth=None, what="", tol=TOL, noise_mult=NOISE_MULT
     """Assert the column metric; with `truth`, allow the reference's own fp64 noise floor."""
     cand = np.asarray(cand); ref = np.asarray(ref)
     assert cand.shape == ref.shape, (cand.shape, ref.shape)
-    assert np.array_equal(np.isnan(cand), np.isnan(ref)), "%s: NaN pattern differs" % what
+    if not np.array_equal(np.isnan(cand), np.isnan(ref)):
+        where = np.argwhere(np.isnan(cand) != np.isnan(ref))[:6]
+        raise AssertionError("%s: NaN pattern differs at %s: candidate %s, reference %s"
+                             % (what, where.tolist(), [cand[tuple(w)] for w in where], [ref[tuple(w)] for w in where]))
     E = column_metric(cand, ref)
     bound = np.full_like(E, tol)
     if truth is not None:

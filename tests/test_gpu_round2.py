@@ -624,6 +624,9 @@ def test_sensitivities_by_inverse_and_mfma(wlsqm, oracle, dim, order, Kn, n, wid
     normal matrix, a second kernel multiplies it with the weighted monomial rows on the matrix cores.  Against the oracle
     (lapack-free restatement of impl.pyx:821-846) and against the generic kernel: ragged nk, knowns (NaN columns), both
     weightings, rows past nk and spare columns untouched, `wide`: strided sens / fi rows."""
+    # (round 4: the dense even-K forms of these shapes take csrc/fit_stage_iter.hip first — covered by tests/test_gpu_round4.py;
+    # this test keeps the kernels they took before covered)
+    monkeypatch.setenv("WLSQM_HIP_STAGE_SENS", "0"); monkeypatch.setenv("WLSQM_HIP_STAGE_REFINE", "0")
     import torch
     import wlsqm.hip as whip
     rng = np.random.default_rng(11 * Kn + order)
@@ -713,6 +716,9 @@ def test_sensitivities_by_inverse_and_mfma(wlsqm, oracle, dim, order, Kn, n, wid
 def test_sensitivities_path_in_slices(wlsqm, dim, order, Kn, n, monkeypatch):
     """The batch is cut into slices that share one scratch block for the inverses (1 024 cases per slice here): every slice must
     find its own inverses — same numbers as one slice, sensitivities and refinement."""
+    # (round 4: the dense even-K forms of these shapes take csrc/fit_stage_iter.hip first — covered by tests/test_gpu_round4.py;
+    # this test keeps the kernels they took before covered)
+    monkeypatch.setenv("WLSQM_HIP_STAGE_SENS", "0"); monkeypatch.setenv("WLSQM_HIP_STAGE_REFINE", "0")
     import torch
     import wlsqm.hip as whip
     rng = np.random.default_rng(Kn + n)
@@ -755,6 +761,7 @@ def test_round2_paths_capture_into_a_hip_graph(wlsqm, staged, monkeypatch):
     import wlsqm.hip as whip
     if not staged:
         monkeypatch.setenv("WLSQM_HIP_STAGE", "0")
+        monkeypatch.setenv("WLSQM_HIP_STAGE_SENS", "0"); monkeypatch.setenv("WLSQM_HIP_STAGE_REFINE", "0")     # (csrc/fit_stage_iter.hip, round 4)
     dev = torch.device("cuda", 0)
     n = 3000
     S = synth.halton(n, 2); S_d = torch.from_numpy(S).to(dev)

@@ -142,6 +142,7 @@ def test_refinement_in_the_chunked_tile_kernel(wlsqm, oracle, dim, order, Kn, kn
     knv = np.full(n, kn, np.int64); knv[::9] = 0
     orders = np.full(n, order, np.int32)
     res = {}
+    monkeypatch.setenv("WLSQM_HIP_STAGE_REFINE", "0")            # (round 4: these shapes take csrc/fit_stage_iter.hip first; this test keeps the chunked kernel covered)
     for tag in ("chunk", "lane"):
         if tag == "lane":
             monkeypatch.setenv("WLSQM_HIP_DISABLE_CHUNK_REFINE", "1")
@@ -170,14 +171,14 @@ def test_refinement_in_the_chunked_tile_kernel(wlsqm, oracle, dim, order, Kn, kn
 
 def test_c3_iterative_vs_reference_golden_at_the_headline_density(wlsqm):
     """fit_2D_iterative_many_parallel of the reference on config_C3_1M (fi_iter of the fixture), through the reference's own
-    signature: lands on the chunk-refine kernel."""
+    signature: lands on the one-lane-per-case refinement kernel (round 4; the chunk-refine kernel before)."""
     import wlsqm.hip as whip
     c = K.config_dense("C3_1M")
     truth = P.truth_fit(2, c["xk"], c["fk"], c["nk_a"], c["xi"], c["fi0"], c["order_a"], c["knowns_a"], c["wm_a"])
     fi = c["fi0"].copy()
     it = wlsqm.fit_2D_iterative_many_parallel(xk=c["xk"], fk=c["fk"], nk=c["nk_a"], xi=c["xi"], fi=fi, sens=None, do_sens=0,
                                               order=c["order_a"], knowns=c["knowns_a"], weighting_method=c["wm_a"], max_iter=10)
-    assert whip.last_kernel() == "chunk-refine", whip.last_kernel()
+    assert whip.last_kernel() == "stage-refine", whip.last_kernel()
     assert 1 <= it <= 10
     P.assert_parity(fi, c["g"]["fi_iter"], truth, "C3_1M iterative vs reference")
 

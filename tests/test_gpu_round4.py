@@ -382,3 +382,173 @@ def test_3d_order4_slices_give_the_same_bits(wlsqm, monkeypatch):
     assert np.array_equal(a0.view(np.int64), a1.view(np.int64)) and np.array_equal(b0.view(np.int64), b1.view(np.int64))
     assert np.array_equal(a0.view(np.int64), b0.view(np.int64))
     assert np.isfinite(a0).all()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# fit + iterative refinement with one lane per case (csrc/fit_stage_iter.hip; impl.pyx:986-1083)
+
+@pytest.mark.parametrize("dim,order,Kn", [(2, 2, 32), (2, 2, 8), (2, 2, 50), (2, 2, 160), (2, 3, 30), (2, 3, 80), (2, 4, 64), (2, 4, 26), (2, 4, 100),
+                                          (3, 2, 40), (3, 2, 12), (3, 2, 124)])
+@pytest.mark.parametrize("n", [1, 63, 65, 1000])
+@pytest.mark.parametrize("neighbours", ["sorted", "unsorted"])
+def test_staged_refinement_kernel(wlsqm, oracle, dim, order, Kn, n, neighbours, monkeypatch):
+    """solve_iterative on the one-lane-per-case mapping: whole rows resident in LDS for small neighbour counts, re-staged chunks
+    otherwise (the moment pass speculative: sorted and unsorted neighbour lists).  Against the oracle's solve_iterative under the
+    noise-floor bound and against the kernels these shapes took before (WLSQM_HIP_STAGE_REFINE=0); ragged nk, knowns masks incl. all
+    known, both weightings, groups around 64, neighbour counts that are not multiples of the 8-neighbour chunk;
+    max_iter 0 returns 1 and the unrefined fit (impl.pyx:1080-1081); the resident and the re-staging forms agree bit for bit."""
+    import torch
+    import wlsqm.hip as whip
+    rng = np.random.default_rng(17 * Kn + n + dim)
+    no = K.NDOF[dim][order]
+    xi = rng.uniform(0, 1, (n, dim))
+    off = 0.05 * rng.uniform(-1, 1, (n, Kn, dim))
+    nk = rng.integers(min(Kn, max(no + 10, Kn // 3)), Kn + 1, n).astype(np.int32); nk[::3] = Kn
+    if neighbours == "sorted":
+        for j in range(n):
+            idx = np.argsort((off[j, :nk[j]] ** 2).sum(axis=1), kind="stable")
+            off[j, :nk[j]] = off[j, :nk[j]][idx]
+    xk = xi[:, None, :] + off
+    fk = np.sin(3 * xk[..., 0]) * np.cos(2 * xk[..., -1])
+    # (no stray mask bits beyond `no` here: with them the reference's refinement is undefined — the unknown that drops out of the
+    # reduced system (infra.pyx:119-121) is never written in the work array `wrk_fi`, yet `fi[om] += wrk_fi[om]` (impl.pyx:1076-1078)
+    # adds that uninitialised entry in every sweep; the oracle restates this and returned NaN rows or not depending on what the heap
+    # held.  The basic fit with such masks is covered by test_staged_kernel.)
+    kn = rng.choice(np.array([0, 0, 1, 1 | (1 << (no - 1)), (1 << no) - 1, 0b110], np.int64), n)
+    wm = rng.choice(np.array([wlsqm.WEIGHT_UNIFORM, wlsqm.WEIGHT_CENTER], np.int32), n)
+    fi0 = rng.uniform(-1, 1, (n, no)); fi0[:, 0] = np.sin(3 * xi[:, 0]) * np.cos(2 * xi[:, -1])
+    orders = np.full(n, order, np.int32)
+
+    def run(max_iter=10, **env):
+        # (=all: every covered shape; by default the small systems come here for few sweeps only, see launch_fit_stage_refine)
+        env = dict(dict(WLSQM_HIP_STAGE_REFINE="all"), **env)
+        for k_, v in env.items():
+            monkeypatch.setenv(k_, v)
+        fi = _t(fi0)
+        it = whip.fit_many_device(dim, order, _t(xk), _t(fk), _t(nk), _t(xi), fi, _t(kn), _t(wm), iterative=True, max_iter=max_iter, want_iterations=True)
+        torch.cuda.synchronize()
+        name = whip.last_kernel()
+        for k_ in env:
+            monkeypatch.delenv(k_)
+        return fi.cpu().numpy(), it, name
+    got, it, name = run()
+    resident = 64 * 16 * sum(((((Kn + 7) // 8 * 8 * m + 1) // 2) | 1) for m in (dim, 1)) <= 53 * 1024
+    assert name == ("stage-refine-resident" if resident else "stage-refine"), name
+    ref = fi0.copy()
+    it_o = oracle.fit_many(dim, xk, fk, nk, xi, ref, None, 0, orders, kn, wm, iterative=True, max_iter=10, ntasks=8)
+    assert 1 <= it <= 10 and 1 <= it_o <= 10
+    if not np.all(kn == (1 << no) - 1) and n >= 63:
+        assert abs(it - it_o) <= 3, (it, it_o)                 # (the stop test compares rounded norms for equality: summation order moves it)
+    truth = P.truth_fit(dim, xk, fk, nk, xi, fi0, orders, kn, wm)
+    known_true = np.array([[(int(k) >> a) & 1 for a in range(no)] for k in kn], bool)
+    assert np.array_equal(got[known_true], fi0[known_true]), "a known DOF was modified"
+    if n >= 63:
+        P.assert_parity(got, ref, truth, "staged refinement vs oracle")
+    else:
+        E = P.column_metric(got, ref); N = P.column_metric(ref, truth)
+        assert np.all(E <= 1e-10 + 25.0 * 8.0 * N), (E, N)
+    # the kernels these shapes took before
+    old, it_old, name_old = run(WLSQM_HIP_STAGE_REFINE="0")
+    assert not name_old.startswith("stage-refine"), name_old
+    if n >= 63:
+        P.assert_parity(got, old, truth, "staged refinement vs %s" % name_old)
+    # resident and re-staging forms: the same arithmetic per case
+    if resident:
+        other, it2, name2 = run(WLSQM_HIP_REFINE_RESIDENT_KB="0")
+        assert name2 == "stage-refine", name2
+    else:
+        other, it2, name2 = run(WLSQM_HIP_REFINE_RESIDENT_KB="160")
+        assert name2 == ("stage-refine-resident" if 64 * 16 * sum(((((Kn + 7) // 8 * 8 * m + 1) // 2) | 1) for m in (dim, 1)) <= 160 * 1024 else "stage-refine"), name2
+    assert np.array_equal(got.view(np.int64), other.view(np.int64)) and it2 == it
+    # run to run
+    again, it3, _ = run()
+    assert np.array_equal(got.view(np.int64), again.view(np.int64)) and it3 == it
+    # the default dispatch: 2D order 4 and 3D order 2 always, 2D order 3 from 40 neighbours on or up to 7 sweeps, 2D order 2 up to 2 sweeps
+    for mi in (2, 10):
+        _, _, name_d = run(max_iter=mi, WLSQM_HIP_STAGE_REFINE="")
+        here = (dim, order) in ((2, 4), (3, 2)) or ((dim, order) == (2, 3) and (Kn >= 40 or mi <= 7)) or ((dim, order) == (2, 2) and mi <= 2)
+        assert name_d.startswith("stage-refine") == here, (name_d, mi)
+    # max_iter 0: the unrefined fit, return value 1
+    f0, it0, name0 = run(max_iter=0)
+    assert it0 == 1 and name0 == name
+    fb = _t(fi0)
+    whip.fit_many_device(dim, order, _t(xk), _t(fk), _t(nk), _t(xi), fb, _t(kn), _t(wm))
+    if n >= 63:
+        P.assert_parity(f0, fb.cpu().numpy(), truth, "max_iter 0 vs basic fit")
+
+
+@pytest.mark.parametrize("dim,order,Kn", [(2, 2, 32), (2, 2, 10), (2, 3, 30), (2, 4, 64), (2, 4, 26), (2, 4, 100), (3, 2, 40), (3, 2, 124)])
+@pytest.mark.parametrize("n", [1, 63, 65, 600])
+@pytest.mark.parametrize("layout", ["dense", "wide", "dense+iter"])
+def test_staged_sensitivities_kernel(wlsqm, oracle, dim, order, Kn, n, layout, monkeypatch):
+    """do_sens on the one-lane-per-case mapping (csrc/fit_stage_iter.hip SENS; built and measured in round 4, slower than the kernels
+    these calls have and therefore behind WLSQM_HIP_STAGE_SENS=all): one substitution per neighbour with the kept factor,
+    a case's rows leaving through the LDS tile as contiguous runs ('dense') or, with strided sens / fi rows ('wide'), lane by lane.
+    Against the oracle (per case, scaled by the conditioning of the reference's own matrix: tests/test_gpu_round2.py) and against the
+    inverse + MFMA path these shapes took before: NaN in the columns of the knowns, rows from nk on and spare columns untouched,
+    cases with every DOF known untouched; ragged nk, both weightings, groups around 64, partial last chunks; with refinement in the
+    same launch the sensitivities are bit-identical to the launch without and fi to the refinement-only launch."""
+    import torch
+    import wlsqm.hip as whip
+    rng = np.random.default_rng(19 * Kn + n + dim)
+    no = K.NDOF[dim][order]
+    wide = layout == "wide"
+    xi = rng.uniform(0, 1, (n, dim))
+    off = 0.08 * rng.uniform(-1, 1, (n, Kn, dim))
+    nk = rng.integers(min(Kn, max(no + 10, Kn // 3)), Kn + 1, n).astype(np.int32); nk[::3] = Kn
+    for j in range(0, n, 2):                                      # every other case sorted by distance (a k-nearest-neighbour list)
+        idx = np.argsort((off[j, :nk[j]] ** 2).sum(axis=1), kind="stable")
+        off[j, :nk[j]] = off[j, :nk[j]][idx]
+    xk = xi[:, None, :] + off
+    fk = np.sin(3 * xk[..., 0]) * np.cos(2 * xk[..., -1])
+    masks = [0, 0, 1, 1 | (1 << (no - 1)), (1 << no) - 1] + ([1 << (no + 2)] if layout != "dense+iter" else [])      # (stray bits and refinement: see above)
+    kn = rng.choice(np.array(masks, np.int64), n)
+    wm = rng.choice(np.array([wlsqm.WEIGHT_UNIFORM, wlsqm.WEIGHT_CENTER], np.int32), n)
+    ncol = no + (3 if wide else 0)
+    fi0 = rng.uniform(-1, 1, (n, ncol)); fi0[:, 0] = np.sin(3 * xi[:, 0]) * np.cos(2 * xi[:, -1])
+    orders = np.full(n, order, np.int32)
+    iterative = layout == "dense+iter"
+
+    def run(sens=True, iterative=iterative, **env):
+        env = dict(dict(WLSQM_HIP_STAGE_SENS="all"), **env)           # (off by default: measured slower than the inverse + MFMA path)
+        for k_, v in env.items():
+            monkeypatch.setenv(k_, v)
+        fi_d = _t(fi0); sens_d = torch.full((n, Kn, ncol), 777.0, dtype=torch.float64, device="cuda:0")
+        whip.fit_many_device(dim, order, _t(xk), _t(fk), _t(nk), _t(xi), fi_d[:, :no] if wide else fi_d, _t(kn), _t(wm),
+                             sens=(sens_d[:, :, :no] if wide else sens_d) if sens else None, iterative=iterative, max_iter=6)
+        torch.cuda.synchronize()
+        name = whip.last_kernel()
+        for k_ in env:
+            monkeypatch.delenv(k_)
+        return fi_d.cpu().numpy(), sens_d.cpu().numpy(), name
+    f_n, s_n, name = run()
+    assert name == ("stage-sens-refine" if iterative else "stage-sens"), name
+    f_b, s_b, name_b = run(WLSQM_HIP_STAGE_SENS="0")
+    assert not name_b.startswith("stage-sens"), name_b
+    fo = fi0[:, :no].copy(); so = np.full((n, Kn, no), 777.0)
+    _, cap = oracle.fit_many(dim, xk, fk, nk, xi, fo, so, 1, orders, kn, wm, iterative=iterative, max_iter=6, debug_capture=True)
+    truth = P.truth_fit(dim, xk, fk, nk, xi, fi0[:, :no], orders, kn, wm)
+    if n >= 63:
+        P.assert_parity(f_n[:, :no], fo, truth, "fit beside the sensitivities vs oracle")
+    known_true = np.array([[(int(k) >> a) & 1 for a in range(no)] for k in kn], bool)
+    assert np.array_equal(f_n[:, :no][known_true], fi0[:, :no][known_true]), "a known DOF was modified"
+    assert np.array_equal(f_n[:, no:], fi0[:, no:]) and np.array_equal(s_n[:, :, no:], np.full((n, Kn, ncol - no), 777.0))
+    eps = np.finfo(float).eps
+    for ref, what in ((so, "oracle"), (s_b[:, :, :no], name_b)):
+        a = s_n[:, :, :no]
+        assert np.array_equal(np.isnan(a), np.isnan(ref)), what               # NaN for knowns (impl.pyx:821-823)
+        assert np.array_equal(a == 777.0, ref == 777.0), what                 # rows k >= nk, all-known cases, dropped columns untouched
+        for j in range(n):
+            m = ~np.isnan(ref[j]) & (ref[j] != 777.0)
+            if m.any():
+                kappa = K.scaled_cond(cap, j, no, kn[j])
+                err = np.abs(a[j][m] - ref[j][m]).max()
+                assert err <= (1e-10 + 1e3 * kappa * eps) * np.abs(ref[j][m]).max(), (what, j, kappa, err / np.abs(ref[j][m]).max())
+    if iterative:
+        _, s_only, _ = run(iterative=False)
+        assert np.array_equal(s_only, s_n, equal_nan=True)                    # the refinement does not disturb the sensitivities
+        f_only, _, name_r = run(sens=False, WLSQM_HIP_STAGE_REFINE="all", WLSQM_HIP_REFINE_RESIDENT_KB="0")
+        assert name_r == "stage-refine", name_r
+        assert np.array_equal(f_only, f_n)                                    # ... nor the sensitivities the refinement
+    again_f, again_s, _ = run()
+    assert np.array_equal(again_f, f_n) and np.array_equal(again_s, s_n, equal_nan=True)

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Time the iterative refinement per (dimension, order, K) shape and max_iter, chunk-refine kernel against the lane kernel.
+"""Time the iterative refinement per (dimension, order, K) shape and max_iter: the one-lane-per-case kernel (round 4) against the kernels
+the shape took before and against the lane kernel (TIME_REFINE_MODES=stage,before,lane).
 usage: python tools/time_refine.py [ncases] [dim,order,K ...]"""
 import os, sys
 import numpy as np
@@ -23,11 +24,12 @@ for dim, order, K in shapes:
     kn = torch.full((n,), 1, dtype=torch.int64, device=dev)
     wm = torch.full((n,), 2, dtype=torch.int32, device=dev)
     fi = torch.zeros((n, no), dtype=torch.float64, device=dev); fi[:, 0] = F
-    for mode in ("chunk", "lane"):
+    for mode in os.environ.get("TIME_REFINE_MODES", "stage,before,lane").split(","):      # stage: csrc/fit_stage_iter.hip (round 4); before: tile1-extras / chunk-refine
+        os.environ.pop("WLSQM_HIP_DISABLE_CHUNK_REFINE", None); os.environ.pop("WLSQM_HIP_STAGE_REFINE", None)
+        if mode != "stage":
+            os.environ["WLSQM_HIP_STAGE_REFINE"] = "0"
         if mode == "lane":
             os.environ["WLSQM_HIP_DISABLE_CHUNK_REFINE"] = "1"
-        else:
-            os.environ.pop("WLSQM_HIP_DISABLE_CHUNK_REFINE", None)
         row = []
         for mi in (0, 1, 2, 4, 10):
             run = lambda: whip.fit_many_device(dim, order, xk, fk, nk, S, fi, kn, wm, iterative=True, max_iter=mi)

@@ -31,7 +31,9 @@ for dim, order, K in shapes:
     sens = torch.zeros((n, K, no), dtype=torch.float64, device=dev)
 
     def run():
-        if iterative:
+        if os.environ.get("TIME_BOTH") == "1":                        # sensitivities and refinement in one call
+            whip.fit_many_device(dim, order, xk_a, fk, nk, xi_a, fi, kn, wm, sens=sens, iterative=True, max_iter=10)
+        elif iterative:
             whip.fit_many_device(dim, order, xk_a, fk, nk, xi_a, fi, kn, wm, iterative=True, max_iter=10)
         else:
             whip.fit_many_device(dim, order, xk_a, fk, nk, xi_a, fi, kn, wm, sens=sens)
