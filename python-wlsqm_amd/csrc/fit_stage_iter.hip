@@ -31,6 +31,9 @@
 #ifndef WLSQM_SITER_GRP
 #define WLSQM_SITER_GRP 4           // neighbours of a lane in flight in the moment pass and in a sweep
 #endif
+#ifndef WLSQM_SITER_DEEP
+#define WLSQM_SITER_DEEP 0          // 1: two chunks in flight for the systems with 7 .. 10 unknowns (see the kernel: measured slower, off)
+#endif
 
 namespace wlsqm {
 
@@ -97,8 +100,15 @@ __global__ __launch_bounds__(64, (!RESIDENT && !SENS && ndofs(DIM, ORDER) <= 6) 
     const bool xlane = lane < XCPI * XPC;
     const char* const xtile = reinterpret_cast<const char*>(p.xk + t0 * (long long)K * DIM);
     const char* const ftile = reinterpret_cast<const char*>(p.fk + t0 * (long long)K);
-    d2_ xr[XNI], fr[FNI];
-    auto fetch = [&](int q) __attribute__((always_inline)) {
+    // DEEP: TWO chunks in flight (two register sets) — an experiment, OFF.  The idea: a lone wave waits out every exposed load, and with
+    // one chunk in flight a sweep of configs[4]'s shape computes ~1.3 us per chunk while 1 024 waves x 18 KB in flight at the measured
+    // 7.5 TB/s say ~2.5 us for a chunk to come back from L2 / the Infinity Cache.  Measured (profiles/r04zb_ab_siter_deep.txt, max_iter
+    // 10): 3D order 2 at 40 neighbours, 1M cases, 3.51 against 2.03 ms, at 124 neighbours 3.83 against 2.92 — the second set costs 118
+    // spilled registers and 13 scratch reloads of load addresses per chunk; 2D order 3 at 80 neighbours (no spill): 1.252 against
+    // 1.240 ms, i.e. the latency is NOT what bounds the sweeps there.
+    constexpr bool DEEP = (WLSQM_SITER_DEEP != 0) && !RESIDENT && NO > 6 && NO <= 10;      // (the 6-unknown systems run two waves per SIMD)
+    d2_ xr[XNI], fr[FNI], xr2[DEEP ? XNI : 1], fr2[DEEP ? FNI : 1];
+    auto fetch_into = [&](d2_ (&xr)[XNI], d2_ (&fr)[FNI], int q) __attribute__((always_inline)) {
         unsigned xo = (unsigned)q * (CH * DIM * 8) + (unsigned)xsub * 16u, fo = (unsigned)q * (CH * 8) + (unsigned)fsub * 16u;
         xo = xo < xrowb ? xo : xrowb - 16u; fo = fo < frowb ? fo : frowb - 16u;      // (rows are multiples of 16 bytes: K even)
         const char* xb = xtile + xo;
@@ -116,7 +126,7 @@ __global__ __launch_bounds__(64, (!RESIDENT && !SENS && ndofs(DIM, ORDER) <= 6) 
             fr[i] = *reinterpret_cast<const d2_*>(fb + (size_t)(unsigned)cc * frowb);
         }
     };
-    auto park = [&](int q) __attribute__((always_inline)) {           // RESIDENT: chunk q at its place in the whole row
+    auto park_from = [&](const d2_ (&xr)[XNI], const d2_ (&fr)[FNI], int q) __attribute__((always_inline)) {      // RESIDENT: chunk q at its place in the whole row
         d2_* xl = xs + xc0 * XP2 + xsub + (RESIDENT ? q * (CH * DIM / 2) : 0);
         d2_* fl = fs + fc0 * FP2 + fsub + (RESIDENT ? q * (CH / 2) : 0);
 #pragma unroll
@@ -130,20 +140,13 @@ __global__ __launch_bounds__(64, (!RESIDENT && !SENS && ndofs(DIM, ORDER) <= 6) 
 
     // One pass over the neighbours, chunks LAST FIRST (descending k, the order of fit_stage.hip).  body(d, f, live, k) per neighbour,
     // after_group(k0) behind every group of GRP neighbours k0 .. k0 + GRP - 1.
-    // Not RESIDENT: the chunks travel through the staging rows; warm: chunk Q - 1 is parked and chunk Q - 2 in flight.
+    // Not RESIDENT: the chunks travel through the staging rows.
     // RESIDENT and !fill: everything is in LDS.  RESIDENT and fill: the first pass, which parks the chunks at their places.
-    auto for_neighbours = [&](auto masked_tag, auto grp_tag, auto body, auto after_group, const bool fill, const bool warm) __attribute__((always_inline)) {
+    auto for_neighbours = [&](auto masked_tag, auto grp_tag, auto body, auto after_group, const bool fill) __attribute__((always_inline)) {
         constexpr bool MASKED = decltype(masked_tag)::value;
         constexpr int GRP = decltype(grp_tag)::value;                 // neighbours of a lane in flight
         const bool staged = !RESIDENT || fill;
-        if (staged && !warm) fetch(Q - 1);
-        for (int q = Q - 1; q >= 0; --q) {
-            if (staged && !(warm && q == Q - 1)) {
-                if (!RESIDENT) __syncthreads();                       // the previous chunk has been read by every lane
-                park(q);
-                __syncthreads();
-                if (q > 0) fetch(q - 1);
-            }
+        auto compute = [&](const int q) __attribute__((always_inline)) {
             const d2_* xq = xrow + (RESIDENT ? q * (CH * DIM / 2) : 0);
             const d2_* fq = frow + (RESIDENT ? q * (CH / 2) : 0);
 #pragma unroll
@@ -167,13 +170,34 @@ __global__ __launch_bounds__(64, (!RESIDENT && !SENS && ndofs(DIM, ORDER) <= 6) 
                 __builtin_amdgcn_sched_barrier(0);                    // GRP neighbours in flight at a time
                 after_group(q * CH + g * GRP);
             }
+        };
+        // chunk q arrives in a register set, is parked and consumed; the set is refilled with the chunk `ahead` further on
+        auto step = [&](d2_ (&xa)[XNI], d2_ (&fa)[FNI], const int q, const int ahead) __attribute__((always_inline)) {
+            if (staged) {
+                if (!RESIDENT) __syncthreads();                       // the previous chunk has been read by every lane
+                park_from(xa, fa, q);
+                __syncthreads();
+                if (q - ahead >= 0) fetch_into(xa, fa, q - ahead);
+            }
+            compute(q);
+        };
+        if constexpr (DEEP) {
+            fetch_into(xr, fr, Q - 1);
+            if (Q > 1) fetch_into(xr2, fr2, Q - 2);
+            for (int q = Q - 1; q >= 0; q -= 2) {
+                step(xr, fr, q, 2);
+                if (q >= 1) step(xr2, fr2, q - 1, 2);
+            }
+        } else {
+            if (staged) fetch_into(xr, fr, Q - 1);
+            for (int q = Q - 1; q >= 0; --q) step(xr, fr, q, 1);
         }
     };
     const bool full = (K % CH == 0) && __all(nkc >= K);               // wave-uniform: no ragged case in this group, whole chunks
     auto no_hook = [](int) __attribute__((always_inline)) {};
-    auto pass = [&](auto body, const bool fill, const bool warm) __attribute__((always_inline)) {
-        if (full) for_neighbours(std::false_type{}, std::integral_constant<int, GRP>{}, body, no_hook, fill, warm);
-        else for_neighbours(std::true_type{}, std::integral_constant<int, GRP>{}, body, no_hook, fill, warm);
+    auto pass = [&](auto body, const bool fill) __attribute__((always_inline)) {
+        if (full) for_neighbours(std::false_type{}, std::integral_constant<int, GRP>{}, body, no_hook, fill);
+        else for_neighbours(std::true_type{}, std::integral_constant<int, GRP>{}, body, no_hook, fill);
     };
 
     // ---- the fit: largest squared distance, moments
@@ -197,10 +221,10 @@ __global__ __launch_bounds__(64, (!RESIDENT && !SENS && ndofs(DIM, ORDER) <= 6) 
         for (int a = 0; a < NO; ++a) nu[a] = 0.0;
         max_d2 = 0.0;
         inv_max = inverse_max(maxv);
-        pass(mom_body, false, false);
+        pass(mom_body, false);
     };
     if constexpr (RESIDENT) {
-        pass(max_body, true, false);
+        pass(max_body, true);
         moments(max_d2);
     } else {
         // speculative (fit_stage.hip): the last neighbour is the farthest for sorted neighbour lists; verified bit for bit
@@ -289,8 +313,8 @@ __global__ __launch_bounds__(64, (!RESIDENT && !SENS && ndofs(DIM, ORDER) <= 6) 
             __syncthreads();                                          // the tile is read
         };
         if (p.sens) {
-            if (full) for_neighbours(std::false_type{}, std::integral_constant<int, SGRP>{}, sens_body, flush, false, false);
-            else for_neighbours(std::true_type{}, std::integral_constant<int, SGRP>{}, sens_body, flush, false, false);
+            if (full) for_neighbours(std::false_type{}, std::integral_constant<int, SGRP>{}, sens_body, flush, false);
+            else for_neighbours(std::true_type{}, std::integral_constant<int, SGRP>{}, sens_body, flush, false);
         }
     }
 
@@ -319,7 +343,7 @@ __global__ __launch_bounds__(64, (!RESIDENT && !SENS && ndofs(DIM, ORDER) <= 6) 
 #pragma unroll
             for (int a = 0; a < NO; ++a) r[a] = fma(wr, (a == 0) ? 1.0 : cc[a], r[a]);
         };
-        pass(sweep_body, false, false);
+        pass(sweep_body, false);
         if (!done) {
             if (norm == prev_norm) { broke = true; done = true; it_case = it; }      // impl.pyx:1057
             else {
