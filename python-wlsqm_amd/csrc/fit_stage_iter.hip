@@ -31,6 +31,9 @@
 #ifndef WLSQM_SITER_GRP
 #define WLSQM_SITER_GRP 4           // neighbours of a lane in flight in the moment pass and in a sweep
 #endif
+#ifndef WLSQM_SITER_MODEL_CHAINS
+#define WLSQM_SITER_MODEL_CHAINS 1  // partial sums of the model evaluation in a sweep (3, also with -amdgpu-sched-strategy=max-ilp: flat, profiles/r04zb_ab_siter_chains.txt)
+#endif
 #ifndef WLSQM_SITER_DEEP
 #define WLSQM_SITER_DEEP 0          // 1: two chunks in flight for the systems with 7 .. 10 unknowns (see the kernel: measured slower, off)
 #endif
@@ -333,9 +336,21 @@ __global__ __launch_bounds__(64, (!RESIDENT && !SENS && ndofs(DIM, ORDER) <= 6) 
             const double d2 = monomials<DIM, ORDER>(d, cc);
             double w = weight(d2, inv_max, uniform);
             w = live ? w : 0.0;
+#if WLSQM_SITER_MODEL_CHAINS > 1
+            // taylor_*D (polyeval.pyx): sum_a c[a] fi[a], as WLSQM_SITER_MODEL_CHAINS interleaved partial sums (shorter dependent chains)
+            double part[WLSQM_SITER_MODEL_CHAINS];
+#pragma unroll
+            for (int i = 0; i < WLSQM_SITER_MODEL_CHAINS; ++i) part[i] = i == 0 ? fi[0] : 0.0;
+#pragma unroll
+            for (int a = 1; a < NO; ++a) part[a % WLSQM_SITER_MODEL_CHAINS] = fma(cc[a], fi[a], part[a % WLSQM_SITER_MODEL_CHAINS]);
+            double model = part[0];
+#pragma unroll
+            for (int i = 1; i < WLSQM_SITER_MODEL_CHAINS; ++i) model += part[i];
+#else
             double model = fi[0];                                     // taylor_*D (polyeval.pyx): sum_a c[a] fi[a]
 #pragma unroll
             for (int a = 1; a < NO; ++a) model = fma(cc[a], fi[a], model);
+#endif
             const double res = live ? f - model : 0.0;
             const double ar = fabs(res);
             norm = ar > norm ? ar : norm;                             // impl.pyx:1037-1041
