@@ -34,6 +34,9 @@
 #ifndef WLSQM_SITER_MODEL_CHAINS
 #define WLSQM_SITER_MODEL_CHAINS 1  // partial sums of the model evaluation in a sweep (3, also with -amdgpu-sched-strategy=max-ilp: flat, profiles/r04zb_ab_siter_chains.txt)
 #endif
+#ifndef WLSQM_SITER_TWO_WAVES_UPTO
+#define WLSQM_SITER_TWO_WAVES_UPTO 6    // systems up to this many unknowns are compiled for two waves per SIMD (re-staging form)
+#endif
 #ifndef WLSQM_SITER_DEEP
 #define WLSQM_SITER_DEEP 0          // 1: two chunks in flight for the systems with 7 .. 10 unknowns (see the kernel: measured slower, off)
 #endif
@@ -55,7 +58,7 @@ __host__ __device__ constexpr int pitch2(int doubles) {               // row pit
 // consecutive doubles of ITS case's sens block: they leave through an LDS tile, one case per store instruction (G NO 8 contiguous
 // bytes), instead of 64 lanes storing 8 bytes each at a pitch of K NO 8 bytes.
 template <int DIM, int ORDER, bool RESIDENT, bool SENS>
-__global__ __launch_bounds__(64, (!RESIDENT && !SENS && ndofs(DIM, ORDER) <= 6) ? 2 : 1) void fit_stage_refine_kernel(const KParams p, const int XP2r, const int FP2r) {
+__global__ __launch_bounds__(64, (!RESIDENT && !SENS && ndofs(DIM, ORDER) <= WLSQM_SITER_TWO_WAVES_UPTO) ? 2 : 1) void fit_stage_refine_kernel(const KParams p, const int XP2r, const int FP2r) {
     using namespace siter;
     constexpr int NO = ndofs(DIM, ORDER), NE = NO * (NO + 1) / 2, NM = mom_count<DIM>(2 * ORDER);
     constexpr int SG = sens_group(NO), SR = SG * NO / 2, TP2 = pitch2(SG * NO);      // neighbours per sens tile; 16-byte pieces of a case's tile; tile pitch
