@@ -34,6 +34,9 @@
 #ifndef WLSQM_SITER_MODEL_CHAINS
 #define WLSQM_SITER_MODEL_CHAINS 1  // partial sums of the model evaluation in a sweep (3, also with -amdgpu-sched-strategy=max-ilp: flat, profiles/r04zb_ab_siter_chains.txt)
 #endif
+#ifndef WLSQM_SITER_WARM
+#define WLSQM_SITER_WARM 0          // 1: the first chunk of the next pass is requested behind the last chunk of the current one (measured slower, off: see the kernel)
+#endif
 #ifndef WLSQM_SITER_TWO_WAVES_UPTO
 #define WLSQM_SITER_TWO_WAVES_UPTO 6    // systems up to this many unknowns are compiled for two waves per SIMD (re-staging form)
 #endif
@@ -141,6 +144,8 @@ __global__ __launch_bounds__(64, (!RESIDENT && !SENS && ndofs(DIM, ORDER) <= WLS
 #pragma unroll
         for (int i = 0; i < FNI; ++i) fl[i * FCPI * FP2] = fr[i];
     };
+    constexpr bool WARM = (WLSQM_SITER_WARM != 0) && !RESIDENT && !DEEP;
+    bool inflight = false;                                            // (wave-uniform) chunk Q - 1 of the next pass is on its way in (xr, fr)
     const d2_* const xrow = xs + lane * XP2;
     const d2_* const frow = fs + lane * FP2;
 
@@ -177,13 +182,19 @@ __global__ __launch_bounds__(64, (!RESIDENT && !SENS && ndofs(DIM, ORDER) <= WLS
                 after_group(q * CH + g * GRP);
             }
         };
-        // chunk q arrives in a register set, is parked and consumed; the set is refilled with the chunk `ahead` further on
+        // chunk q arrives in a register set, is parked and consumed; the set is refilled with the chunk `ahead` further on — behind
+        // the pass's last chunk with the FIRST chunk of the next pass (WARM; an experiment, OFF).  The idea: a lone wave has nothing to
+        // cover the start of a pass with, and there are max_iter + 1 passes.  Measured (profiles/r04zb_ab_siter_warm.txt, max_iter 10):
+        // 2D order 4 at 64 neighbours 1.564 against 1.386 ms per 400k, 2D order 3 at 80 1.295 against 1.239, 3D order 2 at 40 2.070
+        // against 2.014 per 1M — the set's 48 registers stay live across the substitution between two sweeps (2D order 4: 122 instead
+        // of 88 spilled), which costs more than the exposed start
         auto step = [&](d2_ (&xa)[XNI], d2_ (&fa)[FNI], const int q, const int ahead) __attribute__((always_inline)) {
             if (staged) {
                 if (!RESIDENT) __syncthreads();                       // the previous chunk has been read by every lane
                 park_from(xa, fa, q);
                 __syncthreads();
                 if (q - ahead >= 0) fetch_into(xa, fa, q - ahead);
+                else if (WARM && q == 0) { fetch_into(xa, fa, Q - 1); inflight = true; }
             }
             compute(q);
         };
@@ -195,7 +206,7 @@ __global__ __launch_bounds__(64, (!RESIDENT && !SENS && ndofs(DIM, ORDER) <= WLS
                 if (q >= 1) step(xr2, fr2, q - 1, 2);
             }
         } else {
-            if (staged) fetch_into(xr, fr, Q - 1);
+            if (staged && !(WARM && inflight)) fetch_into(xr, fr, Q - 1);
             for (int q = Q - 1; q >= 0; --q) step(xr, fr, q, 1);
         }
     };
@@ -464,6 +475,7 @@ int launch_fit_stage_refine(int dimension, int order, const KParams& p, long lon
     const char* off = getenv("WLSQM_HIP_DISABLE_TILE");
     if (off && off[0] == '1') return WLSQM_OK;
     if (!(p.iterative || p.do_sens) || p.case_index || p.hoods || p.it_stop != 0) return WLSQM_OK;
+    { const char* r = getenv("WLSQM_HIP_REFINE_ROUNDS"); if (r && r[0] == '1') return WLSQM_OK; }      // (the rounds experiment of fit_tilek.hip keeps its shapes)
     if (p.do_sens && !p.sens) return WLSQM_OK;
     const char* e = getenv(p.do_sens ? "WLSQM_HIP_STAGE_SENS" : "WLSQM_HIP_STAGE_REFINE");
     if (e && e[0] == '0') return WLSQM_OK;
