@@ -34,6 +34,9 @@
 #ifndef WLSQM_SITER_MODEL_CHAINS
 #define WLSQM_SITER_MODEL_CHAINS 1  // partial sums of the model evaluation in a sweep (3, also with -amdgpu-sched-strategy=max-ilp: flat, profiles/r04zb_ab_siter_chains.txt)
 #endif
+#ifndef WLSQM_SITER_REDUCED
+#define WLSQM_SITER_REDUCED 1       // 15-unknown systems: a case with exactly F known keeps the factor of its 14 x 14 system
+#endif
 #ifndef WLSQM_SITER_WARM
 #define WLSQM_SITER_WARM 0          // 1: the first chunk of the next pass is requested behind the last chunk of the current one (measured slower, off: see the kernel)
 #endif
@@ -261,7 +264,47 @@ __global__ __launch_bounds__(64, (!RESIDENT && !SENS && ndofs(DIM, ORDER) <= WLS
     constexpr unsigned long long FULL = (1ull << NO) - 1ull;
     double* const fio = p.fi + j * p.sfi_j;
     double M[NE], fi[NO];
-    {
+    // A case with exactly the function value known (knowns = b?_F: the reference's default mask and BASELINE configs[2]) keeps the factor of
+    // its 14 x 14 system (fit_stage.hip: 105 + 14 entries to expand, factor and substitute instead of 120 + 15), chosen by the case's
+    // own mask — a mixed wave runs both forms, a case's bits do not depend on its wave-mates.  M then holds the 105 entries of that factor.
+    constexpr bool REDUCED = (WLSQM_SITER_REDUCED != 0) && NO == 15 && !SENS;
+    constexpr int N1 = NO - 1, NE1 = N1 * (N1 + 1) / 2;
+    const bool mine1 = REDUCED && known == 1ull && dropped == 0ull;
+    if constexpr (REDUCED) {
+        if (mine1) {
+            const double v0 = fio[0];
+            double M1[NE1], r1[N1];
+#pragma unroll
+            for (int a = 1; a < NO; ++a) {
+                const int pa = Mono<DIM>::P[a], qa = Mono<DIM>::Q[a], ra = Mono<DIM>::R[a];
+                r1[a - 1] = nu[mom_index<DIM>(pa, qa, ra)] * (mom_inv_fact(pa) * mom_inv_fact(qa) * mom_inv_fact(ra));
+            }
+#pragma unroll
+            for (int i = 0; i < NM; ++i) {
+                const double m = mu[i];
+#pragma unroll
+                for (int a = 1; a < NO; ++a) {
+                    const int pa = Mono<DIM>::P[a], qa = Mono<DIM>::Q[a], ra = Mono<DIM>::R[a];
+                    const double fa = mom_inv_fact(pa) * mom_inv_fact(qa) * mom_inv_fact(ra);
+                    if (mom_index<DIM>(pa, qa, ra) == i) r1[a - 1] = fma(-(m * (1.0 * fa)), v0, r1[a - 1]);      // M[0, a] * fi[0] (impl.pyx:815-818)
+#pragma unroll
+                    for (int b = a; b < NO; ++b) {
+                        const int pb = Mono<DIM>::P[b], qb = Mono<DIM>::Q[b], rb = Mono<DIM>::R[b];
+                        const double fb = mom_inv_fact(pb) * mom_inv_fact(qb) * mom_inv_fact(rb);
+                        if (mom_index<DIM>(pa + pb, qa + qb, ra + rb) == i) M1[tri<N1>(a - 1, b - 1)] = m * (fa * fb);
+                    }
+                }
+            }
+            ldlt_factor<N1>(M1);
+            ldlt_solve<N1>(M1, r1);
+            fi[0] = v0;
+#pragma unroll
+            for (int a = 1; a < NO; ++a) fi[a] = r1[a - 1];
+#pragma unroll
+            for (int e = 0; e < NE; ++e) M[e] = e < NE1 ? M1[e < NE1 ? e : 0] : 0.0;
+        }
+    }
+    if (!mine1) {
         double g[NO], val[NO];
         expand_moments<DIM, ORDER>(mu, nu, M, g);
 #pragma unroll
@@ -377,11 +420,25 @@ __global__ __launch_bounds__(64, (!RESIDENT && !SENS && ndofs(DIM, ORDER) <= WLS
             if (norm == prev_norm) { broke = true; done = true; it_case = it; }      // impl.pyx:1057
             else {
                 prev_norm = norm;
+                if constexpr (REDUCED) {
+                    if (mine1) {                                      // the 14 x 14 factor: the correction of the known function value is 0
+                        double M1[NE1], r1[N1];
 #pragma unroll
-                for (int a = 0; a < NO; ++a) if ((known >> a) & 1ull) r[a] = 0.0;    // knowns of the correction are 0
-                ldlt_solve<NO>(M, r);
+                        for (int e = 0; e < NE1; ++e) M1[e] = M[e];
 #pragma unroll
-                for (int a = 0; a < NO; ++a) if (!((known >> a) & 1ull)) fi[a] += r[a];
+                        for (int a = 1; a < NO; ++a) r1[a - 1] = r[a];
+                        ldlt_solve<N1>(M1, r1);
+#pragma unroll
+                        for (int a = 1; a < NO; ++a) fi[a] += r1[a - 1];
+                    }
+                }
+                if (!mine1) {
+#pragma unroll
+                    for (int a = 0; a < NO; ++a) if ((known >> a) & 1ull) r[a] = 0.0;    // knowns of the correction are 0
+                    ldlt_solve<NO>(M, r);
+#pragma unroll
+                    for (int a = 0; a < NO; ++a) if (!((known >> a) & 1ull)) fi[a] += r[a];
+                }
             }
         }
     }

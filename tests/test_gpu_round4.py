@@ -549,6 +549,11 @@ def test_staged_sensitivities_kernel(wlsqm, oracle, dim, order, Kn, n, layout, m
         assert np.array_equal(s_only, s_n, equal_nan=True)                    # the refinement does not disturb the sensitivities
         f_only, _, name_r = run(sens=False, WLSQM_HIP_STAGE_REFINE="all", WLSQM_HIP_REFINE_RESIDENT_KB="0")
         assert name_r == "stage-refine", name_r
-        assert np.array_equal(f_only, f_n)                                    # ... nor the sensitivities the refinement
+        # ... nor the sensitivities the refinement.  (15 unknowns: the refinement-only kernel keeps the 14 x 14 factor of a case with
+        # exactly F known, the kernel with sensitivities the masked 15 x 15 one — those cases agree to rounding, the others bit for bit)
+        red = (kn == 1) if no == 15 else np.zeros(n, bool)
+        assert np.array_equal(f_only[~red], f_n[~red])
+        if red.any() and n >= 63:
+            P.assert_parity(f_only[red][:, :no], f_n[red][:, :no], truth[red], "refinement beside the sensitivities, F known")
     again_f, again_s, _ = run()
     assert np.array_equal(again_f, f_n) and np.array_equal(again_s, s_n, equal_nan=True)
