@@ -63,8 +63,13 @@ __host__ __device__ constexpr int pitch2(int doubles) {               // row pit
 // in one more pass over the rows between the fit and the sweeps.  A lane's G x NO results per group of G neighbours are G NO
 // consecutive doubles of ITS case's sens block: they leave through an LDS tile, one case per store instruction (G NO 8 contiguous
 // bytes), instead of 64 lanes storing 8 bytes each at a pitch of K NO 8 bytes.
-template <int DIM, int ORDER, bool RESIDENT, bool SENS>
-__global__ __launch_bounds__(64, (!RESIDENT && !SENS && ndofs(DIM, ORDER) <= WLSQM_SITER_TWO_WAVES_UPTO) ? 2 : 1) void fit_stage_refine_kernel(const KParams p, const int XP2r, const int FP2r) {
+// WCACHE (re-staging form, no sensitivities): the neighbours' WEIGHTS stay in LDS between the sweeps — the moment pass computes them
+// anyway, and a sweep's reciprocal root + Newton steps + blend are 14 of its 52 (3D order 2) / 79 (2D order 4) vector instructions per
+// neighbour.  64 x K doubles per wave at an odd pitch: chosen by the launcher while four waves per CU still fit beside the staging rows
+// (2D: up to 48 neighbours, 3D: up to 40 — configs[4]).
+template <int DIM, int ORDER, bool RESIDENT, bool SENS, bool WCACHE = false>
+__global__ __launch_bounds__(64, (!RESIDENT && !SENS && !WCACHE && ndofs(DIM, ORDER) <= WLSQM_SITER_TWO_WAVES_UPTO) ? 2 : 1) void fit_stage_refine_kernel(const KParams p, const int XP2r, const int FP2r) {
+    static_assert(!WCACHE || (!RESIDENT && !SENS), "the weight cache belongs to the re-staging refinement form");
     using namespace siter;
     constexpr int NO = ndofs(DIM, ORDER), NE = NO * (NO + 1) / 2, NM = mom_count<DIM>(2 * ORDER);
     constexpr int SG = sens_group(NO), SR = SG * NO / 2, TP2 = pitch2(SG * NO);      // neighbours per sens tile; 16-byte pieces of a case's tile; tile pitch
@@ -149,6 +154,7 @@ __global__ __launch_bounds__(64, (!RESIDENT && !SENS && ndofs(DIM, ORDER) <= WLS
     };
     constexpr bool WARM = (WLSQM_SITER_WARM != 0) && !RESIDENT && !DEEP;
     bool inflight = false;                                            // (wave-uniform) chunk Q - 1 of the next pass is on its way in (xr, fr)
+    double* const wrow = reinterpret_cast<double*>(lds_d) + lane * FP2r;      // (WCACHE) this lane's weights; FP2r: the pitch in doubles (odd)
     const d2_* const xrow = xs + lane * XP2;
     const d2_* const frow = fs + lane * FP2;
 
@@ -227,11 +233,12 @@ __global__ __launch_bounds__(64, (!RESIDENT && !SENS && ndofs(DIM, ORDER) <= WLS
         const double d2 = sqdist(d);
         max_d2 = d2 > max_d2 ? d2 : max_d2;                           // (a masked slot contributes 0)
     };
-    auto mom_body = [&](const double (&d)[DIM], double f, bool live, int) __attribute__((always_inline)) {
+    auto mom_body = [&](const double (&d)[DIM], double f, bool live, int k) __attribute__((always_inline)) {
         const double d2 = sqdist(d);
         max_d2 = d2 > max_d2 ? d2 : max_d2;
         double w = weight(d2, inv_max, uniform);
         w = live ? w : 0.0;
+        if constexpr (WCACHE) wrow[k] = w;                            // (a repeated pass overwrites them with the final ones)
         accumulate_moments_best<DIM, ORDER>(mu, nu, d, w, f);
     };
     auto moments = [&](const double maxv) __attribute__((always_inline)) {
@@ -330,8 +337,8 @@ __global__ __launch_bounds__(64, (!RESIDENT && !SENS && ndofs(DIM, ORDER) <= WLS
         double* const srow = p.sens + j * p.ss_j;
         auto sens_body = [&](const double (&d)[DIM], double, bool, int k) __attribute__((always_inline)) {
             double cc[NO], sv[NO];
-            const double d2 = monomials<DIM, ORDER>(d, cc);
-            const double w = weight(d2, inv_max, uniform);
+            monomials<DIM, ORDER>(d, cc);
+            const double w = weight(sqdist(d), inv_max, uniform);     // (the moment pass's weight, bit for bit)
 #pragma unroll
             for (int a = 0; a < NO; ++a) sv[a] = ((known >> a) & 1ull) ? 0.0 : ((a == 0) ? w : w * cc[a]);
             ldlt_solve<NO>(M, sv);
@@ -388,11 +395,14 @@ __global__ __launch_bounds__(64, (!RESIDENT && !SENS && ndofs(DIM, ORDER) <= WLS
         double norm = 0.0, r[NO];
 #pragma unroll
         for (int a = 0; a < NO; ++a) r[a] = 0.0;
-        auto sweep_body = [&](const double (&d)[DIM], double f, bool live, int) __attribute__((always_inline)) {
+        auto sweep_body = [&](const double (&d)[DIM], double f, bool live, int k) __attribute__((always_inline)) {
             double cc[NO];
-            const double d2 = monomials<DIM, ORDER>(d, cc);
-            double w = weight(d2, inv_max, uniform);
-            w = live ? w : 0.0;
+            monomials<DIM, ORDER>(d, cc);
+            // the weight of the moment pass, bit for bit (the reference computes its weights once, infra.pyx:668-702): cached, or
+            // recomputed from the same rounding sequence of the squared distance
+            double w;
+            if constexpr (WCACHE) w = wrow[k];
+            else { w = weight(sqdist(d), inv_max, uniform); w = live ? w : 0.0; }
 #if WLSQM_SITER_MODEL_CHAINS > 1
             // taylor_*D (polyeval.pyx): sum_a c[a] fi[a], as WLSQM_SITER_MODEL_CHAINS interleaved partial sums (shorter dependent chains)
             double part[WLSQM_SITER_MODEL_CHAINS];
@@ -501,6 +511,18 @@ static int launch_stage_refine(const KParams& p, long long K, hipStream_t stream
         WLSQM_HIP_CHECK(hipGetLastError());
         note_kernel("stage-refine-resident");
         return WLSQM_OK;
+    }
+    {
+        // the weights beside the staging rows while four waves per CU still fit (WLSQM_HIP_REFINE_WCACHE=0: never)
+        const char* e = getenv("WLSQM_HIP_REFINE_WCACHE");
+        const int WP = (Q * CH) | 1;
+        const size_t wbytes = (size_t)64 * WP * 8, stat = (size_t)64 * (pitch2(CH * DIM) + pitch2(CH)) * 16;
+        if (!(e && e[0] == '0') && p.max_iter >= 1 && ndofs(DIM, ORDER) > 6 && wbytes + stat <= 40 * 1024) {
+            hipLaunchKernelGGL((fit_stage_refine_kernel<DIM, ORDER, false, false, true>), dim3((unsigned)groups), dim3(64), wbytes, stream, p, 0, WP);
+            WLSQM_HIP_CHECK(hipGetLastError());
+            note_kernel("stage-refine");
+            return WLSQM_OK;
+        }
     }
     hipLaunchKernelGGL((fit_stage_refine_kernel<DIM, ORDER, false, false>), dim3((unsigned)groups), dim3(64), 0, stream, p, 0, 0);
     WLSQM_HIP_CHECK(hipGetLastError());
