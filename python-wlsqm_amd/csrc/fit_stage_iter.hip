@@ -67,9 +67,13 @@ __host__ __device__ constexpr int pitch2(int doubles) {               // row pit
 // anyway, and a sweep's reciprocal root + Newton steps + blend are 14 of its 52 (3D order 2) / 79 (2D order 4) vector instructions per
 // neighbour.  64 x K doubles per wave at an odd pitch: chosen by the launcher while four waves per CU still fit beside the staging rows
 // (2D: up to 48 neighbours, 3D: up to 40 — configs[4]).
-template <int DIM, int ORDER, bool RESIDENT, bool SENS, bool WCACHE = false>
-__global__ __launch_bounds__(64, (!RESIDENT && !SENS && !WCACHE && ndofs(DIM, ORDER) <= WLSQM_SITER_TWO_WAVES_UPTO) ? 2 : 1) void fit_stage_refine_kernel(const KParams p, const int XP2r, const int FP2r) {
-    static_assert(!WCACHE || (!RESIDENT && !SENS), "the weight cache belongs to the re-staging refinement form");
+// CACHE = 2: the neighbours' VALUES fk instead (the same 64 x K doubles): the sweeps then re-stage the coordinates only — 24 of 32 bytes
+// per 3D neighbour.  For the shape whose sweeps are bound by the rows coming back from the Infinity Cache rather than by their
+// instructions: 3D order 2 (configs[4]: the weight cache gave 1.5 % there, against 6-8 % on the 2D shapes).
+template <int DIM, int ORDER, bool RESIDENT, bool SENS, int CACHE = 0>
+__global__ __launch_bounds__(64, (!RESIDENT && !SENS && CACHE == 0 && ndofs(DIM, ORDER) <= WLSQM_SITER_TWO_WAVES_UPTO) ? 2 : 1) void fit_stage_refine_kernel(const KParams p, const int XP2r, const int FP2r) {
+    static_assert(CACHE == 0 || (!RESIDENT && !SENS), "the caches belong to the re-staging refinement form");
+    constexpr bool WCACHE = CACHE == 1, FCACHE = CACHE == 2;
     using namespace siter;
     constexpr int NO = ndofs(DIM, ORDER), NE = NO * (NO + 1) / 2, NM = mom_count<DIM>(2 * ORDER);
     constexpr int SG = sens_group(NO), SR = SG * NO / 2, TP2 = pitch2(SG * NO);      // neighbours per sens tile; 16-byte pieces of a case's tile; tile pitch
@@ -125,7 +129,8 @@ __global__ __launch_bounds__(64, (!RESIDENT && !SENS && !WCACHE && ndofs(DIM, OR
     // 1.240 ms, i.e. the latency is NOT what bounds the sweeps there.
     constexpr bool DEEP = (WLSQM_SITER_DEEP != 0) && !RESIDENT && NO > 6 && NO <= 10;      // (the 6-unknown systems run two waves per SIMD)
     d2_ xr[XNI], fr[FNI], xr2[DEEP ? XNI : 1], fr2[DEEP ? FNI : 1];
-    auto fetch_into = [&](d2_ (&xr)[XNI], d2_ (&fr)[FNI], int q) __attribute__((always_inline)) {
+    auto fetch_into = [&](d2_ (&xr)[XNI], d2_ (&fr)[FNI], int q, auto nof_tag) __attribute__((always_inline)) {
+        constexpr bool NOF = decltype(nof_tag)::value;                // (FCACHE, sweeps) the values are in LDS already: coordinates only
         unsigned xo = (unsigned)q * (CH * DIM * 8) + (unsigned)xsub * 16u, fo = (unsigned)q * (CH * 8) + (unsigned)fsub * 16u;
         xo = xo < xrowb ? xo : xrowb - 16u; fo = fo < frowb ? fo : frowb - 16u;      // (rows are multiples of 16 bytes: K even)
         const char* xb = xtile + xo;
@@ -136,25 +141,30 @@ __global__ __launch_bounds__(64, (!RESIDENT && !SENS && !WCACHE && ndofs(DIM, OR
             cc = cc < nvalid ? cc : nvalid - 1;                       // tail group / idle lanes of the last instruction: replay a valid row
             if (xlane) xr[i] = *reinterpret_cast<const d2_*>(xb + (size_t)(unsigned)cc * xrowb);
         }
+        if constexpr (!NOF) {
 #pragma unroll
-        for (int i = 0; i < FNI; ++i) {
-            int cc = fc0 + i * FCPI;
-            cc = cc < nvalid ? cc : nvalid - 1;
-            fr[i] = *reinterpret_cast<const d2_*>(fb + (size_t)(unsigned)cc * frowb);
+            for (int i = 0; i < FNI; ++i) {
+                int cc = fc0 + i * FCPI;
+                cc = cc < nvalid ? cc : nvalid - 1;
+                fr[i] = *reinterpret_cast<const d2_*>(fb + (size_t)(unsigned)cc * frowb);
+            }
         }
     };
-    auto park_from = [&](const d2_ (&xr)[XNI], const d2_ (&fr)[FNI], int q) __attribute__((always_inline)) {      // RESIDENT: chunk q at its place in the whole row
+    auto park_from = [&](const d2_ (&xr)[XNI], const d2_ (&fr)[FNI], int q, auto nof_tag) __attribute__((always_inline)) {      // RESIDENT: chunk q at its place in the whole row
+        constexpr bool NOF = decltype(nof_tag)::value;
         d2_* xl = xs + xc0 * XP2 + xsub + (RESIDENT ? q * (CH * DIM / 2) : 0);
         d2_* fl = fs + fc0 * FP2 + fsub + (RESIDENT ? q * (CH / 2) : 0);
 #pragma unroll
         for (int i = 0; i < XNI; ++i)
             if (xlane && (i * XCPI + XCPI <= 64 || xc0 + i * XCPI < 64)) xl[i * XCPI * XP2] = xr[i];
+        if constexpr (!NOF) {
 #pragma unroll
-        for (int i = 0; i < FNI; ++i) fl[i * FCPI * FP2] = fr[i];
+            for (int i = 0; i < FNI; ++i) fl[i * FCPI * FP2] = fr[i];
+        }
     };
     constexpr bool WARM = (WLSQM_SITER_WARM != 0) && !RESIDENT && !DEEP;
     bool inflight = false;                                            // (wave-uniform) chunk Q - 1 of the next pass is on its way in (xr, fr)
-    double* const wrow = reinterpret_cast<double*>(lds_d) + lane * FP2r;      // (WCACHE) this lane's weights; FP2r: the pitch in doubles (odd)
+    double* const wrow = reinterpret_cast<double*>(lds_d) + lane * FP2r;      // (WCACHE / FCACHE) this lane's weights / values; FP2r: the pitch in doubles (odd)
     const d2_* const xrow = xs + lane * XP2;
     const d2_* const frow = fs + lane * FP2;
 
@@ -162,8 +172,9 @@ __global__ __launch_bounds__(64, (!RESIDENT && !SENS && !WCACHE && ndofs(DIM, OR
     // after_group(k0) behind every group of GRP neighbours k0 .. k0 + GRP - 1.
     // Not RESIDENT: the chunks travel through the staging rows.
     // RESIDENT and !fill: everything is in LDS.  RESIDENT and fill: the first pass, which parks the chunks at their places.
-    auto for_neighbours = [&](auto masked_tag, auto grp_tag, auto body, auto after_group, const bool fill) __attribute__((always_inline)) {
+    auto for_neighbours = [&](auto masked_tag, auto grp_tag, auto body, auto after_group, const bool fill, auto nof_tag) __attribute__((always_inline)) {
         constexpr bool MASKED = decltype(masked_tag)::value;
+        constexpr bool NOF = decltype(nof_tag)::value;                // (FCACHE) the values come from the lane's cache row
         constexpr int GRP = decltype(grp_tag)::value;                 // neighbours of a lane in flight
         const bool staged = !RESIDENT || fill;
         auto compute = [&](const int q) __attribute__((always_inline)) {
@@ -175,9 +186,14 @@ __global__ __launch_bounds__(64, (!RESIDENT && !SENS && !WCACHE && ndofs(DIM, OR
                 static_assert(GRP % 2 == 0 || (GRP == 1 && DIM == 2), "whole 16-byte pieces per group");
 #pragma unroll
                 for (int i = 0; i < GRP * DIM / 2; ++i) { const d2_ v = xq[g * (GRP * DIM / 2) + i]; xv[2 * i] = v.x; xv[2 * i + 1] = v.y; }
-                if constexpr (GRP == 1) { const d2_ v = fq[g / 2]; fv[0] = (g & 1) ? v.y : v.x; }
+                if constexpr (NOF) {
 #pragma unroll
-                for (int i = 0; i < GRP / 2; ++i) { const d2_ v = fq[g * (GRP / 2) + i]; fv[2 * i] = v.x; fv[2 * i + 1] = v.y; }
+                    for (int i = 0; i < GRP; ++i) fv[i] = wrow[q * CH + g * GRP + i];
+                } else {
+                    if constexpr (GRP == 1) { const d2_ v = fq[g / 2]; fv[0] = (g & 1) ? v.y : v.x; }
+#pragma unroll
+                    for (int i = 0; i < GRP / 2; ++i) { const d2_ v = fq[g * (GRP / 2) + i]; fv[2 * i] = v.x; fv[2 * i + 1] = v.y; }
+                }
 #pragma unroll
                 for (int kk = GRP - 1; kk >= 0; --kk) {
                     const int ks = g * GRP + kk;
@@ -200,30 +216,30 @@ __global__ __launch_bounds__(64, (!RESIDENT && !SENS && !WCACHE && ndofs(DIM, OR
         auto step = [&](d2_ (&xa)[XNI], d2_ (&fa)[FNI], const int q, const int ahead) __attribute__((always_inline)) {
             if (staged) {
                 if (!RESIDENT) __syncthreads();                       // the previous chunk has been read by every lane
-                park_from(xa, fa, q);
+                park_from(xa, fa, q, nof_tag);
                 __syncthreads();
-                if (q - ahead >= 0) fetch_into(xa, fa, q - ahead);
-                else if (WARM && q == 0) { fetch_into(xa, fa, Q - 1); inflight = true; }
+                if (q - ahead >= 0) fetch_into(xa, fa, q - ahead, nof_tag);
+                else if (WARM && q == 0) { fetch_into(xa, fa, Q - 1, std::false_type{}); inflight = true; }
             }
             compute(q);
         };
         if constexpr (DEEP) {
-            fetch_into(xr, fr, Q - 1);
-            if (Q > 1) fetch_into(xr2, fr2, Q - 2);
+            fetch_into(xr, fr, Q - 1, nof_tag);
+            if (Q > 1) fetch_into(xr2, fr2, Q - 2, nof_tag);
             for (int q = Q - 1; q >= 0; q -= 2) {
                 step(xr, fr, q, 2);
                 if (q >= 1) step(xr2, fr2, q - 1, 2);
             }
         } else {
-            if (staged && !(WARM && inflight)) fetch_into(xr, fr, Q - 1);
+            if (staged && !(WARM && inflight)) fetch_into(xr, fr, Q - 1, nof_tag);
             for (int q = Q - 1; q >= 0; --q) step(xr, fr, q, 1);
         }
     };
     const bool full = (K % CH == 0) && __all(nkc >= K);               // wave-uniform: no ragged case in this group, whole chunks
     auto no_hook = [](int) __attribute__((always_inline)) {};
-    auto pass = [&](auto body, const bool fill) __attribute__((always_inline)) {
-        if (full) for_neighbours(std::false_type{}, std::integral_constant<int, GRP>{}, body, no_hook, fill);
-        else for_neighbours(std::true_type{}, std::integral_constant<int, GRP>{}, body, no_hook, fill);
+    auto pass = [&](auto body, const bool fill, auto nof_tag) __attribute__((always_inline)) {
+        if (full) for_neighbours(std::false_type{}, std::integral_constant<int, GRP>{}, body, no_hook, fill, nof_tag);
+        else for_neighbours(std::true_type{}, std::integral_constant<int, GRP>{}, body, no_hook, fill, nof_tag);
     };
 
     // ---- the fit: largest squared distance, moments
@@ -239,6 +255,7 @@ __global__ __launch_bounds__(64, (!RESIDENT && !SENS && !WCACHE && ndofs(DIM, OR
         double w = weight(d2, inv_max, uniform);
         w = live ? w : 0.0;
         if constexpr (WCACHE) wrow[k] = w;                            // (a repeated pass overwrites them with the final ones)
+        if constexpr (FCACHE) wrow[k] = f;                            // (masked: 0 beyond the case's neighbours)
         accumulate_moments_best<DIM, ORDER>(mu, nu, d, w, f);
     };
     auto moments = [&](const double maxv) __attribute__((always_inline)) {
@@ -248,10 +265,10 @@ __global__ __launch_bounds__(64, (!RESIDENT && !SENS && !WCACHE && ndofs(DIM, OR
         for (int a = 0; a < NO; ++a) nu[a] = 0.0;
         max_d2 = 0.0;
         inv_max = inverse_max(maxv);
-        pass(mom_body, false);
+        pass(mom_body, false, std::false_type{});
     };
     if constexpr (RESIDENT) {
-        pass(max_body, true);
+        pass(max_body, true, std::false_type{});
         moments(max_d2);
     } else {
         // speculative (fit_stage.hip): the last neighbour is the farthest for sorted neighbour lists; verified bit for bit
@@ -380,8 +397,8 @@ __global__ __launch_bounds__(64, (!RESIDENT && !SENS && !WCACHE && ndofs(DIM, OR
             __syncthreads();                                          // the tile is read
         };
         if (p.sens) {
-            if (full) for_neighbours(std::false_type{}, std::integral_constant<int, SGRP>{}, sens_body, flush, false);
-            else for_neighbours(std::true_type{}, std::integral_constant<int, SGRP>{}, sens_body, flush, false);
+            if (full) for_neighbours(std::false_type{}, std::integral_constant<int, SGRP>{}, sens_body, flush, false, std::false_type{});
+            else for_neighbours(std::true_type{}, std::integral_constant<int, SGRP>{}, sens_body, flush, false, std::false_type{});
         }
     }
 
@@ -425,7 +442,7 @@ __global__ __launch_bounds__(64, (!RESIDENT && !SENS && !WCACHE && ndofs(DIM, OR
 #pragma unroll
             for (int a = 0; a < NO; ++a) r[a] = fma(wr, (a == 0) ? 1.0 : cc[a], r[a]);
         };
-        pass(sweep_body, false);
+        pass(sweep_body, false, std::bool_constant<FCACHE>{});
         if (!done) {
             if (norm == prev_norm) { broke = true; done = true; it_case = it; }      // impl.pyx:1057
             else {
@@ -518,7 +535,12 @@ static int launch_stage_refine(const KParams& p, long long K, hipStream_t stream
         const int WP = (Q * CH) | 1;
         const size_t wbytes = (size_t)64 * WP * 8, stat = (size_t)64 * (pitch2(CH * DIM) + pitch2(CH)) * 16;
         if (!(e && e[0] == '0') && p.max_iter >= 1 && ndofs(DIM, ORDER) > 6 && wbytes + stat <= 40 * 1024) {
-            hipLaunchKernelGGL((fit_stage_refine_kernel<DIM, ORDER, false, false, true>), dim3((unsigned)groups), dim3(64), wbytes, stream, p, 0, WP);
+            // 3D: the values (the sweeps are bound by the re-staged bytes); 2D: the weights (by their instructions); =w / =f force one
+            constexpr int DEF = DIM == 3 ? 2 : 1;
+            const int which = (e && e[0] == 'w') ? 1 : (e && e[0] == 'f') ? 2 : DEF;
+            if (which == 2) hipLaunchKernelGGL((fit_stage_refine_kernel<DIM, ORDER, false, false, 2>), dim3((unsigned)groups), dim3(64), wbytes, stream, p, 0, WP);
+            else
+            hipLaunchKernelGGL((fit_stage_refine_kernel<DIM, ORDER, false, false, 1>), dim3((unsigned)groups), dim3(64), wbytes, stream, p, 0, WP);
             WLSQM_HIP_CHECK(hipGetLastError());
             note_kernel("stage-refine");
             return WLSQM_OK;
