@@ -515,7 +515,12 @@ static int launch_stage_refine(const KParams& p, long long K, hipStream_t stream
     size_t bound = 53 * 1024;
     if (const char* e = getenv("WLSQM_HIP_REFINE_RESIDENT_KB")) bound = (size_t)atol(e) * 1024;
     if (bound > 160 * 1024) bound = 160 * 1024;
-    if (bytes <= bound && bytes >= (size_t)64 * ndofs(DIM, ORDER) * 8) {
+    // (from three sweeps on: below that the re-staging form's four to five waves per CU win — 2D order 4 at 26 neighbours, max_iter 0 / 1 /
+    // 2 / 4 / 10: 0.132 / 0.216 / 0.297 / 0.433 / 0.813 against 0.158 / 0.218 / 0.276 / 0.394 / 0.738 ms resident, 3D order 2 at 20: 0.088 /
+    // 0.128 / 0.174 / 0.277 / 0.508 against 0.115 / 0.148 / 0.187 / 0.255 / 0.460, profiles/r04zb_ab_siter_resident.txt; an explicit
+    // WLSQM_HIP_REFINE_RESIDENT_KB applies to every max_iter)
+    const bool few = !getenv("WLSQM_HIP_REFINE_RESIDENT_KB") && p.max_iter < 3;
+    if (!few && bytes <= bound && bytes >= (size_t)64 * ndofs(DIM, ORDER) * 8) {
         auto kern = fit_stage_refine_kernel<DIM, ORDER, true, false>;
         static std::atomic<unsigned> optin{0};                        // per device, once: more than 64 KB of dynamic LDS
         int dev = 0;
