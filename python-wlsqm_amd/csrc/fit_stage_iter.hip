@@ -593,7 +593,7 @@ int launch_fit_stage_refine(int dimension, int order, const KParams& p, long lon
     if ((reinterpret_cast<uintptr_t>(p.xk) | reinterpret_cast<uintptr_t>(p.fk)) & 15u) return WLSQM_OK;
     if (p.do_sens && (p.ss_j * 8 * 4 > 0x7fffffffLL)) return WLSQM_OK;            // (32-bit offsets inside a store instruction's four cases)
 #define RCASE(D, O, COND) if (dimension == D && order == O && (all || (COND))) { *handled = true; return launch_stage_refine<D, O>(p, K, stream); }
-    RCASE(2, 2, p.max_iter <= 2)
+    RCASE(2, 2, p.max_iter <= 2 || (K >= 48 && p.max_iter <= 5) || (K > 64 && p.max_iter <= 8))     // (64 neighbours, max_iter 4: 0.504 against 0.596 ms; 160, max_iter 4: 1.31 against 2.08, 10: 2.71 against 2.58)
     RCASE(2, 3, K >= 40 || p.max_iter <= 7)
     RCASE(2, 4, true)
     RCASE(3, 2, true)

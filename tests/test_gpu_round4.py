@@ -466,7 +466,8 @@ def test_staged_refinement_kernel(wlsqm, oracle, dim, order, Kn, n, neighbours, 
     # the default dispatch: 2D order 4 and 3D order 2 always, 2D order 3 from 40 neighbours on or up to 7 sweeps, 2D order 2 up to 2 sweeps
     for mi in (2, 10):
         _, _, name_d = run(max_iter=mi, WLSQM_HIP_STAGE_REFINE="")
-        here = (dim, order) in ((2, 4), (3, 2)) or ((dim, order) == (2, 3) and (Kn >= 40 or mi <= 7)) or ((dim, order) == (2, 2) and mi <= 2)
+        here = (dim, order) in ((2, 4), (3, 2)) or ((dim, order) == (2, 3) and (Kn >= 40 or mi <= 7)) or \
+            ((dim, order) == (2, 2) and (mi <= 2 or (Kn >= 48 and mi <= 5) or (Kn > 64 and mi <= 8)))
         assert name_d.startswith("stage-refine") == here, (name_d, mi)
     # max_iter 0: the unrefined fit, return value 1
     f0, it0, name0 = run(max_iter=0)
