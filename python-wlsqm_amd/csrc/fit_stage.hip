@@ -32,6 +32,9 @@
 #include "wlsqm_kernels.hpp"
 #include "wlsqm_moments.hpp"
 
+#ifndef WLSQM_STAGE_NT_LOADS
+#define WLSQM_STAGE_NT_LOADS 0      // 1: the once-read rows by non-temporal loads — slower: configs[1] 0.175 against 0.152 ms, configs[2] 0.407 against 0.398, configs[4] 0.317 against 0.286 (profiles/r04zb_ab_stage_nt_loads.txt)
+#endif
 #ifndef WLSQM_STAGE_GRP
 #define WLSQM_STAGE_GRP 4           // neighbours the scheduler may interleave in the moment pass (with WLSQM_STAGE_SCHED_BARRIER)
 #endif
@@ -154,13 +157,21 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER)
         for (int i = 0; i < XNI; ++i) {
             int cc = xc0 + i * XCPI;
             cc = cc < nvalid ? cc : nvalid - 1;                       // tail group / idle lanes of the last instruction: replay a valid row
+#if WLSQM_STAGE_NT_LOADS
+            if (xlane) xr[i] = __builtin_nontemporal_load(reinterpret_cast<const d2_*>(xb + (size_t)(unsigned)cc * xrowb));
+#else
             if (xlane) xr[i] = *reinterpret_cast<const d2_*>(xb + (size_t)(unsigned)cc * xrowb);
+#endif
         }
 #pragma unroll
         for (int i = 0; i < FNI; ++i) {
             int cc = fc0 + i * FCPI;
             cc = cc < nvalid ? cc : nvalid - 1;
+#if WLSQM_STAGE_NT_LOADS
+            fr[i] = __builtin_nontemporal_load(reinterpret_cast<const d2_*>(fb + (size_t)(unsigned)cc * frowb));
+#else
             fr[i] = *reinterpret_cast<const d2_*>(fb + (size_t)(unsigned)cc * frowb);
+#endif
         }
     };
     auto gather = [&](int q) __attribute__((always_inline)) {
