@@ -527,6 +527,12 @@ static int solve_iterative(Case* cs, const double* fk, long sfk, double* sens, l
     double* wrk_fk = cs->fk_tmp; double* wrk_fi = cs->fi_tmp; double* fi = cs->fi;
     double norm, prev_norm = -1., tmp;
     solve(cs, fk, sfk, fi, sens, ssk, do_sens);
+    /* The reference zeroes the entries of the KNOWN DOFs only (impl.pyx:1004-1008).  With stray mask bits beyond `no` the unknown that
+     * drops out of the reduced system (infra.pyx:119-121) is never written by the correction solves either, and fi[om] += wrk_fi[om]
+     * (impl.pyx:1076-1078) then adds an UNINITIALISED entry of the work array in every sweep: undefined in the reference (whatever the
+     * heap held; a fresh heap holds zeros).  The oracle defines it as 0 — the fresh-heap behaviour, and what the GPU kernels do (the
+     * dropped DOF keeps the caller's value) — so that its output does not depend on the allocator's history. */
+    for (om = 0; om < no; om++) wrk_fi[om] = 0.;
     for (om = 0; om < no; om++)
         if (cs->knowns & (1LL << om)) wrk_fi[om] = 0.;
     for (i = 0; i < max_iter; i++) {

@@ -410,11 +410,11 @@ def test_staged_refinement_kernel(wlsqm, oracle, dim, order, Kn, n, neighbours, 
             off[j, :nk[j]] = off[j, :nk[j]][idx]
     xk = xi[:, None, :] + off
     fk = np.sin(3 * xk[..., 0]) * np.cos(2 * xk[..., -1])
-    # (no stray mask bits beyond `no` here: with them the reference's refinement is undefined — the unknown that drops out of the
-    # reduced system (infra.pyx:119-121) is never written in the work array `wrk_fi`, yet `fi[om] += wrk_fi[om]` (impl.pyx:1076-1078)
-    # adds that uninitialised entry in every sweep; the oracle restates this and returned NaN rows or not depending on what the heap
-    # held.  The basic fit with such masks is covered by test_staged_kernel.)
-    kn = rng.choice(np.array([0, 0, 1, 1 | (1 << (no - 1)), (1 << no) - 1, 0b110], np.int64), n)
+    # (stray mask bits beyond `no`: the reference's refinement is undefined there — the unknown that drops out of the reduced system
+    # (infra.pyx:119-121) is never written in the work array `wrk_fi`, yet `fi[om] += wrk_fi[om]` (impl.pyx:1076-1078) adds that
+    # uninitialised entry in every sweep; the oracle first restated this literally and returned NaN rows or not depending on what the
+    # heap held, and now defines the entry as 0, the fresh-heap behaviour: the dropped DOF keeps the caller's value, as on the GPU)
+    kn = rng.choice(np.array([0, 0, 1, 1 | (1 << (no - 1)), (1 << no) - 1, 0b110, 1 << (no + 2)], np.int64), n)
     wm = rng.choice(np.array([wlsqm.WEIGHT_UNIFORM, wlsqm.WEIGHT_CENTER], np.int32), n)
     fi0 = rng.uniform(-1, 1, (n, no)); fi0[:, 0] = np.sin(3 * xi[:, 0]) * np.cos(2 * xi[:, -1])
     orders = np.full(n, order, np.int32)
@@ -502,7 +502,7 @@ def test_staged_sensitivities_kernel(wlsqm, oracle, dim, order, Kn, n, layout, m
         off[j, :nk[j]] = off[j, :nk[j]][idx]
     xk = xi[:, None, :] + off
     fk = np.sin(3 * xk[..., 0]) * np.cos(2 * xk[..., -1])
-    masks = [0, 0, 1, 1 | (1 << (no - 1)), (1 << no) - 1] + ([1 << (no + 2)] if layout != "dense+iter" else [])      # (stray bits and refinement: see above)
+    masks = [0, 0, 1, 1 | (1 << (no - 1)), (1 << no) - 1, 1 << (no + 2)]
     kn = rng.choice(np.array(masks, np.int64), n)
     wm = rng.choice(np.array([wlsqm.WEIGHT_UNIFORM, wlsqm.WEIGHT_CENTER], np.int32), n)
     ncol = no + (3 if wide else 0)
