@@ -19,8 +19,16 @@
 //   otherwise  every pass re-stages the rows in 8-neighbour chunks exactly as fit_stage.hip does (the chunks of a wave are 50-100 KB
 //              that were read a few microseconds ago: they come back from L2 / the Infinity Cache, not from HBM).  The moment pass is
 //              speculative as there (largest squared distance = the last neighbour's, verified bit for bit, repeated otherwise).
-// One sum per moment / per right-hand-side entry over k DESCENDING in one lane (the order of fit_stage.hip): the fit in front of
-// the sweeps has the bits of the staged kernel's generic solve.
+//              Where four waves per CU still fit beside the staging rows, 64 x K doubles per wave stay in LDS between the sweeps: the
+//              WEIGHTS (2D: a sweep is bound by its instructions, and the weight is 14 of them per neighbour) or the VALUES fk (3D:
+//              bound by the re-staged bytes; the sweeps then fetch the coordinates only).  See CACHE at the kernel.
+// One sum per moment / per right-hand-side entry over k DESCENDING in one lane (the order of fit_stage.hip).  A case with exactly the
+// function value known keeps the factor of its 14 x 14 system (2D order 4), as in the staged fit kernel.  Every form — resident,
+// re-staging, cached or not — returns the same bits for a case (tests/test_gpu_round4.py::test_staged_refinement_kernel).
+//
+// Measured and left off (switches at the top; records under profiles/r04zb_*): two chunks in flight, the next pass's first chunk behind
+// the current pass's last, two waves per SIMD for the 10-unknown systems, partial sums of the model evaluation, the caches at three
+// waves per CU, and the SENS form (sensitivities on this mapping: correct, 1.2-1.9x slower than the inverse + matrix-core path).
 #include <atomic>
 #include <type_traits>
 
