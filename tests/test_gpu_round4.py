@@ -388,7 +388,8 @@ def test_3d_order4_slices_give_the_same_bits(wlsqm, monkeypatch):
 # fit + iterative refinement with one lane per case (csrc/fit_stage_iter.hip; impl.pyx:986-1083)
 
 @pytest.mark.parametrize("dim,order,Kn", [(2, 2, 32), (2, 2, 8), (2, 2, 50), (2, 2, 160), (2, 3, 30), (2, 3, 80), (2, 4, 64), (2, 4, 26), (2, 4, 100),
-                                          (3, 2, 40), (3, 2, 12), (3, 2, 124)])
+                                          (3, 2, 40), (3, 2, 12), (3, 2, 124),
+                                          (2, 4, 40), (2, 3, 44), (3, 2, 34)])      # (re-staging with the weights / the values cached in LDS)
 @pytest.mark.parametrize("n", [1, 63, 65, 1000])
 @pytest.mark.parametrize("neighbours", ["sorted", "unsorted"])
 def test_staged_refinement_kernel(wlsqm, oracle, dim, order, Kn, n, neighbours, monkeypatch):
@@ -460,6 +461,11 @@ def test_staged_refinement_kernel(wlsqm, oracle, dim, order, Kn, n, neighbours, 
         other, it2, name2 = run(WLSQM_HIP_REFINE_RESIDENT_KB="160")
         assert name2 == ("stage-refine-resident" if 64 * 16 * sum(((((Kn + 7) // 8 * 8 * m + 1) // 2) | 1) for m in (dim, 1)) <= 160 * 1024 else "stage-refine"), name2
     assert np.array_equal(got.view(np.int64), other.view(np.int64)) and it2 == it
+    # the LDS caches of the re-staging form (weights in 2D, values in 3D, neither): the same bits
+    if not resident:
+        for which in ("0", "w", "f"):
+            alt, it4, name4 = run(WLSQM_HIP_REFINE_WCACHE=which)
+            assert name4 == "stage-refine" and np.array_equal(got.view(np.int64), alt.view(np.int64)) and it4 == it, which
     # run to run
     again, it3, _ = run()
     assert np.array_equal(got.view(np.int64), again.view(np.int64)) and it3 == it
