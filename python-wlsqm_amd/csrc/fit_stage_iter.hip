@@ -549,7 +549,7 @@ static int launch_stage_refine(const KParams& p, long long K, hipStream_t stream
         const size_t wbytes = (size_t)64 * WP * 8, stat = (size_t)64 * (pitch2(CH * DIM) + pitch2(CH)) * 16;
         size_t budget = 40 * 1024;                                   // four waves per CU (WLSQM_HIP_REFINE_CACHE_KB: A/B)
         if (const char* b = getenv("WLSQM_HIP_REFINE_CACHE_KB")) budget = (size_t)atol(b) * 1024;
-        if (!(e && e[0] == '0') && p.max_iter >= 1 && ndofs(DIM, ORDER) > 6 && wbytes + stat <= budget && wbytes <= 64 * 1024) {
+        if (!(e && e[0] == '0') && p.max_iter >= 1 && ndofs(DIM, ORDER) > 6 && wbytes + stat <= budget && wbytes + stat <= 64 * 1024) {        // (no opt-in to more than 64 KB of LDS for this kernel)
             // 3D: the values (the sweeps are bound by the re-staged bytes); 2D: the weights (by their instructions); =w / =f force one
             constexpr int DEF = DIM == 3 ? 2 : 1;
             const int which = (e && e[0] == 'w') ? 1 : (e && e[0] == 'f') ? 2 : DEF;
