@@ -527,7 +527,11 @@ static int launch_stage_refine(const KParams& p, long long K, hipStream_t stream
     // 2 / 4 / 10: 0.132 / 0.216 / 0.297 / 0.433 / 0.813 against 0.158 / 0.218 / 0.276 / 0.394 / 0.738 ms resident, 3D order 2 at 20: 0.088 /
     // 0.128 / 0.174 / 0.277 / 0.508 against 0.115 / 0.148 / 0.187 / 0.255 / 0.460, profiles/r04zb_ab_siter_resident.txt; an explicit
     // WLSQM_HIP_REFINE_RESIDENT_KB applies to every max_iter)
-    const bool few = !getenv("WLSQM_HIP_REFINE_RESIDENT_KB") && p.max_iter < 3;
+    // 2D order 3 never (with the weight cache the re-staging form wins at every sweep count: 24 / 30 / 32 neighbours, max_iter 10: 0.371 /
+    // 0.554 / 0.523 against 0.377 / 0.638 / 0.558 ms resident; 2D order 4 and 3D order 2 the other way round: 26 neighbours 0.81 against
+    // 0.73, 20 neighbours 0.51 against 0.46)
+    // (rows of at most 40 KB leave four waves per CU as well: resident always — 2D order 3 at 16 neighbours 0.234 against 0.258 ms)
+    const bool few = !getenv("WLSQM_HIP_REFINE_RESIDENT_KB") && bytes > 40 * 1024 && (p.max_iter < 3 || (DIM == 2 && ORDER == 3));
     if (!few && bytes <= bound && bytes >= (size_t)64 * ndofs(DIM, ORDER) * 8) {
         auto kern = fit_stage_refine_kernel<DIM, ORDER, true, false>;
         static std::atomic<unsigned> optin{0};                        // per device, once: more than 64 KB of dynamic LDS
@@ -585,7 +589,8 @@ static int launch_stage_refine(const KParams& p, long long K, hipStream_t stream
 // order 3 at 30 0.62 against 0.54 and 2D order 2 at 16 / 32 / 64 0.19 / 0.43 / 1.08 against 0.17 / 0.31 / 0.75: a 64-case wave sweeps
 // until its LAST case stops and re-reads its rows per sweep where the 16-case tiles of those kernels keep them in LDS at two waves per
 // SIMD.  The fit in front of the sweeps is 2-3x faster here, so the small systems come here for few sweeps only (the crossover:
-// max_iter 2 for 2D order 2, 7 for 2D order 3 below 40 neighbours).
+// max_iter 2 for 2D order 2 — later by neighbour count —, the figures above are from before the LDS caches: with the weight
+// cache 2D order 3 wins at every neighbour and sweep count, profiles/r04zb_time_refine_23.txt).
 int launch_fit_stage_refine(int dimension, int order, const KParams& p, long long K, hipStream_t stream, bool* handled) {
     *handled = false;
     const char* off = getenv("WLSQM_HIP_DISABLE_TILE");
@@ -604,7 +609,7 @@ int launch_fit_stage_refine(int dimension, int order, const KParams& p, long lon
     if (p.do_sens && (p.ss_j * 8 * 4 > 0x7fffffffLL)) return WLSQM_OK;            // (32-bit offsets inside a store instruction's four cases)
 #define RCASE(D, O, COND) if (dimension == D && order == O && (all || (COND))) { *handled = true; return launch_stage_refine<D, O>(p, K, stream); }
     RCASE(2, 2, p.max_iter <= 2 || (K >= 48 && p.max_iter <= 5) || (K > 64 && p.max_iter <= 8))     // (64 neighbours, max_iter 4: 0.504 against 0.596 ms; 160, max_iter 4: 1.31 against 2.08, 10: 2.71 against 2.58)
-    RCASE(2, 3, K >= 40 || p.max_iter <= 7)
+    RCASE(2, 3, true)                                               // (16 / 20 / 24 / 30 / 32 / 36 neighbours, max_iter 10: 0.234 / 0.386 / 0.385 / 0.539 / 0.523 / 0.639 against 0.336 / 0.451 / 0.480 / 0.542 / 0.543 / 0.876 ms on tile1-extras)
     RCASE(2, 4, true)
     RCASE(3, 2, true)
 #undef RCASE

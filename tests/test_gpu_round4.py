@@ -433,7 +433,8 @@ def test_staged_refinement_kernel(wlsqm, oracle, dim, order, Kn, n, neighbours, 
             monkeypatch.delenv(k_)
         return fi.cpu().numpy(), it, name
     got, it, name = run()
-    resident = 64 * 16 * sum(((((Kn + 7) // 8 * 8 * m + 1) // 2) | 1) for m in (dim, 1)) <= 53 * 1024
+    rows_b = 64 * 16 * sum(((((Kn + 7) // 8 * 8 * m + 1) // 2) | 1) for m in (dim, 1))
+    resident = rows_b <= 40 * 1024 or (rows_b <= 53 * 1024 and (dim, order) != (2, 3))      # (three waves per CU: not for 2D order 3)
     assert name == ("stage-refine-resident" if resident else "stage-refine"), name
     ref = fi0.copy()
     it_o = oracle.fit_many(dim, xk, fk, nk, xi, ref, None, 0, orders, kn, wm, iterative=True, max_iter=10, ntasks=8)
@@ -472,12 +473,12 @@ def test_staged_refinement_kernel(wlsqm, oracle, dim, order, Kn, n, neighbours, 
     # the default dispatch: 2D order 4 and 3D order 2 always, 2D order 3 from 40 neighbours on or up to 7 sweeps, 2D order 2 up to 2 sweeps
     for mi in (2, 10):
         _, _, name_d = run(max_iter=mi, WLSQM_HIP_STAGE_REFINE="")
-        here = (dim, order) in ((2, 4), (3, 2)) or ((dim, order) == (2, 3) and (Kn >= 40 or mi <= 7)) or \
+        here = (dim, order) in ((2, 4), (3, 2), (2, 3)) or \
             ((dim, order) == (2, 2) and (mi <= 2 or (Kn >= 48 and mi <= 5) or (Kn > 64 and mi <= 8)))
         assert name_d.startswith("stage-refine") == here, (name_d, mi)
     # max_iter 0: the unrefined fit, return value 1
     f0, it0, name0 = run(max_iter=0)
-    assert it0 == 1 and name0 == "stage-refine"                # (few sweeps: always the re-staging form)
+    assert it0 == 1 and name0 == ("stage-refine-resident" if rows_b <= 40 * 1024 else "stage-refine")      # (few sweeps: resident only where four waves per CU remain)
     fb = _t(fi0)
     whip.fit_many_device(dim, order, _t(xk), _t(fk), _t(nk), _t(xi), fb, _t(kn), _t(wm))
     if n >= 63:

@@ -28,6 +28,8 @@ for dim, order, K in shapes:
         os.environ.pop("WLSQM_HIP_DISABLE_CHUNK_REFINE", None); os.environ.pop("WLSQM_HIP_STAGE_REFINE", None)
         if mode != "stage":
             os.environ["WLSQM_HIP_STAGE_REFINE"] = "0"
+        elif os.environ.get("TIME_REFINE_FORCE") == "1":          # every covered shape on the kernel, whatever the dispatch rule says
+            os.environ["WLSQM_HIP_STAGE_REFINE"] = "all"
         if mode == "lane":
             os.environ["WLSQM_HIP_DISABLE_CHUNK_REFINE"] = "1"
         row = []
