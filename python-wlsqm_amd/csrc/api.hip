@@ -81,11 +81,11 @@ __global__ void repack_rows_kernel(const KParams p, int dim, long long K, long l
 // Index-based rows (S / F / hoods) of a shape without an index-based tile kernel: gathered once into dense scratch rows
 // (slots k >= nk[j] are never dereferenced: they replay the case's own point and stay masked).
 __global__ void gather_rows_kernel(const KParams p, int dim, long long K, long long Kp, double* __restrict__ xk, double* __restrict__ fk,
-                                   double* __restrict__ xi, int* __restrict__ nkc, long long pbase) {
+                                   double* __restrict__ xi, int* __restrict__ nkc) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= p.ncases * Kp) return;
     const long long j = t / Kp; const long long k = t - j * Kp;
-    const long long pj = p.pidx ? (long long)p.pidx[j] : pbase + j;       // without point_index, case j of the batch sits at point j
+    const long long pj = own_point(p, j);                                 // without point_index, case j of the batch sits at point pbase + j
     const long long idx = (k < K && k < p.nk[j * p.snk]) ? (long long)p.hoods[j * p.shoods_j + k] : pj;
     for (int m = 0; m < dim; ++m) xk[t * dim + m] = p.S[idx * dim + m];
     fk[t] = p.F[idx];
@@ -134,7 +134,7 @@ static int fit_through_dense_scratch(int dimension, int order, const KParams& p,
         const long long threads = n * Kp;
         if (gather)
             hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, src, dimension, max_nk, Kp,
-                               ws, ws + nx, ws + nx + nf, nkc, j0);
+                               ws, ws + nx, ws + nx + nf, nkc);
         else
             hipLaunchKernelGGL(repack_rows_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, src, dimension, max_nk, Kp,
                                ws, ws + nx, nkc);

@@ -37,9 +37,26 @@
 //   * the neighbour rows of the 64 cases of a wave reach their lanes through LDS in chunks of 8 neighbours: global loads are
 //     coalesced 16-byte pieces of whole 128- / 192-byte runs (the strict register kernel's lanes each read their own row: 64 cache
 //     lines per load instruction), the next chunk is in flight in registers while the current one is consumed.
-// One lane per case; a wave owns 64 consecutive cases.  Cases with a known DOF, sensitivities, refinement, systems above 10
-// unknowns and 1D fits are NOT taken here: in accurate mode they run the strict kernels (the reference's operations one for one, i.e. at least
-// as close to the reference).  Which kernel takes a case depends on that case alone.
+// One lane per case; a wave owns 64 consecutive cases.  Round 5: cases WITH known DOFs are taken too — any mask
+// inside the polynomial's DOFs, the reference's default knowns = b?_F (simple.pyx:60-61) included:
+//   * systems up to 10 unknowns: the MASKED FULL system.  Known rows and columns of the assembled matrix become rows of the identity; the
+//     equilibration leaves them at scale 1 (their only quotient is 1 / (1 x 1)) and never sees them in another row's maximum (their
+//     quotients there are 0), the pivot search never picks them for another column (their entries are 0 and the first maximum wins)
+//     and their multipliers are 0: every operation on the unknowns' entries is the reduced system's (infra.pyx:145-200 remap),
+//     bit for bit, with every index a compile-time constant.
+//   * the known values move to the right-hand side as the reference does it (impl.pyx:792-823): term by term into b[j], every term
+//     carrying the row scale — so after the equilibration, in one more pass over the neighbours PER known DOF (the sums of two knowns
+//     must not interleave: b[j] walks all neighbours of the first before the second).  The rows come back from L2 / the Infinity Cache.
+//   * 2D order 4 with exactly the function value known (BASELINE configs[2]: the 14 x 14 system) has a kernel of its own (RED1).  There
+//     the mirrored triangle is NOT free (profiles/r03_attribution.txt: 1.4e-4 from the reference, whose own noise is 3.5e-4, where the
+//     reference's operations one for one are 4e-7 away), so this form replays ALL of them — all 196 sums (w c_m) c_j of impl.pyx:601 in
+//     two passes of seven matrix rows each, the equilibration with its separate row and column factors, the reduced system with
+//     compile-time indices — and returns the bits of the strict kernels.  The LU carries the forward substitution
+//     along as an augmented column (the multipliers are never stored) and keeps its top rows in LDS.  The strict mode sends the same
+//     cases here as well.
+// Sensitivities, refinement, 1D fits, the other masks of 2D order 4 and masks with stray bits beyond the polynomial's DOFs
+// (infra.pyx:119-121) are NOT taken here: in accurate mode they run the strict kernels (the reference's operations one for one, i.e. at
+// least as close to the reference).  Which kernel takes a case depends on that case alone.
 #include <atomic>
 #include <type_traits>
 
@@ -77,6 +94,12 @@ constexpr int GRP = WLSQM_ACC_GRP < CH ? WLSQM_ACC_GRP : CH;                    
 template <int N> __host__ __device__ constexpr int utri(int i, int m) { return i * N - i * (i - 1) / 2 + (m - i); }   // i <= m < N
 
 __host__ __device__ constexpr int minw(int NO) { return NO <= 6 ? WLSQM_ACC_MINW6 : WLSQM_ACC_MINW10; }
+#ifndef WLSQM_ACC_LU_LDS_ROWS
+#define WLSQM_ACC_LU_LDS_ROWS 4     // top rows of the 14 x 14 matrix kept in LDS behind the staging rows (56 of 196 entries: 28 KB + 8 KB of 4-neighbour chunks per wave, four waves per CU)
+#endif
+__host__ __device__ constexpr int lu_lds_rows(int N) { return N > 10 ? WLSQM_ACC_LU_LDS_ROWS : 0; }
+// neighbours per staged chunk: the 14 x 14 form stages 4 (8 KB instead of 14 KB: the rest of its 40 KB share of the LDS holds matrix rows)
+__host__ __device__ constexpr int chunk_of(int N) { return N > 10 ? 4 : CH; }
 
 }  // namespace acc
 
@@ -186,12 +209,14 @@ __device__ __forceinline__ bool ruiz_sym(const double (&U)[N * (N + 1) / 2], dou
     return in_range;
 }
 
-// apply_scaling_c (lapackdrivers.pyx:293-299), dgetrf (unblocked dgetf2 semantics, :1628-1635), solve without knowns
-// (impl.pyx:731-846: b = row_scale * sums, dgetrs('N'), un-scale) and the store of the case's DOFs.  The row exchange is written as
-// selects over the candidate rows; a wave none of whose cases leaves the diagonal pivot in a column skips it.  (The 2 N quotients
-// here are the compiler's IEEE sequences: a pivot may be anything.)
+// apply_scaling_c (lapackdrivers.pyx:293-299), dgetrf (unblocked dgetf2 semantics, :1628-1635), dgetrs('N') and the un-scaling of
+// solve (impl.pyx:827-846) for the systems up to 10 unknowns, everything in registers.  b arrives as the reference's right-hand side
+// (row-scaled sums, knowns eliminated); `known`: DOFs that are not written (rows of the identity in U: see the header).  The row
+// exchange is written as selects over the candidate rows; a wave none of whose cases leaves the diagonal pivot in a column skips it.
+// (The 2 N quotients here are the compiler's IEEE sequences: a pivot may be anything.)
 template <int N>
-__device__ __forceinline__ void lu_solve_store(const double (&U)[N * (N + 1) / 2], const double (&rs)[N], double (&b)[N], double* fio) {
+__device__ __forceinline__ void lu_solve_store(const double (&U)[N * (N + 1) / 2], const double (&rs)[N], double (&b)[N], const unsigned known,
+                                               double* fio) {
     double A[N][N];
 #pragma unroll
     for (int i = 0; i < N; ++i)
@@ -225,8 +250,6 @@ __device__ __forceinline__ void lu_solve_store(const double (&U)[N * (N + 1) / 2
         }
     }
 #pragma unroll
-    for (int i = 0; i < N; ++i) b[i] = rs[i] * b[i];
-#pragma unroll
     for (int i = 0; i < N; ++i) {
         if (__any(ipiv[i] != i)) {
 #pragma unroll
@@ -244,7 +267,186 @@ __device__ __forceinline__ void lu_solve_store(const double (&U)[N * (N + 1) / 2
         for (int i = 0; i < c0; ++i) b[i] -= A[i][c0] * b[c0];
     }
 #pragma unroll
-    for (int i = 0; i < N; ++i) fio[i] = b[i] * rs[i];
+    for (int i = 0; i < N; ++i)
+        if (!((known >> i) & 1u)) fio[i] = b[i] * rs[i];
+}
+
+// The same operations for a system that does not fit the lane's registers beside its own LU (2D order 4 with the function value known:
+// 14 x 14, 196 + 14 doubles): the forward substitution of dgetrs RIDES ALONG as an augmented column — b's rows are exchanged with the
+// matrix rows and b[i] -= l_i b[c0] follows row i's update, the same operations on the same values in the same order as exchanging
+// all rows first and substituting afterwards (a multiplier l_i is applied to b[i] after the same earlier steps either way) — so the
+// multipliers are never stored and a finished row of U is only read again by the back substitution.  The matrix is addressed through
+// at / put (the caller keeps its top rows in LDS, entry (r, m) of lane l at [(r N + m) 64 + l]: conflict-free, the others in
+// registers) and is factored in place.  Rows are exchanged in two sweeps of selects: the pivot row is gathered from the candidates,
+// then every candidate takes row c0's old entries if it was the pivot.
+template <int N, class GET, class PUT>
+__device__ __forceinline__ void lu_aug_solve_store(GET&& at, PUT&& put, const double (&rs)[N], const double (&cs)[N], double (&b)[N], double* fio) {
+#pragma unroll
+    for (int m = 0; m < N; ++m)
+#pragma unroll
+        for (int i = 0; i < N; ++i) put(i, m, at(i, m) * (rs[i] * cs[m]));          // apply_scaling_c (lapackdrivers.pyx:293-299)
+#pragma unroll
+    for (int c0 = 0; c0 < N; ++c0) {
+        double col[N];                                                // column c0 of the rows from c0 on
+#pragma unroll
+        for (int i = c0; i < N; ++i) col[i] = at(i, c0);
+        int pv = c0; double best = fabs(col[c0]), pval = col[c0];
+#pragma unroll
+        for (int i = c0 + 1; i < N; ++i) { const double v = fabs(col[i]); if (v > best) { best = v; pv = i; pval = col[i]; } }
+        double prow[N], pb = b[c0];                                   // the pivot row right of the diagonal, and its b
+#pragma unroll
+        for (int m = c0 + 1; m < N; ++m) prow[m] = at(c0, m);
+        const bool exch = __any(pv != c0);                            // wave-uniform
+        if (exch) {
+            const double c00 = col[c0], b00 = pb;
+#pragma unroll
+            for (int i = c0 + 1; i < N; ++i) {
+                const bool sw = (pv == i);
+#pragma unroll
+                for (int m = c0 + 1; m < N; ++m) { const double v = at(i, m); prow[m] = sw ? v : prow[m]; }
+                pb = sw ? b[i] : pb;
+            }
+#pragma unroll
+            for (int i = c0 + 1; i < N; ++i) {
+                const bool sw = (pv == i);
+                col[i] = sw ? c00 : col[i];
+                b[i] = sw ? b00 : b[i];
+            }
+            // (row i's entries right of the diagonal take row c0's old ones inside the update below: one read and one write per entry)
+            if (pval != 0.) {
+                const double r = 1. / pval;
+#pragma unroll
+                for (int i = c0 + 1; i < N; ++i) col[i] *= r;
+            }
+#pragma unroll
+            for (int i = c0 + 1; i < N; ++i) {
+                const bool sw = (pv == i);
+#pragma unroll
+                for (int m = c0 + 1; m < N; ++m) { const double v = at(i, m); put(i, m, (sw ? at(c0, m) : v) - col[i] * prow[m]); }      // (row c0 is still in place)
+                b[i] -= col[i] * pb;
+            }
+        } else {
+            if (pval != 0.) {
+                const double r = 1. / pval;
+#pragma unroll
+                for (int i = c0 + 1; i < N; ++i) col[i] *= r;
+            }
+#pragma unroll
+            for (int i = c0 + 1; i < N; ++i) {
+#pragma unroll
+                for (int m = c0 + 1; m < N; ++m) put(i, m, at(i, m) - col[i] * prow[m]);
+                b[i] -= col[i] * pb;
+            }
+        }
+        b[c0] = pb;
+        put(c0, c0, pval);
+#pragma unroll
+        for (int m = c0 + 1; m < N; ++m) put(c0, m, prow[m]);
+        __builtin_amdgcn_sched_barrier(0);                            // one elimination step at a time (fit_stage.hip: interleaved steps keep more of the matrix live than there are registers)
+    }
+#pragma unroll
+    for (int c0 = N - 1; c0 >= 0; --c0) {
+        b[c0] /= at(c0, c0);
+#pragma unroll
+        for (int i = 0; i < c0; ++i) b[i] -= at(i, c0) * b[c0];
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) fio[i] = b[i] * cs[i];
+}
+
+// rescale_ruiz2001_c (lapackdrivers.pyx:553-623) on the reference's own, not bit-symmetric matrix (A[j][m] sums (w c_m) c_j, A[m][j]
+// sums (w c_j) c_m: impl.pyx:601) — the operations of fit_strict_reg_kernel.  Returns whether every running scale factor stayed in
+// the safe range of the fast sequences.
+// DIAG (fast path only; see ruiz_sym): once the diagonal quotients of a sweep are within 1 / c_max^2 of each other every row and every
+// column maximum IS its diagonal quotient — the off-diagonal quotient (i, m) squared is c_im^2 q_ii q_mm times (DCp[i] DRp[m]) /
+// (DRp[i] DCp[m]), a ratio of running products that agree to a few ulps (the matrix is symmetric to rounding), far inside the 2^-16
+// margin — and the other N (N - 1) quotients of the sweep are not computed: the same doubles.  The test is wave-uniform.
+template <int N, class OPS, bool DIAG = false, class GET>
+__device__ __forceinline__ bool ruiz_full(GET&& at, double (&rs)[N], double (&cs)[N]) {
+    using strict::ruiz_epsilon;
+    double DRp[N], DCp[N], DR[N], DC[N];
+    bool in_range = true;
+#pragma unroll
+    for (int i = 0; i < N; ++i) { rs[i] = 1.; cs[i] = 1.; DRp[i] = 1.; DCp[i] = 1.; }
+    double thresh = 2.;                                               // c_max^2 (1 + 2^-16); NaN / inf (a zero diagonal entry): never passes
+    if constexpr (DIAG) {
+        double ra[N], cm2 = 0.;
+#pragma unroll
+        for (int i = 0; i < N; ++i) ra[i] = __builtin_amdgcn_rcp(at(i, i));
+#pragma unroll
+        for (int m = 0; m < N; ++m)
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+                if (i != m) { const double a = at(i, m); cm2 = __builtin_fmax(cm2, (a * a) * (ra[i] * ra[m])); }
+        thresh = cm2 * (1. + 0x1p-16);
+        if (!(thresh >= 0.)) thresh = 2.;
+    }
+    for (int it = 0; it < 100; ++it) {
+        bool diag_only = false;
+        if constexpr (DIAG) {
+            if (it > 0) {
+                double qlo = 0., qhi = 0.;
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    const double q = fabs(OPS::div_seeded(at(i, i), DRp[i] * DCp[i], rs[i] * cs[i]));
+                    DR[i] = OPS::maxnum(0., q); DC[i] = DR[i];
+                    qlo = i ? __builtin_fmin(qlo, DR[i]) : DR[i]; qhi = i ? __builtin_fmax(qhi, DR[i]) : DR[i];
+                }
+                diag_only = __all(thresh * qhi <= qlo);               // (a NaN quotient fails it)
+            }
+        }
+        if (!diag_only) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) { DR[i] = 0.; DC[i] = 0.; }
+#pragma unroll
+            for (int m = 0; m < N; ++m) {
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    // (the row and the column pass divide by the same product: one quotient serves both maxima; fast path: rs[i] cs[m] is
+                    // within 2^-48 of its reciprocal — the seed)
+                    const double q = fabs(OPS::div_seeded(at(i, m), DRp[i] * DCp[m], rs[i] * cs[m]));
+                    DC[m] = OPS::maxnum(DC[m], q);
+                    DR[i] = OPS::maxnum(DR[i], q);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            double hr, hc;
+            DR[i] = OPS::sqrt_h(DR[i], hr); DC[i] = OPS::sqrt_h(DC[i], hc);
+            DRp[i] *= DR[i]; rs[i] = OPS::div_by_root(rs[i], DR[i], hr);
+            DCp[i] *= DC[i]; cs[i] = OPS::div_by_root(cs[i], DC[i], hc);
+            in_range = in_range && DRp[i] >= SCALE_LO && DRp[i] <= SCALE_HI && DCp[i] >= SCALE_LO && DCp[i] <= SCALE_HI;
+        }
+        double accm = fabs(1. - DR[0] * DR[0]);
+#pragma unroll
+        for (int i = 1; i < N; ++i) { const double tmp = fabs(1. - DR[i] * DR[i]); if (tmp > accm) accm = tmp; }
+        if (accm < ruiz_epsilon) {
+            accm = fabs(1. - DC[0] * DC[0]);
+#pragma unroll
+            for (int i = 1; i < N; ++i) { const double tmp = fabs(1. - DC[i] * DC[i]); if (tmp > accm) accm = tmp; }
+            if (accm < ruiz_epsilon) break;
+        }
+    }
+    return in_range;
+}
+
+// range check of the fast sweeps on the full matrix: every nonzero entry in the safe range, no zero row and no zero column
+template <int N, class GET>
+__device__ __forceinline__ bool entries_in_range_full(GET&& at) {
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        double rowmax = 0., colmax = 0.;
+#pragma unroll
+        for (int m = 0; m < N; ++m) {
+            const double a = fabs(at(i, m)), t2 = fabs(at(m, i));
+            ok = ok && (a == 0. || (a >= RANGE_LO && a <= RANGE_HI));
+            rowmax = a > rowmax ? a : rowmax; colmax = t2 > colmax ? t2 : colmax;
+        }
+        ok = ok && rowmax >= RANGE_LO && colmax >= RANGE_LO;
+    }
+    return ok;
 }
 
 }  // namespace acc
@@ -255,36 +457,44 @@ __device__ __forceinline__ void lu_solve_store(const double (&U)[N * (N + 1) / 2
 // groups, [2 .. 2 + G) the redo groups, [2 + G .. 2 + 2 G) the leftover groups (G = 64-case groups of the launch).
 //   redo:     the speculative kernel could not vouch for a group (its guess of the largest squared distance was wrong, or an
 //             operand left the safe range of the fast sequences): the two-pass kernel fits the group again, from scratch;
-//   leftover: the group holds a case with a known DOF: the strict kernels fit those cases (they stay idle when there are none).
+//   leftover: the group holds a case this kernel does not take (takes_case below): the strict kernels fit those cases (they stay
+//             idle when there are none).
 struct AccLists { int* ws; long long ngroups; };
 
-// One 64-case group.  SPEC (dense rows only): ONE pass over the neighbours.  The weights need the largest squared distance of the
-// case before the first term can be summed, which is what makes the reference (and the two-pass form of this kernel) read every
+// One 64-case group.  SPEC (dense rows only): ONE pass over the neighbours for the sums.  The weights need the largest squared distance
+// of the case before the first term can be summed, which is what makes the reference (and the two-pass form of this kernel) read every
 // neighbourhood twice — 1.31 GB instead of 0.85 through the fabric per 1M configs[1] cases, and a first pass whose few
 // instructions per neighbour cannot cover its own load latency.  Neighbour lists that come out of a k-nearest-neighbour search
 // are sorted by distance (scipy's cKDTree.query, wlsqm.hip.knn: the reference's examples and every BASELINE config), so the LAST
 // neighbour is the farthest: the pass runs with that guess while it also tracks the true maximum, and the guess is VERIFIED bit for
 // bit afterwards.  A group with a wrong guess (unsorted neighbours: a ball query) or an operand outside the safe range of the fast
 // sequences is written to the redo list and fitted again by the two-pass kernel: speculation, never approximation.
-template <int DIM, int ORDER, bool DENSE, bool SPEC>
-__device__ __forceinline__ void accurate_group(const KParams& p, const long long t0, const AccLists& lists, double* xs, double* fs) {
+template <int DIM, int ORDER, bool DENSE, bool SPEC, bool RED1>
+__device__ __forceinline__ void accurate_group(const KParams& p, const long long t0, const AccLists& lists, double* const lds) {
     using namespace strict;
     using namespace acc;
     static_assert(!SPEC || DENSE, "the speculative single pass stages dense rows");
-    constexpr int N = ndofs(DIM, ORDER), NE = N * (N + 1) / 2;
+    constexpr int NO = ndofs(DIM, ORDER);
+    constexpr int O0 = RED1 ? 1 : 0, N = NO - O0, NE = N * (N + 1) / 2;      // the system: DOFs O0 .. NO - 1
+    constexpr unsigned FULL = (NO >= 32) ? ~0u : ((1u << NO) - 1u);
+    constexpr int CH = chunk_of(N);
     constexpr int XPC = CH * DIM * 8 / 16, FPC = CH * 8 / 16;        // 16-byte pieces of one case's chunk: coordinates, values
     constexpr int XPITCH = CH * DIM + 2, FPITCH = CH + 2;            // doubles per staged row (+ 16 bytes: conflict-free b128 reads)
+    double* const xs = lds;
+    double* const fs = lds + 64 * XPITCH;
 
     const long long ncases = live_cases(p);
     const int lane = threadIdx.x;
     const long long t = t0 + lane;
     const bool in_batch = t < ncases;
     const long long j = in_batch ? (p.case_index ? p.case_index[t] : t) : 0;
-    // a case is taken here iff it has no known DOF (wave-mates do not matter: per case); p.do_sens / p.iterative never reach this kernel
+    // (p.do_sens / p.iterative never reach this kernel)
     const long long kn = in_batch ? p.knowns[j * p.sknowns] : 0;
-    const bool active = in_batch && kn == 0;
+    const bool mine = in_batch && accurate_takes_case<NO, RED1>(kn);
+    const unsigned known = mine ? ((unsigned)kn & FULL) : 0u;         // RED1: 1
+    const bool active = mine && known != FULL;                        // every DOF known: nothing to solve (impl.pyx:740-742)
     if constexpr (SPEC) {
-        if (__any(in_batch && kn != 0) && lane == 0) lists.ws[2 + lists.ngroups + atomicAdd(lists.ws + 1, 1)] = (int)(t0 >> 6);
+        if (__any(in_batch && !mine) && lane == 0) lists.ws[2 + lists.ngroups + atomicAdd(lists.ws + 1, 1)] = (int)(t0 >> 6);
         // the speculative kernel moves whole 64-case groups in whole chunks only (no predicated loads in its loop): the last,
         // partial group of a launch goes to the two-pass kernel (the launcher sends neighbour counts that are not a multiple of CH there altogether)
         if (ncases - t0 < 64) {
@@ -296,6 +506,7 @@ __device__ __forceinline__ void accurate_group(const KParams& p, const long long
     const int K = (int)p.max_nk;
     const int nk = active ? min(p.nk[j * p.snk], K) : 0;
     const bool uniform = active ? (p.wm[j * p.swm] == WLSQM_WEIGHT_UNIFORM) : true;
+    double* const fio = p.fi + j * p.sfi_j;
     double xi[DIM];
     Rows<DIM> rows{};
     if constexpr (DENSE) {
@@ -303,7 +514,7 @@ __device__ __forceinline__ void accurate_group(const KParams& p, const long long
         for (int m = 0; m < DIM; ++m) xi[m] = in_batch ? p.xi[j * p.sxi_j + m] : 0.;
     } else {
         if (p.hoods) {
-            const long long pj = p.pidx ? p.pidx[j] : j;
+            const long long pj = own_point(p, j);
 #pragma unroll
             for (int m = 0; m < DIM; ++m) xi[m] = in_batch ? p.S[pj * DIM + m] : 0.;
             rows = Rows<DIM>{nullptr, 0, nullptr, 0, p.hoods + j * p.shoods_j, p.S, p.F};
@@ -379,7 +590,6 @@ __device__ __forceinline__ void accurate_group(const KParams& p, const long long
         }
     };
     auto park = [&](bool want_f) { park_from(xr, want_f); };
-    // (the staged passes run back to back: pass P's first chunk is requested under pass P - 1's last)
     // the neighbours of chunk q, staged in LDS: straight-line code for GRP neighbours at a time (all CH at once: the scheduler hoists
     // every LDS read and the kernel spills; the group size itself measured flat, profiles/r04b_ab_accurate.txt)
     auto chunk = [&](auto masked_tag, int q, bool want_f, auto&& consume) {
@@ -387,7 +597,7 @@ __device__ __forceinline__ void accurate_group(const KParams& p, const long long
         const double* xrow = xs + lane * XPITCH;
         const double* frow = fs + lane * FPITCH;
         // (the 10-unknown systems run one wave per SIMD with registers to spare: the whole chunk at once, 0.758 against 0.809 ms)
-        constexpr int GRP = N > 6 ? CH : acc::GRP;
+        constexpr int GRP = N > 10 ? 2 : N > 6 ? CH : acc::GRP;
         if (SPEC || (q + 1) * CH <= K) {
 #pragma nounroll
             for (int g = 0; g < CH / GRP; ++g) {
@@ -482,17 +692,149 @@ __device__ __forceinline__ void accurate_group(const KParams& p, const long long
         else run_pass_windowed(std::true_type{}, next_want_f, consume);
     };
 
-    double U[NE], b[N];
+    // SYM: the upper triangle U (the accurate mode of the systems up to 10 unknowns).  RED1: all N x N sums, entry (row j, column m) —
+    // rows [0, R0) in LDS behind the staging rows (entry (r, m) of lane l at [(r N + m) 64 + l]), rows [R0, N) in registers; 196
+    // doubles beside the equilibration's 84 are more than a lane's 512 registers hold.
+    constexpr int R0 = lu_lds_rows(N);
+    double U[RED1 ? (N - R0) * N : NE], b[N];
+    double* const Ltop = lds + (DENSE ? 64 * XPITCH + 64 * FPITCH : 0) + lane;
+    // (the empty asm keeps an LDS read a VALUE: left alone, the optimizer turns `sw ? lds_entry : register_entry` into a load through a
+    // selected generic pointer and the register rows become a stack array — 1.7 KB of scratch per lane)
+    auto mat = [&](int r, int m) __attribute__((always_inline)) -> double {
+        if (r < R0) { double v = Ltop[(r * N + m) * 64]; asm("" : "+v"(v)); return v; }
+        return U[(r - R0) * N + m];
+    };
+    auto mat_put = [&](int r, int m, double v) __attribute__((always_inline)) { if (r < R0) Ltop[(r * N + m) * 64] = v; else U[(r - R0) * N + m] = v; };
+    if constexpr (!RED1) {
 #pragma unroll
-    for (int e = 0; e < NE; ++e) U[e] = 0.;
+        for (int e = 0; e < NE; ++e) U[e] = 0.;
+    }
 #pragma unroll
     for (int i = 0; i < N; ++i) b[i] = 0.;
+    // make_A (impl.pyx:566-602) and the right-hand side sums of solve (impl.pyx:768-787): one neighbour's terms (SYM)
+    auto add_terms = [&](const double (&c)[NO], double w, double f) __attribute__((always_inline)) {
+        const double wf = w * f;
+#pragma unroll
+        for (int om = 0; om < N; ++om) {
+            const double wc = w * c[om + O0];
+#pragma unroll
+            for (int oj = 0; oj <= om; ++oj) U[utri<N>(oj, om)] += wc * c[oj + O0];
+        }
+#pragma unroll
+        for (int oj = 0; oj < N; ++oj) b[oj] += wf * c[oj + O0];
+    };
+    // RED1: the matrix rows [J0, J1) of one neighbour into `acc` (a pass sums 4-5 rows: 56-70 accumulators fit the lane's
+    // architectural registers beside the monomials; all 196 do not), the right-hand side with the first rows
+    auto add_rows = [&](auto j0_tag, auto j1_tag, double (&acc)[5 * (RED1 ? N : 1)], const double (&c)[NO], double w, double f) __attribute__((always_inline)) {
+        constexpr int J0 = decltype(j0_tag)::value, J1 = decltype(j1_tag)::value;
+        static_assert(J1 - J0 <= 5, "rows per pass");
+#pragma unroll
+        for (int om = 0; om < N; ++om) {
+            const double wc = w * c[om + O0];
+#pragma unroll
+            for (int oj = J0; oj < J1; ++oj) acc[(oj - J0) * N + om] += wc * c[oj + O0];
+        }
+        if constexpr (J0 == 0) {
+            const double wf = w * f;
+#pragma unroll
+            for (int oj = 0; oj < N; ++oj) b[oj] += wf * c[oj + O0];
+        }
+    };
+    constexpr int JA = (N + 2) / 3, JB = 2 * JA < N ? 2 * JA : N;     // three passes over the neighbours: rows [0, JA), [JA, JB), [JB, N)
+    using T0 = std::integral_constant<int, 0>;
+    using TA = std::integral_constant<int, JA>;
+    using TB = std::integral_constant<int, JB>;
+    using TN = std::integral_constant<int, N>;
+    // Known DOFs of the masked full system (the header): rows of the identity, right-hand side 0 (a wave-uniform test: the common
+    // wave has none).  RED1 assembles the reduced system directly.
+    const bool any_known = !RED1 && __any(active && known != 0u);
+    auto mask_knowns = [&]() __attribute__((always_inline)) {
+        if constexpr (!RED1) {
+            if (any_known) {
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+#pragma unroll
+                    for (int m = i; m < N; ++m) {
+                        const bool kk = ((known >> i) | (known >> m)) & 1u;
+                        U[utri<N>(i, m)] = kk ? (i == m ? 1. : 0.) : U[utri<N>(i, m)];
+                    }
+                    b[i] = ((known >> i) & 1u) ? 0. : b[i];
+                }
+            }
+        }
+    };
+    // solve, impl.pyx:792-823: b[j] = row_scale[j] * sum, then for every known DOF om (ascending) and every neighbour k (ascending)
+    // b[j] -= fi[om] * w[k] * c[k, om] * c[k, j] * row_scale[j], term by term.  One pass over the neighbours per known DOF of the wave's
+    // most-masked case; a lane without a known in this round subtracts (0 * w * c * c * rs) = 0 from a sum that is never -0.
+    // weight_of: the pass's weight, the same rounding sequence as in the accumulation.  All barriers inside: every lane takes part.
+    auto eliminate = [&](const double (&rs)[N], auto&& weight_of) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) b[i] = rs[i] * b[i];
+        if (!RED1 && !any_known) return;
+        unsigned rem = active ? known : 0u;
+        while (__any(rem != 0u)) {                                    // wave-uniform
+            const bool has = rem != 0u;
+            const int om = has ? (__ffs(rem) - 1) : 0;
+            rem &= rem - 1u;
+            const double fv = has ? fio[om] : 0.;
+            const bool only_f = RED1 || __all(!has || om == 0);       // c[k, 0] = 1: the product with it is exact and skipped
+            pass(false, false, false, false, [&](int, bool live, const double (&d)[DIM], double) {
+                double c[NO];
+                const double d2 = make_c<DIM, ORDER>(d, c);
+                double w = weight_of(d2);
+                w = live ? w : 0.;
+                double t = fv * w;
+                if (!only_f) t = t * pick<NO>(c, om);
+#pragma unroll
+                for (int i = 0; i < N; ++i) b[i] -= t * c[i + O0] * rs[i];
+            });
+        }
+        if constexpr (!RED1) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) b[i] = ((known >> i) & 1u) ? 0. : b[i];
+        }
+    };
+    auto solve_store = [&](const double (&rs)[N], const double (&cs)[N]) __attribute__((always_inline)) {
+        if constexpr (RED1) { if (active) lu_aug_solve_store<N>(mat, mat_put, rs, cs, b, fio + O0); }
+        else { if (active) lu_solve_store<N>(U, rs, b, known, fio); }
+    };
+    // the equilibration: true when the fast sequences could vouch for it
+    auto equilibrate = [&](auto ops_tag, double (&rs)[N], double (&cs)[N]) __attribute__((always_inline)) -> bool {
+        using OPS = decltype(ops_tag);
+        if constexpr (RED1) return ruiz_full<N, OPS, std::is_same<OPS, FastOps>::value && SPEC && WLSQM_ACC_RUIZ_DIAG != 0>(mat, rs, cs);
+        else return ruiz_sym<N, OPS, std::is_same<OPS, FastOps>::value && SPEC && WLSQM_ACC_RUIZ_DIAG != 0>(U, rs);
+    };
+    auto in_range = [&]() __attribute__((always_inline)) -> bool {
+        if constexpr (RED1) return entries_in_range_full<N>(mat); else return entries_in_range<N>(U);
+    };
+    // RED1: one pass over the neighbours for the matrix rows [J0, J1)
+    auto rows_pass = [&](auto j0_tag, auto j1_tag, bool want_f, bool prefetched, auto&& weight_of, auto&& give_up, auto&& track) __attribute__((always_inline)) {
+        constexpr int J0 = decltype(j0_tag)::value, J1 = decltype(j1_tag)::value;
+        double acc[5 * (RED1 ? N : 1)];
+#pragma unroll
+        for (int e = 0; e < 5 * (RED1 ? N : 1); ++e) acc[e] = 0.;
+        pass_until(want_f, prefetched, false, false, [&](int, bool live, const double (&d)[DIM], double f) {
+            double c[NO];
+            const double d2 = make_c<DIM, ORDER>(d, c);
+            track(live, d2);
+            double w = weight_of(d2);
+            w = live ? w : 0.;
+            add_rows(j0_tag, j1_tag, acc, c, w, f);
+        }, give_up);
+#pragma unroll
+        for (int r = J0; r < J1; ++r)
+#pragma unroll
+            for (int m = 0; m < N; ++m) mat_put(r, m, acc[(r - J0) * N + m]);
+        return acc[0];
+    };
+    auto never = [] { return false; };
+    auto no_track = [](bool, double) {};
     if constexpr (SPEC) {
         // ---- the speculative single pass (see above): guess = squared distance of the last neighbour, same operations as make_c
         double guess = 0.;
         if (active && nk > 0) {
             const double* q = p.xk + j * (long long)K * DIM + (long long)(nk - 1) * DIM;
-            double dg[DIM], cg[N];
+            double dg[DIM], cg[NO];
 #pragma unroll
             for (int m = 0; m < DIM; ++m) dg[m] = q[m] - xi[m];
             guess = make_c<DIM, ORDER>(dg, cg);
@@ -500,42 +842,55 @@ __device__ __forceinline__ void accurate_group(const KParams& p, const long long
         fetch(0, true);
         const double rg = rcp_refined(guess);
         double max_d2 = 0., min_d2 = RANGE_HI;
-        auto one = [&](int, bool live, const double (&d)[DIM], double f) {
-            double c[N];
-            const double d2 = make_c<DIM, ORDER>(d, c);
-            if (live) { max_d2 = __builtin_fmax(max_d2, d2); min_d2 = __builtin_fmin(min_d2, d2); }
+        auto weight_of = [&](double d2) __attribute__((always_inline)) {
             const double tmp = 1. - FastOps::sqrt(div_by(d2, guess, rg));
-            double w = uniform ? 1. : weights_alpha + weights_beta * tmp * tmp;
-            w = live ? w : 0.;
-            const double wf = w * f;
-#pragma unroll
-            for (int om = 0; om < N; ++om) {
-                const double wc = w * c[om];
-#pragma unroll
-                for (int oj = 0; oj <= om; ++oj) U[utri<N>(oj, om)] += wc * c[oj];
-            }
-#pragma unroll
-            for (int oj = 0; oj < N; ++oj) b[oj] += wf * c[oj];
+            return uniform ? 1. : weights_alpha + weights_beta * tmp * tmp;
+        };
+        auto track = [&](bool live, double d2) __attribute__((always_inline)) {
+            if (live) { max_d2 = __builtin_fmax(max_d2, d2); min_d2 = __builtin_fmin(min_d2, d2); }
         };
         // (unsorted neighbours — a ball query — refute the guess within the first chunk: the group leaves for the two-pass kernel
         // there instead of finishing a pass whose sums are thrown away)
 #ifndef WLSQM_ACC_EARLY_OUT
 #define WLSQM_ACC_EARLY_OUT 1
 #endif
-        pass_until(true, true, false, false, one, [&] { return WLSQM_ACC_EARLY_OUT && __any(!uniform && max_d2 > guess); });
+        auto give_up = [&] { return WLSQM_ACC_EARLY_OUT && __any(!uniform && max_d2 > guess); };
+        double first = 0.;                                            // a finite sum of the pass (NaN test)
+        if constexpr (RED1) first = rows_pass(T0{}, TA{}, true, true, weight_of, give_up, track);
+        else {
+            pass_until(true, true, false, false, [&](int, bool live, const double (&d)[DIM], double f) {
+                double c[NO];
+                const double d2 = make_c<DIM, ORDER>(d, c);
+                track(live, d2);
+                double w = weight_of(d2);
+                w = live ? w : 0.;
+                add_terms(c, w, f);
+            }, give_up);
+            first = U[0];
+        }
         // vouch for the case: the guess WAS the largest squared distance (bit for bit), every squared distance in the safe range
         // of the fast quotient and root (fmax / fmin drop a NaN distance: the sum test catches it), every matrix entry and every
         // running scale factor of the equilibration too
         bool sure = !active || ((uniform || (max_d2 == guess && min_d2 >= RANGE_LO && max_d2 <= RANGE_HI)) && nk > 0 &&
-                                (U[0] - U[0] == 0.) && entries_in_range<N>(U));
-        double rs[N];
-        if (__all(sure)) sure = !active || ruiz_sym<N, FastOps, WLSQM_ACC_RUIZ_DIAG != 0>(U, rs);
+                                (first - first == 0.));
+        if constexpr (RED1) {
+            if (__all(sure)) {                                        // the other rows, with the verified maximum
+                (void)rows_pass(TA{}, TB{}, false, false, weight_of, never, no_track);
+                (void)rows_pass(TB{}, TN{}, false, false, weight_of, never, no_track);
+            }
+        }
+        mask_knowns();
+        sure = sure && (!active || in_range());
+        double rs[N], cs[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) { rs[i] = 1.; cs[i] = 1.; }
+        if (__all(sure)) sure = !active || equilibrate(FastOps{}, rs, cs);
         if (!__all(sure)) {                                           // wave-uniform: the whole group goes to the two-pass kernel
             if (lane == 0) lists.ws[2 + atomicAdd(lists.ws, 1)] = (int)(t0 >> 6);
             return;
         }
-        if (!active) return;
-        lu_solve_store<N>(U, rs, b, p.fi + j * p.sfi_j);
+        eliminate(rs, weight_of);
+        solve_store(rs, cs);
         return;
     }
     // ---- pass 1 (make_c_nD, first half): the largest squared distance; the smallest too, for the range check of the fast weights
@@ -545,7 +900,7 @@ __device__ __forceinline__ void accurate_group(const KParams& p, const long long
 #endif
     auto pass1 = [&](auto&& consume) { if (WLSQM_ACC_WINDOW) pass_windowed(true, consume); else pass(false, false, true, true, consume); };
     pass1([&](int, bool live, const double (&d)[DIM], double) {
-        double c[N];
+        double c[NO];
         const double d2 = make_c<DIM, ORDER>(d, c);
         if (live) { if (d2 > max_d2) max_d2 = d2; if (!(d2 >= min_d2)) min_d2 = d2; }      // (a NaN distance lands in min_d2)
     });
@@ -554,62 +909,69 @@ __device__ __forceinline__ void accurate_group(const KParams& p, const long long
     const bool w_ok = !active || uniform || (min_d2 >= RANGE_LO && max_d2 <= RANGE_HI && nk > 0);
     const bool fast_w = __all(w_ok);
 
-    // ---- pass 2: make_A (upper triangle) and the right-hand side sums of solve (impl.pyx:768-787), k ascending
-    auto accumulate = [&](auto ops_tag) {
+    // ---- pass 2 (make_A, right-hand side sums), equilibration (fast sequences where every operand is in their safe range, the IEEE
+    // sequences for the whole wave otherwise: the same bits where both apply), knowns, scaling, LU, solve
+    auto rest = [&](auto ops_tag) __attribute__((always_inline)) {
         using OPS = decltype(ops_tag);
         const double rmax = OPS::rcp_of(max_d2);
-        pass(true, true, false, false, [&](int, bool live, const double (&d)[DIM], double f) {
-            double c[N];
-            const double d2 = make_c<DIM, ORDER>(d, c);
+        auto weight_of = [&](double d2) __attribute__((always_inline)) {
             const double tmp = 1. - OPS::sqrt(OPS::div_r(d2, max_d2, rmax));
-            double w = uniform ? 1. : weights_alpha + weights_beta * tmp * tmp;
-            w = live ? w : 0.;
-            const double wf = w * f;
+            return uniform ? 1. : weights_alpha + weights_beta * tmp * tmp;
+        };
+        if constexpr (RED1) {
+            (void)rows_pass(T0{}, TA{}, true, true, weight_of, never, no_track);
+            (void)rows_pass(TA{}, TB{}, false, false, weight_of, never, no_track);
+            (void)rows_pass(TB{}, TN{}, false, false, weight_of, never, no_track);
+        } else {
+            pass(true, true, false, false, [&](int, bool live, const double (&d)[DIM], double f) {
+                double c[NO];
+                const double d2 = make_c<DIM, ORDER>(d, c);
+                double w = weight_of(d2);
+                w = live ? w : 0.;
+                add_terms(c, w, f);
+            });
+        }
+        mask_knowns();
+        double rs[N], cs[N];
 #pragma unroll
-            for (int om = 0; om < N; ++om) {
-                const double wc = w * c[om];
-#pragma unroll
-                for (int oj = 0; oj <= om; ++oj) U[utri<N>(oj, om)] += wc * c[oj];
-            }
-#pragma unroll
-            for (int oj = 0; oj < N; ++oj) b[oj] += wf * c[oj];
-        });
+        for (int i = 0; i < N; ++i) { rs[i] = 1.; cs[i] = 1.; }
+        bool r_ok = !active || in_range(), fast_done = false;
+        if (__all(r_ok)) { r_ok = !active || equilibrate(FastOps{}, rs, cs); fast_done = true; }
+        if (!fast_done || !__all(r_ok)) { if (active) (void)equilibrate(IeeeOps{}, rs, cs); }
+        eliminate(rs, weight_of);
+        solve_store(rs, cs);
     };
-    if (fast_w) accumulate(FastOps{}); else accumulate(IeeeOps{});
-    if (!active) return;                                              // (no barrier below this line)
-
-    // ---- equilibration (fast sequences where every operand is in their safe range, the IEEE sequences for the whole wave
-    // otherwise: the same bits where both apply), scaling, LU, solve
-    double rs[N];
-    bool r_ok = entries_in_range<N>(U), fast_done = false;
-    if (__all(r_ok)) { r_ok = ruiz_sym<N, FastOps>(U, rs); fast_done = true; }
-    if (!fast_done || !__all(r_ok)) (void)ruiz_sym<N, IeeeOps>(U, rs);
-    lu_solve_store<N>(U, rs, b, p.fi + j * p.sfi_j);
+    if (fast_w) rest(FastOps{}); else rest(IeeeOps{});
 }
 
-template <int DIM, int ORDER, bool DENSE, bool SPEC>
+// LDS of a one-wave workgroup, in doubles: the staging rows; for RED1 the top rows of the matrix behind them
+template <int DIM, int ORDER, bool DENSE, bool RED1>
+__host__ __device__ constexpr int acc_lds_doubles() {
+    constexpr int N = ndofs(DIM, ORDER) - (RED1 ? 1 : 0), CHN = acc::chunk_of(N);
+    constexpr int stage = DENSE ? 64 * (CHN * DIM + 2) + 64 * (CHN + 2) : 0;
+    constexpr int top = RED1 ? 64 * acc::lu_lds_rows(N) * N : 0;
+    return stage + top > 2 ? stage + top : 2;
+}
+
+template <int DIM, int ORDER, bool DENSE, bool SPEC, bool RED1>
 __global__ __launch_bounds__(64, acc::minw(ndofs(DIM, ORDER))) void fit_accurate_kernel(const KParams p, const AccLists lists, const long long ngroups) {
-    constexpr int XPITCH = acc::CH * DIM + 2, FPITCH = acc::CH + 2;
-    __shared__ __attribute__((aligned(16))) double xs[DENSE ? 64 * XPITCH : 2];
-    __shared__ __attribute__((aligned(16))) double fs[DENSE ? 64 * FPITCH : 2];
+    __shared__ __attribute__((aligned(16))) double lds[acc_lds_doubles<DIM, ORDER, DENSE, RED1>()];
     // (a workgroup per resident slot walks the groups: a finished wave's slot took ~5 us to be handed a new workgroup — 1.67 resident
     // waves per SIMD of the 2 the registers allow with one group per workgroup)
     for (long long g = blockIdx.x; g < ngroups; g += gridDim.x) {
-        accurate_group<DIM, ORDER, DENSE, SPEC>(p, g * 64, lists, xs, fs);
-        if (DENSE) __syncthreads();                                   // the staging buffers are reused by the next group
+        accurate_group<DIM, ORDER, DENSE, SPEC, RED1>(p, g * 64, lists, lds);
+        if (DENSE || RED1) __syncthreads();                           // the LDS is reused by the next group
     }
 }
 
 // the redo groups of a speculative launch: a grid of the resident waves walks the list (empty in the common case: idle waves)
-template <int DIM, int ORDER>
+template <int DIM, int ORDER, bool RED1>
 __global__ __launch_bounds__(64, acc::minw(ndofs(DIM, ORDER))) void fit_accurate_redo_kernel(const KParams p, const AccLists lists) {
-    constexpr int XPITCH = acc::CH * DIM + 2, FPITCH = acc::CH + 2;
-    __shared__ __attribute__((aligned(16))) double xs[64 * XPITCH];
-    __shared__ __attribute__((aligned(16))) double fs[64 * FPITCH];
+    __shared__ __attribute__((aligned(16))) double lds[acc_lds_doubles<DIM, ORDER, true, RED1>()];
     const int n = lists.ws[0];
     for (int g = blockIdx.x; g < n; g += gridDim.x) {
-        accurate_group<DIM, ORDER, true, false>(p, (long long)lists.ws[2 + g] * 64, lists, xs, fs);
-        __syncthreads();                                              // the staging buffers are reused by the next group
+        accurate_group<DIM, ORDER, true, false, RED1>(p, (long long)lists.ws[2 + g] * 64, lists, lds);
+        __syncthreads();                                              // the LDS is reused by the next group
     }
 }
 
@@ -617,6 +979,7 @@ __global__ void acc_lists_zero_kernel(int* ws) { if (threadIdx.x < 2) ws[threadI
 
 template <int DIM, int ORDER>
 static int launch_accurate(const KParams& p, hipStream_t stream, int** lists_out) {
+    constexpr bool RED1 = strict::accurate_red1(DIM, ORDER);
     *lists_out = nullptr;
     const long long groups = (p.ncases + 63) / 64;
     if (groups <= 0) return WLSQM_OK;
@@ -644,39 +1007,40 @@ static int launch_accurate(const KParams& p, hipStream_t stream, int** lists_out
         return (int)WLSQM_OK;
     };
     unsigned grid = 0;
-    if (dense && K % acc::CH == 0 && !(nospec && nospec[0] == '1')) {
+    if (dense && K % acc::chunk_of(ndofs(DIM, ORDER) - (RED1 ? 1 : 0)) == 0 && !(nospec && nospec[0] == '1')) {
         int rc = scratch_alloc_async(reinterpret_cast<void**>(&lists.ws), (size_t)(2 + 2 * groups) * sizeof(int), stream);
         if (rc != WLSQM_OK) return rc;
         *lists_out = lists.ws;                                        // (freed by the caller behind the strict kernels, which read the leftover list)
         hipLaunchKernelGGL(acc_lists_zero_kernel, dim3(1), dim3(64), 0, stream, lists.ws);
-        rc = grid_for(reinterpret_cast<const void*>(&fit_accurate_kernel<DIM, ORDER, true, true>), &grid);
+        rc = grid_for(reinterpret_cast<const void*>(&fit_accurate_kernel<DIM, ORDER, true, true, RED1>), &grid);
         if (rc != WLSQM_OK) return rc;
-        hipLaunchKernelGGL((fit_accurate_kernel<DIM, ORDER, true, true>), dim3(grid), dim3(64), 0, stream, p, lists, groups);
+        hipLaunchKernelGGL((fit_accurate_kernel<DIM, ORDER, true, true, RED1>), dim3(grid), dim3(64), 0, stream, p, lists, groups);
         // the redo grid fills the chip when every group comes back (unsorted neighbours: with 256 workgroups 1M configs[1] cases took
         // 1.72 ms, profiles/r04s_ab_early_out.txt) and is a few microseconds of idle waves when none does
         const long long resident = 1024LL * acc::minw(ndofs(DIM, ORDER));
         const unsigned redo_grid = (unsigned)(groups < resident ? groups : resident);
-        hipLaunchKernelGGL((fit_accurate_redo_kernel<DIM, ORDER>), dim3(redo_grid), dim3(64), 0, stream, p, lists);
+        hipLaunchKernelGGL((fit_accurate_redo_kernel<DIM, ORDER, RED1>), dim3(redo_grid), dim3(64), 0, stream, p, lists);
     } else if (dense) {
-        const int rc = grid_for(reinterpret_cast<const void*>(&fit_accurate_kernel<DIM, ORDER, true, false>), &grid);
+        const int rc = grid_for(reinterpret_cast<const void*>(&fit_accurate_kernel<DIM, ORDER, true, false, RED1>), &grid);
         if (rc != WLSQM_OK) return rc;
-        hipLaunchKernelGGL((fit_accurate_kernel<DIM, ORDER, true, false>), dim3(grid), dim3(64), 0, stream, p, lists, groups);
+        hipLaunchKernelGGL((fit_accurate_kernel<DIM, ORDER, true, false, RED1>), dim3(grid), dim3(64), 0, stream, p, lists, groups);
     } else {
-        hipLaunchKernelGGL((fit_accurate_kernel<DIM, ORDER, false, false>), dim3((unsigned)groups), dim3(64), 0, stream, p, lists, groups);
+        hipLaunchKernelGGL((fit_accurate_kernel<DIM, ORDER, false, false, RED1>), dim3((unsigned)groups), dim3(64), 0, stream, p, lists, groups);
     }
     WLSQM_HIP_CHECK(hipGetLastError());
     return WLSQM_OK;
 }
 
-// Accurate mode, basic fits of the 2D / 3D systems up to 10 unknowns: every case WITHOUT a known DOF is fitted here (the strict
-// kernels, launched behind this one by launch_fit_strict, leave exactly those cases alone).  *handled = false: the shape has no
-// accurate kernel (1D, more than 10 unknowns) and the strict kernels take every case.
+// Accurate mode, basic fits of the 2D / 3D systems up to 10 unknowns and of 2D order 4 with exactly the function value known: every
+// case strict::accurate_takes_case names is fitted here (the strict kernels, launched behind this one by launch_fit_strict, leave
+// exactly those cases alone).  *handled = false: the shape has no accurate kernel (1D, 3D orders 3-4) and the strict kernels take
+// every case.
 int launch_fit_accurate(int dimension, int order, const KParams& p, hipStream_t stream, bool* handled, int** lists_out) {
     *handled = false;
     *lists_out = nullptr;
     if (p.do_sens || p.iterative) return WLSQM_OK;
 #define CASE(D, O) if (dimension == D && order == O) { *handled = true; return launch_accurate<D, O>(p, stream, lists_out); }
-    CASE(2, 0) CASE(2, 1) CASE(2, 2) CASE(2, 3)
+    CASE(2, 0) CASE(2, 1) CASE(2, 2) CASE(2, 3) CASE(2, 4)
     CASE(3, 0) CASE(3, 1) CASE(3, 2)
 #undef CASE
     return WLSQM_OK;

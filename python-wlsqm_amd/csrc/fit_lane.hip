@@ -49,7 +49,7 @@ __global__ __launch_bounds__(LANE_BLOCK) void fit_lane_kernel(const KParams p) {
     double xi[DIM];
     CaseRows<DIM> rows;
     if (p.hoods) {
-        const long long pj = p.pidx ? p.pidx[j] : j;
+        const long long pj = own_point(p, j);
 #pragma unroll
         for (int m = 0; m < DIM; ++m) xi[m] = p.S[pj * DIM + m];
         rows = CaseRows<DIM>{nullptr, 0, nullptr, 0, p.hoods + j * p.shoods_j, p.S, p.F};

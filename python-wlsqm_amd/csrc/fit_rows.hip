@@ -87,7 +87,7 @@ __global__ __launch_bounds__(RW) void fit_rows_kernel(const KParams p) {
     auto value = [&](int k) { return hr ? p.F[hr[k]] : fr[k * p.sfk_k]; };
     double xi[DIM];
     {
-        const long long pj = hr ? (p.pidx ? (long long)p.pidx[j] : j) : 0;
+        const long long pj = hr ? (own_point(p, j)) : 0;
 #pragma unroll
         for (int m = 0; m < DIM; ++m) xi[m] = hr ? p.S[pj * DIM + m] : p.xi[j * p.sxi_j + m];
     }

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER)
     unsigned long long known, dropped;
     effective_mask<NO>(p.knowns[j * p.sknowns], known, dropped);
     double xi[DIM];
-    const long long pj = GATHER ? (p.pidx ? (long long)p.pidx[j] : j) : 0;      // the case's own point (also the stand-in for padding slots)
+    const long long pj = GATHER ? (own_point(p, j)) : 0;      // the case's own point (also the stand-in for padding slots)
     const int* const hrow = GATHER ? p.hoods + j * p.shoods_j : nullptr;
 #pragma unroll
     for (int m = 0; m < DIM; ++m) xi[m] = GATHER ? p.S[pj * DIM + m] : p.xi[j * p.sxi_j + m];

@@ -146,18 +146,20 @@ __device__ __forceinline__ void fit_strict_block(const KParams& p, const StrictD
     constexpr int NO = ndofs(DIM, ORDER);
     constexpr int LPW = lanes_for(NO);
     const int lane = threadIdx.x;
-    if (skip_plain_groups) {
-        // the register kernel takes the 64-case groups without any known DOF: this block's cases lie in group (block * LPW) / 64
-        // (2 = accurate mode: fit_accurate_kernel has every CASE without a known DOF, whatever its group — see below)
+    if (skip_plain_groups == 1) {
+        // the register kernels take the 64-case groups without any known DOF and those with exactly F known everywhere: this block's
+        // cases lie in group (block * LPW) / 64
         const long long g0 = (vblock * LPW) / 64 * 64;
-        if (skip_plain_groups == 1 && fit_strict_group_is_plain(p, g0 + lane, live_cases(p), 0)) return;
+        if (fit_strict_group_is_plain(p, g0 + lane, live_cases(p), 0)) return;
         if (NO >= 2 && fit_strict_group_is_plain(p, g0 + lane, live_cases(p), 1)) return;      // the F-known register kernel has it
     }
     if (lane >= LPW) return;
     const long long t = vblock * LPW + lane;
     if (t >= live_cases(p)) return;
     const long long j = p.case_index ? p.case_index[t] : t;
-    if (skip_plain_groups == 2 && p.knowns[j * p.sknowns] == 0) return;      // (the lanes of this kernel never meet again: no barrier below)
+    // 2 = accurate mode: fit_accurate_kernel has every CASE it takes (strict::accurate_takes_case), whatever its group
+    // (the lanes of this kernel never meet again: no barrier below)
+    if (skip_plain_groups == 2 && accurate_takes_case<NO, accurate_red1(DIM, ORDER)>(p.knowns[j * p.sknowns])) return;
 
     // LDS image of this case: slot s at smem[s * LPW + lane]
     double* const base = smem + lane;
@@ -180,7 +182,7 @@ __device__ __forceinline__ void fit_strict_block(const KParams& p, const StrictD
                 const double* fio0 = p.fi + j * p.sfi_j;
                 Rows<DIM> r0;
                 if (p.hoods) {
-                    const long long pj = p.pidx ? p.pidx[j] : j;
+                    const long long pj = own_point(p, j);
 #pragma unroll
                     for (int m = 0; m < DIM; ++m) xi0[m] = p.S[pj * DIM + m];
                     r0 = Rows<DIM>{nullptr, 0, nullptr, 0, p.hoods + j * p.shoods_j, p.S, p.F};
@@ -206,7 +208,7 @@ __device__ __forceinline__ void fit_strict_block(const KParams& p, const StrictD
     double xi[DIM];
     Rows<DIM> rows;
     if (p.hoods) {
-        const long long pj = p.pidx ? p.pidx[j] : j;
+        const long long pj = own_point(p, j);
 #pragma unroll
         for (int m = 0; m < DIM; ++m) xi[m] = p.S[pj * DIM + m];
         rows = Rows<DIM>{nullptr, 0, nullptr, 0, p.hoods + j * p.shoods_j, p.S, p.F};
@@ -483,7 +485,7 @@ __device__ __forceinline__ void fit_strict_reg_block(const KParams& p, const lon
     double xi[DIM];
     Rows<DIM> rows;
     if (p.hoods) {
-        const long long pj = p.pidx ? p.pidx[j] : j;
+        const long long pj = own_point(p, j);
 #pragma unroll
         for (int m = 0; m < DIM; ++m) xi[m] = p.S[pj * DIM + m];
         rows = Rows<DIM>{nullptr, 0, nullptr, 0, p.hoods + j * p.shoods_j, p.S, p.F};
@@ -705,23 +707,6 @@ __device__ __forceinline__ double grp_max(double v) {
     for (int s = 16; s < LPC; s <<= 1) v = fmax(v, __shfl_xor(v, s, LPC));
     return v;
 }
-// c[a] for a per-lane index, registers only: a binary tree of selects on the bits of a.  (A chain of `a == q ? c[q] : r` is
-// turned into an indexed load from a scratch copy of c by the optimizer.)
-template <int N>
-__device__ __forceinline__ double pick(const double (&c)[N], int a) {
-    constexpr int P = N <= 1 ? 1 : N <= 2 ? 2 : N <= 4 ? 4 : N <= 8 ? 8 : N <= 16 ? 16 : N <= 32 ? 32 : 64;
-    long long t[P];
-#pragma unroll
-    for (int q = 0; q < P; ++q) t[q] = __double_as_longlong(c[q < N ? q : N - 1]);
-#pragma unroll
-    for (int w = P / 2, bit = 0; w >= 1; w >>= 1, ++bit) {
-        const bool odd = (a >> bit) & 1;
-#pragma unroll
-        for (int q = 0; q < w; ++q) t[q] = odd ? t[2 * q + 1] : t[2 * q];
-    }
-    return __longlong_as_double(t[0]);
-}
-
 // Waves per SIMD the row kernel is compiled for.  It is bound by the issue of dependent vector instructions (IEEE divides, selects), so a
 // third / fourth resident wave pays for a few spilled registers: 1M cases, 2D order 4 (F known): 9.5 ms as allocated freely (190
 // VGPRs), 7.97 at three waves (168 + 33 spilled), 8.03 at four; with sensitivities 28.6 / 23.0 / 25.9; 3D order 2 with sensitivities:
@@ -730,18 +715,20 @@ __host__ __device__ constexpr int rows_minw(int NO) {
     return WLSQM_STRICT_ROWS_MINW ? WLSQM_STRICT_ROWS_MINW : (NO > 16 ? 1 : NO > 10 ? 3 : 4);
 }
 
+// (vblock: the workgroup's number in the batch; skip_red1: accurate mode — fit_accurate_kernel<.., RED1> has the cases with exactly
+// the function value known, they are idle lanes here)
 template <int DIM, int ORDER, int LPC>
-__global__ __launch_bounds__(64, rows_minw(ndofs(DIM, ORDER))) void fit_strict_rows_kernel(const KParams p, const int KP) {
+__device__ __forceinline__ void fit_strict_rows_block(const KParams& p, const int KP, const long long vblock, const bool skip_red1, double* smem) {
     using namespace strict;
     constexpr int NO = ndofs(DIM, ORDER);
     constexpr int G = 64 / LPC;                       // cases per wave
     static_assert(NO <= LPC, "one lane per row");
-    extern __shared__ double smem[];
     const int lane = threadIdx.x, g = lane / LPC, i = lane % LPC;
     const long long ncases = live_cases(p);
-    const long long t = (long long)blockIdx.x * G + g;
-    const bool valid = t < ncases;
+    const long long t = vblock * G + g;
+    bool valid = t < ncases;
     const long long j = valid ? (p.case_index ? p.case_index[t] : t) : 0;
+    if (skip_red1 && valid && accurate_takes_case<NO, true>(p.knowns[j * p.sknowns])) valid = false;
     // LDS of the group: w[KP], f[KP], res[KP], d[DIM][KP]; the pitch is odd in 8-byte words so that the G broadcast reads of one
     // instruction fall into different banks
     const int pitch = ((3 + DIM) * KP) | 1;
@@ -773,7 +760,7 @@ __global__ __launch_bounds__(64, rows_minw(ndofs(DIM, ORDER))) void fit_strict_r
     double xi[DIM];
     Rows<DIM> rows;
     if (p.hoods) {
-        const long long pj = p.pidx ? p.pidx[j] : j;
+        const long long pj = own_point(p, j);
 #pragma unroll
         for (int m = 0; m < DIM; ++m) xi[m] = p.S[pj * DIM + m];
         rows = Rows<DIM>{nullptr, 0, nullptr, 0, p.hoods + j * p.shoods_j, p.S, p.F};
@@ -1048,6 +1035,21 @@ __global__ __launch_bounds__(64, rows_minw(ndofs(DIM, ORDER))) void fit_strict_r
     if (valid && i == 0 && p.iters_out) atomicMax(p.iters_out, iters);
 }
 
+// Accurate mode behind fit_accurate_kernel<2, 4, .., RED1>: `lists` as for fit_strict_kernel (the 64-case groups that hold a case the
+// accurate kernel did not take); without it (no speculative launch) every workgroup runs and skips the taken cases.
+template <int DIM, int ORDER, int LPC>
+__global__ __launch_bounds__(64, rows_minw(ndofs(DIM, ORDER))) void fit_strict_rows_kernel(const KParams p, const int KP, const int skip_red1,
+                                                                                          const int* __restrict__ lists, const long long ngroups) {
+    extern __shared__ double smem[];
+    if (!lists) { fit_strict_rows_block<DIM, ORDER, LPC>(p, KP, blockIdx.x, skip_red1 != 0, smem); return; }
+    constexpr int PER = LPC;                                          // workgroups (64 / LPC cases each) per 64-case group
+    const long long n = (long long)lists[1] * PER;
+    for (long long v = blockIdx.x; v < n; v += gridDim.x) {
+        fit_strict_rows_block<DIM, ORDER, LPC>(p, KP, (long long)lists[2 + ngroups + v / PER] * PER + v % PER, skip_red1 != 0, smem);
+        __syncthreads();
+    }
+}
+
 template <int DIM, int ORDER>
 static int launch_strict(const KParams& p, const StrictDebug& dbg, hipStream_t stream, const bool accurate_taken, const int* lists) {
     constexpr int NO = ndofs(DIM, ORDER);
@@ -1082,9 +1084,12 @@ static int launch_strict(const KParams& p, const StrictDebug& dbg, hipStream_t s
             }
             const long long wgs = (p.ncases + (64 / LPC) - 1) / (64 / LPC);
             if (wgs > 0x7fffffffLL) { set_error("too many cases for one launch"); return WLSQM_EVALUE; }
-            hipLaunchKernelGGL((fit_strict_rows_kernel<DIM, ORDER, LPC>), dim3((unsigned)wgs), dim3(64), rl, stream, p, KP);
+            // (accurate mode, 2D order 4: the cases with exactly F known are fit_accurate_kernel's; a small grid walks the leftover list)
+            const bool skip = accurate_taken && strict::accurate_red1(DIM, ORDER);
+            hipLaunchKernelGGL((fit_strict_rows_kernel<DIM, ORDER, LPC>), dim3((unsigned)(skip && lists && wgs > 512 ? 512 : wgs)), dim3(64), rl, stream, p,
+                               KP, skip ? 1 : 0, skip ? lists : (const int*)nullptr, (p.ncases + 63) / 64);
             WLSQM_HIP_CHECK(hipGetLastError());
-            note_kernel("strict-rows");
+            note_kernel(skip ? (accurate_mode() ? "accurate" : "strict-lane") : "strict-rows");
             return WLSQM_OK;
         }
     }
@@ -1092,21 +1097,18 @@ static int launch_strict(const KParams& p, const StrictDebug& dbg, hipStream_t s
     // ACCURATE mode (fit_accurate.hip): every case without a known DOF has been fitted by fit_accurate_kernel (launched by
     // launch_fit_strict in front of this function); the kernels below leave exactly those cases alone — per CASE, so that the
     // arithmetic a case gets does not depend on the other cases of its group
+    // (accurate mode: fit_accurate_kernel has taken every case without stray mask bits — the LDS kernel walks what is left)
     bool split = false;
     if constexpr (NO <= STRICT_REG_MAX_NO) {
         const char* e = getenv("WLSQM_HIP_STRICT_NO_REG");
-        split = !p.do_sens && !p.iterative && !dbg.A && !dbg.w && !(e && e[0] == '1');
-        if (split || accurate_taken) {
+        split = !accurate_taken && !p.do_sens && !p.iterative && !dbg.A && !dbg.w && !(e && e[0] == '1');
+        if (split) {
             const long long groups = (p.ncases + 63) / 64;
-            if (!accurate_taken) {
-                hipLaunchKernelGGL((fit_strict_reg_kernel<DIM, ORDER, false>), dim3((unsigned)groups), dim3(64), 0, stream, p, (const int*)nullptr, 0ll);
-                WLSQM_HIP_CHECK(hipGetLastError());
-            }
+            hipLaunchKernelGGL((fit_strict_reg_kernel<DIM, ORDER, false>), dim3((unsigned)groups), dim3(64), 0, stream, p, (const int*)nullptr, 0ll);
+            WLSQM_HIP_CHECK(hipGetLastError());
             if constexpr (NO >= 2) {
-                if (split) {
-                    hipLaunchKernelGGL((fit_strict_reg_kernel<DIM, ORDER, true>), dim3((unsigned)(lists && groups > 128 ? 128 : groups)), dim3(64), 0, stream, p, lists, groups);
-                    WLSQM_HIP_CHECK(hipGetLastError());
-                }
+                hipLaunchKernelGGL((fit_strict_reg_kernel<DIM, ORDER, true>), dim3((unsigned)groups), dim3(64), 0, stream, p, (const int*)nullptr, 0ll);
+                WLSQM_HIP_CHECK(hipGetLastError());
             }
         }
     }
@@ -1123,7 +1125,15 @@ int launch_fit_strict(int dimension, int order, const KParams& p, const StrictDe
     const StrictDebug dbg = dbg_in ? *dbg_in : StrictDebug{};
     bool accurate_taken = false;
     int* lists = nullptr;                             // work lists of the speculative accurate kernel ([1] = leftover groups), or null
-    if (accurate_mode() && !dbg_in) {
+    // accurate mode: fit_accurate.hip takes the cases strict::accurate_takes_case names.  Its 2D order-4 form (exactly the function value
+    // known: the 14 x 14 system of the reference's default mask; the strict arithmetic itself with one lane per case, bit-identical to
+    // the row-per-lane kernel) is OFF by default in both modes: it needs 196 matrix entries beside the equilibration's 84 scale factors
+    // in one lane, spills 1.7 KB per lane and runs 3.5-3.9 ms per 400k cases against the row-per-lane kernel's 3.3
+    // (profiles/r05a_lane14.txt: 81k vector instructions per 64 cases, 70 % of the wave cycles waiting on scratch).
+    // WLSQM_HIP_LANE14=1 turns it on (tests: bit-identity with the strict kernels' CPU checker).
+    const char* l14 = getenv("WLSQM_HIP_LANE14");
+    const bool lane14 = strict::accurate_red1(dimension, order) && l14 && l14[0] == '1';
+    if (((accurate_mode() && !strict::accurate_red1(dimension, order)) || lane14) && !dbg_in) {
         const int rc = launch_fit_accurate(dimension, order, p, stream, &accurate_taken, &lists);
         if (rc != WLSQM_OK) { (void)scratch_free_async(lists, stream); return rc; }
     }

@@ -236,7 +236,7 @@ __global__ __launch_bounds__(KW, MINW) void fit_tile1_kernel(const KParams p, co
         if (p.hoods) {
             // ---- index-based input: this lane gathers ITS neighbours' rows of the point tables S / F through hoods[j, k]
             // and parks the coordinates in the same padded LDS image the dense path builds (its own slots of row c)
-            const long long pj = p.pidx ? (long long)p.pidx[jc] : jc;
+            const long long pj = own_point(p, jc);
 #pragma unroll
             for (int m = 0; m < DIM; ++m) xi[m] = p.S[pj * DIM + m];
             const int* hr = p.hoods + jc * p.shoods_j;

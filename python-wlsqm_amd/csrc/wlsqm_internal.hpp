@@ -31,6 +31,9 @@ struct KParams {
     const int* hoods;  long long shoods_j;
     const double* S;   const double* F;
     const int* pidx;
+    // Without pidx, case j of the launch sits at point pbase + j: a launch over the sub-batch [j0, j0 + n) of an index-based call
+    // (slice_cases) keeps the cases' own points (the sliced 3D order-4 path fitted slices after the first around S[j - j0]).
+    long long pbase = 0;
     const long long* case_index;   // nullable
     long long ncases;              // cases this launch processes
     // Nullable: the number of entries of case_index that are real, in DEVICE memory (the order buckets built on the device by
@@ -59,6 +62,9 @@ __device__ __forceinline__ long long live_cases(const KParams& p) {
     return d < p.ncases ? d : p.ncases;
 }
 
+// The case's own point of an index-based launch (xi = S[own_point]).
+__device__ __forceinline__ long long own_point(const KParams& p, long long j) { return p.pidx ? (long long)p.pidx[j] : p.pbase + j; }
+
 // The sub-batch [j0, j0 + n) of a launch (dense or index-based input, no case_index).
 inline KParams slice_cases(const KParams& p, long long j0, long long n) {
     KParams q = p;
@@ -71,7 +77,7 @@ inline KParams slice_cases(const KParams& p, long long j0, long long n) {
     q.knowns = p.knowns + j0 * p.sknowns;
     q.wm = p.wm + j0 * p.swm;
     if (p.hoods) q.hoods = p.hoods + j0 * p.shoods_j;
-    if (p.pidx) q.pidx = p.pidx + j0;
+    if (p.pidx) q.pidx = p.pidx + j0; else q.pbase = p.pbase + j0;
     q.ncases = n;
     return q;
 }

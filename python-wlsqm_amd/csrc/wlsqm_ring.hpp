@@ -208,7 +208,7 @@ __global__ __launch_bounds__(64, MINW) void fit_ring_kernel(const KParams p, con
             const int cc = c < nvalid ? c : nvalid - 1;
             const long long jc = j0 + cc;
             nxt.nk = nk_ahead; nxt.wm = p.wm[jc * p.swm]; nxt.kn = p.knowns[jc * p.sknowns];
-            const long long pj = p.pidx ? p.pidx[jc] : jc;
+            const long long pj = own_point(p, jc);
 #pragma unroll
             for (int m = 0; m < DIM; ++m) nxt.xi[m] = p.S[pj * DIM + m];
 #pragma unroll

@@ -100,6 +100,35 @@ __device__ __forceinline__ double make_weight(double d2, double max_d2, bool uni
     return weights_alpha + weights_beta * tmp * tmp;
 }
 
+// c[a] for a per-lane index, registers only: a binary tree of selects on the bits of a.  (A chain of `a == q ? c[q] : r` is
+// turned into an indexed load from a scratch copy of c by the optimizer.)
+template <int N>
+__device__ __forceinline__ double pick(const double (&c)[N], int a) {
+    constexpr int P = N <= 1 ? 1 : N <= 2 ? 2 : N <= 4 ? 4 : N <= 8 ? 8 : N <= 16 ? 16 : N <= 32 ? 32 : 64;
+    long long t[P];
+#pragma unroll
+    for (int q = 0; q < P; ++q) t[q] = __double_as_longlong(c[q < N ? q : N - 1]);
+#pragma unroll
+    for (int w = P / 2, bit = 0; w >= 1; w >>= 1, ++bit) {
+        const bool odd = (a >> bit) & 1;
+#pragma unroll
+        for (int q = 0; q < w; ++q) t[q] = odd ? t[2 * q + 1] : t[2 * q];
+    }
+    return __longlong_as_double(t[0]);
+}
+
+
+// ACCURATE mode (fit_accurate.hip): which cases its kernels take — a property of the case alone; the strict kernels launched behind
+// them skip exactly these.  RED1 (2D order 4: the 14 x 14 system of the reference's default mask): exactly the function value known.
+// Otherwise (2D orders 0-3, 3D orders 0-2): any mask without stray bits beyond the polynomial's DOFs (infra.pyx:119-121).
+__host__ __device__ constexpr bool accurate_red1(int dim, int order) { return dim == 2 && order == 4; }
+__host__ __device__ constexpr bool accurate_shape(int dim, int order) { return (dim == 2 && order <= 4) || (dim == 3 && order <= 2); }
+template <int NO, bool RED1>
+__host__ __device__ __forceinline__ bool accurate_takes_case(long long raw) {
+    if (RED1) return raw == 1;
+    return ((unsigned long long)raw >> NO) == 0ull;
+}
+
 }  // namespace strict
 
 // ---- correctly rounded quotients and roots without the range machinery (round 4; fit_accurate.hip's header has the story) ----

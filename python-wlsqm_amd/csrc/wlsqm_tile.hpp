@@ -228,7 +228,7 @@ __global__ __launch_bounds__(WV * KSPLIT, MINW) void fit_tile_kernel(const KPara
                     live_slots[i] = p.nk[(j0 + rr) * p.snk] - HW * (int)(qq - (long long)rr * CPRH);
                 }
             }
-            const long long pj = p.pidx ? (long long)p.pidx[jc] : jc;
+            const long long pj = own_point(p, jc);
 #pragma unroll
             for (int m = 0; m < DIM; ++m) xi[m] = p.S[pj * DIM + m];
             // ... then the gathers of the point rows they name (HW per index chunk), all in flight together.  Slots

@@ -384,6 +384,37 @@ def test_3d_order4_slices_give_the_same_bits(wlsqm, monkeypatch):
     assert np.isfinite(a0).all()
 
 
+@pytest.mark.parametrize("dim,order,Kn,kernel", [(3, 4, 48, "quad-gather"), (3, 3, 40, "stage-gather"), (2, 4, 40, "stage-gather"), (3, 2, 40, "stage-gather")])
+def test_index_based_slices_without_point_index(wlsqm, monkeypatch, dim, order, Kn, kernel):
+    """without point_index case j of an index-based call sits at point j; a launch over a SLICE of the batch must keep
+    that (KParams::pbase) — the sliced 3D order-4 path fitted every slice after the first around S[j - j0].  The first n points of
+    the cloud are the cases; sliced (1 024 cases), unsliced, with an explicit point_index = arange and dense: the same bits."""
+    import torch
+    import synth
+    import wlsqm.hip as whip
+    n, npts = 3000 + 37, 5000
+    no = {(3, 4): 35, (3, 3): 20, (2, 4): 15, (3, 2): 10}[(dim, order)]
+    S = synth.halton(npts, dim); F = synth.field(S)
+    pidx = np.arange(n, dtype=np.int32)
+    hoods = synth.knn(S, Kn, query=pidx).astype(np.int32)
+    nk = np.full(n, Kn, np.int32); kn = np.zeros(n, np.int64); wm = np.full(n, wlsqm.WEIGHT_CENTER, np.int32)
+    fi0 = np.zeros((n, no)); fi0[:, 0] = F[pidx]
+
+    def run(point_index):
+        f = _t(fi0)
+        whip.fit_cloud_device(dim, order, _t(S), _t(F), _t(hoods), f, _t(nk), _t(kn), _t(wm), point_index=point_index)
+        assert whip.last_kernel() == kernel, whip.last_kernel()
+        torch.cuda.synchronize()
+        return f.cpu().numpy()
+    a = run(_t(pidx))
+    b = run(None)
+    monkeypatch.setenv("WLSQM_HIP_QUAD_SLICE", "1024")
+    c = run(None)
+    assert np.isfinite(a).all()
+    assert np.array_equal(a.view(np.int64), b.view(np.int64)), "point_index=None differs from point_index=arange"
+    assert np.array_equal(a.view(np.int64), c.view(np.int64)), "the sliced launch lost the cases' own points"
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # fit + iterative refinement with one lane per case (csrc/fit_stage_iter.hip; impl.pyx:986-1083)
 

@@ -75,7 +75,7 @@ def test_strict_intermediates_bit_identical_to_the_reference(wlsqm, oracle, dim)
         out = whip.strict_intermediates(dim, o, _t(d["xk"][sel]), _t(d["fk"][sel]), _t(d["nk"][sel]), _t(d["xi"][sel]), fi_d,
                                         _t(d["knowns"][sel]), _t(d["wm"][sel]))
         torch.cuda.synchronize()
-        assert whip.last_kernel() in ("strict", "strict-rows")
+        assert whip.last_kernel() in ("strict", "strict-rows", "strict-lane")
         out = {k: v.cpu().numpy() for k, v in out.items()}
         fi = fi_d.cpu().numpy()
         for r, j in enumerate(sel):
@@ -113,7 +113,7 @@ def test_strict_outputs_bit_identical_to_the_oracle(wlsqm, oracle, dim, mode):
     with whip.strict():
         it = getattr(wlsqm, name)(xk=d["xk"], fk=d["fk"], nk=d["nk"], xi=d["xi"], fi=fi, sens=sens, do_sens=int(do_sens),
                                   order=d["order"], knowns=d["knowns"], weighting_method=d["wm"], **kw)
-        assert whip.last_kernel() in ("strict", "strict-rows")
+        assert whip.last_kernel() in ("strict", "strict-rows", "strict-lane")
     assert not whip.get_strict()
     assert_bits(fi, fi_o, "fi (%s)" % mode)
     if do_sens:
@@ -142,7 +142,7 @@ def test_strict_meets_1e10_at_the_headline_density(wlsqm, oracle, name):
     whip.fit_many_device(dim, order, _t(c["xk"]), _t(c["fk"]), _t(c["nk_a"]), _t(c["xi"]), fi_d, _t(c["knowns_a"]), _t(c["wm_a"]),
                          strict=True)
     torch.cuda.synchronize()
-    assert whip.last_kernel() in ("strict", "strict-rows")
+    assert whip.last_kernel() in ("strict", "strict-rows", "strict-lane")
     fi = fi_d.cpu().numpy()
     fi_o = c["fi0"].copy()
     oracle.fit_many(dim, c["xk"], c["fk"], c["nk_a"], c["xi"], fi_o, None, 0, c["order_a"], c["knowns_a"], c["wm_a"])
@@ -185,14 +185,14 @@ def test_strict_c1_and_index_based_and_expert(wlsqm, oracle):
     whip.fit_cloud_device(2, 2, _t(c["S"]), _t(c["F"]), _t(c["hoods"].astype(np.int32)), cloud, _t(c["nk_a"]), _t(c["knowns_a"]),
                           _t(c["wm_a"]), strict=True)
     torch.cuda.synchronize()
-    assert whip.last_kernel() in ("strict", "strict-rows")
+    assert whip.last_kernel() in ("strict", "strict-rows", "strict-lane")
     assert_bits(cloud.cpu().numpy(), dense.cpu().numpy(), "index-based strict vs dense strict")
     with whip.strict():
         solver = wlsqm.ExpertSolver(dimension=2, nk=c["nk_a"], order=c["order_a"], knowns=c["knowns_a"], weighting_method=c["wm_a"])
         solver.prepare(xi=c["xi"], xk=c["xk"])
         fi_e = c["fi0"].copy()
         solver.solve(fk=c["fk"], fi=fi_e, sens=None)
-        assert whip.last_kernel() in ("strict", "strict-rows")
+        assert whip.last_kernel() in ("strict", "strict-rows", "strict-lane")
         fk2 = np.stack([c["fk"], 2.0 * c["fk"] + 1.0])
         fi2 = np.zeros((2, n, no))
         solver.solve_many(fk2, fi2)
@@ -240,7 +240,7 @@ def test_strict_register_kernels_with_the_default_knowns_mask(wlsqm, oracle, nam
     fi_d = _t(fi0)
     whip.fit_many_device(dim, order, _t(xk), _t(c["fk"]), _t(c["nk_a"]), _t(c["xi"]), fi_d, _t(kn), _t(c["wm_a"]), strict=True)
     torch.cuda.synchronize()
-    assert whip.last_kernel() in ("strict", "strict-rows")
+    assert whip.last_kernel() in ("strict", "strict-rows", "strict-lane")
     fo = fi0.copy()
     oracle.fit_many(dim, c["xk"], c["fk"], c["nk_a"], c["xi"], fo, None, 0, c["order_a"], kn, c["wm_a"])
     assert_bits(fi_d.cpu().numpy(), fo, "%s strict, knowns pattern %s" % (name, mask_pattern))

@@ -216,6 +216,37 @@ def test_accurate_mode_statement_against_the_reference_goldens(name):
     assert np.all(E <= 0.5e-10), E
 
 
+@pytest.mark.parametrize("dim,order,Kn", [(2, 2, 32), (3, 2, 40), (2, 3, 36), (2, 1, 12)])
+def test_accurate_mode_statement_with_known_dofs(dim, order, Kn):
+    """Round 5: the accurate kernels take cases WITH known DOFs (any mask inside the polynomial's DOFs; knowns eliminated term by term as
+    impl.pyx:792-823).  variants.c without a switch still equals the oracle bit for bit on such batches (ragged nk, both weightings);
+    with V_SYM it stays within 0.5e-10 of the oracle on every unknown column, and never writes a known DOF."""
+    import _cases as K
+    import _parity as P
+    from oracle import oracle as O
+    rng = np.random.default_rng(100 * dim + order)
+    n, no = 600, K.NDOF[dim][order]
+    xi = rng.uniform(0, 1, (n, dim))
+    xk = xi[:, None, :] + 0.05 * rng.uniform(-1, 1, (n, Kn, dim))
+    fk = np.sin(3 * xk[..., 0]) * np.cos(2 * xk[..., -1])
+    nk = rng.integers(no + 3, Kn + 1, n).astype(np.int32)
+    kn = rng.choice(np.array([1, 1, 2, 5, (1 << (no - 1)) | 2], np.int64), n)
+    wm = rng.choice(np.array([1, 2], np.int32), n)
+    fi0 = rng.uniform(-1, 1, (n, no)); fi0[:, 0] = np.sin(3 * xi[:, 0]) * np.cos(2 * xi[:, -1])
+    ora = fi0.copy()
+    O.fit_many(dim, xk, fk, nk, xi, ora, None, 0, np.full(n, order, np.int32), kn, wm, ntasks=8)
+    v0 = fi0.copy(); O.variant_fit_many(dim, order, xk, fk, nk, xi, v0, kn, wm, flags=0)
+    assert np.array_equal(v0.view(np.int64), ora.view(np.int64)), "variants.c without a switch must be the oracle"
+    vs = fi0.copy(); O.variant_fit_many(dim, order, xk, fk, nk, xi, vs, kn, wm, flags=O.V_SYM)
+    known = ((kn[:, None] >> np.arange(no)[None, :]) & 1).astype(bool)
+    assert np.array_equal(vs[known].view(np.int64), fi0[known].view(np.int64)), "a known DOF was written"
+    for m in range(no):
+        sel = ~known[:, m]
+        if sel.sum() > 0:
+            e = np.abs(vs[sel, m] - ora[sel, m]).max() / np.abs(ora[sel, m]).max()
+            assert e <= 0.5e-10, (m, e)
+
+
 def test_oracle_on_the_prepare_once_time_levels_of_configs3():
     """tests/golden/config_C4_1M.npz: the reference's ExpertSolver prepared once and solved for four time levels (BASELINE
     configs[3]'s pattern, expert.pyx:309-655).  The oracle, one fit per level, agrees to LAPACK's rounding (column metric 1e-10)."""

@@ -122,7 +122,7 @@ while time.time() - t0 < budget:
         fi_s = fi0.copy(); sens_s = np.full((n, K, ncol), 777.0) if mode == "sens" else None
         with whip.strict():
             it_s = f(xk_a, fk, nk, xi_a, fi_s, sens_s, int(mode == "sens"), orders, knowns, wm, **kw)
-            assert whip.last_kernel() in ("strict", "strict-rows"), whip.last_kernel()
+            assert whip.last_kernel() in ("strict", "strict-rows", "strict-lane"), whip.last_kernel()
         it_o = oracle.fit_many(dim, xk_a, fk, nk, xi_a, fi0.copy(), None, 0, orders, knowns, wm, iterative=(mode == "iter"), max_iter=6,
                                ntasks=8) if mode == "iter" else 0
         assert np.array_equal(fi_s, fi_o, equal_nan=True), desc + ": STRICT mode differs from the oracle (%d of %d doubles)" % (

@@ -30,8 +30,9 @@ def main():
         no = _ndofs(dim, order)
         nk_d = torch.full((n,), nk, dtype=torch.int32, device=dev)
         wm_d = torch.full((n,), cfg["wm"], dtype=torch.int32, device=dev)
-        kn_d = torch.full((n,), cfg["knowns"], dtype=torch.int64, device=dev)
-        for mode in (False, 2, True):
+        kn_d = torch.full((n,), int(os.environ.get("WLSQM_TIME_KNOWNS", cfg["knowns"])), dtype=torch.int64, device=dev)
+        modes = [{"fast": False, "accurate": 2, "strict": True}[m] for m in os.environ.get("WLSQM_TIME_MODES", "fast,accurate,strict").split(",")]
+        for mode in modes:
             fi = torch.zeros((n, no), dtype=torch.float64, device=dev); fi[:, 0] = F_d
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             def run():
