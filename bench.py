@@ -257,9 +257,10 @@ def golden_parity(name, dev):
     return acc
 
 
-def measure_fit(name, cfg, n, dev, timer, steps, warmup, rank, parity=True, keep=False, extras=None):
+def measure_fit(name, cfg, n, dev, timer, steps, warmup, rank, parity=True, keep=False, extras=None, unsorted=False):
     """One BASELINE config through the device-resident dense API: build, time, roofline, parity.
-    extras: None (basic fit), "sens" (do_sens: + 8 nk no bytes written per fit) or "iter" (iterative refinement, max_iter 10)."""
+    extras: None (basic fit), "sens" (do_sens: + 8 nk no bytes written per fit) or "iter" (iterative refinement, max_iter 10).
+    unsorted: every case's neighbours in random order (what a ball query or any caller that does not sort by distance hands over)."""
     import torch
     import wlsqm.hip as whip
     dim, order, nk = cfg["dim"], cfg["order"], cfg["nk"]
@@ -269,6 +270,9 @@ def measure_fit(name, cfg, n, dev, timer, steps, warmup, rank, parity=True, keep
     S_d = torch.from_numpy(np.ascontiguousarray(S)).to(dev)
     F_d = torch.from_numpy(F).to(dev)
     h_d = torch.from_numpy(hoods).to(dev)
+    if unsorted:
+        g = torch.Generator(device=dev); g.manual_seed(11 + rank)
+        h_d = torch.gather(h_d, 1, torch.argsort(torch.rand(h_d.shape, device=dev, generator=g), dim=1)).contiguous()
     chunk = 2_000_000
     xk_d = torch.empty((n, nk) + ((dim,) if dim > 1 else ()), dtype=torch.float64, device=dev)
     fk_d = torch.empty((n, nk), dtype=torch.float64, device=dev)
@@ -333,7 +337,7 @@ def measure_fit(name, cfg, n, dev, timer, steps, warmup, rank, parity=True, keep
         vb, vsrc = load_valu_busy("C3")
         roof.update({"valu_flop_per_fit": fl, "valu_achieved_tflops": tf, "valu_peak_tflops": FP64_PEAK_TFLOPS,
                      "valu_frac": tf / FP64_PEAK_TFLOPS, "valu_busy_pmc": vb, "valu_busy_source": vsrc})
-    res = {"workload": "%s: %s; %d local fits per GPU per step, device-resident dense xk/fk" % (name, cfg["desc"], n),
+    res = {"workload": "%s: %s%s; %d local fits per GPU per step, device-resident dense xk/fk" % (name, cfg["desc"], ", neighbours in RANDOM order" if unsorted else "", n),
            "fits_per_gpu": n, "bytes_per_fit": B_fit, "ms_per_step": dt / steps * 1e3, "fits_per_s": n * steps / dt,
            "roofline": roof}
     if parity and rank == 0 and name in GOLDEN_OF:
@@ -774,7 +778,11 @@ def side_configs(a, dev, timer, rank, parity):
     side = {}
     short = dict(steps=max(1, min(a.steps, 20)), warmup=min(a.warmup, 3))
 
+    only = [s for s in os.environ.get("WLSQM_BENCH_SIDE", "").split(",") if s]      # (experiments: only the side lines whose key contains one of these)
+
     def add(key, fn):
+        if only and not any(s in key for s in only):
+            return
         t0 = time.perf_counter()
         try:
             res = fn()
@@ -809,15 +817,74 @@ def side_configs(a, dev, timer, rank, parity):
     add("C3-indexed@1M", lambda: measure_cloud("C3", CONFIGS["C3"], 1_000_000, dev, timer, short["steps"], short["warmup"], rank))
     # 3D orders 3 and 4 (20 / 35 unknowns; round 4: the staged kernel with LDS rows / moments + the four-lanes-per-case solve), with a
     # sample of the batch checked against the CPU port as in the sharded line (no reference golden at these shapes)
+    # neighbour lists that are NOT sorted by distance: the BASELINE shapes with every row shuffled, and the shape of
+    # the reference's own harness (ball query, ragged counts, order 4, F known)
+    for cname in ("C2", "C3", "C5"):
+        add("%s-unsorted@1M" % cname, lambda cname=cname: measure_extra_shape(cname + "-unsorted", CONFIGS[cname], 1_000_000, dev, timer,
+                                                                             short["steps"], short["warmup"], rank, parity, unsorted=True))
+    add("C3-ball@400k", lambda: measure_ball("C3-ball", 400_000, dev, timer, short["steps"], short["warmup"], rank, parity))
     for key, order, cn in (("3Do3@1M", 3, 1_000_000), ("3Do4@400k", 4, 400_000)):
         cfg = dict(CONFIGS["C5"], order=order, desc="3D order-%d, Halton, 40 neighbours, WEIGHT_CENTER, all DOFs unknown" % order)
         add(key, lambda key=key, cfg=cfg, cn=cn: measure_extra_shape(key, cfg, cn, dev, timer, short["steps"], short["warmup"], rank, parity))
     return side
 
 
-def measure_extra_shape(name, cfg, n, dev, timer, steps, warmup, rank, parity):
+def measure_ball(name, n, dev, timer, steps, warmup, rank, parity, order=4, max_nk=100, mean_nk=64):
+    """The shape of the reference's own harness (examples/wlsqm_example.py:103-133: `cKDTree.query_ball_point`, order 4, knowns = F,
+    max_nk = 100): every point's neighbours are ALL points within a radius — a ragged count per case, in NO particular order (the
+    tree's), padded to max_nk slots.  Radius chosen for ~mean_nk neighbours on n Halton points; the GPU ball search returns them
+    nearest first, so every row's valid entries are shuffled to look like the reference's input.  Dense device-resident rows."""
+    import math
+    import torch
+    import wlsqm.hip as whip
+    dim, no = 2, NDOF[2][order]
+    S = synth.halton(n, dim, skip=1 + rank * n); F = synth.field(S)
+    S_d = torch.from_numpy(np.ascontiguousarray(S)).to(dev); F_d = torch.from_numpy(F).to(dev)
+    radius = math.sqrt(mean_nk / (math.pi * n))
+    h_d, nk_d = whip.ball(S_d, radius, max_nk)
+    g = torch.Generator(device=dev); g.manual_seed(7 + rank)
+    keys = torch.rand((n, max_nk), device=dev, generator=g)
+    keys[torch.arange(max_nk, device=dev)[None, :] >= nk_d[:, None]] = 2.0          # padding stays behind the valid entries
+    h_d = torch.gather(h_d, 1, torch.argsort(keys, dim=1)).contiguous()
+    del keys
+    hh = h_d.long()
+    xk_d = S_d[hh].contiguous(); fk_d = F_d[hh].contiguous()
+    del hh
+    xi_d = S_d.clone()
+    fi_d = torch.zeros((n, no), dtype=torch.float64, device=dev); fi_d[:, 0] = F_d
+    kn_d = torch.ones((n,), dtype=torch.int64, device=dev)
+    wm_d = torch.full((n,), 2, dtype=torch.int32, device=dev)
+    args = (dim, order, xk_d, fk_d, nk_d, xi_d, fi_d, kn_d, wm_d)
+    dt = timer.run(lambda: whip.fit_many_device(*args), steps, warmup)
+    kernel = whip.last_kernel()
+    ms_kernel = whip.time_fit_device(*args, reps=min(max(steps, 10), 100))
+    nk_mean = float(nk_d.double().mean()); nk_min = int(nk_d.min()); nk_max = int(nk_d.max())
+    B_fit = 8.0 * nk_mean * (dim + 1) + 8 * dim + 8 * no + 8 + 20          # SURVEY section 8d with the cases' own neighbour counts
+    achieved = B_fit * n / (ms_kernel * 1e-3) / 1e9
+    res = {"workload": "%s: 2D order-%d, %d Halton points, ball query r = %.5f (nk %d..%d, mean %.1f, %d slots), neighbours UNSORTED, "
+                       "WEIGHT_CENTER, F known; device-resident dense xk/fk" % (name, order, n, radius, nk_min, nk_max, nk_mean, max_nk),
+           "fits_per_gpu": n, "bytes_per_fit": B_fit, "ms_per_step": dt / steps * 1e3, "fits_per_s": n * steps / dt,
+           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                        "traffic": None, "kernel_ms": ms_kernel, "kernel": kernel, "algorithmic_bytes_per_launch": B_fit * n,
+                        "note": "algorithmic bytes count the valid neighbours only; the rows are padded to %d slots" % max_nk}}
+    if parity and rank == 0:
+        from oracle import oracle
+        sel = torch.nonzero(nk_d >= no + 8)[:1024, 0]                      # (nearly determined neighbourhoods are noise, not signal)
+        m = int(sel.numel())
+        xk, fk, xi = (t[sel].cpu().numpy() for t in (xk_d, fk_d, xi_d))
+        got = fi_d[sel].cpu().numpy()
+        ref = np.zeros((m, no)); ref[:, 0] = F_d[sel].cpu().numpy()
+        oracle.fit_many(dim, xk, fk, nk_d[sel].cpu().numpy(), xi, ref, None, 0, np.full(m, order, np.int32), np.ones(m, np.int64),
+                        np.full(m, 2, np.int32), ntasks=8)
+        scale = np.abs(ref).max(axis=0)
+        E = np.abs(got - ref).max(axis=0) / np.where(scale > 0, scale, 1.0)
+        res["parity"] = {"vs_oracle": {"cases": m, "E_max": float(E.max()), "columns": int(no), "columns_le_1e-8": int((E <= 1e-8).sum())}}
+    return res, dt
+
+
+def measure_extra_shape(name, cfg, n, dev, timer, steps, warmup, rank, parity, unsorted=False):
     """measure_fit for a shape outside BASELINE's configs; the first 1 024 cases of the batch against the CPU port (checker only)."""
-    res, dt = measure_fit(name, cfg, n, dev, timer, steps, warmup, rank, False, keep=True)
+    res, dt = measure_fit(name, cfg, n, dev, timer, steps, warmup, rank, False, keep=True, unsorted=unsorted)
     t = res.pop("_tensors")
     if parity and rank == 0:
         from oracle import oracle

@@ -137,6 +137,59 @@ __device__ __forceinline__ void accumulate_moments_outer3d(double (&mu)[mom_coun
     }
 }
 
+// ONE pass for neighbours in ANY order (round 5).  The weight needs the largest squared distance of the case, which unsorted input does
+// not reveal before the last neighbour; but alpha + beta (1 - sqrt(d2 / max))^2 = (alpha + beta) - 2 beta sqrt(d2) / sqrt(max) + beta d2 / max
+// is LINEAR in 1, sqrt(d2) and d2 with coefficients that depend on the maximum alone: three sets of moments — sum P, sum sqrt(d2) P,
+// sum d2 P over the unweighted monomials P — are summed in one pass and combined at the end (combine_triple).  Three accumulators per
+// moment (2D order 2: 63 instead of 21) and three fused multiply-adds; the combination cancels a few bits (the three terms are of the
+// size of sum P, the result of the size of the mean weight, 0.2-0.3, times that).  Used where the accumulators fit (2D up to order 2).
+template <int DIM, int ORDER>
+__device__ __forceinline__ void accumulate_moments_triple(double (&mu3)[3][mom_count<DIM>(2 * ORDER)], double (&nu3)[3][mom_count<DIM>(ORDER)],
+                                                          const double (&d)[DIM], double one, double r, double d2, double f) {
+    constexpr int D = 2 * ORDER, NM = mom_count<DIM>(D);
+    double P[NM];
+    P[0] = 1.0;
+    mu3[0][0] += one; mu3[1][0] += r; mu3[2][0] += d2;                 // (one = 0 for a masked slot, whose d, r, d2 and f are 0 too)
+    nu3[0][0] += f; nu3[1][0] = fma(f, r, nu3[1][0]); nu3[2][0] = fma(f, d2, nu3[2][0]);
+#pragma unroll
+    for (int deg = 1; deg <= D; ++deg) {
+        const int base = mom_count<DIM>(deg - 1), pbase = deg >= 2 ? mom_count<DIM>(deg - 2) : 0;
+        const int smax = (DIM == 1) ? 0 : deg;
+#pragma unroll
+        for (int s = 0; s <= smax; ++s) {
+            const int rmax = (DIM == 3) ? s : 0;
+#pragma unroll
+            for (int rr = 0; rr <= rmax; ++rr) {
+                const int q = s - rr;
+                const int pos = (DIM == 3) ? mtri(s) + rr : s;
+                int ppos; int var;                                     // parent monomial (degree deg - 1), as in accumulate_moments
+                if (DIM == 3 && rr > 0) { ppos = mtri(s - 1) + (rr - 1); var = 2; }
+                else if (DIM >= 2 && q > 0) { ppos = (DIM == 3) ? mtri(s - 1) : s - 1; var = 1; }
+                else { ppos = (DIM == 3) ? mtri(s) + rr : s; var = 0; }
+                const double t = P[pbase + ppos] * d[var];
+                P[base + pos] = t;
+                // (the first set exactly as accumulate_moments sums it with the weight 1: a uniformly weighted case gets the same bits here)
+                if (deg < D) mu3[0][base + pos] += t; else mu3[0][base + pos] = fma(P[pbase + ppos], d[var], mu3[0][base + pos]);
+                mu3[1][base + pos] = fma(t, r, mu3[1][base + pos]);
+                mu3[2][base + pos] = fma(t, d2, mu3[2][base + pos]);
+                if (deg <= ORDER) {
+                    const double tf = t * f;
+                    nu3[0][base + pos] = fma(t, f, nu3[0][base + pos]);
+                    nu3[1][base + pos] = fma(tf, r, nu3[1][base + pos]);
+                    nu3[2][base + pos] = fma(tf, d2, nu3[2][base + pos]);
+                }
+            }
+        }
+    }
+}
+// the weighted moments from the three sets: inv_max = 1 / max_d2, root_inv = sqrt(inv_max); uniform weighting keeps the first set
+template <int N>
+__device__ __forceinline__ void combine_triple(double (&out)[N], double (&in3)[3][N], double inv_max, double root_inv, bool uniform) {
+    const double a1 = -2.0 * (1.0 - 1e-4) * root_inv, a2 = (1.0 - 1e-4) * inv_max;      // (alpha + beta = 1)
+#pragma unroll
+    for (int i = 0; i < N; ++i) { const double v = fma(a2, in3[2][i], fma(a1, in3[1][i], in3[0][i])); out[i] = uniform ? in3[0][i] : v; }
+}
+
 // The cheaper of the two forms for (DIM, ORDER) (the 3D outer form is the staged kernel's: csrc/fit_stage.hip).
 template <int DIM, int ORDER>
 __device__ __forceinline__ void accumulate_moments_best(double (&mu)[mom_count<DIM>(2 * ORDER)], double (&nu)[mom_count<DIM>(ORDER)],

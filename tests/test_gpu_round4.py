@@ -296,6 +296,46 @@ def test_staged_kernel(wlsqm, oracle, dim, order, Kn, n, neighbours, monkeypatch
         assert np.array_equal(got.view(np.int64), again.view(np.int64))
 
 
+@pytest.mark.parametrize("dim,order,Kn", [(2, 2, 32), (2, 2, 40), (2, 4, 64), (3, 2, 40)])
+def test_staged_kernel_bits_do_not_depend_on_wave_mates(wlsqm, dim, order, Kn):
+    """Round 5: 2D order 2 fits a case whose neighbours are NOT sorted by distance in ONE pass (three sets of sums, combined with the
+    largest squared distance at the end); a sorted-looking case keeps the speculative pass, and a wave that holds both kinds runs both.
+    Which arithmetic a case gets must depend on the case alone: the same cases in a batch of their own kind, interleaved with the other
+    kind (mixed 64-case groups), and permuted carry the same bits — sorted, unsorted and uniformly weighted cases alike."""
+    import torch
+    import wlsqm.hip as whip
+    rng = np.random.default_rng(77 + Kn)
+    n, no = 640, K.NDOF[dim][order]
+    xi = rng.uniform(0, 1, (n, dim))
+    off = 0.05 * rng.uniform(-1, 1, (n, Kn, dim))
+    srt = off.copy()
+    for j in range(n):
+        srt[j] = off[j][np.argsort((off[j] ** 2).sum(axis=1), kind="stable")]
+    nk = np.full(n, Kn, np.int32); nk[::7] = Kn - 3
+    kn = rng.choice(np.array([0, 0, 1], np.int64), n)
+    wm = rng.choice(np.array([wlsqm.WEIGHT_UNIFORM, wlsqm.WEIGHT_CENTER, wlsqm.WEIGHT_CENTER], np.int32), n)
+    fi0 = rng.uniform(-1, 1, (n, no))
+
+    def run(o, sel=slice(None)):
+        xk = (xi[:, None, :] + o)[sel]
+        fk = np.sin(3 * xk[..., 0]) * np.cos(2 * xk[..., -1])
+        fi = _t(fi0[sel])
+        whip.fit_many_device(dim, order, _t(xk), _t(fk), _t(nk[sel]), _t(xi[sel]), fi, _t(kn[sel]), _t(wm[sel]))
+        torch.cuda.synchronize()
+        assert whip.last_kernel() == "stage"
+        return fi.cpu().numpy().view(np.int64)
+    all_sorted, all_unsorted = run(srt), run(off)
+    mixed = srt.copy(); odd = np.arange(n) % 2 == 1
+    mixed[odd] = off[odd]
+    got = run(mixed)
+    assert np.array_equal(got[~odd], all_sorted[~odd]), "a sorted case changed bits next to unsorted wave-mates"
+    assert np.array_equal(got[odd], all_unsorted[odd]), "an unsorted case changed bits next to sorted wave-mates"
+    perm = rng.permutation(n)
+    assert np.array_equal(run(mixed, perm), got[perm]), "bits depend on the position in the batch"
+    uni = wm == wlsqm.WEIGHT_UNIFORM
+    assert np.array_equal(all_sorted[uni & (nk == Kn)], run(srt)[uni & (nk == Kn)])
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # the gathering form of the staged kernel: index-based input (csrc/fit_stage.hip, GATHER)
 
