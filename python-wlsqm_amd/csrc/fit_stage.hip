@@ -61,6 +61,12 @@ constexpr int CH = 8;               // neighbours per staged chunk
 #ifndef WLSQM_STAGE_MINW10
 #define WLSQM_STAGE_MINW10 1        // waves per SIMD the systems up to 10 unknowns are compiled for
 #endif
+#ifndef WLSQM_STAGE_MINW15
+#define WLSQM_STAGE_MINW15 1        // ... the 15-unknown systems
+#endif
+#ifndef WLSQM_STAGE_GRP15
+#define WLSQM_STAGE_GRP15 8         // neighbours the scheduler may interleave in their moment pass
+#endif
 // PART = 0: the whole fit.  PART = 1 / 2 (3D order 4, 35 unknowns): the kernel stops after the moment pass and leaves HALF of the case's
 // 165 + 35 moments (wlsqm_moments.hpp: stage_part) at p.ws — entry e of case t at ws[((t / 64) 200 + e) 64 + t % 64] — for the
 // four-lanes-per-case solve of csrc/fit_quad.hip; all 200 accumulators at once are 400 registers, more than an instruction can name.
@@ -69,7 +75,7 @@ constexpr int CH = 8;               // neighbours per staged chunk
 // registers while the current ones are consumed.  Everything behind the fetch is the dense kernel's code (same bits as the dense
 // kernel on the gathered rows).
 template <int DIM, int ORDER, int PART = 0, bool GATHER = false>
-__global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER) <= 10 ? WLSQM_STAGE_MINW10 : 1)) void fit_stage_kernel(const KParams p) {
+__global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER) <= 10 ? WLSQM_STAGE_MINW10 : ndofs(DIM, ORDER) <= 15 ? WLSQM_STAGE_MINW15 : 1)) void fit_stage_kernel(const KParams p) {
     using namespace stage;
     constexpr int NO = ndofs(DIM, ORDER), NE = NO * (NO + 1) / 2, NM = mom_count<DIM>(2 * ORDER);
 #ifndef WLSQM_STAGE_CH10
@@ -83,8 +89,8 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER)
     constexpr int FCPI = 64 / FPC, FNI = 64 / FCPI;
     // neighbours the scheduler may interleave: the 6-unknown systems run two waves per SIMD and fit their 256 registers only with
     // two at a time (no scratch; four: 44 B, eight: 76 B); the larger systems own their SIMD and take the whole chunk
-    constexpr bool SCHED_BARRIER = WLSQM_STAGE_SCHED_BARRIER || NO <= 6 || NO >= 20;
-    constexpr int GRP = WLSQM_STAGE_SCHED_BARRIER ? (WLSQM_STAGE_GRP < CH ? WLSQM_STAGE_GRP : CH) : (NO <= 6 ? 2 : NO >= 20 ? WLSQM_STAGE_GRP20 : CH);
+    constexpr bool SCHED_BARRIER = WLSQM_STAGE_SCHED_BARRIER || NO <= 6 || NO >= 20 || (NO > 10 && WLSQM_STAGE_GRP15 < CH);
+    constexpr int GRP = WLSQM_STAGE_SCHED_BARRIER ? (WLSQM_STAGE_GRP < CH ? WLSQM_STAGE_GRP : CH) : (NO <= 6 ? 2 : NO >= 20 ? WLSQM_STAGE_GRP20 : NO > 10 ? (WLSQM_STAGE_GRP15 < CH ? WLSQM_STAGE_GRP15 : CH) : CH);
     // the staging rows; behind them (reusing the same bytes after the last chunk) the 64 result rows of the wave
     // (and, for the 20-unknown systems, the top R0 rows of every lane's normal matrix during the solve: see below)
     constexpr int R0 = NO == 20 ? WLSQM_STAGE_LDS_ROWS : 0, TOP_D = 64 * tri<NO>(R0, R0);
