@@ -746,13 +746,19 @@ static int launch_stage34(const KParams& p, hipStream_t stream) {
         int rc = scratch_alloc_async(reinterpret_cast<void**>(&ws), (size_t)groups * 200 * 64 * sizeof(double), stream);
         if (rc != WLSQM_OK) return rc;
         q.ws = ws; q.ws_stride = 0;
+        // (round 5: both halves in ONE launch — the second pass re-staging the rows from L2 — was built and dropped: the compiler's register
+        // allocation of the fused kernel puts 380-780 accumulation-register moves into every 8-neighbour chunk where the two kernels have
+        // ~60, and 848 B of scratch)
         hipLaunchKernelGGL((fit_stage_kernel<3, 4, 1, GATHER>), dim3((unsigned)groups), dim3(64), 0, stream, q);
-        hipLaunchKernelGGL((fit_stage_kernel<3, 4, 2, GATHER>), dim3((unsigned)groups), dim3(64), 0, stream, q);
-        rc = launch_quad_solve(q, stream);
+        hipError_t le = hipGetLastError();                            // (a failed moment launch must not run the solve on an uninitialised workspace)
+        if (le == hipSuccess) {
+            hipLaunchKernelGGL((fit_stage_kernel<3, 4, 2, GATHER>), dim3((unsigned)groups), dim3(64), 0, stream, q);
+            le = hipGetLastError();
+        }
+        rc = le == hipSuccess ? launch_quad_solve(q, stream) : hip_fail(le, "fit_stage_kernel<3, 4>");
         const int rc2 = scratch_free_async(ws, stream);
         if (rc != WLSQM_OK) return rc;
         if (rc2 != WLSQM_OK) return rc2;
-        WLSQM_HIP_CHECK(hipGetLastError());
     }
     note_kernel(GATHER ? "quad-gather" : "quad");
     return WLSQM_OK;

@@ -179,14 +179,36 @@ class HaloCloudSolver:
             ball = {1: 2.0, 2: np.pi, 3: 4.0 * np.pi / 3.0}[dim]
             r = 1.5 * float((self.nk * float(ext.prod()) / (N * ball)) ** (1.0 / dim))
             for attempt in range(8):
-                boxes = self._allgather(torch.cat([blo - r, bhi + r])).reshape(world, 2 * dim)
+                # Who needs which of my points: round 3 sent every point inside the asking rank's BOUNDING BOX inflated by r — for a Morton
+                # block 2-4x the block's own volume.  Round 5: an occupancy grid over the global extent with cells of side >= r; a rank
+                # marks the cells that hold its points, grows the marks by one cell in every direction (every point within r of one of
+                # its points lies in a marked cell) and publishes the marks (all_gather of one byte per cell, <= 64^dim cells); a point
+                # is sent to the ranks whose marks cover its cell.  The band shrinks to the block's own outline; the search result —
+                # verified against r below as before — cannot change (tests/test_sharded_gloo.py: bit-identical to one rank).
+                ncell = torch.clamp((ext / r).floor(), 1, {1: 4096, 2: 256, 3: 64}[dim]).to(torch.int64)      # cells per axis, side ext / ncell >= r
+                hcell = ext / ncell.to(torch.float64)
+                stride = torch.ones(dim, dtype=torch.int64, device=dev)
+                for m in range(dim - 2, -1, -1):
+                    stride[m] = stride[m + 1] * ncell[m + 1]
+                ntot = int(ncell.prod().item())
+                shape = tuple(int(v) for v in ncell.tolist())
+                if n_own:
+                    cell = torch.minimum(((own - glo) / hcell).floor().to(torch.int64).clamp_min(0), ncell - 1)
+                    lin = (cell * stride).sum(1)
+                    occ = torch.zeros(ntot, dtype=torch.float32, device=dev)
+                    occ[lin] = 1.0
+                    pool = {1: torch.nn.functional.max_pool1d, 2: torch.nn.functional.max_pool2d, 3: torch.nn.functional.max_pool3d}[dim]
+                    occ = pool(occ.reshape((1, 1) + shape), kernel_size=3, stride=1, padding=1).reshape(-1)
+                else:
+                    lin = torch.zeros(0, dtype=torch.int64, device=dev)
+                    occ = torch.zeros(ntot, dtype=torch.float32, device=dev)
+                marks = self._allgather(occ.to(torch.uint8)).reshape(world, ntot)
                 parts, counts = [], []
                 for q in range(world):
                     if q == rank or n_own == 0:
                         parts.append(torch.zeros(0, dtype=torch.int64, device=dev)); counts.append(0)
                         continue
-                    inside = ((own >= boxes[q, :dim]) & (own <= boxes[q, dim:])).all(1)
-                    idx = torch.nonzero(inside)[:, 0]
+                    idx = torch.nonzero(marks[q][lin])[:, 0]
                     parts.append(idx); counts.append(int(idx.numel()))
                 sel = torch.cat(parts)
                 payload = torch.cat([own[sel], (own_g[sel]).to(torch.float64)[:, None]], 1).contiguous()      # indices < 2^53: exact

@@ -30,6 +30,25 @@ def _t(a, dev="cuda:0"):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
 
+# Batches of fewer than 64 cases are a small sample for a max-over-cases statistic (the reference may be accurate by luck, so its noise floor
+# N is not one): each is held to a GROSS criterion only (wrong neighbours / indexing show as 1e-8 .. 1e-1), and all of them are POOLED per
+# (what, dimension, order) and held to the usual `1e-10 + 8 N` bound as one sample at the end of the module (VERDICT r4 hygiene item).
+_POOL = {}
+
+
+def _pool(key, got, ref, truth, known=None):
+    g, r, t = (np.array(a, dtype=float, copy=True) for a in (got, ref, truth))
+    if known is not None:                                        # known DOFs are bit-identical copies: keep them out of the statistic's scale
+        g[known] = r[known] = t[known] = 0.0
+    _POOL.setdefault(key, []).append((g, r, t))
+
+
+def _small_batch(key, got, ref, truth, msg=""):
+    E = P.column_metric(got, ref); N = P.column_metric(ref, truth)
+    assert np.all(E <= 1e-10 + 25.0 * 8.0 * N), (msg, E, N)       # gross errors only: see _POOL
+    _pool(key, got, ref, truth)
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # index-based 2D order 4, 26..64 slots: the tail tile of the gather ring (examples/wlsqm_example.py:103-133 is this layout)
 
@@ -105,8 +124,7 @@ def test_gather_ring_tail_tile(wlsqm, oracle, Kn, monkeypatch):
                 else:
                     # a few dozen cases make the noise floor a small sample (the oracle may be accurate by luck): the gross criterion
                     # of tools/fuzz.py — wrong neighbours show as 1e-8 .. 1e-1
-                    E = P.column_metric(got, ref); N = P.column_metric(ref, truth)
-                    assert np.all(E <= 1e-10 + 25.0 * 8.0 * N), "K %d n %d pidx %s: E %s N %s" % (Kn, n, with_pidx, E, N)
+                    _small_batch(("gather ring tail", 2, 4), got, ref, truth, "K %d n %d pidx %s" % (Kn, n, with_pidx))
                     assert np.array_equal(got[:, 0][kn & 1 == 1], fi0[:, 0][kn & 1 == 1])
             del keep
 
@@ -287,8 +305,7 @@ def test_staged_kernel(wlsqm, oracle, dim, order, Kn, n, neighbours, monkeypatch
     if n >= 64:
         P.assert_parity(got, ref, truth, "staged kernel, %s neighbours" % neighbours)
     else:
-        E = P.column_metric(got, ref); N = P.column_metric(ref, truth)
-        assert np.all(E <= 1e-10 + 25.0 * 8.0 * N), (E, N)
+        _small_batch(("staged", dim, order), got, ref, truth)
     if neighbours == "sorted":
         # the same cases with the SAME neighbour order again but the speculation switched off by an unsorted first case is not
         # expressible per case; instead: the ring / tile kernels' route-independence — run to run
@@ -390,8 +407,7 @@ def test_staged_gather_kernel(wlsqm, oracle, dim, order, Kn, n, pad):
     if n >= 500:                                                 # (the max-over-cases statistics of assert_parity want a sample: 65 cases of 35 unknowns on 50 neighbours are not one)
         P.assert_parity(got, ref, truth, "gathering staged kernel, padding %s" % pad)
     else:
-        E = P.column_metric(got, ref); N = P.column_metric(ref, truth)
-        assert np.all(E <= 1e-10 + 25.0 * 8.0 * N), (E, N)
+        _small_batch(("staged gather", dim, order), got, ref, truth)
 
 
 def test_3d_order4_slices_give_the_same_bits(wlsqm, monkeypatch):
@@ -518,8 +534,7 @@ def test_staged_refinement_kernel(wlsqm, oracle, dim, order, Kn, n, neighbours, 
     if n >= 63:
         P.assert_parity(got, ref, truth, "staged refinement vs oracle")
     else:
-        E = P.column_metric(got, ref); N = P.column_metric(ref, truth)
-        assert np.all(E <= 1e-10 + 25.0 * 8.0 * N), (E, N)
+        _small_batch(("staged refinement", dim, order), got, ref, truth)
     # the kernels these shapes took before
     old, it_old, name_old = run(WLSQM_HIP_STAGE_REFINE="0")
     assert not name_old.startswith("stage-refine"), name_old
@@ -636,3 +651,19 @@ def test_staged_sensitivities_kernel(wlsqm, oracle, dim, order, Kn, n, layout, m
             P.assert_parity(f_only[red][:, :no], f_n[red][:, :no], truth[red], "refinement beside the sensitivities, F known")
     again_f, again_s, _ = run()
     assert np.array_equal(again_f, f_n) and np.array_equal(again_s, s_n, equal_nan=True)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def test_zz_pooled_small_batches_meet_the_usual_bound():
+    """The small batches of this module (fewer than 64 cases each: held to a gross criterion where they ran), pooled per kernel family and
+    shape into ONE sample each, against the usual per-column bound `1e-10 + 8 N`.  (Runs last; a partial run of the module has a partial pool —
+    pools of fewer than 200 cases are skipped, they are no better a sample than their parts.)"""
+    checked = 0
+    for key, parts in sorted(_POOL.items()):
+        got, ref, truth = (np.concatenate([p[i] for p in parts], axis=0) for i in range(3))
+        if len(got) < 200:
+            continue
+        P.assert_parity(got, ref, truth, "pooled small batches %s (%d cases in %d batches)" % (key, len(got), len(parts)))
+        checked += 1
+    if not checked:
+        pytest.skip("no pool of at least 200 cases in this run")
