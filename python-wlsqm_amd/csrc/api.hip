@@ -267,8 +267,60 @@ int scratch_alloc_async(void** out, size_t bytes, hipStream_t stream) {
     if (e != hipSuccess) return hip_fail(e, "hipMallocFromPoolAsync");
     return WLSQM_OK;
 }
+namespace {
+struct StreamCounters { int dev; hipStream_t stream; int* p; size_t ints; bool dirty; int set; };
+std::vector<StreamCounters>& stream_counters_table() { static std::vector<StreamCounters> t; return t; }
+std::mutex& stream_counters_mutex() { static std::mutex m; return m; }
+}  // namespace
+bool is_stream_counters(const void* p) {
+    if (!p) return false;
+    std::lock_guard<std::mutex> lock(stream_counters_mutex());
+    for (const auto& e : stream_counters_table()) if (e.p == p) return true;
+    return false;
+}
+void stream_counters_release_clean(const void* p) {
+    std::lock_guard<std::mutex> lock(stream_counters_mutex());
+    for (auto& e : stream_counters_table()) if (e.p == p) e.dirty = false;
+}
+int stream_counters_acquire(int** out, size_t ints, hipStream_t stream, int* set_out) {
+    *out = nullptr;
+    if (set_out) *set_out = 0;
+    int dev = 0;
+    WLSQM_HIP_CHECK(hipGetDevice(&dev));
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+    const bool capturing = cap != hipStreamCaptureStatusNone;
+    std::lock_guard<std::mutex> lock(stream_counters_mutex());
+    StreamCounters* hit = nullptr;
+    for (auto& e : stream_counters_table()) if (e.dev == dev && e.stream == stream) hit = &e;
+    if (!hit || hit->ints < ints) {
+        if (capturing) return WLSQM_OK;                            // (no allocation inside a capture: the caller's fallback)
+        size_t want = ints < 4096 ? 4096 : ints + ints / 2;
+        int* p = nullptr;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), want * sizeof(int));
+        if (e != hipSuccess) return hip_fail(e, "hipMalloc (stream counters)");
+        if (hit) {
+            (void)hipFreeAsync(hit->p, stream);                     // behind whatever still reads the old one on this stream
+            hit->p = p; hit->ints = want; hit->dirty = true;
+        } else {
+            if (stream_counters_table().size() >= 64) {             // (a process that keeps creating streams: recycle the oldest entry)
+                (void)hipFree(stream_counters_table().front().p);
+                stream_counters_table().erase(stream_counters_table().begin());
+            }
+            stream_counters_table().push_back(StreamCounters{dev, stream, p, want, true, 0});
+            hit = &stream_counters_table().back();
+        }
+    }
+    if (hit->dirty) WLSQM_HIP_CHECK(hipMemsetAsync(hit->p, 0, 4 * sizeof(int), stream));      // both counter sets; the lists behind them are write-before-read
+    hit->dirty = true;                                              // until the user releases it clean
+    hit->set ^= 1;
+    if (set_out) *set_out = hit->set;
+    *out = hit->p;
+    return WLSQM_OK;
+}
 int scratch_free_async(void* p, hipStream_t stream) {
     if (!p) return WLSQM_OK;
+    if (is_stream_counters(p)) return WLSQM_OK;                     // (persistent: see stream_counters_acquire)
     WLSQM_HIP_CHECK(hipFreeAsync(p, stream));
     return WLSQM_OK;
 }

@@ -266,9 +266,14 @@ __device__ __forceinline__ void lu_solve_store(const double (&U)[N * (N + 1) / 2
 #pragma unroll
         for (int i = 0; i < c0; ++i) b[i] -= A[i][c0] * b[c0];
     }
+    // un-scale (impl.pyx:838-846); `fio` == nullptr: the caller stores the wave's rows as one run (b is left holding the results)
 #pragma unroll
-    for (int i = 0; i < N; ++i)
-        if (!((known >> i) & 1u)) fio[i] = b[i] * rs[i];
+    for (int i = 0; i < N; ++i) b[i] = b[i] * rs[i];
+    if (fio) {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            if (!((known >> i) & 1u)) fio[i] = b[i];
+    }
 }
 
 // The same operations for a system that does not fit the lane's registers beside its own LU (2D order 4 with the function value known:
@@ -459,7 +464,7 @@ __device__ __forceinline__ bool entries_in_range_full(GET&& at) {
 //             operand left the safe range of the fast sequences): the two-pass kernel fits the group again, from scratch;
 //   leftover: the group holds a case this kernel does not take (takes_case below): the strict kernels fit those cases (they stay
 //             idle when there are none).
-struct AccLists { int* ws; long long ngroups; };
+struct AccLists { int* ws; long long ngroups; int no_run_store; int set; };      // no_run_store: WLSQM_HIP_ACCURATE_RUN_STORE=0 (A/B); set: the counter set of this call
 
 // One 64-case group.  SPEC (dense rows only): ONE pass over the neighbours for the sums.  The weights need the largest squared distance
 // of the case before the first term can be summed, which is what makes the reference (and the two-pass form of this kernel) read every
@@ -494,11 +499,11 @@ __device__ __forceinline__ void accurate_group(const KParams& p, const long long
     const unsigned known = mine ? ((unsigned)kn & FULL) : 0u;         // RED1: 1
     const bool active = mine && known != FULL;                        // every DOF known: nothing to solve (impl.pyx:740-742)
     if constexpr (SPEC) {
-        if (__any(in_batch && !mine) && lane == 0) lists.ws[2 + lists.ngroups + atomicAdd(lists.ws + 1, 1)] = (int)(t0 >> 6);
+        if (__any(in_batch && !mine) && lane == 0) lists.ws[ACC_LIST_BASE + lists.ngroups + atomicAdd(lists.ws + 2 * lists.set + 1, 1)] = (int)(t0 >> 6);
         // the speculative kernel moves whole 64-case groups in whole chunks only (no predicated loads in its loop): the last,
         // partial group of a launch goes to the two-pass kernel (the launcher sends neighbour counts that are not a multiple of CH there altogether)
         if (ncases - t0 < 64) {
-            if (__any(active) && lane == 0) lists.ws[2 + atomicAdd(lists.ws, 1)] = (int)(t0 >> 6);
+            if (__any(active) && lane == 0) lists.ws[ACC_LIST_BASE + atomicAdd(lists.ws + 2 * lists.set, 1)] = (int)(t0 >> 6);
             return;
         }
     }
@@ -796,7 +801,25 @@ __device__ __forceinline__ void accurate_group(const KParams& p, const long long
     };
     auto solve_store = [&](const double (&rs)[N], const double (&cs)[N]) __attribute__((always_inline)) {
         if constexpr (RED1) { if (active) lu_aug_solve_store<N>(mat, mat_put, rs, cs, b, fio + O0); }
-        else { if (active) lu_solve_store<N>(U, rs, b, known, fio); }
+        else {
+            // A full group of cases without a known DOF and contiguous fi rows: the wave's 64 rows are ONE run of 64 N doubles; they go
+            // through LDS (the staging rows are free: the last pass is over) and leave as whole 16-byte pieces, non-temporal — separate
+            // 8-byte stores at a row pitch are partial-sector writes (fit_stage.hip: -2.5 % on configs[1]).  Wave-uniform choice.
+            // (systems up to 6 unknowns: the 10-unknown kernels are at their 512 registers and paid for it with spills in their sweeps)
+            const bool run = DENSE && N <= 6 && !lists.no_run_store && (64 * N) % 2 == 0 && (N * 64 * 8 <= (int)sizeof(double) * (64 * XPITCH + 64 * FPITCH)) && nvalid == 64 &&
+                             !p.case_index && p.sfi_j == N && ((reinterpret_cast<uintptr_t>(p.fi) & 15u) == 0) && __all(active && known == 0u);
+            if (active) lu_solve_store<N>(U, rs, b, known, run ? nullptr : fio);
+            if (run) {
+                __syncthreads();                                      // the last chunk has been read
+#pragma unroll
+                for (int i = 0; i < N; ++i) lds[lane * N + i] = b[i];
+                __syncthreads();
+                d2_* out = reinterpret_cast<d2_*>(p.fi + t0 * N);
+                const d2_* src = reinterpret_cast<const d2_*>(lds);
+#pragma unroll
+                for (int q = lane; q < 64 * N / 2; q += 64) __builtin_nontemporal_store(src[q], &out[q]);
+            }
+        }
     };
     // the equilibration: true when the fast sequences could vouch for it
     auto equilibrate = [&](auto ops_tag, double (&rs)[N], double (&cs)[N]) __attribute__((always_inline)) -> bool {
@@ -886,7 +909,7 @@ __device__ __forceinline__ void accurate_group(const KParams& p, const long long
         for (int i = 0; i < N; ++i) { rs[i] = 1.; cs[i] = 1.; }
         if (__all(sure)) sure = !active || equilibrate(FastOps{}, rs, cs);
         if (!__all(sure)) {                                           // wave-uniform: the whole group goes to the two-pass kernel
-            if (lane == 0) lists.ws[2 + atomicAdd(lists.ws, 1)] = (int)(t0 >> 6);
+            if (lane == 0) lists.ws[ACC_LIST_BASE + atomicAdd(lists.ws + 2 * lists.set, 1)] = (int)(t0 >> 6);
             return;
         }
         eliminate(rs, weight_of);
@@ -968,17 +991,17 @@ __global__ __launch_bounds__(64, acc::minw(ndofs(DIM, ORDER))) void fit_accurate
 template <int DIM, int ORDER, bool RED1>
 __global__ __launch_bounds__(64, acc::minw(ndofs(DIM, ORDER))) void fit_accurate_redo_kernel(const KParams p, const AccLists lists) {
     __shared__ __attribute__((aligned(16))) double lds[acc_lds_doubles<DIM, ORDER, true, RED1>()];
-    const int n = lists.ws[0];
+    const int n = lists.ws[2 * lists.set];
     for (int g = blockIdx.x; g < n; g += gridDim.x) {
-        accurate_group<DIM, ORDER, true, false, RED1>(p, (long long)lists.ws[2 + g] * 64, lists, lds);
+        accurate_group<DIM, ORDER, true, false, RED1>(p, (long long)lists.ws[strict::ACC_LIST_BASE + g] * 64, lists, lds);
         __syncthreads();                                              // the LDS is reused by the next group
     }
 }
 
-__global__ void acc_lists_zero_kernel(int* ws) { if (threadIdx.x < 2) ws[threadIdx.x] = 0; }
+__global__ void acc_lists_zero_kernel(int* ws) { if (threadIdx.x < strict::ACC_LIST_BASE) ws[threadIdx.x] = 0; }
 
 template <int DIM, int ORDER>
-static int launch_accurate(const KParams& p, hipStream_t stream, int** lists_out) {
+static int launch_accurate(const KParams& p, hipStream_t stream, int** lists_out, int* set_out) {
     constexpr bool RED1 = strict::accurate_red1(DIM, ORDER);
     *lists_out = nullptr;
     const long long groups = (p.ncases + 63) / 64;
@@ -989,7 +1012,8 @@ static int launch_accurate(const KParams& p, hipStream_t stream, int** lists_out
                        p.sfk_k == 1 && p.sfk_j == K && ((reinterpret_cast<uintptr_t>(p.xk) | reinterpret_cast<uintptr_t>(p.fk)) & 15u) == 0 &&
                        !getenv("WLSQM_HIP_ACCURATE_NO_STAGE");
     const char* nospec = getenv("WLSQM_HIP_ACCURATE_NO_SPEC");        // A/B and tests: the two-pass kernel for every group
-    AccLists lists{nullptr, groups};
+    const char* rs_env = getenv("WLSQM_HIP_ACCURATE_RUN_STORE");
+    AccLists lists{nullptr, groups, (rs_env && rs_env[0] == '0') ? 1 : 0, 0};
     // grid: one workgroup per group (default), or with WLSQM_HIP_ACCURATE_PERSIST=1 the resident slots times a small factor
     auto grid_for = [&](const void* kern, unsigned* out) {
         static KernelSetup setup[2];
@@ -1008,10 +1032,16 @@ static int launch_accurate(const KParams& p, hipStream_t stream, int** lists_out
     };
     unsigned grid = 0;
     if (dense && K % acc::chunk_of(ndofs(DIM, ORDER) - (RED1 ? 1 : 0)) == 0 && !(nospec && nospec[0] == '1')) {
-        int rc = scratch_alloc_async(reinterpret_cast<void**>(&lists.ws), (size_t)(2 + 2 * groups) * sizeof(int), stream);
+        // the work lists: the stream's persistent buffer (its counters are left at zero by the consumers of the previous call); inside
+        // a graph capture that has no buffer yet, stream-ordered scratch and a kernel that clears the counters
+        int rc = stream_counters_acquire(&lists.ws, (size_t)(strict::ACC_LIST_BASE + 2 * groups), stream, &lists.set);
         if (rc != WLSQM_OK) return rc;
-        *lists_out = lists.ws;                                        // (freed by the caller behind the strict kernels, which read the leftover list)
-        hipLaunchKernelGGL(acc_lists_zero_kernel, dim3(1), dim3(64), 0, stream, lists.ws);
+        if (!lists.ws) {
+            rc = scratch_alloc_async(reinterpret_cast<void**>(&lists.ws), (size_t)(strict::ACC_LIST_BASE + 2 * groups) * sizeof(int), stream);
+            if (rc != WLSQM_OK) return rc;
+            hipLaunchKernelGGL(acc_lists_zero_kernel, dim3(1), dim3(64), 0, stream, lists.ws);
+        }
+        *lists_out = lists.ws; *set_out = lists.set;                  // (released / freed by the caller behind the strict kernels, which read the leftover list)
         rc = grid_for(reinterpret_cast<const void*>(&fit_accurate_kernel<DIM, ORDER, true, true, RED1>), &grid);
         if (rc != WLSQM_OK) return rc;
         hipLaunchKernelGGL((fit_accurate_kernel<DIM, ORDER, true, true, RED1>), dim3(grid), dim3(64), 0, stream, p, lists, groups);
@@ -1035,11 +1065,11 @@ static int launch_accurate(const KParams& p, hipStream_t stream, int** lists_out
 // case strict::accurate_takes_case names is fitted here (the strict kernels, launched behind this one by launch_fit_strict, leave
 // exactly those cases alone).  *handled = false: the shape has no accurate kernel (1D, 3D orders 3-4) and the strict kernels take
 // every case.
-int launch_fit_accurate(int dimension, int order, const KParams& p, hipStream_t stream, bool* handled, int** lists_out) {
+int launch_fit_accurate(int dimension, int order, const KParams& p, hipStream_t stream, bool* handled, int** lists_out, int* set_out) {
     *handled = false;
-    *lists_out = nullptr;
+    *lists_out = nullptr; *set_out = 0;
     if (p.do_sens || p.iterative) return WLSQM_OK;
-#define CASE(D, O) if (dimension == D && order == O) { *handled = true; return launch_accurate<D, O>(p, stream, lists_out); }
+#define CASE(D, O) if (dimension == D && order == O) { *handled = true; return launch_accurate<D, O>(p, stream, lists_out, set_out); }
     CASE(2, 0) CASE(2, 1) CASE(2, 2) CASE(2, 3) CASE(2, 4)
     CASE(3, 0) CASE(3, 1) CASE(3, 2)
 #undef CASE

@@ -431,13 +431,14 @@ __device__ __forceinline__ void fit_strict_block(const KParams& p, const StrictD
 // ([1] their number, [2 + ngroups ..) the groups); a small grid walks them — none in the common case: a few idle waves.
 template <int DIM, int ORDER>
 __global__ __launch_bounds__(64) void fit_strict_kernel(const KParams p, const StrictDebug dbg, const int skip_plain_groups,
-                                                        const int* __restrict__ lists, const long long ngroups) {
+                                                        int* __restrict__ lists, const long long ngroups, const int lset) {
     extern __shared__ double smem[];
     if (!lists) { fit_strict_block<DIM, ORDER>(p, dbg, skip_plain_groups, blockIdx.x, smem); return; }
     constexpr int PER = 64 / strict::lanes_for(ndofs(DIM, ORDER));   // workgroups of this kernel per 64-case group
-    const long long n = (long long)lists[1] * PER;
+    strict::acc_list_clear_other_set(lists, lset);                    // (the last kernel of the call: the other counter set for the next call)
+    const long long n = (long long)lists[2 * lset + 1] * PER;
     for (long long v = blockIdx.x; v < n; v += gridDim.x) {
-        fit_strict_block<DIM, ORDER>(p, dbg, skip_plain_groups, (long long)lists[2 + ngroups + v / PER] * PER + v % PER, smem);
+        fit_strict_block<DIM, ORDER>(p, dbg, skip_plain_groups, (long long)lists[strict::ACC_LIST_BASE + ngroups + v / PER] * PER + v % PER, smem);
         __syncthreads();
     }
 }
@@ -666,7 +667,7 @@ template <int DIM, int ORDER, bool KN1>
 __global__ __launch_bounds__(64, reg_minw(ndofs(DIM, ORDER))) void fit_strict_reg_kernel(const KParams p, const int* __restrict__ lists, const long long ngroups) {
     if (!lists) { fit_strict_reg_block<DIM, ORDER, KN1>(p, blockIdx.x); return; }
     const long long n = lists[1];                                     // (see fit_strict_kernel)
-    for (long long v = blockIdx.x; v < n; v += gridDim.x) fit_strict_reg_block<DIM, ORDER, KN1>(p, lists[2 + ngroups + v]);
+    for (long long v = blockIdx.x; v < n; v += gridDim.x) fit_strict_reg_block<DIM, ORDER, KN1>(p, lists[strict::ACC_LIST_BASE + ngroups + v]);
 }
 
 constexpr int STRICT_REG_MAX_NO = 10;      // register kernel: systems up to this size (3D order 2 / 2D order 3: one wave per SIMD)
@@ -1039,19 +1040,20 @@ __device__ __forceinline__ void fit_strict_rows_block(const KParams& p, const in
 // accurate kernel did not take); without it (no speculative launch) every workgroup runs and skips the taken cases.
 template <int DIM, int ORDER, int LPC>
 __global__ __launch_bounds__(64, rows_minw(ndofs(DIM, ORDER))) void fit_strict_rows_kernel(const KParams p, const int KP, const int skip_red1,
-                                                                                          const int* __restrict__ lists, const long long ngroups) {
+                                                                                          int* __restrict__ lists, const long long ngroups, const int lset) {
     extern __shared__ double smem[];
     if (!lists) { fit_strict_rows_block<DIM, ORDER, LPC>(p, KP, blockIdx.x, skip_red1 != 0, smem); return; }
     constexpr int PER = LPC;                                          // workgroups (64 / LPC cases each) per 64-case group
-    const long long n = (long long)lists[1] * PER;
+    strict::acc_list_clear_other_set(lists, lset);
+    const long long n = (long long)lists[2 * lset + 1] * PER;
     for (long long v = blockIdx.x; v < n; v += gridDim.x) {
-        fit_strict_rows_block<DIM, ORDER, LPC>(p, KP, (long long)lists[2 + ngroups + v / PER] * PER + v % PER, skip_red1 != 0, smem);
+        fit_strict_rows_block<DIM, ORDER, LPC>(p, KP, (long long)lists[strict::ACC_LIST_BASE + ngroups + v / PER] * PER + v % PER, skip_red1 != 0, smem);
         __syncthreads();
     }
 }
 
 template <int DIM, int ORDER>
-static int launch_strict(const KParams& p, const StrictDebug& dbg, hipStream_t stream, const bool accurate_taken, const int* lists) {
+static int launch_strict(const KParams& p, const StrictDebug& dbg, hipStream_t stream, const bool accurate_taken, int* lists, const int lset) {
     constexpr int NO = ndofs(DIM, ORDER);
     constexpr int LPW = strict::lanes_for(NO);
     constexpr size_t lds = (size_t)strict::slots(NO) * LPW * sizeof(double);
@@ -1087,7 +1089,7 @@ static int launch_strict(const KParams& p, const StrictDebug& dbg, hipStream_t s
             // (accurate mode, 2D order 4: the cases with exactly F known are fit_accurate_kernel's; a small grid walks the leftover list)
             const bool skip = accurate_taken && strict::accurate_red1(DIM, ORDER);
             hipLaunchKernelGGL((fit_strict_rows_kernel<DIM, ORDER, LPC>), dim3((unsigned)(skip && lists && wgs > 512 ? 512 : wgs)), dim3(64), rl, stream, p,
-                               KP, skip ? 1 : 0, skip ? lists : (const int*)nullptr, (p.ncases + 63) / 64);
+                               KP, skip ? 1 : 0, skip ? lists : (int*)nullptr, (p.ncases + 63) / 64, lset);
             WLSQM_HIP_CHECK(hipGetLastError());
             note_kernel(skip ? (accurate_mode() ? "accurate" : "strict-lane") : "strict-rows");
             return WLSQM_OK;
@@ -1113,18 +1115,18 @@ static int launch_strict(const KParams& p, const StrictDebug& dbg, hipStream_t s
         }
     }
     hipLaunchKernelGGL((fit_strict_kernel<DIM, ORDER>), dim3((unsigned)(lists && blocks > 128 ? 128 : blocks)), dim3(64), lds, stream, p, dbg,
-                       accurate_taken ? 2 : (split ? 1 : 0), lists, (p.ncases + 63) / 64);
+                       accurate_taken ? 2 : (split ? 1 : 0), lists, (p.ncases + 63) / 64, lset);
     WLSQM_HIP_CHECK(hipGetLastError());
     note_kernel(accurate_taken ? "accurate" : "strict");
     return WLSQM_OK;
 }
 
-int launch_fit_accurate(int dimension, int order, const KParams& p, hipStream_t stream, bool* handled, int** lists_out);      // fit_accurate.hip
+int launch_fit_accurate(int dimension, int order, const KParams& p, hipStream_t stream, bool* handled, int** lists_out, int* set_out);      // fit_accurate.hip
 
 int launch_fit_strict(int dimension, int order, const KParams& p, const StrictDebug* dbg_in, hipStream_t stream) {
     const StrictDebug dbg = dbg_in ? *dbg_in : StrictDebug{};
     bool accurate_taken = false;
-    int* lists = nullptr;                             // work lists of the speculative accurate kernel ([1] = leftover groups), or null
+    int* lists = nullptr; int lset = 0;               // work lists of the speculative accurate kernel and the counter set of this call, or null
     // accurate mode: fit_accurate.hip takes the cases strict::accurate_takes_case names.  Its 2D order-4 form (exactly the function value
     // known: the 14 x 14 system of the reference's default mask; the strict arithmetic itself with one lane per case, bit-identical to
     // the row-per-lane kernel) is OFF by default in both modes: it needs 196 matrix entries beside the equilibration's 84 scale factors
@@ -1134,11 +1136,15 @@ int launch_fit_strict(int dimension, int order, const KParams& p, const StrictDe
     const char* l14 = getenv("WLSQM_HIP_LANE14");
     const bool lane14 = strict::accurate_red1(dimension, order) && l14 && l14[0] == '1';
     if (((accurate_mode() && !strict::accurate_red1(dimension, order)) || lane14) && !dbg_in) {
-        const int rc = launch_fit_accurate(dimension, order, p, stream, &accurate_taken, &lists);
+        const int rc = launch_fit_accurate(dimension, order, p, stream, &accurate_taken, &lists, &lset);
         if (rc != WLSQM_OK) { (void)scratch_free_async(lists, stream); return rc; }
     }
-    auto done = [&](int rc) { const int rf = scratch_free_async(lists, stream); return rc != WLSQM_OK ? rc : rf; };
-#define CASE(D, O) if (dimension == D && order == O) return done(launch_strict<D, O>(p, dbg, stream, accurate_taken, lists));
+    // (the stream's persistent buffer goes back clean once every consumer has been launched; a failed launch leaves it to be cleared)
+    auto done = [&](int rc) {
+        if (is_stream_counters(lists)) { if (rc == WLSQM_OK) stream_counters_release_clean(lists); return rc; }
+        const int rf = scratch_free_async(lists, stream); return rc != WLSQM_OK ? rc : rf;
+    };
+#define CASE(D, O) if (dimension == D && order == O) return done(launch_strict<D, O>(p, dbg, stream, accurate_taken, lists, lset));
     CASE(1, 0) CASE(1, 1) CASE(1, 2) CASE(1, 3) CASE(1, 4)
     CASE(2, 0) CASE(2, 1) CASE(2, 2) CASE(2, 3) CASE(2, 4)
     CASE(3, 0) CASE(3, 1) CASE(3, 2) CASE(3, 3) CASE(3, 4)
