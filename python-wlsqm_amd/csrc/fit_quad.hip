@@ -119,14 +119,17 @@ __global__ __launch_bounds__(64, 1) void quad_solve_kernel(const KParams p) {
         R[off(s) + seg(s) - 1] = mc[g_tab.nuidx[i]] * fa[s];
     }
     if (any_known) {
-#pragma unroll
+        // (rolled, table look-ups at run time: unrolled over the 35 DOFs this rare path cost the whole kernel 243 spilled registers and
+        // 976 B of scratch — without it the kernel needs 442 registers and no scratch; round 5)
+#pragma nounroll
         for (int om = 0; om < NO; ++om) {
             const double v = ((vals >> om) & 1ull) ? fio[om] : 0.0;
+            const double fom = g_tab.fact[om];
 #pragma unroll
             for (int s = 0; s < SLOTS; ++s) {
                 const int i = 4 * s + l;
                 const double vi = (i == om) ? 0.0 : v;
-                R[off(s) + seg(s) - 1] = fma(-(mc[s_idx[i * NP + om]] * (fa[s] * fact_of(om))), vi, R[off(s) + seg(s) - 1]);
+                R[off(s) + seg(s) - 1] = fma(-(mc[s_idx[i * NP + om]] * (fa[s] * fom)), vi, R[off(s) + seg(s) - 1]);
             }
         }
 #pragma unroll
