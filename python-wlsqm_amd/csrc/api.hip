@@ -289,7 +289,10 @@ int stream_counters_acquire(int** out, size_t ints, hipStream_t stream, int* set
     WLSQM_HIP_CHECK(hipGetDevice(&dev));
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
-    const bool capturing = cap != hipStreamCaptureStatusNone;
+    // Inside a graph capture the caller's fallback (stream-ordered scratch + a clearing kernel) is used ALWAYS: the counter set is a
+    // launch parameter, a replayed graph would use the same set every time and find it as the previous replay left it.
+    if (cap != hipStreamCaptureStatusNone) return WLSQM_OK;
+    const bool capturing = false;
     std::lock_guard<std::mutex> lock(stream_counters_mutex());
     StreamCounters* hit = nullptr;
     for (auto& e : stream_counters_table()) if (e.dev == dev && e.stream == stream) hit = &e;

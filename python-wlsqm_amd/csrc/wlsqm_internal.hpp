@@ -195,8 +195,8 @@ int scratch_free_async(void* p, hipStream_t stream);
 // A small device buffer of ints that PERSISTS per (device, stream) — counters and short work lists a call's kernels hand to each
 // other.  Zeroed when it is first handed out and whenever its previous user did not release it clean; a user whose kernels put
 // the counters back to zero themselves (wlsqm_strict.hpp: acc_list_clear_other_set) releases it clean and the next call on the stream pays
-// nothing.  *out = nullptr (WLSQM_OK) when the stream is being captured into a graph and the buffer does not exist yet or is too
-// small (hipMalloc is not legal there): the caller falls back to scratch_alloc_async.  scratch_free_async ignores these buffers.
+// nothing.  *out = nullptr (WLSQM_OK) when the stream is being captured into a graph (a replay would reuse one counter set every time):
+// the caller falls back to scratch_alloc_async and a clearing kernel.  scratch_free_async ignores these buffers.
 int stream_counters_acquire(int** out, size_t ints, hipStream_t stream, int* set_out = nullptr);      // *set_out: 0 / 1, alternating per call on the stream
 void stream_counters_release_clean(const void* p);
 bool is_stream_counters(const void* p);

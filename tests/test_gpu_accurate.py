@@ -256,3 +256,52 @@ def test_accurate_mode_through_the_reference_signatures_and_expertsolver(wlsqm, 
         es.solve(fk=b["fk"], fi=fi)
         es.close()
         assert np.array_equal(_bits(fi), _bits(want))
+
+
+def test_accurate_mode_work_lists_across_streams_graphs_and_repeated_calls(wlsqm, oracle):
+    """Round 5: the accurate mode's work lists live in a buffer that persists per stream, with two counter sets used alternately (the last
+    kernel of a call clears the set of the next one).  Many calls in a row on one stream, calls alternating between two streams, batches
+    that DO fill both lists (unsorted neighbours: every group is redone; stray mask bits: leftover groups) and a call captured into a
+    HIP graph and replayed must all return the bits of a fresh call."""
+    import torch
+    import wlsqm.hip as whip
+    rng = np.random.default_rng(21)
+    b = _hetero(2, 2, 32, 1000, 5, wlsqm)
+    b["nk"][:] = 32
+    for j in range(0, 1000, 3):                                   # a third of the cases with shuffled neighbours: their groups are redone
+        perm = rng.permutation(32)
+        b["xk"][j] = b["xk"][j][perm]; b["fk"][j] = b["fk"][j][perm]
+    want = _expected(oracle, 2, 2, b["xk"], b["fk"], b["nk"], b["xi"], b["fi0"], b["kn"], b["wm"])
+    args = [_t(b[k]) for k in ("xk", "fk", "nk", "xi")]
+    kn, wm = _t(b["kn"]), _t(b["wm"])
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    with whip.accurate():
+        outs = []
+        for rep in range(7):                                       # one stream, back to back; then alternating streams
+            for st in ((None,) if rep < 3 else (s1, s2)):
+                fi = _t(b["fi0"])
+                if st is None:
+                    whip.fit_many_device(2, 2, *args, fi, kn, wm)
+                else:
+                    st.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(st):
+                        whip.fit_many_device(2, 2, *args, fi, kn, wm)
+                outs.append(fi)
+        torch.cuda.synchronize()
+        for fi in outs:
+            assert np.array_equal(_bits(fi.cpu().numpy()), _bits(want))
+        # captured and replayed
+        fi = _t(b["fi0"])
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s1):
+            whip.fit_many_device(2, 2, *args, fi, kn, wm)
+        for rep in range(3):
+            fi.copy_(_t(b["fi0"]))
+            g.replay()
+            torch.cuda.synchronize()
+            assert np.array_equal(_bits(fi.cpu().numpy()), _bits(want)), "replay %d" % rep
+        fi2 = _t(b["fi0"])                                          # and an eager call on the captured stream afterwards
+        with torch.cuda.stream(s1):
+            whip.fit_many_device(2, 2, *args, fi2, kn, wm)
+        torch.cuda.synchronize()
+        assert np.array_equal(_bits(fi2.cpu().numpy()), _bits(want))
