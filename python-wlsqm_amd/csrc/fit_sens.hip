@@ -39,6 +39,7 @@ int launch_fit_wave_inverse(int dimension, int order, const KParams& p, double* 
 int launch_fit_rows_inverse(int dimension, int order, const KParams& p, double* inv, hipStream_t stream);
 bool moment_inverse_ok(int dimension, int order, const KParams& p, long long max_nk);
 int launch_fit_moment_inverse(int dimension, int order, const KParams& p, long long max_nk, double* inv, hipStream_t stream);
+int launch_fit_stage_inverse(int dimension, int order, const KParams& p, long long K, double* inv, hipStream_t stream, bool* handled);      // fit_stage.hip
 
 typedef double sd4_ __attribute__((ext_vector_type(4)));
 
@@ -394,7 +395,7 @@ static int apply_dispatch(int dimension, int order, const KParams& p, const doub
 
 // Dense input (any strides for the 3D order-3/4 systems; contiguous even-K rows for the others — api.hip repacks), sensitivities
 // without refinement.  WLSQM_HIP_DISABLE_SENS_APPLY=1 leaves these shapes to the generic kernels (A/B);
-// WLSQM_HIP_SENS_SLICE_MB sets the size of a slice's inverses (default 256).
+// WLSQM_HIP_SENS_SLICE_MB sets the size of a slice's inverses (default 1024).
 int launch_fit_sens(int dimension, int order, const KParams& p, long long K, hipStream_t stream, bool* handled) {
     *handled = false;
     const char* off = getenv("WLSQM_HIP_DISABLE_SENS_APPLY");
@@ -418,7 +419,9 @@ int launch_fit_sens(int dimension, int order, const KParams& p, long long K, hip
     const char* wf = getenv("WLSQM_HIP_SENS_WAVE");                       // A/B: the LDS form of fit_wave.hip for the 3D order-3/4 inverses
     const bool wave_form = wf && wf[0] == '1';
     const char* mb = getenv("WLSQM_HIP_SENS_SLICE_MB");
-    const double slice_mb = (mb && atof(mb) > 0.0) ? atof(mb) : 256.0;
+    // (round 5: 1 GB instead of 256 MB — 400k configs[2] cases in one slice instead of three: 1.335 -> 1.264 ms; the launches and the
+    // workspace of every slice cost more than the Infinity Cache residency of a small slice's inverses gains)
+    const double slice_mb = (mb && atof(mb) > 0.0) ? atof(mb) : 1024.0;
     long long per = (long long)(slice_mb * 1048576.0 / (8.0 * no * no));
     per = per < 1024 ? 1024 : per;
     per = (per / 64) * 64;                                                 // whole tiles and whole groups of 64 cases
@@ -431,7 +434,11 @@ int launch_fit_sens(int dimension, int order, const KParams& p, long long K, hip
         KParams q = slice_cases(p, j0, n);
         q.max_nk = K;
         if (big) rc = wave_form ? launch_fit_wave_inverse(dimension, order, q, inv, stream) : launch_fit_rows_inverse(dimension, order, q, inv, stream);
-        else if (mom) rc = launch_fit_moment_inverse(dimension, order, q, K, inv, stream);
+        else if (mom) {
+            bool staged = false;                                      // (round 5: the staged one-lane-per-case fit writes the inverse itself where the input is its kind)
+            rc = launch_fit_stage_inverse(dimension, order, q, K, inv, stream, &staged);
+            if (rc == WLSQM_OK && !staged) rc = launch_fit_moment_inverse(dimension, order, q, K, inv, stream);
+        }
         else {
             KParams a = q;
             a.ws = inv; a.do_sens = 0; a.sens = nullptr; a.iterative = 0;

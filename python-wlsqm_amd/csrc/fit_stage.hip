@@ -67,6 +67,8 @@ constexpr int CH = 8;               // neighbours per staged chunk
 #ifndef WLSQM_STAGE_GRP15
 #define WLSQM_STAGE_GRP15 8         // neighbours the scheduler may interleave in their moment pass
 #endif
+// PART = 4 (round 5, 2D order 4): the whole fit, and the INVERSE of every case's knowns-eliminated normal matrix at p.ws for the
+// sensitivities (fit_sens.hip) — layout and meaning of moment_solve_kernel<.., INV> (fit_moment.hip): inv[group of 64][column][case][row].
 // PART = 0: the whole fit.  PART = 1 / 2 (3D order 4, 35 unknowns): the kernel stops after the moment pass and leaves HALF of the case's
 // 165 + 35 moments (wlsqm_moments.hpp: stage_part) at p.ws — entry e of case t at ws[((t / 64) 200 + e) 64 + t % 64] — for the
 // four-lanes-per-case solve of csrc/fit_quad.hip; all 200 accumulators at once are 400 registers, more than an instruction can name.
@@ -303,6 +305,7 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER)
 #define WLSQM_STAGE_TRIPLE 0
 #endif
     constexpr bool TRIPLE = WLSQM_STAGE_TRIPLE && DIM == 2 && ORDER <= 2 && PART == 0;
+    constexpr bool INVERSE = PART == 4;                               // (the moment pass of PART 4 is PART 0's)
     double mu[NM], nu[NO];
     double mu3[TRIPLE ? 3 : 1][TRIPLE ? NM : 1], nu3[TRIPLE ? 3 : 1][TRIPLE ? NO : 1];
     double max_d2 = 0.0;
@@ -363,7 +366,7 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER)
 #ifndef WLSQM_STAGE_OUTER3D_FROM
 #define WLSQM_STAGE_OUTER3D_FROM 3
 #endif
-                        if constexpr (DIM == 3 && ORDER >= WLSQM_STAGE_OUTER3D_FROM && WLSQM_STAGE_OUTER3D) accumulate_moments_outer3d<ORDER, PART>(mu, nu, d, w, f);
+                        if constexpr (DIM == 3 && ORDER >= WLSQM_STAGE_OUTER3D_FROM && WLSQM_STAGE_OUTER3D) accumulate_moments_outer3d<ORDER, (PART == 1 || PART == 2) ? PART : 0>(mu, nu, d, w, f);
                         else accumulate_moments_best<DIM, ORDER>(mu, nu, d, w, f);
                     }
                 }
@@ -493,7 +496,7 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER)
         moments(max_d2, false);
     }
 
-    if constexpr (PART != 0) {
+    if constexpr (PART == 1 || PART == 2) {
         // ---- this half of the moments to the workspace: 512 contiguous bytes per entry (tail lanes store their replayed case too: the
         // solve reads whole 16-case runs)
         double* const out = p.ws + (long long)blockIdx.x * (200 * 64) + lane;
@@ -522,6 +525,7 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER)
     // 330 registers to 512 + 704 B of scratch with the second form compiled in)
     constexpr bool REDUCED = NO == 15;
     const bool mine1 = REDUCED && known == 1ull && dropped == 0ull;
+    double Mf[INVERSE ? NE : 1];                                      // PART 4: the factor the solve leaves (the reduced form's 105 entries first)
     if constexpr (REDUCED) {
         if (mine1) {
             constexpr int N1 = NO - 1, NE1 = N1 * (N1 + 1) / 2;
@@ -550,6 +554,10 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER)
             }
             ldlt_factor<N1>(M1);
             ldlt_solve<N1>(M1, r1);
+            if constexpr (INVERSE) {
+#pragma unroll
+                for (int e = 0; e < NE1; ++e) Mf[e] = M1[e];
+            }
             rhs[0] = v0;                                              // (for the whole-row store below: its own bits)
 #pragma unroll
             for (int a = 1; a < NO; ++a) rhs[a] = r1[a - 1];
@@ -694,6 +702,10 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER)
         ldlt_solve<NO>(M, sol);
 #pragma unroll
         for (int a = 0; a < NO; ++a) if (!((known >> a) & 1ull)) rhs[a] = sol[a];
+        if constexpr (INVERSE) {
+#pragma unroll
+            for (int e = 0; e < NE; ++e) Mf[e] = M[e];
+        }
     }
     // ---- results.  A full group with contiguous fi rows and no dropped DOF: the wave's 64 rows are ONE run of 64 NO doubles; they go
     // through LDS and leave as whole 16-byte pieces, known DOFs re-written with their own bits (what the reference's Case_get_fi
@@ -714,6 +726,41 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER)
         for (int a = 0; a < NO; ++a)
             if (!((known >> a) & 1ull)) fio[a] = rhs[a];
     }
+    if constexpr (INVERSE) {
+        // ---- the inverse, column by column: a unit vector through the factor that is in registers anyway (NO substitutions instead of
+        // one per neighbour); a column of the wave's 64 cases is one contiguous run of 64 NO doubles, through LDS.  Rows and columns of
+        // known DOFs are zero.  Tail lanes replay the last case into their own slot of the scratch block (sized in whole groups).
+        static_assert(R0 == 0, "the inverse is emitted from a factor in registers");
+        double* const blk = p.ws + (long long)blockIdx.x * (64 * NO * NO);
+#pragma unroll 1
+        for (int col = 0; col < NO; ++col) {
+            double o[NO];
+            if (REDUCED && mine1) {
+                constexpr int N1 = NO - 1, NE1 = N1 * (N1 + 1) / 2;
+                double M1[NE1], sv[N1];
+#pragma unroll
+                for (int e = 0; e < NE1; ++e) M1[e] = Mf[e];
+#pragma unroll
+                for (int a = 0; a < N1; ++a) sv[a] = (a + 1 == col) ? 1.0 : 0.0;      // column 0 (the known DOF): zeros
+                ldlt_solve<N1>(M1, sv);
+                o[0] = 0.0;
+#pragma unroll
+                for (int a = 0; a < N1; ++a) o[a + 1] = sv[a];
+            } else {
+                const bool kcol = (known >> col) & 1ull;              // known: zero row and column (the rows are identity rows)
+#pragma unroll
+                for (int a = 0; a < NO; ++a) o[a] = (a == col && !kcol) ? 1.0 : 0.0;
+                ldlt_solve<NO>(Mf, o);
+            }
+            __syncthreads();                                          // the previous column / the result rows have left the LDS
+#pragma unroll
+            for (int a = 0; a < NO; ++a) lds[lane * NO + a] = o[a];
+            __syncthreads();
+            double* const dst = blk + col * (64 * NO);
+#pragma unroll
+            for (int i = 0; i < NO; ++i) dst[lane + 64 * i] = lds[lane + 64 * i];
+        }
+    }
     }   // PART == 0
 }
 
@@ -729,6 +776,26 @@ static int launch_stage(const KParams& p, hipStream_t stream) {
 }
 
 int launch_quad_solve(const KParams& p, hipStream_t stream);          // fit_quad.hip
+
+// The basic fit of a dense contiguous 2D order-4 batch that ALSO leaves every case's inverse normal matrix at inv[group][column][case][row]
+// (first kernel of the sensitivities' path, fit_sens.hip; round 5: instead of the four-lanes-per-case tile kernel + moment_solve_kernel pair).
+// *handled = false: the input is not the staged kernel's (strides, alignment, odd K): the caller keeps the pair.
+int launch_fit_stage_inverse(int dimension, int order, const KParams& p, long long K, double* inv, hipStream_t stream, bool* handled) {
+    *handled = false;
+    const char* e = getenv("WLSQM_HIP_STAGE_INVERSE");
+    if ((e && e[0] == '0') || dimension != 2 || order != 4) return WLSQM_OK;
+    if (p.hoods || p.case_index || !p.xk || !p.fk || K < 8 || K % 2 != 0 || K > 65536) return WLSQM_OK;
+    if (p.sxk_k != dimension || p.sxk_j != K * dimension || p.sfk_k != 1 || p.sfk_j != K) return WLSQM_OK;
+    if ((reinterpret_cast<uintptr_t>(p.xk) | reinterpret_cast<uintptr_t>(p.fk)) & 15u) return WLSQM_OK;
+    const long long groups = (p.ncases + 63) / 64;
+    if (groups <= 0 || groups > 0x7fffffffLL) return WLSQM_OK;
+    KParams q = p;
+    q.ws = inv; q.do_sens = 0; q.sens = nullptr; q.iterative = 0;
+    hipLaunchKernelGGL((fit_stage_kernel<2, 4, 4, false>), dim3((unsigned)groups), dim3(64), 0, stream, q);
+    WLSQM_HIP_CHECK(hipGetLastError());
+    *handled = true;
+    return WLSQM_OK;
+}
 
 // 3D order 4: two moment launches (half of the 200 sums each) and the four-lanes-per-case solve, in slices that bound the workspace
 // (1 600 bytes per case, stream-ordered) at 1.7 GB.
