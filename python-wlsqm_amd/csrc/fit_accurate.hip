@@ -1001,7 +1001,7 @@ __global__ __launch_bounds__(64, acc::minw(ndofs(DIM, ORDER))) void fit_accurate
 __global__ void acc_lists_zero_kernel(int* ws) { if (threadIdx.x < strict::ACC_LIST_BASE) ws[threadIdx.x] = 0; }
 
 template <int DIM, int ORDER>
-static int launch_accurate(const KParams& p, hipStream_t stream, int** lists_out, int* set_out) {
+static int launch_accurate(const KParams& p, hipStream_t stream, int** lists_out, int* set_out, bool* handled) {
     constexpr bool RED1 = strict::accurate_red1(DIM, ORDER);
     *lists_out = nullptr;
     const long long groups = (p.ncases + 63) / 64;
@@ -1031,6 +1031,11 @@ static int launch_accurate(const KParams& p, hipStream_t stream, int** lists_out
         return (int)WLSQM_OK;
     };
     unsigned grid = 0;
+    if constexpr (RED1) {
+        // (the 14 x 14 form — off by default, WLSQM_HIP_LANE14 — exists for dense rows in whole 4-neighbour chunks only: its four kernels for
+        // the other layouts were a quarter of this file's compile time; those batches keep the row-per-lane strict kernel)
+        if (!(dense && K % acc::chunk_of(ndofs(DIM, ORDER) - 1) == 0 && !(nospec && nospec[0] == '1'))) { *handled = false; return WLSQM_OK; }
+    }
     if (dense && K % acc::chunk_of(ndofs(DIM, ORDER) - (RED1 ? 1 : 0)) == 0 && !(nospec && nospec[0] == '1')) {
         // the work lists: the stream's persistent buffer (its counters are left at zero by the consumers of the previous call); inside
         // a graph capture that has no buffer yet, stream-ordered scratch and a kernel that clears the counters
@@ -1050,12 +1055,14 @@ static int launch_accurate(const KParams& p, hipStream_t stream, int** lists_out
         const long long resident = 1024LL * acc::minw(ndofs(DIM, ORDER));
         const unsigned redo_grid = (unsigned)(groups < resident ? groups : resident);
         hipLaunchKernelGGL((fit_accurate_redo_kernel<DIM, ORDER, RED1>), dim3(redo_grid), dim3(64), 0, stream, p, lists);
-    } else if (dense) {
-        const int rc = grid_for(reinterpret_cast<const void*>(&fit_accurate_kernel<DIM, ORDER, true, false, RED1>), &grid);
-        if (rc != WLSQM_OK) return rc;
-        hipLaunchKernelGGL((fit_accurate_kernel<DIM, ORDER, true, false, RED1>), dim3(grid), dim3(64), 0, stream, p, lists, groups);
-    } else {
-        hipLaunchKernelGGL((fit_accurate_kernel<DIM, ORDER, false, false, RED1>), dim3((unsigned)groups), dim3(64), 0, stream, p, lists, groups);
+    } else if constexpr (!RED1) {
+        if (dense) {
+            const int rc = grid_for(reinterpret_cast<const void*>(&fit_accurate_kernel<DIM, ORDER, true, false, false>), &grid);
+            if (rc != WLSQM_OK) return rc;
+            hipLaunchKernelGGL((fit_accurate_kernel<DIM, ORDER, true, false, false>), dim3(grid), dim3(64), 0, stream, p, lists, groups);
+        } else {
+            hipLaunchKernelGGL((fit_accurate_kernel<DIM, ORDER, false, false, false>), dim3((unsigned)groups), dim3(64), 0, stream, p, lists, groups);
+        }
     }
     WLSQM_HIP_CHECK(hipGetLastError());
     return WLSQM_OK;
@@ -1069,7 +1076,7 @@ int launch_fit_accurate(int dimension, int order, const KParams& p, hipStream_t 
     *handled = false;
     *lists_out = nullptr; *set_out = 0;
     if (p.do_sens || p.iterative) return WLSQM_OK;
-#define CASE(D, O) if (dimension == D && order == O) { *handled = true; return launch_accurate<D, O>(p, stream, lists_out, set_out); }
+#define CASE(D, O) if (dimension == D && order == O) { *handled = true; return launch_accurate<D, O>(p, stream, lists_out, set_out, handled); }
     CASE(2, 0) CASE(2, 1) CASE(2, 2) CASE(2, 3) CASE(2, 4)
     CASE(3, 0) CASE(3, 1) CASE(3, 2)
 #undef CASE

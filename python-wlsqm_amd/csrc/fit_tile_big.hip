@@ -1,4 +1,5 @@
-// fit_tile_big.hip — 64 < K <= 128, dense and index-based
+// fit_tile_big.hip — 64 < K <= 128, dense (order 1: the shapes of order 2-3 run the staged kernel since round 4; their dense
+// instantiations here were retired in round 5) and index-based
 // One of the per-family dispatch tables of the fixed-K tile kernels (wlsqm_tile.hpp; see fit_tile.hip).
 #include "wlsqm_tile.hpp"
 
@@ -29,11 +30,8 @@ int launch_fit_tile_big(int dimension, int order, const KParams& p, long long ma
 #define BIG_2D3(KK) BIG_CASE(2, 3, KK, 2)
 #define BIG_ONE(F, KK) F(KK)
     if (!gather) {
-        if (dimension == 2 && order == 2) { BIG_K(BIG_ONE, BIG_2D2) }
-        if (dimension == 3 && order == 2) { BIG_K(BIG_ONE, BIG_3D2) }
         if (dimension == 2 && order == 1) { BIG_K(BIG_ONE, BIG_2D1) }
         if (dimension == 3 && order == 1) { BIG_K(BIG_ONE, BIG_3D1) }
-        if (dimension == 2 && order == 3) { BIG_K(BIG_ONE, BIG_2D3) }
     }
     // index-based input at these sizes (order 2): the same shape without direct fk, shares padded to a multiple of 8 slots;
     // 400k cases, 2D K = 80 / 128: 0.250 / 0.275 ms against 1.45 / 2.53 on the generic kernel, 3D K = 80 / 124: 0.355 / 0.699

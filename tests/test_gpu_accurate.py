@@ -150,7 +150,8 @@ def test_accurate_mode_heterogeneous_batches(wlsqm, oracle, dim, order, Kn, n, m
     with whip.accurate():
         whip.fit_many_device(dim, order, _t(b["xk"]), _t(b["fk"]), _t(b["nk"]), _t(b["xi"]), fi, _t(b["kn"]), _t(b["wm"]))
         torch.cuda.synchronize()
-        assert whip.last_kernel() == "accurate", whip.last_kernel()
+        # (the 14 x 14 one-lane form takes dense rows in whole 4-neighbour chunks; other layouts of 2D order 4 keep the row-per-lane kernel)
+        assert whip.last_kernel() == ("strict-rows" if (dim, order) == (2, 4) and Kn % 4 else "accurate"), whip.last_kernel()
     got = fi.cpu().numpy()
     want = _expected(oracle, dim, order, b["xk"], b["fk"], b["nk"], b["xi"], b["fi0"], b["kn"], b["wm"])
     bad = np.nonzero((_bits(got) != _bits(want)).any(axis=1))[0]
