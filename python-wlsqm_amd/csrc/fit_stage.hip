@@ -108,38 +108,7 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER)
     const bool valid = lane < nvalid;
     const long long j = valid ? t : t0 + nvalid - 1;                          // tail lanes replay the last case (never stored)
     const int K = (int)p.max_nk;
-    const int nkc = min(p.nk[j * p.snk], K);
-    const bool uniform = (p.wm[j * p.swm] == WLSQM_WEIGHT_UNIFORM);
-    unsigned long long known, dropped;
-    effective_mask<NO>(p.knowns[j * p.sknowns], known, dropped);
-    double xi[DIM];
-    const long long pj = GATHER ? (own_point(p, j)) : 0;      // the case's own point (also the stand-in for padding slots)
-    const int* const hrow = GATHER ? p.hoods + j * p.shoods_j : nullptr;
-#pragma unroll
-    for (int m = 0; m < DIM; ++m) xi[m] = GATHER ? p.S[pj * DIM + m] : p.xi[j * p.sxi_j + m];
-
-    auto sqdist = [&](const double (&d)[DIM]) {       // one rounding sequence for the guess and for the pass: they are compared for equality
-        double d2 = d[0] * d[0];
-#pragma unroll
-        for (int m = 1; m < DIM; ++m) d2 = fma(d[m], d[m], d2);
-        return d2;
-    };
-    // the guess: the last neighbour is the farthest (see the header).  The chunks are processed LAST CHUNK FIRST (neighbours in
-    // descending k: a fixed order per case, so results do not depend on the route), so that the guess comes out of the first staged
-    // chunk: a separate load of the last neighbour at the start fetched a whole line per case that the staging fetched AGAIN four
-    // to eight chunks later (954 instead of 800 MB read per 1M configs[1] cases, 1 530 instead of 1 321 MB on configs[4]:
-    // profiles/r04m_*_pmc_summary.json).  Only a ragged case whose last neighbour lies in an earlier chunk loads it directly.
     const int Q = (K + CH - 1) / CH;                                  // (a last partial chunk: its pieces beyond the row replay the row's last one; masked)
-    double guess = 0.0;
-    const bool guess_staged = nkc > (Q - 1) * CH;                     // the last neighbour sits in the chunk that is staged first
-    if (nkc > 0 && !guess_staged) {
-        const double* q = GATHER ? p.S + (long long)hrow[nkc - 1] * DIM : p.xk + j * (long long)K * DIM + (long long)(nkc - 1) * DIM;
-        double dg[DIM];
-#pragma unroll
-        for (int m = 0; m < DIM; ++m) dg[m] = q[m] - xi[m];
-        guess = sqdist(dg);
-    }
-
     // ---- staging: a load instruction moves the chunks of XCPI (FCPI) whole cases, XPC (FPC) consecutive lanes per case
     const int xsub = lane % XPC, xc0 = lane / XPC, fsub = lane % FPC, fc0 = lane / FPC;
     const unsigned xrowb = (unsigned)K * DIM * 8, frowb = (unsigned)K * 8;
@@ -185,6 +154,67 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER)
             }
         }
     };
+    // EARLY FETCH (round 5): the first staged chunk is requested BEFORE the case's scalars are — its addresses depend on the launch
+    // parameters alone.  In source order the scalars (nk, weighting, knowns: one round trip), then the centre and a ragged case's last
+    // neighbour (a second), then the chunk (a third) were three memory latencies in a row at the head of every 64-case group, ~3.5 us of a
+    // lone wave's 18-26 us per group (ISA: s_waitcnt vmcnt(1) / vmcnt(0) in front of the chunk's first load); now they overlap.
+    // Measured (tools/ab_unit.sh, one box, profiles/r05f_ab_early_fetch.txt): configs[2] 0.392 -> 0.3876 ms (+1.2 %); configs[1] and configs[4]
+    // within +-0.5 % either way (on for the 15-unknown systems and up: 2).  The head of a group is not where a lone wave loses its time.
+#ifndef WLSQM_STAGE_EARLY_FETCH
+#define WLSQM_STAGE_EARLY_FETCH 2
+#endif
+    constexpr bool EARLY = (WLSQM_STAGE_EARLY_FETCH != 0) && !GATHER && (WLSQM_STAGE_EARLY_FETCH == 1 || NO > 10);      // (2: the 15-unknown systems and up only)
+    if constexpr (EARLY) fetch_into(xr, fr, Q - 1);
+#ifndef WLSQM_STAGE_SCALARS_FIRST
+#define WLSQM_STAGE_SCALARS_FIRST 1
+#endif
+#if WLSQM_STAGE_SCALARS_FIRST
+    // (every scalar of the case is requested before the first of them is looked at: the mask arithmetic below waits for its own)
+    double xi[DIM];
+    const long long pj = GATHER ? (own_point(p, j)) : 0;      // the case's own point (also the stand-in for padding slots)
+    const int* const hrow = GATHER ? p.hoods + j * p.shoods_j : nullptr;
+#pragma unroll
+    for (int m = 0; m < DIM; ++m) xi[m] = GATHER ? p.S[pj * DIM + m] : p.xi[j * p.sxi_j + m];
+    const int nk_raw = p.nk[j * p.snk];
+    const int wm_raw = p.wm[j * p.swm];
+    const long long kn_raw = p.knowns[j * p.sknowns];
+    const int nkc = min(nk_raw, K);
+    const bool uniform = (wm_raw == WLSQM_WEIGHT_UNIFORM);
+    unsigned long long known, dropped;
+    effective_mask<NO>(kn_raw, known, dropped);
+#else
+    const int nkc = min(p.nk[j * p.snk], K);
+    const bool uniform = (p.wm[j * p.swm] == WLSQM_WEIGHT_UNIFORM);
+    unsigned long long known, dropped;
+    effective_mask<NO>(p.knowns[j * p.sknowns], known, dropped);
+    double xi[DIM];
+    const long long pj = GATHER ? (own_point(p, j)) : 0;      // the case's own point (also the stand-in for padding slots)
+    const int* const hrow = GATHER ? p.hoods + j * p.shoods_j : nullptr;
+#pragma unroll
+    for (int m = 0; m < DIM; ++m) xi[m] = GATHER ? p.S[pj * DIM + m] : p.xi[j * p.sxi_j + m];
+#endif
+
+    auto sqdist = [&](const double (&d)[DIM]) {       // one rounding sequence for the guess and for the pass: they are compared for equality
+        double d2 = d[0] * d[0];
+#pragma unroll
+        for (int m = 1; m < DIM; ++m) d2 = fma(d[m], d[m], d2);
+        return d2;
+    };
+    // the guess: the last neighbour is the farthest (see the header).  The chunks are processed LAST CHUNK FIRST (neighbours in
+    // descending k: a fixed order per case, so results do not depend on the route), so that the guess comes out of the first staged
+    // chunk: a separate load of the last neighbour at the start fetched a whole line per case that the staging fetched AGAIN four
+    // to eight chunks later (954 instead of 800 MB read per 1M configs[1] cases, 1 530 instead of 1 321 MB on configs[4]:
+    // profiles/r04m_*_pmc_summary.json).  Only a ragged case whose last neighbour lies in an earlier chunk loads it directly.
+    double guess = 0.0;
+    const bool guess_staged = nkc > (Q - 1) * CH;                     // the last neighbour sits in the chunk that is staged first
+    if (nkc > 0 && !guess_staged) {
+        const double* q = GATHER ? p.S + (long long)hrow[nkc - 1] * DIM : p.xk + j * (long long)K * DIM + (long long)(nkc - 1) * DIM;
+        double dg[DIM];
+#pragma unroll
+        for (int m = 0; m < DIM; ++m) dg[m] = q[m] - xi[m];
+        guess = sqdist(dg);
+    }
+
     // AGPR (round 5; the lone-wave shapes, dense input): TWO chunks in flight with no register set of their own in the vector file.  The
     // loads of a chunk land in the accumulation file (global_load_dwordx4 a[..]: gfx950 loads and LDS stores take AGPR data operands)
     // and are parked from there (ds_write_b128 v, a[..]), so the second set costs no architectural register and no v_accvgpr move —
@@ -446,7 +476,7 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER)
         __syncthreads();
         if (Q > 2) fetch_agpr(S0{}, Q - 3);
     } else {
-        fetch(Q - 1);
+        if constexpr (!EARLY) fetch(Q - 1);
         __syncthreads();
         park();
         __syncthreads();
