@@ -817,6 +817,9 @@ def side_configs(a, dev, timer, rank, parity):
     # index-based input of configs[2]'s shape (the gathering form of the staged kernel); last, so that the order of the earlier entries is the one
     # of the earlier rounds' records
     add("C3-indexed@1M", lambda: measure_cloud("C3", CONFIGS["C3"], 1_000_000, dev, timer, short["steps"], short["warmup"], rank))
+    if only:        # (experiments only — WLSQM_BENCH_SIDE=indexed: the other two BASELINE shapes through the gathering kernels)
+        for cname in ("C2", "C5"):
+            add("%s-indexed@1M" % cname, lambda cname=cname: measure_cloud(cname, CONFIGS[cname], 1_000_000, dev, timer, short["steps"], short["warmup"], rank))
     # 3D orders 3 and 4 (20 / 35 unknowns; round 4: the staged kernel with LDS rows / moments + the four-lanes-per-case solve), with a
     # sample of the batch checked against the CPU port as in the sharded line (no reference golden at these shapes)
     # neighbour lists that are NOT sorted by distance: the BASELINE shapes with every row shuffled, and the shape of

@@ -58,8 +58,14 @@ constexpr int CH = 8;               // neighbours per staged chunk
 #ifndef WLSQM_STAGE_LDS_ROWS
 #define WLSQM_STAGE_LDS_ROWS 4      // rows of a 20 x 20 normal matrix kept in LDS during the solve (74 of its 210 entries: 37 KB per wave)
 #endif
+#ifndef WLSQM_STAGE_MINW6
+#define WLSQM_STAGE_MINW6 2         // waves per SIMD the systems up to 6 unknowns are compiled for
+#endif
+#ifndef WLSQM_STAGE_MINW6G
+#define WLSQM_STAGE_MINW6G 2        // ... their gathering form
+#endif
 #ifndef WLSQM_STAGE_MINW10
-#define WLSQM_STAGE_MINW10 1        // waves per SIMD the systems up to 10 unknowns are compiled for
+#define WLSQM_STAGE_MINW10 2        // waves per SIMD the systems with 7..10 unknowns are compiled for (dense input; the gathering form keeps its SIMD)
 #endif
 #ifndef WLSQM_STAGE_MINW15
 #define WLSQM_STAGE_MINW15 1        // ... the 15-unknown systems
@@ -77,7 +83,7 @@ constexpr int CH = 8;               // neighbours per staged chunk
 // registers while the current ones are consumed.  Everything behind the fetch is the dense kernel's code (same bits as the dense
 // kernel on the gathered rows).
 template <int DIM, int ORDER, int PART = 0, bool GATHER = false>
-__global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER) <= 10 ? WLSQM_STAGE_MINW10 : ndofs(DIM, ORDER) <= 15 ? WLSQM_STAGE_MINW15 : 1)) void fit_stage_kernel(const KParams p) {
+__global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? (GATHER ? WLSQM_STAGE_MINW6G : WLSQM_STAGE_MINW6) : ndofs(DIM, ORDER) <= 10 ? (GATHER ? 1 : WLSQM_STAGE_MINW10) : ndofs(DIM, ORDER) <= 15 ? WLSQM_STAGE_MINW15 : 1)) void fit_stage_kernel(const KParams p) {
     using namespace stage;
     constexpr int NO = ndofs(DIM, ORDER), NE = NO * (NO + 1) / 2, NM = mom_count<DIM>(2 * ORDER);
 #ifndef WLSQM_STAGE_CH10
@@ -95,8 +101,30 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER)
     constexpr int GRP = WLSQM_STAGE_SCHED_BARRIER ? (WLSQM_STAGE_GRP < CH ? WLSQM_STAGE_GRP : CH) : (NO <= 6 ? 2 : NO >= 20 ? WLSQM_STAGE_GRP20 : NO > 10 ? (WLSQM_STAGE_GRP15 < CH ? WLSQM_STAGE_GRP15 : CH) : CH);
     // the staging rows; behind them (reusing the same bytes after the last chunk) the 64 result rows of the wave
     // (and, for the 20-unknown systems, the top R0 rows of every lane's normal matrix during the solve: see below)
-    constexpr int R0 = NO == 20 ? WLSQM_STAGE_LDS_ROWS : 0, TOP_D = 64 * tri<NO>(R0, R0);
-    constexpr int STAGE_D = 64 * XPITCH + 64 * FPITCH, OUT_D = 64 * NO;
+#ifndef WLSQM_STAGE_LDS_ROWS10
+#define WLSQM_STAGE_LDS_ROWS10 0     // rows of a 10 x 10 normal matrix kept in LDS during the solve (the two-waves-per-SIMD experiment: see WLSQM_STAGE_MINW10)
+#endif
+    constexpr int R0 = NO == 20 ? WLSQM_STAGE_LDS_ROWS : (NO == 10 ? WLSQM_STAGE_LDS_ROWS10 : 0), TOP_D = 64 * tri<NO>(R0, R0);
+    // DMA (round 5): the chunks go from memory STRAIGHT into LDS (global_load_lds_dwordx4: no vector register holds a chunk in flight), into
+    // a ring of NSLOT slots with NSLOT - 1 chunks in flight while one is consumed.  A wave instruction's 64 pieces land lane-linear —
+    // piece of lane l at 16 l of the instruction's KiB — so the image of a slot is [instruction][case in instruction][piece] and case c reads
+    // its CH neighbours at KiB c / XCPI, offset (c % XCPI) XPC 16 (contiguous, as in the padded rows of the register-staged form; the idle
+    // lanes of an instruction land in the tail of its KiB, which nobody reads).  The wave waits for its OWN transfers with a counted
+    // s_waitcnt vmcnt — all that orders a ds_read behind an LDS-DMA of the same wave (MI355X_MICROARCH.md, co-residence item 7).
+#ifndef WLSQM_STAGE_DMA
+#define WLSQM_STAGE_DMA 18           // bit 0: the systems up to 6 unknowns, 1: 7..10, 2: 11..15, 3: 20, 4: 35
+#endif
+#ifndef WLSQM_STAGE_DMA_SLOTS
+#define WLSQM_STAGE_DMA_SLOTS 2      // slots of the ring (1: no chunk in flight while one is consumed — the second wave of the SIMD covers the wait)
+#endif
+#ifndef WLSQM_STAGE_DMA_SLOTS10
+#define WLSQM_STAGE_DMA_SLOTS10 1    // ... of the systems with 7..10 unknowns (two waves per SIMD: 17 KB each)
+#endif
+    constexpr bool DMA = !GATHER && (((WLSQM_STAGE_DMA) >> (NO <= 6 ? 0 : NO <= 10 ? 1 : NO <= 15 ? 2 : NO <= 20 ? 3 : 4)) & 1);
+    constexpr int NSLOT = DMA ? ((NO > 6 && NO <= 10) ? WLSQM_STAGE_DMA_SLOTS10 : WLSQM_STAGE_DMA_SLOTS) : 1, PF = NSLOT - 1;
+    constexpr int SLOT_D = (XNI + FNI) * 128;                         // doubles of one slot: a KiB per load instruction
+    static_assert(!DMA || (NSLOT >= 1 && PF * (XNI + FNI) <= 63), "the chunks in flight must fit the vmcnt counter");
+    constexpr int STAGE_D = DMA ? NSLOT * SLOT_D : 64 * XPITCH + 64 * FPITCH, OUT_D = 64 * NO;
     constexpr int LDS_D = (STAGE_D > OUT_D ? STAGE_D : OUT_D) > TOP_D ? (STAGE_D > OUT_D ? STAGE_D : OUT_D) : TOP_D;
     __shared__ __attribute__((aligned(16))) double lds[LDS_D];
     double* const xs = lds;
@@ -154,6 +182,54 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER)
             }
         }
     };
+    // ---- DMA: chunk q into slot q % NSLOT; wait for a chunk with `younger` chunks requested after it
+    auto dma_fetch = [&](int q) __attribute__((always_inline)) {
+        const char* const xt = xtile; const char* const ft = ftile;
+        (void)xt; (void)ft;
+        if constexpr (DMA) {
+            unsigned xo = (unsigned)q * (CH * DIM * 8) + (unsigned)xsub * 16u, fo = (unsigned)q * (CH * 8) + (unsigned)fsub * 16u;
+            xo = xo < xrowb ? xo : xrowb - 16u; fo = fo < frowb ? fo : frowb - 16u;
+            const unsigned slot = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(uintptr_t)lds + (unsigned)(q % NSLOT) * (unsigned)(SLOT_D * 8)));
+#pragma unroll
+            for (int i = 0; i < XNI; ++i) {
+                int cc = xc0 + i * XCPI;
+                cc = cc < nvalid ? cc : nvalid - 1;                   // (idle lanes and tail groups replay a valid row)
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(xo + (unsigned)cc * xrowb), "s"(xt), "s"(slot + (unsigned)i * 1024u) : "memory");
+            }
+            if (want_f) {
+#pragma unroll
+                for (int i = 0; i < FNI; ++i) {
+                    int cc = fc0 + i * FCPI;
+                    cc = cc < nvalid ? cc : nvalid - 1;
+                    unsigned keep;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep) : "v"(fo + (unsigned)cc * frowb), "s"(ft), "s"(slot + (unsigned)(XNI + i) * 1024u) : "memory");
+                }
+            }
+        }
+    };
+    auto dma_wait = [&](int younger) __attribute__((always_inline)) {
+        if constexpr (DMA) {
+            // (in-order counter: anything else in flight only makes the wait longer, never too short)
+            if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (younger == 1) { if (want_f) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(XNI + FNI) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(XNI) : "memory"); }
+            else if (PF >= 2 && younger == 2) { if (want_f) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PF >= 2 ? 2 * (XNI + FNI) : 0) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * XNI) : "memory"); }
+            else { if (want_f) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PF >= 3 ? 3 * (XNI + FNI) : 0) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PF >= 3 ? 3 * XNI : 0) : "memory"); }
+        }
+    };
+    auto dma_prime = [&]() __attribute__((always_inline)) {            // the first PF chunks of a pass (processed last chunk first)
+#pragma unroll
+        for (int i = 1; i <= PF; ++i) if (Q - i >= 0) dma_fetch(Q - i);
+    };
+    // the rows of lane's case in chunk q
+    auto xrow_of = [&](int q) __attribute__((always_inline)) -> const double* {
+        return DMA ? lds + (q % NSLOT) * SLOT_D + (lane / XCPI) * 128 + (lane % XCPI) * (XPC * 2) : xs + lane * XPITCH;
+    };
+    auto frow_of = [&](int q) __attribute__((always_inline)) -> const double* {
+        return DMA ? lds + (q % NSLOT) * SLOT_D + XNI * 128 + (lane / FCPI) * 128 + (lane % FCPI) * (FPC * 2) : fs + lane * FPITCH;
+    };
     // EARLY FETCH (round 5): the first staged chunk is requested BEFORE the case's scalars are — its addresses depend on the launch
     // parameters alone.  In source order the scalars (nk, weighting, knowns: one round trip), then the centre and a ragged case's last
     // neighbour (a second), then the chunk (a third) were three memory latencies in a row at the head of every 64-case group, ~3.5 us of a
@@ -164,7 +240,8 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER)
 #define WLSQM_STAGE_EARLY_FETCH 2
 #endif
     constexpr bool EARLY = (WLSQM_STAGE_EARLY_FETCH != 0) && !GATHER && (WLSQM_STAGE_EARLY_FETCH == 1 || NO > 10);      // (2: the 15-unknown systems and up only)
-    if constexpr (EARLY) fetch_into(xr, fr, Q - 1);
+    if constexpr (EARLY && DMA) dma_prime();
+    else if constexpr (EARLY) fetch_into(xr, fr, Q - 1);
 #ifndef WLSQM_STAGE_SCALARS_FIRST
 #define WLSQM_STAGE_SCALARS_FIRST 1
 #endif
@@ -365,9 +442,9 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER)
         }
         max_d2 = 0.0;
         const double inv_max = MAXONLY ? 0.0 : inverse_max(maxv);
-        const double* xrow = xs + lane * XPITCH;
-        const double* frow = fs + lane * FPITCH;
         auto chunk = [&](const int q) __attribute__((always_inline)) {
+            const double* const xrow = xrow_of(q);
+            const double* const frow = frow_of(q);
 #pragma unroll
             for (int g = CH / GRP - 1; g >= 0; --g) {
 #pragma unroll
@@ -424,6 +501,16 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER)
                     chunk(c - 1);
                 }
             }
+        } else if constexpr (DMA) {
+            // (warm: chunk Q - 1 landed, chunks Q - 2 .. Q - 1 - PF in flight: the prologue)
+            if (!warm) dma_prime();
+            for (int q = Q - 1; q >= 0; --q) {
+                if (!(warm && q == Q - 1)) {
+                    if (q - PF >= 0) dma_fetch(q - PF);               // into the slot of chunk q + 1: consumed
+                    dma_wait(q < PF ? q : PF);
+                }
+                chunk(q);
+            }
         } else if constexpr (DEEP) {
             // (warm: chunk Q - 1 parked, chunks Q - 2 (second set) and Q - 3 (first set) in flight)
             if (!warm) { fetch_into(xr, fr, Q - 1); if (Q > 1) fetch_into(xr2, fr2, Q - 2); }
@@ -475,6 +562,10 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER)
         park_agpr(S0{});
         __syncthreads();
         if (Q > 2) fetch_agpr(S0{}, Q - 3);
+    } else if constexpr (DMA) {
+        if constexpr (!EARLY) dma_prime();
+        if (Q - 1 - PF >= 0) dma_fetch(Q - 1 - PF);
+        dma_wait(Q - 1 < PF ? Q - 1 : PF);
     } else {
         if constexpr (!EARLY) fetch(Q - 1);
         __syncthreads();
@@ -485,7 +576,7 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? 2 : ndofs(DIM, ORDER)
     }
     bool mono = true;
     {
-        const double* xrow = xs + lane * XPITCH;
+        const double* xrow = xrow_of(Q - 1);
         double prev = 0.0;
 #pragma unroll
         for (int ks = 0; ks < CH; ++ks) {
