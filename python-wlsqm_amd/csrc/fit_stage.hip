@@ -64,6 +64,9 @@ constexpr int CH = 8;               // neighbours per staged chunk
 #ifndef WLSQM_STAGE_MINW6G
 #define WLSQM_STAGE_MINW6G 2        // ... their gathering form
 #endif
+#ifndef WLSQM_STAGE_MINW35
+#define WLSQM_STAGE_MINW35 1        // ... the two moment passes of the 35-unknown systems (dense input)
+#endif
 #ifndef WLSQM_STAGE_MINW10
 #define WLSQM_STAGE_MINW10 2        // waves per SIMD the systems with 7..10 unknowns are compiled for (dense input; the gathering form keeps its SIMD)
 #endif
@@ -83,7 +86,7 @@ constexpr int CH = 8;               // neighbours per staged chunk
 // registers while the current ones are consumed.  Everything behind the fetch is the dense kernel's code (same bits as the dense
 // kernel on the gathered rows).
 template <int DIM, int ORDER, int PART = 0, bool GATHER = false>
-__global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? (GATHER ? WLSQM_STAGE_MINW6G : WLSQM_STAGE_MINW6) : ndofs(DIM, ORDER) <= 10 ? (GATHER ? 1 : WLSQM_STAGE_MINW10) : ndofs(DIM, ORDER) <= 15 ? WLSQM_STAGE_MINW15 : 1)) void fit_stage_kernel(const KParams p) {
+__global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? (GATHER ? WLSQM_STAGE_MINW6G : WLSQM_STAGE_MINW6) : ndofs(DIM, ORDER) <= 10 ? (GATHER ? 1 : WLSQM_STAGE_MINW10) : ndofs(DIM, ORDER) <= 15 ? WLSQM_STAGE_MINW15 : (ndofs(DIM, ORDER) == 35 && !GATHER) ? WLSQM_STAGE_MINW35 : 1)) void fit_stage_kernel(const KParams p) {
     using namespace stage;
     constexpr int NO = ndofs(DIM, ORDER), NE = NO * (NO + 1) / 2, NM = mom_count<DIM>(2 * ORDER);
 #ifndef WLSQM_STAGE_CH10
@@ -114,6 +117,14 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? (GATHER ? WLSQM_STAGE
 #ifndef WLSQM_STAGE_DMA
 #define WLSQM_STAGE_DMA 18           // bit 0: the systems up to 6 unknowns, 1: 7..10, 2: 11..15, 3: 20, 4: 35
 #endif
+#ifndef WLSQM_STAGE_DMA_NT
+#define WLSQM_STAGE_DMA_NT 0        // the transfers with the non-temporal policy
+#endif
+#if WLSQM_STAGE_DMA_NT
+#define WLSQM_STAGE_DMA_POLICY " nt"
+#else
+#define WLSQM_STAGE_DMA_POLICY ""
+#endif
 #ifndef WLSQM_STAGE_DMA_SLOTS
 #define WLSQM_STAGE_DMA_SLOTS 2      // slots of the ring (1: no chunk in flight while one is consumed — the second wave of the SIMD covers the wait)
 #endif
@@ -121,7 +132,10 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? (GATHER ? WLSQM_STAGE
 #define WLSQM_STAGE_DMA_SLOTS10 1    // ... of the systems with 7..10 unknowns (two waves per SIMD: 17 KB each)
 #endif
     constexpr bool DMA = !GATHER && (((WLSQM_STAGE_DMA) >> (NO <= 6 ? 0 : NO <= 10 ? 1 : NO <= 15 ? 2 : NO <= 20 ? 3 : 4)) & 1);
-    constexpr int NSLOT = DMA ? ((NO > 6 && NO <= 10) ? WLSQM_STAGE_DMA_SLOTS10 : WLSQM_STAGE_DMA_SLOTS) : 1, PF = NSLOT - 1;
+#ifndef WLSQM_STAGE_DMA_SLOTS35
+#define WLSQM_STAGE_DMA_SLOTS35 2
+#endif
+    constexpr int NSLOT = DMA ? ((NO > 6 && NO <= 10) ? WLSQM_STAGE_DMA_SLOTS10 : NO == 35 ? WLSQM_STAGE_DMA_SLOTS35 : WLSQM_STAGE_DMA_SLOTS) : 1, PF = NSLOT - 1;
     constexpr int SLOT_D = (XNI + FNI) * 128;                         // doubles of one slot: a KiB per load instruction
     static_assert(!DMA || (NSLOT >= 1 && PF * (XNI + FNI) <= 63), "the chunks in flight must fit the vmcnt counter");
     constexpr int STAGE_D = DMA ? NSLOT * SLOT_D : 64 * XPITCH + 64 * FPITCH, OUT_D = 64 * NO;
@@ -195,7 +209,7 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? (GATHER ? WLSQM_STAGE
                 int cc = xc0 + i * XCPI;
                 cc = cc < nvalid ? cc : nvalid - 1;                   // (idle lanes and tail groups replay a valid row)
                 unsigned keep;
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" WLSQM_STAGE_DMA_POLICY "\n\ts_mov_b32 m0, %0"
                              : "=&s"(keep) : "v"(xo + (unsigned)cc * xrowb), "s"(xt), "s"(slot + (unsigned)i * 1024u) : "memory");
             }
             if (want_f) {
@@ -204,7 +218,7 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? (GATHER ? WLSQM_STAGE
                     int cc = fc0 + i * FCPI;
                     cc = cc < nvalid ? cc : nvalid - 1;
                     unsigned keep;
-                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" WLSQM_STAGE_DMA_POLICY "\n\ts_mov_b32 m0, %0"
                                  : "=&s"(keep) : "v"(fo + (unsigned)cc * frowb), "s"(ft), "s"(slot + (unsigned)(XNI + i) * 1024u) : "memory");
                 }
             }
@@ -224,11 +238,11 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? (GATHER ? WLSQM_STAGE
         for (int i = 1; i <= PF; ++i) if (Q - i >= 0) dma_fetch(Q - i);
     };
     // the rows of lane's case in chunk q
-    auto xrow_of = [&](int q) __attribute__((always_inline)) -> const double* {
-        return DMA ? lds + (q % NSLOT) * SLOT_D + (lane / XCPI) * 128 + (lane % XCPI) * (XPC * 2) : xs + lane * XPITCH;
+    auto xrow_of = [&](int q, bool image) __attribute__((always_inline)) -> const double* {
+        return image ? lds + (q % NSLOT) * SLOT_D + (lane / XCPI) * 128 + (lane % XCPI) * (XPC * 2) : xs + lane * XPITCH;
     };
-    auto frow_of = [&](int q) __attribute__((always_inline)) -> const double* {
-        return DMA ? lds + (q % NSLOT) * SLOT_D + XNI * 128 + (lane / FCPI) * 128 + (lane % FCPI) * (FPC * 2) : fs + lane * FPITCH;
+    auto frow_of = [&](int q, bool image) __attribute__((always_inline)) -> const double* {
+        return image ? lds + (q % NSLOT) * SLOT_D + XNI * 128 + (lane / FCPI) * 128 + (lane % FCPI) * (FPC * 2) : fs + lane * FPITCH;
     };
     // EARLY FETCH (round 5): the first staged chunk is requested BEFORE the case's scalars are — its addresses depend on the launch
     // parameters alone.  In source order the scalars (nk, weighting, knowns: one round trip), then the centre and a ragged case's last
@@ -443,8 +457,8 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? (GATHER ? WLSQM_STAGE
         max_d2 = 0.0;
         const double inv_max = MAXONLY ? 0.0 : inverse_max(maxv);
         auto chunk = [&](const int q) __attribute__((always_inline)) {
-            const double* const xrow = xrow_of(q);
-            const double* const frow = frow_of(q);
+            const double* const xrow = xrow_of(q, DMA);
+            const double* const frow = frow_of(q, DMA);
 #pragma unroll
             for (int g = CH / GRP - 1; g >= 0; --g) {
 #pragma unroll
@@ -576,7 +590,7 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? (GATHER ? WLSQM_STAGE
     }
     bool mono = true;
     {
-        const double* xrow = xrow_of(Q - 1);
+        const double* xrow = xrow_of(Q - 1, DMA);
         double prev = 0.0;
 #pragma unroll
         for (int ks = 0; ks < CH; ++ks) {

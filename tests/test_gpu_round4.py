@@ -313,7 +313,7 @@ def test_staged_kernel(wlsqm, oracle, dim, order, Kn, n, neighbours, monkeypatch
         assert np.array_equal(got.view(np.int64), again.view(np.int64))
 
 
-@pytest.mark.parametrize("dim,order,Kn", [(2, 2, 32), (2, 2, 40), (2, 4, 64), (3, 2, 40)])
+@pytest.mark.parametrize("dim,order,Kn", [(2, 2, 32), (2, 2, 40), (2, 4, 64), (3, 2, 40), (2, 3, 30)])
 def test_staged_kernel_bits_do_not_depend_on_wave_mates(wlsqm, dim, order, Kn):
     """Round 5: 2D order 2 fits a case whose neighbours are NOT sorted by distance in ONE pass (three sets of sums, combined with the
     largest squared distance at the end); a sorted-looking case keeps the speculative pass, and a wave that holds both kinds runs both.

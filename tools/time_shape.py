@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time the basic fit of ANY shape on device-resident dense input sorted by distance (a k-nearest-neighbour search's order).
-usage: python tools/time_shape.py DIM ORDER [ncases] [K] [reps]   -> ms per call, kernel name, fraction of the 8 TB/s HBM peak at SURVEY section 8d's bytes"""
+usage: python tools/time_shape.py DIM ORDER [ncases] [K] [reps] [unsorted]   -> ms per call, kernel name, fraction of the 8 TB/s HBM peak at SURVEY section 8d's bytes"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "python-wlsqm_amd"))
@@ -16,6 +16,8 @@ g = torch.Generator(device=dev); g.manual_seed(1)
 xi = torch.rand((n, dim), dtype=torch.float64, device=dev, generator=g)
 xk = xi[:, None, :] + 0.05 * (2 * torch.rand((n, K, dim), dtype=torch.float64, device=dev, generator=g) - 1)
 idx = ((xk - xi[:, None, :]) ** 2).sum(-1).argsort(dim=1)
+if len(sys.argv) > 6 and sys.argv[6] == "unsorted":      # every row in random order (a ball query's)
+    idx = torch.rand((n, K), device=dev, generator=g).argsort(dim=1)
 xk = torch.gather(xk, 1, idx[..., None].expand(-1, -1, dim)).contiguous()
 fk = torch.sin(3 * xk[..., 0]) * torch.cos(2 * xk[..., 1])
 fk = (fk * torch.exp(xk[..., 2]) if dim == 3 else fk).contiguous()
