@@ -91,7 +91,10 @@ __global__ __launch_bounds__(64, 1) void quad_solve_kernel(const KParams p) {
         // the 16 cases of this wave are 16 consecutive lanes of one 64-case group of the moment kernels: 128 contiguous bytes per entry
         const double* src = p.ws + (case0 >> 6) * (long long)(NW * 64) + (case0 & 63);
         const int cc = lane & 15, e0 = lane >> 4;
-#pragma unroll 10
+#ifndef WLSQM_QUAD_LOAD_UNROLL
+#define WLSQM_QUAD_LOAD_UNROLL 50       // all of a lane's 50 moments requested at once (10 at a time: 3Do4@400k 1.14 against 1.09 ms)
+#endif
+#pragma unroll WLSQM_QUAD_LOAD_UNROLL
         for (int it = 0; it < NW / 4; ++it) mom[cc * PITCH + it * 4 + e0] = src[(it * 4 + e0) * 64 + cc];
         if (lane < 16) mom[lane * PITCH + NW] = 0.0;
     }

@@ -254,7 +254,7 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? (GATHER ? WLSQM_STAGE
 #define WLSQM_STAGE_EARLY_FETCH 2
 #endif
     constexpr bool EARLY = (WLSQM_STAGE_EARLY_FETCH != 0) && !GATHER && (WLSQM_STAGE_EARLY_FETCH == 1 || NO > 10);      // (2: the 15-unknown systems and up only)
-    if constexpr (EARLY && DMA) dma_prime();
+    if constexpr (EARLY && DMA) { dma_prime(); if constexpr (PF == 0) dma_fetch(Q - 1); }      // (a ring of one slot: its only chunk)
     else if constexpr (EARLY) fetch_into(xr, fr, Q - 1);
 #ifndef WLSQM_STAGE_SCALARS_FIRST
 #define WLSQM_STAGE_SCALARS_FIRST 1
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? (GATHER ? WLSQM_STAGE
         if (Q > 2) fetch_agpr(S0{}, Q - 3);
     } else if constexpr (DMA) {
         if constexpr (!EARLY) dma_prime();
-        if (Q - 1 - PF >= 0) dma_fetch(Q - 1 - PF);
+        if constexpr (!(EARLY && PF == 0)) { if (Q - 1 - PF >= 0) dma_fetch(Q - 1 - PF); }
         dma_wait(Q - 1 < PF ? Q - 1 : PF);
     } else {
         if constexpr (!EARLY) fetch(Q - 1);
