@@ -204,11 +204,29 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? (GATHER ? WLSQM_STAGE
             unsigned xo = (unsigned)q * (CH * DIM * 8) + (unsigned)xsub * 16u, fo = (unsigned)q * (CH * 8) + (unsigned)fsub * 16u;
             xo = xo < xrowb ? xo : xrowb - 16u; fo = fo < frowb ? fo : frowb - 16u;
             const unsigned slot = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(uintptr_t)lds + (unsigned)(q % NSLOT) * (unsigned)(SLOT_D * 8)));
+#ifndef WLSQM_STAGE_DMA_SPLIT
+#define WLSQM_STAGE_DMA_SPLIT 1      // (configs[4]: same 0.275 ms, FETCH_SIZE 1.80 -> 1.64 GB per launch; its shuffled form 0.427 -> 0.406 ms: profiles/r05g_ab_stage_dma.txt)
+#endif
+            constexpr bool SPLIT = WLSQM_STAGE_DMA_SPLIT && PF == 0;      // (two masked instructions per transfer: only where every wait is vmcnt(0))
+            const unsigned xt_lo = (unsigned)(uintptr_t)xt & 127u;
+            (void)xt_lo;
 #pragma unroll
             for (int i = 0; i < XNI; ++i) {
                 int cc = xc0 + i * XCPI;
                 cc = cc < nvalid ? cc : nvalid - 1;                   // (idle lanes and tail groups replay a valid row)
                 unsigned keep;
+                if constexpr (SPLIT) {
+                    // a piece whose 128-byte line lies wholly inside this chunk's run of the row is read once: non-temporal; a line shared
+                    // with the neighbouring chunk (or row) keeps the default policy, so that L2 holds the halves that WILL be read again
+                    const unsigned a = xt_lo + xo + (unsigned)cc * xrowb, line = a & ~127u;
+                    const unsigned r0 = xt_lo + (unsigned)cc * xrowb + (unsigned)q * (CH * DIM * 8);
+                    const unsigned rend = xt_lo + (unsigned)(cc + 1) * xrowb, r1 = r0 + CH * DIM * 8 < rend ? r0 + CH * DIM * 8 : rend;
+                    const unsigned long long inner = __ballot(line >= r0 && line + 128u <= r1);
+                    unsigned long long keepx;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_mov_b64 %1, exec\n\ts_and_b64 exec, %1, %5\n\tglobal_load_lds_dwordx4 %2, %3 nt\n\t"
+                                 "s_andn2_b64 exec, %1, %5\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep), "=&s"(keepx) : "v"(xo + (unsigned)cc * xrowb), "s"(xt), "s"(slot + (unsigned)i * 1024u), "s"(inner) : "memory");
+                } else
                 asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" WLSQM_STAGE_DMA_POLICY "\n\ts_mov_b32 m0, %0"
                              : "=&s"(keep) : "v"(xo + (unsigned)cc * xrowb), "s"(xt), "s"(slot + (unsigned)i * 1024u) : "memory");
             }
