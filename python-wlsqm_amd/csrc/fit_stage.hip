@@ -22,6 +22,12 @@
 // so it runs with the last neighbour's squared distance as the maximum while it tracks the true one, and the guess is verified bit for
 // bit; a wave with a wrong guess (unsorted neighbours) repeats the pass with the true maxima — same bits either way.
 //
+// Round 5: the chunks of the 7..10- and 35-unknown systems go from memory straight into LDS (global_load_lds_dwordx4, `DMA` in the
+// kernel: no vector register holds a chunk in flight).  That took the 10-unknown kernels from 330-408 to 184-186 registers: they run TWO
+// waves per SIMD on one 17 KB slot each (configs[4] 0.290 -> 0.275 ms), the transfers with a split cache policy (whole-line pieces
+// non-temporal, pieces in a line shared with the next chunk default); 3D order 4's moment halves lost their scratch.  What was measured
+// on the way, and what did not pay: DESIGN section 4.1 (round-5 part), profiles/r05g_ab_stage_dma.txt.
+//
 // One sum per moment over k (descending: the chunks are staged last-first, see the kernel) in ONE lane: of the fast kernels this one is
 // the closest to the reference's summation
 // (profiles/r03_attribution.txt: the lane-split sums are the largest single contribution to the fast kernels' distance from it).
@@ -70,6 +76,9 @@ constexpr int CH = 8;               // neighbours per staged chunk
 #ifndef WLSQM_STAGE_MINW10
 #define WLSQM_STAGE_MINW10 2        // waves per SIMD the systems with 7..10 unknowns are compiled for (dense input; the gathering form keeps its SIMD)
 #endif
+#ifndef WLSQM_STAGE_MINW10G
+#define WLSQM_STAGE_MINW10G 1       // ... their gathering form (two: 3D order 2 spills)
+#endif
 #ifndef WLSQM_STAGE_MINW15
 #define WLSQM_STAGE_MINW15 1        // ... the 15-unknown systems
 #endif
@@ -86,7 +95,7 @@ constexpr int CH = 8;               // neighbours per staged chunk
 // registers while the current ones are consumed.  Everything behind the fetch is the dense kernel's code (same bits as the dense
 // kernel on the gathered rows).
 template <int DIM, int ORDER, int PART = 0, bool GATHER = false>
-__global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? (GATHER ? WLSQM_STAGE_MINW6G : WLSQM_STAGE_MINW6) : ndofs(DIM, ORDER) <= 10 ? (GATHER ? 1 : WLSQM_STAGE_MINW10) : ndofs(DIM, ORDER) <= 15 ? WLSQM_STAGE_MINW15 : (ndofs(DIM, ORDER) == 35 && !GATHER) ? WLSQM_STAGE_MINW35 : 1)) void fit_stage_kernel(const KParams p) {
+__global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? (GATHER ? WLSQM_STAGE_MINW6G : WLSQM_STAGE_MINW6) : ndofs(DIM, ORDER) <= 10 ? (GATHER ? WLSQM_STAGE_MINW10G : WLSQM_STAGE_MINW10) : ndofs(DIM, ORDER) <= 15 ? WLSQM_STAGE_MINW15 : (ndofs(DIM, ORDER) == 35 && !GATHER) ? WLSQM_STAGE_MINW35 : 1)) void fit_stage_kernel(const KParams p) {
     using namespace stage;
     constexpr int NO = ndofs(DIM, ORDER), NE = NO * (NO + 1) / 2, NM = mom_count<DIM>(2 * ORDER);
 #ifndef WLSQM_STAGE_CH10
