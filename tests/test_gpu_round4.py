@@ -248,7 +248,9 @@ def test_prepare_once_time_levels_vs_reference_golden(wlsqm, path, monkeypatch):
 # ----------------------------------------------------------------------------------------------------------------------
 # the one-lane-per-case staged kernel (csrc/fit_stage.hip)
 
-@pytest.mark.parametrize("dim,order,Kn", [(2, 4, 64), (2, 4, 100), (2, 4, 26), (3, 2, 40), (3, 2, 124), (2, 3, 30), (2, 2, 32), (2, 2, 50), (3, 3, 64), (3, 3, 42), (3, 4, 64), (3, 4, 50)])
+@pytest.mark.parametrize("dim,order,Kn", [(2, 4, 64), (2, 4, 100), (2, 4, 26), (3, 2, 40), (3, 2, 124), (2, 3, 30), (2, 2, 32), (2, 2, 50), (3, 3, 64), (3, 3, 42), (3, 4, 64), (3, 4, 50),
+                                          # (round 5: the LDS-DMA forms — one chunk, partial last chunks)
+                                          (3, 2, 20), (3, 2, 22), (3, 2, 26), (3, 2, 66), (2, 3, 20), (2, 3, 22), (2, 3, 44)])
 @pytest.mark.parametrize("n", [1, 63, 64, 65, 1000])
 @pytest.mark.parametrize("neighbours", ["sorted", "unsorted", "nearly sorted"])
 def test_staged_kernel(wlsqm, oracle, dim, order, Kn, n, neighbours, monkeypatch):
