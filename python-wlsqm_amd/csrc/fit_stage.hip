@@ -71,7 +71,7 @@ constexpr int CH = 8;               // neighbours per staged chunk
 #define WLSQM_STAGE_MINW6G 2        // ... their gathering form
 #endif
 #ifndef WLSQM_STAGE_MINW35
-#define WLSQM_STAGE_MINW35 1        // ... the two moment passes of the 35-unknown systems (dense input)
+#define WLSQM_STAGE_MINW35 1        // ... the two moment passes of the 35-unknown systems (dense input; two: ~100 sums per lane leave no room, 1 898 / 49 spilled registers)
 #endif
 #ifndef WLSQM_STAGE_MINW10
 #define WLSQM_STAGE_MINW10 2        // waves per SIMD the systems with 7..10 unknowns are compiled for (dense input; the gathering form keeps its SIMD)
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? (GATHER ? WLSQM_STAGE
     using namespace stage;
     constexpr int NO = ndofs(DIM, ORDER), NE = NO * (NO + 1) / 2, NM = mom_count<DIM>(2 * ORDER);
 #ifndef WLSQM_STAGE_CH10
-#define WLSQM_STAGE_CH10 8          // neighbours per staged chunk of the systems with 7 .. 10 unknowns (A/B: with 4 and two waves per SIMD the loops still spill — configs[4] 0.74-0.87 against 0.32 ms; 4 at one wave: 0.338: profiles/r04z_ab_c5_two_waves.txt)
+#define WLSQM_STAGE_CH10 8          // neighbours per staged chunk of the systems with 7 .. 10 unknowns (4: 96-byte pieces straddle 64-byte sectors — by LDS-DMA at two waves per SIMD 0.30 against 0.275 ms and 1.83 GB fetched per 1M configs[4] cases, profiles/r05g_ab_stage_dma.txt; register-staged the loops spilled, r04z_ab_c5_two_waves.txt)
 #endif
     constexpr int CH = (NO > 6 && NO <= 10) ? WLSQM_STAGE_CH10 : stage::CH;
     static_assert(mom_count<DIM>(ORDER) == NO, "one right-hand-side moment per DOF");
@@ -113,10 +113,7 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? (GATHER ? WLSQM_STAGE
     constexpr int GRP = WLSQM_STAGE_SCHED_BARRIER ? (WLSQM_STAGE_GRP < CH ? WLSQM_STAGE_GRP : CH) : (NO <= 6 ? 2 : NO >= 20 ? WLSQM_STAGE_GRP20 : NO > 10 ? (WLSQM_STAGE_GRP15 < CH ? WLSQM_STAGE_GRP15 : CH) : CH);
     // the staging rows; behind them (reusing the same bytes after the last chunk) the 64 result rows of the wave
     // (and, for the 20-unknown systems, the top R0 rows of every lane's normal matrix during the solve: see below)
-#ifndef WLSQM_STAGE_LDS_ROWS10
-#define WLSQM_STAGE_LDS_ROWS10 0     // rows of a 10 x 10 normal matrix kept in LDS during the solve (the two-waves-per-SIMD experiment: see WLSQM_STAGE_MINW10)
-#endif
-    constexpr int R0 = NO == 20 ? WLSQM_STAGE_LDS_ROWS : (NO == 10 ? WLSQM_STAGE_LDS_ROWS10 : 0), TOP_D = 64 * tri<NO>(R0, R0);
+    constexpr int R0 = NO == 20 ? WLSQM_STAGE_LDS_ROWS : 0, TOP_D = 64 * tri<NO>(R0, R0);
     // DMA (round 5): the chunks go from memory STRAIGHT into LDS (global_load_lds_dwordx4: no vector register holds a chunk in flight), into
     // a ring of NSLOT slots with NSLOT - 1 chunks in flight while one is consumed.  A wave instruction's 64 pieces land lane-linear —
     // piece of lane l at 16 l of the instruction's KiB — so the image of a slot is [instruction][case in instruction][piece] and case c reads
