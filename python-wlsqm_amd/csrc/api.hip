@@ -321,6 +321,39 @@ int stream_counters_acquire(int** out, size_t ints, hipStream_t stream, int* set
     *out = hit->p;
     return WLSQM_OK;
 }
+namespace {
+struct StageHint { int dev; hipStream_t stream; int shape; unsigned char* host; unsigned char* device; };
+std::vector<StageHint>& stage_hint_table() { static std::vector<StageHint> t; return t; }
+}  // namespace
+int stage_hint_acquire(int dimension, int order, hipStream_t stream, unsigned char** dev_out, int* sorted, int* unsorted) {
+    *dev_out = nullptr; *sorted = 0; *unsorted = 0;
+    int dev = 0;
+    WLSQM_HIP_CHECK(hipGetDevice(&dev));
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+    if (cap != hipStreamCaptureStatusNone) return WLSQM_OK;         // (no allocation inside a capture; a replay would report into the same slots for ever)
+    const int shape = dimension * 8 + order;
+    std::lock_guard<std::mutex> lock(stream_counters_mutex());
+    StageHint* hit = nullptr;
+    for (auto& e : stage_hint_table()) if (e.dev == dev && e.stream == stream && e.shape == shape) hit = &e;
+    if (!hit) {
+        unsigned char* h = nullptr; unsigned char* d = nullptr;
+        if (hipHostMalloc(reinterpret_cast<void**>(&h), 64, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return WLSQM_OK; }
+        if (hipHostGetDevicePointer(reinterpret_cast<void**>(&d), h, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(h); return WLSQM_OK; }
+        std::memset(h, 0, 64);
+        if (stage_hint_table().size() >= 256) {                      // (a process that keeps creating streams: recycle the oldest entry)
+            (void)hipHostFree(stage_hint_table().front().host);
+            stage_hint_table().erase(stage_hint_table().begin());
+        }
+        stage_hint_table().push_back(StageHint{dev, stream, shape, h, d});
+        hit = &stage_hint_table().back();
+    }
+    // (plain reads of memory the previous launch's groups wrote — or are still writing: a heuristic, never a result)
+    volatile unsigned char* v = hit->host;
+    for (int i = 0; i < 64; ++i) { const unsigned char b = v[i]; if (b == 2) ++*sorted; else if (b == 1) ++*unsorted; v[i] = 0; }
+    *dev_out = hit->device;
+    return WLSQM_OK;
+}
 int scratch_free_async(void* p, hipStream_t stream) {
     if (!p) return WLSQM_OK;
     if (is_stream_counters(p)) return WLSQM_OK;                     // (persistent: see stream_counters_acquire)

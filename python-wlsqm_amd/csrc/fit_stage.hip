@@ -95,7 +95,7 @@ constexpr int CH = 8;               // neighbours per staged chunk
 // registers while the current ones are consumed.  Everything behind the fetch is the dense kernel's code (same bits as the dense
 // kernel on the gathered rows).
 template <int DIM, int ORDER, int PART = 0, bool GATHER = false>
-__global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? (GATHER ? WLSQM_STAGE_MINW6G : WLSQM_STAGE_MINW6) : ndofs(DIM, ORDER) <= 10 ? (GATHER ? WLSQM_STAGE_MINW10G : WLSQM_STAGE_MINW10) : ndofs(DIM, ORDER) <= 15 ? WLSQM_STAGE_MINW15 : (ndofs(DIM, ORDER) == 35 && !GATHER) ? WLSQM_STAGE_MINW35 : 1)) void fit_stage_kernel(const KParams p) {
+__global__ __launch_bounds__(64, (PART == 5 ? 1 : ndofs(DIM, ORDER) <= 6 ? (GATHER ? WLSQM_STAGE_MINW6G : WLSQM_STAGE_MINW6) : ndofs(DIM, ORDER) <= 10 ? (GATHER ? WLSQM_STAGE_MINW10G : WLSQM_STAGE_MINW10) : ndofs(DIM, ORDER) <= 15 ? WLSQM_STAGE_MINW15 : (ndofs(DIM, ORDER) == 35 && !GATHER) ? WLSQM_STAGE_MINW35 : 1)) void fit_stage_kernel(const KParams p) {
     using namespace stage;
     constexpr int NO = ndofs(DIM, ORDER), NE = NO * (NO + 1) / 2, NM = mom_count<DIM>(2 * ORDER);
 #ifndef WLSQM_STAGE_CH10
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? (GATHER ? WLSQM_STAGE
 #ifndef WLSQM_STAGE_DMA_SLOTS10
 #define WLSQM_STAGE_DMA_SLOTS10 1    // ... of the systems with 7..10 unknowns (two waves per SIMD: 17 KB each)
 #endif
-    constexpr bool DMA = !GATHER && (((WLSQM_STAGE_DMA) >> (NO <= 6 ? 0 : NO <= 10 ? 1 : NO <= 15 ? 2 : NO <= 20 ? 3 : 4)) & 1);
+    constexpr bool DMA = !GATHER && PART != 5 && (((WLSQM_STAGE_DMA) >> (NO <= 6 ? 0 : NO <= 10 ? 1 : NO <= 15 ? 2 : NO <= 20 ? 3 : 4)) & 1);
 #ifndef WLSQM_STAGE_DMA_SLOTS35
 #define WLSQM_STAGE_DMA_SLOTS35 2
 #endif
@@ -631,6 +631,13 @@ __global__ __launch_bounds__(64, (ndofs(DIM, ORDER) <= 6 ? (GATHER ? WLSQM_STAGE
     // pass, repeated if the guess was wrong); where three sets of sums fit the lane (TRIPLE) a case with an unsorted chunk gets the
     // one-pass form, and a uniformly weighted case has the same bits in both.  A wave that holds both kinds runs both passes.
     const bool elig_r = uniform || mono, elig_t = TRIPLE && (uniform || !mono);
+    if constexpr (!GATHER && (PART == 0 || PART == 5)) {
+        // (sampled groups tell the NEXT call on the stream whether this input was sorted by distance: launch_stage)
+        if (p.hint != nullptr && (int)(blockIdx.x % (unsigned)p.hint_stride) == 0 && blockIdx.x / (unsigned)p.hint_stride < 64u) {
+            const bool sorted_group = __all(elig_r);
+            if (lane == 0) p.hint[blockIdx.x / (unsigned)p.hint_stride] = sorted_group ? 2 : 1;
+        }
+    }
     if (__all(elig_r)) {
         moments(guess, true);
         // the guess must have been the largest squared distance, bit for bit (uniform weighting does not use it); otherwise the wave
@@ -928,6 +935,32 @@ static int launch_stage(const KParams& p, hipStream_t stream) {
     const long long groups = (p.ncases + 63) / 64;
     if (groups <= 0) return WLSQM_OK;
     if (groups > 0x7fffffffLL) { set_error("fit_stage: batch too large for one launch"); return WLSQM_EVALUE; }
+    // TWO FORMS for the dense systems up to 10 unknowns (round 5).  The default (PART 0) runs two waves per SIMD; PART 5 is the same code
+    // compiled to own its SIMD (register-staged chunks; same bits per case).  Neighbours that are NOT sorted by distance take two passes over
+    // a group's rows, and the second pass finds them in L2 only with one wave per SIMD resident: 1M cases with shuffled rows, configs[1]
+    // 0.218 -> 0.200 ms, configs[4] 0.406 -> 0.373 — while sorted input loses 5-9 % there.  Sortedness is a property of the data, known only
+    // on the device: sampled groups report it into host-mapped memory and the NEXT launch of the shape on the stream picks its form from what
+    // the previous one saw (no synchronisation, nothing read back: a stale or missing report only costs speed).
+    // WLSQM_HIP_STAGE_FORM=two / one forces a form (A/B, tests).
+    constexpr int NO = ndofs(DIM, ORDER);
+    if constexpr (!GATHER && NO <= 10) {
+        const char* e = getenv("WLSQM_HIP_STAGE_FORM");
+        bool own_simd = false;
+        KParams q = p;
+        if (e && (e[0] == 't' || e[0] == 'o')) own_simd = e[0] == 'o';
+        else {
+            int n_sorted = 0, n_unsorted = 0;
+            const int rc = stage_hint_acquire(DIM, ORDER, stream, &q.hint, &n_sorted, &n_unsorted);
+            if (rc != WLSQM_OK) return rc;
+            q.hint_stride = (int)(groups / 64 > 0 ? groups / 64 : 1);
+            own_simd = n_unsorted > n_sorted;
+        }
+        if (own_simd) hipLaunchKernelGGL((fit_stage_kernel<DIM, ORDER, 5, false>), dim3((unsigned)groups), dim3(64), 0, stream, q);
+        else hipLaunchKernelGGL((fit_stage_kernel<DIM, ORDER, 0, false>), dim3((unsigned)groups), dim3(64), 0, stream, q);
+        WLSQM_HIP_CHECK(hipGetLastError());
+        note_kernel("stage");
+        return WLSQM_OK;
+    }
     hipLaunchKernelGGL((fit_stage_kernel<DIM, ORDER, 0, GATHER>), dim3((unsigned)groups), dim3(64), 0, stream, p);
     WLSQM_HIP_CHECK(hipGetLastError());
     note_kernel(GATHER ? "stage-gather" : "stage");

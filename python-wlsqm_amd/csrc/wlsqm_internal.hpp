@@ -53,6 +53,11 @@ struct KParams {
     int it_first = 0, it_stop = 0;
     long long* cont_list = nullptr; long long* cont_count = nullptr;
     double* it_state = nullptr;
+    // fit_stage.hip, dense systems up to 10 unknowns: 64 bytes of host-mapped memory per (stream, shape) in which sampled 64-case groups
+    // (every hint_stride-th) report whether their neighbours were sorted by distance (2) or not (1): the NEXT call on the stream picks the
+    // kernel form by it (stage_hint_acquire).  nullptr: nothing is reported.
+    unsigned char* hint = nullptr;
+    int hint_stride = 1;
 };
 
 // Cases a launch really has (see KParams::ncases_dev).
@@ -199,6 +204,10 @@ int scratch_free_async(void* p, hipStream_t stream);
 // the caller falls back to scratch_alloc_async and a clearing kernel.  scratch_free_async ignores these buffers.
 int stream_counters_acquire(int** out, size_t ints, hipStream_t stream, int* set_out = nullptr);      // *set_out: 0 / 1, alternating per call on the stream
 void stream_counters_release_clean(const void* p);
+// The sortedness reports of the previous staged launch of this (dimension, order) on the stream: *sorted / *unsorted = sampled groups of
+// each kind (0 / 0 on the first call), *dev = where this launch's sampled groups report (nullptr inside a graph capture or if host-mapped
+// memory is not to be had: the caller takes its default form).  The slots are cleared for the new launch.
+int stage_hint_acquire(int dimension, int order, hipStream_t stream, unsigned char** dev, int* sorted, int* unsorted);
 bool is_stream_counters(const void* p);
 
 // Host mirror of effective_mask() in wlsqm_kernels.hpp (infra.pyx:119-121 quirk): returns the

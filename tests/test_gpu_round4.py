@@ -355,6 +355,68 @@ def test_staged_kernel_bits_do_not_depend_on_wave_mates(wlsqm, dim, order, Kn):
     assert np.array_equal(all_sorted[uni & (nk == Kn)], run(srt)[uni & (nk == Kn)])
 
 
+@pytest.mark.parametrize("dim,order,Kn", [(2, 2, 32), (2, 2, 46), (2, 3, 30), (3, 2, 40), (3, 2, 26)])
+def test_staged_kernel_forms_agree_and_follow_the_input(wlsqm, monkeypatch, dim, order, Kn):
+    """Round 5: the dense systems up to 10 unknowns have two forms of the staged kernel — two waves per SIMD (default; chunks by LDS-DMA for
+    the 10-unknown systems) and one that owns its SIMD (faster when the neighbours are NOT sorted by distance: the second pass finds the
+    rows in L2).  The launch picks by what sampled groups of the PREVIOUS launch on the stream reported (host-mapped bytes, no
+    synchronisation).  Whatever is picked, a case's bits are the same: forced forms (WLSQM_HIP_STAGE_FORM=two / one) and the automatic choice
+    over a sequence of sorted, shuffled and mixed batches, eager and inside a replayed graph."""
+    import torch
+    import wlsqm.hip as whip
+    rng = np.random.default_rng(99 + Kn)
+    n, no = 64 * 70 + 9, K.NDOF[dim][order]
+    xi = rng.uniform(0, 1, (n, dim))
+    off = 0.05 * rng.uniform(-1, 1, (n, Kn, dim))
+    srt = off.copy()
+    for j in range(n):
+        srt[j] = off[j][np.argsort((off[j] ** 2).sum(axis=1), kind="stable")]
+    mixed = srt.copy(); mixed[(np.arange(n) // 64) % 4 == 1] = off[(np.arange(n) // 64) % 4 == 1]
+    nk = np.full(n, Kn, np.int32); nk[::13] = Kn - 2
+    kn = rng.choice(np.array([0, 0, 1], np.int64), n)
+    wm = np.full(n, wlsqm.WEIGHT_CENTER, np.int32)
+    fi0 = rng.uniform(-1, 1, (n, no))
+
+    def run(o, fi=None):
+        xk = xi[:, None, :] + o
+        fk = np.sin(3 * xk[..., 0]) * np.cos(2 * xk[..., -1])
+        fi = _t(fi0) if fi is None else fi
+        args = (dim, order, _t(xk), _t(fk), _t(nk), _t(xi), fi, _t(kn), _t(wm))
+        whip.fit_many_device(*args)
+        torch.cuda.synchronize()
+        assert whip.last_kernel() == "stage"
+        return fi.cpu().numpy().view(np.int64), args
+    want = {}
+    for form in ("two", "one"):
+        monkeypatch.setenv("WLSQM_HIP_STAGE_FORM", form)
+        for name, o in (("sorted", srt), ("shuffled", off), ("mixed", mixed)):
+            got, _ = run(o)
+            if form == "two":
+                want[name] = got
+            else:
+                assert np.array_equal(got, want[name]), "the two forms differ on %s input" % name
+    monkeypatch.delenv("WLSQM_HIP_STAGE_FORM")
+    # automatic: every call sees the reports of the one before it
+    for name, o in (("sorted", srt), ("shuffled", off), ("shuffled", off), ("shuffled", off), ("mixed", mixed), ("sorted", srt), ("sorted", srt)):
+        got, args = run(o)
+        assert np.array_equal(got, want[name]), name
+    # captured (no reports inside a capture) and replayed after shuffled calls
+    s = torch.cuda.Stream()
+    fi_g = _t(fi0)
+    gargs = args[:6] + (fi_g,) + args[7:]
+    with torch.cuda.stream(s):
+        whip.fit_many_device(*gargs)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            whip.fit_many_device(*gargs)
+        for _ in range(2):
+            fi_g.copy_(_t(fi0))
+            g.replay()
+            torch.cuda.synchronize()
+            assert np.array_equal(fi_g.cpu().numpy().view(np.int64), want["sorted"])
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # the gathering form of the staged kernel: index-based input (csrc/fit_stage.hip, GATHER)
 
