@@ -337,16 +337,27 @@ int stage_hint_acquire(int dimension, int order, hipStream_t stream, unsigned ch
     StageHint* hit = nullptr;
     for (auto& e : stage_hint_table()) if (e.dev == dev && e.stream == stream && e.shape == shape) hit = &e;
     if (!hit) {
-        unsigned char* h = nullptr; unsigned char* d = nullptr;
-        if (hipHostMalloc(reinterpret_cast<void**>(&h), 64, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return WLSQM_OK; }
-        if (hipHostGetDevicePointer(reinterpret_cast<void**>(&d), h, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(h); return WLSQM_OK; }
-        std::memset(h, 0, 64);
-        if (stage_hint_table().size() >= 256) {                      // (a process that keeps creating streams: recycle the oldest entry)
-            (void)hipHostFree(stage_hint_table().front().host);
-            stage_hint_table().erase(stage_hint_table().begin());
+        if (stage_hint_table().size() >= 256) {
+            // a process that keeps creating streams: the oldest entry of this device changes hands WITH its memory (never freed: a launch
+            // that is still running may report into it — into somebody else's heuristic, at worst)
+            for (size_t i = 0; i < stage_hint_table().size() && !hit; ++i)
+                if (stage_hint_table()[i].dev == dev) {
+                    StageHint e = stage_hint_table()[i];
+                    stage_hint_table().erase(stage_hint_table().begin() + (long)i);
+                    e.stream = stream; e.shape = shape;
+                    std::memset(e.host, 0, 64);
+                    stage_hint_table().push_back(e);
+                    hit = &stage_hint_table().back();
+                }
+            if (!hit) return WLSQM_OK;
+        } else {
+            unsigned char* h = nullptr; unsigned char* d = nullptr;
+            if (hipHostMalloc(reinterpret_cast<void**>(&h), 64, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return WLSQM_OK; }
+            if (hipHostGetDevicePointer(reinterpret_cast<void**>(&d), h, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(h); return WLSQM_OK; }
+            std::memset(h, 0, 64);
+            stage_hint_table().push_back(StageHint{dev, stream, shape, h, d});
+            hit = &stage_hint_table().back();
         }
-        stage_hint_table().push_back(StageHint{dev, stream, shape, h, d});
-        hit = &stage_hint_table().back();
     }
     // (plain reads of memory the previous launch's groups wrote — or are still writing: a heuristic, never a result)
     volatile unsigned char* v = hit->host;
