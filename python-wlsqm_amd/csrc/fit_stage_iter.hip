@@ -26,6 +26,9 @@
 // function value known keeps the factor of its 14 x 14 system (2D order 4), as in the staged fit kernel.  Every form — resident,
 // re-staging, cached or not — returns the same bits for a case (tests/test_gpu_round4.py::test_staged_refinement_kernel).
 //
+// Round 5: the 15-unknown re-staging forms take their chunks by LDS-DMA (DMA at the kernel: 168 -> 40 registers in scratch, C3+iter@400k
+// 1.33 -> 1.10 ms; profiles/r05j_refine_dma.txt).
+//
 // Measured and left off (switches at the top; records under profiles/r04zb_*): two chunks in flight, the next pass's first chunk behind
 // the current pass's last, two waves per SIMD for the 10-unknown systems, partial sums of the model evaluation, the caches at three
 // waves per CU, and the SENS form (sensitivities on this mapping: correct, 1.2-1.9x slower than the inverse + matrix-core path).
@@ -78,12 +81,19 @@ __host__ __device__ constexpr int pitch2(int doubles) {               // row pit
 // CACHE = 2: the neighbours' VALUES fk instead (the same 64 x K doubles): the sweeps then re-stage the coordinates only — 24 of 32 bytes
 // per 3D neighbour.  For the shape whose sweeps are bound by the rows coming back from the Infinity Cache rather than by their
 // instructions: 3D order 2 (configs[4]: the weight cache gave 1.5 % there, against 6-8 % on the 2D shapes).
+// DMA (round 5): the re-staging forms of the 15-unknown systems take their chunks by global_load_lds_dwordx4 into a ring of two slots
+// (lane-linear image and hand-counted waits: fit_stage.hip) — at the same one wave per SIMD: the point is the ~50 registers the staging
+// sets, their addresses and the hoisted LDS reads occupied in a kernel that spilled into scratch next to its 105-entry factor.
+#ifndef WLSQM_SITER_DMA
+#define WLSQM_SITER_DMA 1
+#endif
 template <int DIM, int ORDER, bool RESIDENT, bool SENS, int CACHE = 0>
 __global__ __launch_bounds__(64, (!RESIDENT && !SENS && CACHE == 0 && ndofs(DIM, ORDER) <= WLSQM_SITER_TWO_WAVES_UPTO) ? 2 : 1) void fit_stage_refine_kernel(const KParams p, const int XP2r, const int FP2r) {
     static_assert(CACHE == 0 || (!RESIDENT && !SENS), "the caches belong to the re-staging refinement form");
     constexpr bool WCACHE = CACHE == 1, FCACHE = CACHE == 2;
     using namespace siter;
     constexpr int NO = ndofs(DIM, ORDER), NE = NO * (NO + 1) / 2, NM = mom_count<DIM>(2 * ORDER);
+    constexpr bool DMA = (WLSQM_SITER_DMA != 0) && !RESIDENT && !SENS && NO == 15;
     constexpr int SG = sens_group(NO), SR = SG * NO / 2, TP2 = pitch2(SG * NO);      // neighbours per sens tile; 16-byte pieces of a case's tile; tile pitch
     constexpr int TILE2 = SENS ? 64 * TP2 : 0;
     constexpr int XPC = CH * DIM * 8 / 16, FPC = CH * 8 / 16;        // 16-byte pieces of one case's chunk: coordinates, values
@@ -91,7 +101,8 @@ __global__ __launch_bounds__(64, (!RESIDENT && !SENS && CACHE == 0 && ndofs(DIM,
     constexpr int FCPI = 64 / FPC, FNI = 64 / FCPI;
     constexpr int GRP = WLSQM_SITER_GRP < CH ? WLSQM_SITER_GRP : CH;
     constexpr int XP2s = pitch2(CH * DIM), FP2s = pitch2(CH);         // chunk staging pitches (not RESIDENT)
-    constexpr int STAGE2 = 64 * XP2s + 64 * FP2s, OUT2 = 64 * NO / 2;
+    constexpr int SLOT2 = (XNI + FNI) * 64;                           // (DMA) 16-byte units of a slot: a KiB per load instruction
+    constexpr int STAGE2 = DMA ? 2 * SLOT2 : 64 * XP2s + 64 * FP2s, OUT2 = 64 * NO / 2;
     constexpr int ROWS2s = STAGE2 > OUT2 ? STAGE2 : OUT2;
     __shared__ __attribute__((aligned(16))) d2_ lds_s[RESIDENT ? 1 : ROWS2s + TILE2];
     extern __shared__ __attribute__((aligned(16))) d2_ lds_d[];
@@ -173,8 +184,44 @@ __global__ __launch_bounds__(64, (!RESIDENT && !SENS && CACHE == 0 && ndofs(DIM,
     constexpr bool WARM = (WLSQM_SITER_WARM != 0) && !RESIDENT && !DEEP;
     bool inflight = false;                                            // (wave-uniform) chunk Q - 1 of the next pass is on its way in (xr, fr)
     double* const wrow = reinterpret_cast<double*>(lds_d) + lane * FP2r;      // (WCACHE / FCACHE) this lane's weights / values; FP2r: the pitch in doubles (odd)
-    const d2_* const xrow = xs + lane * XP2;
-    const d2_* const frow = fs + lane * FP2;
+    const d2_* const xrow = DMA ? lds + (lane / XCPI) * 64 + (lane % XCPI) * XPC : xs + lane * XP2;      // (DMA: in slot 0; slot q & 1 at + SLOT2)
+    const d2_* const frow = DMA ? lds + XNI * 64 + (lane / FCPI) * 64 + (lane % FCPI) * FPC : fs + lane * FP2;
+    auto dma_fetch = [&](int q, auto nof_tag) __attribute__((always_inline)) {
+        constexpr bool NOF = decltype(nof_tag)::value;
+        const char* const xt = xtile; const char* const ft = ftile;
+        (void)xt; (void)ft;
+        if constexpr (DMA) {
+            unsigned xo = (unsigned)q * (CH * DIM * 8) + (unsigned)xsub * 16u, fo = (unsigned)q * (CH * 8) + (unsigned)fsub * 16u;
+            xo = xo < xrowb ? xo : xrowb - 16u; fo = fo < frowb ? fo : frowb - 16u;
+            const unsigned slot = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(uintptr_t)lds + (unsigned)(q & 1) * (unsigned)(SLOT2 * 16)));
+#pragma unroll
+            for (int i = 0; i < XNI; ++i) {
+                int cc = xc0 + i * XCPI;
+                cc = cc < nvalid ? cc : nvalid - 1;
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(xo + (unsigned)cc * xrowb), "s"(xt), "s"(slot + (unsigned)i * 1024u) : "memory");
+            }
+            if constexpr (!NOF) {
+#pragma unroll
+                for (int i = 0; i < FNI; ++i) {
+                    int cc = fc0 + i * FCPI;
+                    cc = cc < nvalid ? cc : nvalid - 1;
+                    unsigned keep;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep) : "v"(fo + (unsigned)cc * frowb), "s"(ft), "s"(slot + (unsigned)(XNI + i) * 1024u) : "memory");
+                }
+            }
+        }
+    };
+    // wait for a chunk with `younger` (0 / 1) chunks requested behind it (in-order counter: anything else in flight only lengthens the wait)
+    auto dma_wait = [&](bool younger, auto nof_tag) __attribute__((always_inline)) {
+        constexpr bool NOF = decltype(nof_tag)::value;
+        if constexpr (DMA) {
+            if (!younger) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NOF ? XNI : XNI + FNI) : "memory");
+        }
+    };
 
     // One pass over the neighbours, chunks LAST FIRST (descending k, the order of fit_stage.hip).  body(d, f, live, k) per neighbour,
     // after_group(k0) behind every group of GRP neighbours k0 .. k0 + GRP - 1.
@@ -186,8 +233,8 @@ __global__ __launch_bounds__(64, (!RESIDENT && !SENS && CACHE == 0 && ndofs(DIM,
         constexpr int GRP = decltype(grp_tag)::value;                 // neighbours of a lane in flight
         const bool staged = !RESIDENT || fill;
         auto compute = [&](const int q) __attribute__((always_inline)) {
-            const d2_* xq = xrow + (RESIDENT ? q * (CH * DIM / 2) : 0);
-            const d2_* fq = frow + (RESIDENT ? q * (CH / 2) : 0);
+            const d2_* xq = xrow + (RESIDENT ? q * (CH * DIM / 2) : DMA ? (q & 1) * SLOT2 : 0);
+            const d2_* fq = frow + (RESIDENT ? q * (CH / 2) : DMA ? (q & 1) * SLOT2 : 0);
 #pragma unroll
             for (int g = CH / GRP - 1; g >= 0; --g) {
                 double xv[GRP * DIM], fv[GRP];
@@ -231,7 +278,14 @@ __global__ __launch_bounds__(64, (!RESIDENT && !SENS && CACHE == 0 && ndofs(DIM,
             }
             compute(q);
         };
-        if constexpr (DEEP) {
+        if constexpr (DMA) {
+            dma_fetch(Q - 1, nof_tag);
+            for (int q = Q - 1; q >= 0; --q) {
+                if (q >= 1) dma_fetch(q - 1, nof_tag);                // into the slot of chunk q + 1: consumed
+                dma_wait(q >= 1, nof_tag);
+                compute(q);
+            }
+        } else if constexpr (DEEP) {
             fetch_into(xr, fr, Q - 1, nof_tag);
             if (Q > 1) fetch_into(xr2, fr2, Q - 2, nof_tag);
             for (int q = Q - 1; q >= 0; q -= 2) {
@@ -550,7 +604,11 @@ static int launch_stage_refine(const KParams& p, long long K, hipStream_t stream
         // the weights beside the staging rows while four waves per CU still fit (WLSQM_HIP_REFINE_WCACHE=0: never)
         const char* e = getenv("WLSQM_HIP_REFINE_WCACHE");
         const int WP = (Q * CH) | 1;
-        const size_t wbytes = (size_t)64 * WP * 8, stat = (size_t)64 * (pitch2(CH * DIM) + pitch2(CH)) * 16;
+        // (static LDS of the kernel: the padded staging rows, or the DMA form's two slots of a KiB per load instruction — 24 KB for the
+        // 15-unknown systems, whose weight cache therefore ends at 30 neighbours instead of 48)
+        constexpr bool dma15 = (WLSQM_SITER_DMA != 0) && ndofs(DIM, ORDER) == 15;
+        constexpr int xni = 64 / (64 / (CH * DIM * 8 / 16)) + ((64 % (64 / (CH * DIM * 8 / 16))) ? 1 : 0), fni = 64 / (64 / (CH * 8 / 16));
+        const size_t wbytes = (size_t)64 * WP * 8, stat = dma15 ? (size_t)2 * (xni + fni) * 1024 : (size_t)64 * (pitch2(CH * DIM) + pitch2(CH)) * 16;
         size_t budget = 40 * 1024;                                   // four waves per CU (WLSQM_HIP_REFINE_CACHE_KB: A/B)
         if (const char* b = getenv("WLSQM_HIP_REFINE_CACHE_KB")) budget = (size_t)atol(b) * 1024;
         if (!(e && e[0] == '0') && p.max_iter >= 1 && ndofs(DIM, ORDER) > 6 && wbytes + stat <= budget && wbytes + stat <= 64 * 1024) {        // (no opt-in to more than 64 KB of LDS for this kernel)
