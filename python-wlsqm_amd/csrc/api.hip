@@ -322,11 +322,11 @@ int stream_counters_acquire(int** out, size_t ints, hipStream_t stream, int* set
     return WLSQM_OK;
 }
 namespace {
-struct StageHint { int dev; hipStream_t stream; int shape; unsigned char* host; unsigned char* device; };
+struct StageHint { int dev; hipStream_t stream; int shape; unsigned char* host; unsigned char* device; bool unsorted; };
 std::vector<StageHint>& stage_hint_table() { static std::vector<StageHint> t; return t; }
 }  // namespace
-int stage_hint_acquire(int dimension, int order, hipStream_t stream, unsigned char** dev_out, int* sorted, int* unsorted) {
-    *dev_out = nullptr; *sorted = 0; *unsorted = 0;
+int stage_hint_acquire(int dimension, int order, hipStream_t stream, unsigned char** dev_out, bool* unsorted) {
+    *dev_out = nullptr; *unsorted = false;
     int dev = 0;
     WLSQM_HIP_CHECK(hipGetDevice(&dev));
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -344,7 +344,7 @@ int stage_hint_acquire(int dimension, int order, hipStream_t stream, unsigned ch
                 if (stage_hint_table()[i].dev == dev) {
                     StageHint e = stage_hint_table()[i];
                     stage_hint_table().erase(stage_hint_table().begin() + (long)i);
-                    e.stream = stream; e.shape = shape;
+                    e.stream = stream; e.shape = shape; e.unsorted = false;
                     std::memset(e.host, 0, 64);
                     stage_hint_table().push_back(e);
                     hit = &stage_hint_table().back();
@@ -355,13 +355,21 @@ int stage_hint_acquire(int dimension, int order, hipStream_t stream, unsigned ch
             if (hipHostMalloc(reinterpret_cast<void**>(&h), 64, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return WLSQM_OK; }
             if (hipHostGetDevicePointer(reinterpret_cast<void**>(&d), h, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(h); return WLSQM_OK; }
             std::memset(h, 0, 64);
-            stage_hint_table().push_back(StageHint{dev, stream, shape, h, d});
+            stage_hint_table().push_back(StageHint{dev, stream, shape, h, d, false});
             hit = &stage_hint_table().back();
         }
     }
-    // (plain reads of memory the previous launch's groups wrote — or are still writing: a heuristic, never a result)
+    // (plain reads of memory earlier launches' groups wrote — or are still writing: a heuristic, never a result).  Launches are
+    // asynchronous: the previous one has usually not RUN yet when the next is enqueued, so the verdict is sticky — it changes when reports
+    // have arrived and say otherwise, and the slots are cleared only then (a later launch's reports overwrite them)
     volatile unsigned char* v = hit->host;
-    for (int i = 0; i < 64; ++i) { const unsigned char b = v[i]; if (b == 2) ++*sorted; else if (b == 1) ++*unsorted; v[i] = 0; }
+    int n_sorted = 0, n_unsorted = 0;
+    for (int i = 0; i < 64; ++i) { const unsigned char b = v[i]; if (b == 2) ++n_sorted; else if (b == 1) ++n_unsorted; }
+    if (n_sorted + n_unsorted > 0) {
+        hit->unsorted = n_unsorted > n_sorted;
+        for (int i = 0; i < 64; ++i) v[i] = 0;
+    }
+    *unsorted = hit->unsorted;
     *dev_out = hit->device;
     return WLSQM_OK;
 }

@@ -940,7 +940,8 @@ static int launch_stage(const KParams& p, hipStream_t stream) {
     // a group's rows, and the second pass finds them in L2 only with one wave per SIMD resident: 1M cases with shuffled rows, configs[1]
     // 0.218 -> 0.200 ms, configs[4] 0.406 -> 0.373 — while sorted input loses 5-9 % there.  Sortedness is a property of the data, known only
     // on the device: sampled groups report it into host-mapped memory and the NEXT launch of the shape on the stream picks its form from what
-    // the previous one saw (no synchronisation, nothing read back: a stale or missing report only costs speed).
+    // the reports that have arrived say (no synchronisation, nothing enqueued; the verdict is sticky between reports — the previous launch has
+    // usually not run yet when the next is enqueued; a stale or missing report only costs speed).
     // WLSQM_HIP_STAGE_FORM=two / one forces a form (A/B, tests).
     constexpr int NO = ndofs(DIM, ORDER);
     if constexpr (!GATHER && NO <= 10) {
@@ -949,11 +950,9 @@ static int launch_stage(const KParams& p, hipStream_t stream) {
         KParams q = p;
         if (e && (e[0] == 't' || e[0] == 'o')) own_simd = e[0] == 'o';
         else {
-            int n_sorted = 0, n_unsorted = 0;
-            const int rc = stage_hint_acquire(DIM, ORDER, stream, &q.hint, &n_sorted, &n_unsorted);
+            const int rc = stage_hint_acquire(DIM, ORDER, stream, &q.hint, &own_simd);
             if (rc != WLSQM_OK) return rc;
             q.hint_stride = (int)(groups / 64 > 0 ? groups / 64 : 1);
-            own_simd = n_unsorted > n_sorted;
         }
         if (own_simd) hipLaunchKernelGGL((fit_stage_kernel<DIM, ORDER, 5, false>), dim3((unsigned)groups), dim3(64), 0, stream, q);
         else hipLaunchKernelGGL((fit_stage_kernel<DIM, ORDER, 0, false>), dim3((unsigned)groups), dim3(64), 0, stream, q);

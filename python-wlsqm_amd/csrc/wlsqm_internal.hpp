@@ -204,10 +204,11 @@ int scratch_free_async(void* p, hipStream_t stream);
 // the caller falls back to scratch_alloc_async and a clearing kernel.  scratch_free_async ignores these buffers.
 int stream_counters_acquire(int** out, size_t ints, hipStream_t stream, int* set_out = nullptr);      // *set_out: 0 / 1, alternating per call on the stream
 void stream_counters_release_clean(const void* p);
-// The sortedness reports of the previous staged launch of this (dimension, order) on the stream: *sorted / *unsorted = sampled groups of
-// each kind (0 / 0 on the first call), *dev = where this launch's sampled groups report (nullptr inside a graph capture or if host-mapped
-// memory is not to be had: the caller takes its default form).  The slots are cleared for the new launch.
-int stage_hint_acquire(int dimension, int order, hipStream_t stream, unsigned char** dev, int* sorted, int* unsorted);
+// What the staged launches of this (dimension, order) on the stream have reported about their input so far: *unsorted = most sampled groups
+// of the latest reports that have ARRIVED had neighbours in no order (false until a report arrives; sticky between reports — launches are
+// asynchronous), *dev = where this launch's sampled groups report (nullptr inside a graph capture or if host-mapped memory is not to be
+// had: the caller takes its default form).
+int stage_hint_acquire(int dimension, int order, hipStream_t stream, unsigned char** dev, bool* unsorted);
 bool is_stream_counters(const void* p);
 
 // Host mirror of effective_mask() in wlsqm_kernels.hpp (infra.pyx:119-121 quirk): returns the
