@@ -116,6 +116,9 @@ static void fit_case(int dim, int order, int no, int nk, const double* xk, const
     }
     int r2o[35], nr = 0;
     for (int a = 0; a < no; a++) if (!((knowns >> a) & 1)) r2o[nr++] = a;
+    /* infra.pyx:119-121: the reference's nr = no - popcount(knowns) counts stray bits beyond the DOFs too, its remap (:145-200) does not:
+     * the FIRST nr unknown DOFs are solved for, the others are never touched (as wlsqm_oracle.c does it) */
+    nr = no - __builtin_popcountll((unsigned long long)knowns);
     if (nr < 1) return;
     if (flags & V_LDLT) {
         /* knowns to the right-hand side through the assembled matrix, masked full system, unpivoted LDL^T */

@@ -268,58 +268,54 @@ int scratch_alloc_async(void** out, size_t bytes, hipStream_t stream) {
     return WLSQM_OK;
 }
 namespace {
-struct StreamCounters { int dev; hipStream_t stream; int* p; size_t ints; bool dirty; int set; };
-std::vector<StreamCounters>& stream_counters_table() { static std::vector<StreamCounters> t; return t; }
-std::mutex& stream_counters_mutex() { static std::mutex m; return m; }
+struct StreamBuffer { int dev; hipStream_t stream; void* p; size_t bytes; unsigned long long used; };
+std::vector<StreamBuffer>& stream_buffer_table() { static std::vector<StreamBuffer> t; return t; }
+std::mutex& stream_buffer_mutex() { static std::mutex m; return m; }
+unsigned long long g_stream_buffer_clock = 0;
 }  // namespace
-bool is_stream_counters(const void* p) {
-    if (!p) return false;
-    std::lock_guard<std::mutex> lock(stream_counters_mutex());
-    for (const auto& e : stream_counters_table()) if (e.p == p) return true;
-    return false;
-}
-void stream_counters_release_clean(const void* p) {
-    std::lock_guard<std::mutex> lock(stream_counters_mutex());
-    for (auto& e : stream_counters_table()) if (e.p == p) e.dirty = false;
-}
-int stream_counters_acquire(int** out, size_t ints, hipStream_t stream, int* set_out) {
-    *out = nullptr;
-    if (set_out) *set_out = 0;
+int call_scratch_acquire(CallScratch* cs, size_t bytes, hipStream_t stream) {
+    cs->p = nullptr; cs->pooled = false;
     int dev = 0;
     WLSQM_HIP_CHECK(hipGetDevice(&dev));
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
-    // Inside a graph capture the caller's fallback (stream-ordered scratch + a clearing kernel) is used ALWAYS: the counter set is a
-    // launch parameter, a replayed graph would use the same set every time and find it as the previous replay left it.
-    if (cap != hipStreamCaptureStatusNone) return WLSQM_OK;
-    const bool capturing = false;
-    std::lock_guard<std::mutex> lock(stream_counters_mutex());
-    StreamCounters* hit = nullptr;
-    for (auto& e : stream_counters_table()) if (e.dev == dev && e.stream == stream) hit = &e;
-    if (!hit || hit->ints < ints) {
-        if (capturing) return WLSQM_OK;                            // (no allocation inside a capture: the caller's fallback)
-        size_t want = ints < 4096 ? 4096 : ints + ints / 2;
-        int* p = nullptr;
-        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), want * sizeof(int));
-        if (e != hipSuccess) return hip_fail(e, "hipMalloc (stream counters)");
-        if (hit) {
-            (void)hipFreeAsync(hit->p, stream);                     // behind whatever still reads the old one on this stream
-            hit->p = p; hit->ints = want; hit->dirty = true;
-        } else {
-            if (stream_counters_table().size() >= 64) {             // (a process that keeps creating streams: recycle the oldest entry)
-                (void)hipFree(stream_counters_table().front().p);
-                stream_counters_table().erase(stream_counters_table().begin());
-            }
-            stream_counters_table().push_back(StreamCounters{dev, stream, p, want, true, 0});
-            hit = &stream_counters_table().back();
+    if (cap == hipStreamCaptureStatusNone) {
+        // (one lock for the table and for the launches around the buffer: a call holds it for the few microseconds its enqueues take)
+        std::unique_lock<std::mutex> lock(stream_buffer_mutex());
+        auto& tab = stream_buffer_table();
+        StreamBuffer* hit = nullptr;
+        for (auto& e : tab) if (e.dev == dev && e.stream == stream) hit = &e;
+        if (!hit && tab.size() >= 64) {
+            // a process that keeps creating streams: the entry used longest ago goes.  Its stream may be gone: hipFree (which waits for the
+            // device) rather than a stream-ordered free
+            size_t old = 0;
+            for (size_t i = 1; i < tab.size(); ++i) if (tab[i].used < tab[old].used) old = i;
+            (void)hipFree(tab[old].p);
+            tab.erase(tab.begin() + (long)old);
         }
+        if (!hit) { tab.push_back(StreamBuffer{dev, stream, nullptr, 0, 0}); hit = &tab.back(); }
+        if (hit->bytes < bytes) {
+            const size_t want = bytes < 65536 ? 65536 : bytes + bytes / 2;
+            void* p = nullptr;
+            hipError_t e = hipMalloc(&p, want);
+            if (e != hipSuccess) return hip_fail(e, "hipMalloc (call scratch)");
+            if (hit->p) (void)hipFreeAsync(hit->p, stream);          // behind whatever still reads the old one on this stream
+            hit->p = p; hit->bytes = want;
+        }
+        hit->used = ++g_stream_buffer_clock;
+        cs->p = hit->p;
+        cs->lock = std::move(lock);
+        return WLSQM_OK;
     }
-    if (hit->dirty) WLSQM_HIP_CHECK(hipMemsetAsync(hit->p, 0, 4 * sizeof(int), stream));      // both counter sets; the lists behind them are write-before-read
-    hit->dirty = true;                                              // until the user releases it clean
-    hit->set ^= 1;
-    if (set_out) *set_out = hit->set;
-    *out = hit->p;
-    return WLSQM_OK;
+    cs->pooled = true;
+    return scratch_alloc_async(&cs->p, bytes, stream);
+}
+int call_scratch_release(CallScratch* cs, hipStream_t stream) {
+    int rc = WLSQM_OK;
+    if (cs->pooled) rc = scratch_free_async(cs->p, stream);
+    cs->p = nullptr; cs->pooled = false;
+    if (cs->lock.owns_lock()) cs->lock.unlock();
+    return rc;
 }
 namespace {
 struct StageHint { int dev; hipStream_t stream; int shape; unsigned char* host; unsigned char* device; bool unsorted; };
@@ -333,7 +329,8 @@ int stage_hint_acquire(int dimension, int order, hipStream_t stream, unsigned ch
     if (hipStreamIsCapturing(stream, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
     if (cap != hipStreamCaptureStatusNone) return WLSQM_OK;         // (no allocation inside a capture; a replay would report into the same slots for ever)
     const int shape = dimension * 8 + order;
-    std::lock_guard<std::mutex> lock(stream_counters_mutex());
+    static std::mutex hint_mutex;
+    std::lock_guard<std::mutex> lock(hint_mutex);
     StageHint* hit = nullptr;
     for (auto& e : stage_hint_table()) if (e.dev == dev && e.stream == stream && e.shape == shape) hit = &e;
     if (!hit) {
@@ -375,7 +372,6 @@ int stage_hint_acquire(int dimension, int order, hipStream_t stream, unsigned ch
 }
 int scratch_free_async(void* p, hipStream_t stream) {
     if (!p) return WLSQM_OK;
-    if (is_stream_counters(p)) return WLSQM_OK;                     // (persistent: see stream_counters_acquire)
     WLSQM_HIP_CHECK(hipFreeAsync(p, stream));
     return WLSQM_OK;
 }

@@ -37,9 +37,9 @@
 //   * the neighbour rows of the 64 cases of a wave reach their lanes through LDS in chunks of 8 neighbours: global loads are
 //     coalesced 16-byte pieces of whole 128- / 192-byte runs (the strict register kernel's lanes each read their own row: 64 cache
 //     lines per load instruction), the next chunk is in flight in registers while the current one is consumed.
-// One lane per case; a wave owns 64 consecutive cases.  Round 5: cases WITH known DOFs are taken too — any mask
-// inside the polynomial's DOFs, the reference's default knowns = b?_F (simple.pyx:60-61) included:
-//   * systems up to 10 unknowns: the MASKED FULL system.  Known rows and columns of the assembled matrix become rows of the identity; the
+// One lane per case; a wave owns 64 consecutive cases.  EVERY knowns mask is taken (round 5: masks inside the polynomial's DOFs, the
+// reference's default knowns = b?_F of simple.pyx:60-61 included; round 6: masks with stray bits beyond them too):
+//   * the MASKED FULL system.  Known rows and columns of the assembled matrix become rows of the identity; the
 //     equilibration leaves them at scale 1 (their only quotient is 1 / (1 x 1)) and never sees them in another row's maximum (their
 //     quotients there are 0), the pivot search never picks them for another column (their entries are 0 and the first maximum wins)
 //     and their multipliers are 0: every operation on the unknowns' entries is the reduced system's (infra.pyx:145-200 remap),
@@ -47,16 +47,19 @@
 //   * the known values move to the right-hand side as the reference does it (impl.pyx:792-823): term by term into b[j], every term
 //     carrying the row scale — so after the equilibration, in one more pass over the neighbours PER known DOF (the sums of two knowns
 //     must not interleave: b[j] walks all neighbours of the first before the second).  The rows come back from L2 / the Infinity Cache.
-//   * 2D order 4 with exactly the function value known (BASELINE configs[2]: the 14 x 14 system) has a kernel of its own (RED1).  There
-//     the mirrored triangle is NOT free (profiles/r03_attribution.txt: 1.4e-4 from the reference, whose own noise is 3.5e-4, where the
-//     reference's operations one for one are 4e-7 away), so this form replays ALL of them — all 196 sums (w c_m) c_j of impl.pyx:601 in
-//     two passes of seven matrix rows each, the equilibration with its separate row and column factors, the reduced system with
-//     compile-time indices — and returns the bits of the strict kernels.  The LU carries the forward substitution
-//     along as an augmented column (the multipliers are never stored) and keeps its top rows in LDS.  The strict mode sends the same
-//     cases here as well.
-// Sensitivities, refinement, 1D fits, the other masks of 2D order 4 and masks with stray bits beyond the polynomial's DOFs
-// (infra.pyx:119-121) are NOT taken here: in accurate mode they run the strict kernels (the reference's operations one for one, i.e. at
-// least as close to the reference).  Which kernel takes a case depends on that case alone.
+//   * stray mask bits (infra.pyx:119-121: nr = no - popcount(knowns) counts them, remap does not): the reference solves for the FIRST nr
+//     unknown DOFs only and never touches the others — here the others are rows of the identity like a known DOF, without an
+//     elimination pass and never written (wlsqm_kernels.hpp: effective_mask; the same bits as the reduced system, as above).
+// ONE LAUNCH PER CALL (round 6).  Rounds 4-5 sent a group the speculative pass could not vouch for (unsorted
+// neighbours, an operand outside the safe range, the partial last group) to a REDO LIST walked by a second kernel, and cases with stray
+// mask bits to a LEFTOVER LIST walked by the strict kernels: three launches per call, two of them idle in the common case, and a
+// persistent per-stream counter buffer to feed them (~25 us of a 0.28 ms call on the driver's box; ADVICE r5: not safe for two host
+// threads on one stream).  Now the wave that cannot vouch for its group runs the two-pass form ON THE SPOT (a wave-uniform branch inside
+// the same kernel: the same code as before, the same bits), and no case is left over: no lists, no counters, no second kernel.
+// 2D order 4, sensitivities, refinement and 1D fits are NOT taken here: in accurate mode they run the strict kernels (the reference's
+// operations one for one, i.e. at least as close to the reference).  (Round 5's one-lane-per-case strict form of 2D order 4 with F known —
+// `LANE14`: bit-identical to the oracle, 1 693 spilled registers, slower than the row-per-lane kernel — is gone from the library; it is
+// in the history at commit c9ef97d.)
 #include <atomic>
 #include <type_traits>
 
@@ -94,12 +97,6 @@ constexpr int GRP = WLSQM_ACC_GRP < CH ? WLSQM_ACC_GRP : CH;                    
 template <int N> __host__ __device__ constexpr int utri(int i, int m) { return i * N - i * (i - 1) / 2 + (m - i); }   // i <= m < N
 
 __host__ __device__ constexpr int minw(int NO) { return NO <= 6 ? WLSQM_ACC_MINW6 : WLSQM_ACC_MINW10; }
-#ifndef WLSQM_ACC_LU_LDS_ROWS
-#define WLSQM_ACC_LU_LDS_ROWS 4     // top rows of the 14 x 14 matrix kept in LDS behind the staging rows (56 of 196 entries: 28 KB + 8 KB of 4-neighbour chunks per wave, four waves per CU)
-#endif
-__host__ __device__ constexpr int lu_lds_rows(int N) { return N > 10 ? WLSQM_ACC_LU_LDS_ROWS : 0; }
-// neighbours per staged chunk: the 14 x 14 form stages 4 (8 KB instead of 14 KB: the rest of its 40 KB share of the LDS holds matrix rows)
-__host__ __device__ constexpr int chunk_of(int N) { return N > 10 ? 4 : CH; }
 
 }  // namespace acc
 
@@ -276,196 +273,10 @@ __device__ __forceinline__ void lu_solve_store(const double (&U)[N * (N + 1) / 2
     }
 }
 
-// The same operations for a system that does not fit the lane's registers beside its own LU (2D order 4 with the function value known:
-// 14 x 14, 196 + 14 doubles): the forward substitution of dgetrs RIDES ALONG as an augmented column — b's rows are exchanged with the
-// matrix rows and b[i] -= l_i b[c0] follows row i's update, the same operations on the same values in the same order as exchanging
-// all rows first and substituting afterwards (a multiplier l_i is applied to b[i] after the same earlier steps either way) — so the
-// multipliers are never stored and a finished row of U is only read again by the back substitution.  The matrix is addressed through
-// at / put (the caller keeps its top rows in LDS, entry (r, m) of lane l at [(r N + m) 64 + l]: conflict-free, the others in
-// registers) and is factored in place.  Rows are exchanged in two sweeps of selects: the pivot row is gathered from the candidates,
-// then every candidate takes row c0's old entries if it was the pivot.
-template <int N, class GET, class PUT>
-__device__ __forceinline__ void lu_aug_solve_store(GET&& at, PUT&& put, const double (&rs)[N], const double (&cs)[N], double (&b)[N], double* fio) {
-#pragma unroll
-    for (int m = 0; m < N; ++m)
-#pragma unroll
-        for (int i = 0; i < N; ++i) put(i, m, at(i, m) * (rs[i] * cs[m]));          // apply_scaling_c (lapackdrivers.pyx:293-299)
-#pragma unroll
-    for (int c0 = 0; c0 < N; ++c0) {
-        double col[N];                                                // column c0 of the rows from c0 on
-#pragma unroll
-        for (int i = c0; i < N; ++i) col[i] = at(i, c0);
-        int pv = c0; double best = fabs(col[c0]), pval = col[c0];
-#pragma unroll
-        for (int i = c0 + 1; i < N; ++i) { const double v = fabs(col[i]); if (v > best) { best = v; pv = i; pval = col[i]; } }
-        double prow[N], pb = b[c0];                                   // the pivot row right of the diagonal, and its b
-#pragma unroll
-        for (int m = c0 + 1; m < N; ++m) prow[m] = at(c0, m);
-        const bool exch = __any(pv != c0);                            // wave-uniform
-        if (exch) {
-            const double c00 = col[c0], b00 = pb;
-#pragma unroll
-            for (int i = c0 + 1; i < N; ++i) {
-                const bool sw = (pv == i);
-#pragma unroll
-                for (int m = c0 + 1; m < N; ++m) { const double v = at(i, m); prow[m] = sw ? v : prow[m]; }
-                pb = sw ? b[i] : pb;
-            }
-#pragma unroll
-            for (int i = c0 + 1; i < N; ++i) {
-                const bool sw = (pv == i);
-                col[i] = sw ? c00 : col[i];
-                b[i] = sw ? b00 : b[i];
-            }
-            // (row i's entries right of the diagonal take row c0's old ones inside the update below: one read and one write per entry)
-            if (pval != 0.) {
-                const double r = 1. / pval;
-#pragma unroll
-                for (int i = c0 + 1; i < N; ++i) col[i] *= r;
-            }
-#pragma unroll
-            for (int i = c0 + 1; i < N; ++i) {
-                const bool sw = (pv == i);
-#pragma unroll
-                for (int m = c0 + 1; m < N; ++m) { const double v = at(i, m); put(i, m, (sw ? at(c0, m) : v) - col[i] * prow[m]); }      // (row c0 is still in place)
-                b[i] -= col[i] * pb;
-            }
-        } else {
-            if (pval != 0.) {
-                const double r = 1. / pval;
-#pragma unroll
-                for (int i = c0 + 1; i < N; ++i) col[i] *= r;
-            }
-#pragma unroll
-            for (int i = c0 + 1; i < N; ++i) {
-#pragma unroll
-                for (int m = c0 + 1; m < N; ++m) put(i, m, at(i, m) - col[i] * prow[m]);
-                b[i] -= col[i] * pb;
-            }
-        }
-        b[c0] = pb;
-        put(c0, c0, pval);
-#pragma unroll
-        for (int m = c0 + 1; m < N; ++m) put(c0, m, prow[m]);
-        __builtin_amdgcn_sched_barrier(0);                            // one elimination step at a time (fit_stage.hip: interleaved steps keep more of the matrix live than there are registers)
-    }
-#pragma unroll
-    for (int c0 = N - 1; c0 >= 0; --c0) {
-        b[c0] /= at(c0, c0);
-#pragma unroll
-        for (int i = 0; i < c0; ++i) b[i] -= at(i, c0) * b[c0];
-    }
-#pragma unroll
-    for (int i = 0; i < N; ++i) fio[i] = b[i] * cs[i];
-}
-
-// rescale_ruiz2001_c (lapackdrivers.pyx:553-623) on the reference's own, not bit-symmetric matrix (A[j][m] sums (w c_m) c_j, A[m][j]
-// sums (w c_j) c_m: impl.pyx:601) — the operations of fit_strict_reg_kernel.  Returns whether every running scale factor stayed in
-// the safe range of the fast sequences.
-// DIAG (fast path only; see ruiz_sym): once the diagonal quotients of a sweep are within 1 / c_max^2 of each other every row and every
-// column maximum IS its diagonal quotient — the off-diagonal quotient (i, m) squared is c_im^2 q_ii q_mm times (DCp[i] DRp[m]) /
-// (DRp[i] DCp[m]), a ratio of running products that agree to a few ulps (the matrix is symmetric to rounding), far inside the 2^-16
-// margin — and the other N (N - 1) quotients of the sweep are not computed: the same doubles.  The test is wave-uniform.
-template <int N, class OPS, bool DIAG = false, class GET>
-__device__ __forceinline__ bool ruiz_full(GET&& at, double (&rs)[N], double (&cs)[N]) {
-    using strict::ruiz_epsilon;
-    double DRp[N], DCp[N], DR[N], DC[N];
-    bool in_range = true;
-#pragma unroll
-    for (int i = 0; i < N; ++i) { rs[i] = 1.; cs[i] = 1.; DRp[i] = 1.; DCp[i] = 1.; }
-    double thresh = 2.;                                               // c_max^2 (1 + 2^-16); NaN / inf (a zero diagonal entry): never passes
-    if constexpr (DIAG) {
-        double ra[N], cm2 = 0.;
-#pragma unroll
-        for (int i = 0; i < N; ++i) ra[i] = __builtin_amdgcn_rcp(at(i, i));
-#pragma unroll
-        for (int m = 0; m < N; ++m)
-#pragma unroll
-            for (int i = 0; i < N; ++i)
-                if (i != m) { const double a = at(i, m); cm2 = __builtin_fmax(cm2, (a * a) * (ra[i] * ra[m])); }
-        thresh = cm2 * (1. + 0x1p-16);
-        if (!(thresh >= 0.)) thresh = 2.;
-    }
-    for (int it = 0; it < 100; ++it) {
-        bool diag_only = false;
-        if constexpr (DIAG) {
-            if (it > 0) {
-                double qlo = 0., qhi = 0.;
-#pragma unroll
-                for (int i = 0; i < N; ++i) {
-                    const double q = fabs(OPS::div_seeded(at(i, i), DRp[i] * DCp[i], rs[i] * cs[i]));
-                    DR[i] = OPS::maxnum(0., q); DC[i] = DR[i];
-                    qlo = i ? __builtin_fmin(qlo, DR[i]) : DR[i]; qhi = i ? __builtin_fmax(qhi, DR[i]) : DR[i];
-                }
-                diag_only = __all(thresh * qhi <= qlo);               // (a NaN quotient fails it)
-            }
-        }
-        if (!diag_only) {
-#pragma unroll
-            for (int i = 0; i < N; ++i) { DR[i] = 0.; DC[i] = 0.; }
-#pragma unroll
-            for (int m = 0; m < N; ++m) {
-#pragma unroll
-                for (int i = 0; i < N; ++i) {
-                    // (the row and the column pass divide by the same product: one quotient serves both maxima; fast path: rs[i] cs[m] is
-                    // within 2^-48 of its reciprocal — the seed)
-                    const double q = fabs(OPS::div_seeded(at(i, m), DRp[i] * DCp[m], rs[i] * cs[m]));
-                    DC[m] = OPS::maxnum(DC[m], q);
-                    DR[i] = OPS::maxnum(DR[i], q);
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            double hr, hc;
-            DR[i] = OPS::sqrt_h(DR[i], hr); DC[i] = OPS::sqrt_h(DC[i], hc);
-            DRp[i] *= DR[i]; rs[i] = OPS::div_by_root(rs[i], DR[i], hr);
-            DCp[i] *= DC[i]; cs[i] = OPS::div_by_root(cs[i], DC[i], hc);
-            in_range = in_range && DRp[i] >= SCALE_LO && DRp[i] <= SCALE_HI && DCp[i] >= SCALE_LO && DCp[i] <= SCALE_HI;
-        }
-        double accm = fabs(1. - DR[0] * DR[0]);
-#pragma unroll
-        for (int i = 1; i < N; ++i) { const double tmp = fabs(1. - DR[i] * DR[i]); if (tmp > accm) accm = tmp; }
-        if (accm < ruiz_epsilon) {
-            accm = fabs(1. - DC[0] * DC[0]);
-#pragma unroll
-            for (int i = 1; i < N; ++i) { const double tmp = fabs(1. - DC[i] * DC[i]); if (tmp > accm) accm = tmp; }
-            if (accm < ruiz_epsilon) break;
-        }
-    }
-    return in_range;
-}
-
-// range check of the fast sweeps on the full matrix: every nonzero entry in the safe range, no zero row and no zero column
-template <int N, class GET>
-__device__ __forceinline__ bool entries_in_range_full(GET&& at) {
-    bool ok = true;
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        double rowmax = 0., colmax = 0.;
-#pragma unroll
-        for (int m = 0; m < N; ++m) {
-            const double a = fabs(at(i, m)), t2 = fabs(at(m, i));
-            ok = ok && (a == 0. || (a >= RANGE_LO && a <= RANGE_HI));
-            rowmax = a > rowmax ? a : rowmax; colmax = t2 > colmax ? t2 : colmax;
-        }
-        ok = ok && rowmax >= RANGE_LO && colmax >= RANGE_LO;
-    }
-    return ok;
-}
-
 }  // namespace acc
-
 // DENSE: contiguous rows xk[ncases][K][DIM], fk[ncases][K] with 16-byte aligned bases and rows (staged through LDS); otherwise the
 // rows are read per lane through strict::Rows (any strides, index-based input, order buckets) — the same arithmetic, the same bits.
-// Work lists of an accurate-mode launch (device ints, stream-ordered scratch): [0] number of REDO groups, [1] number of LEFTOVER
-// groups, [2 .. 2 + G) the redo groups, [2 + G .. 2 + 2 G) the leftover groups (G = 64-case groups of the launch).
-//   redo:     the speculative kernel could not vouch for a group (its guess of the largest squared distance was wrong, or an
-//             operand left the safe range of the fast sequences): the two-pass kernel fits the group again, from scratch;
-//   leftover: the group holds a case this kernel does not take (takes_case below): the strict kernels fit those cases (they stay
-//             idle when there are none).
-struct AccLists { int* ws; long long ngroups; int no_run_store; int set; };      // no_run_store: WLSQM_HIP_ACCURATE_RUN_STORE=0 (A/B); set: the counter set of this call
-
+//
 // One 64-case group.  SPEC (dense rows only): ONE pass over the neighbours for the sums.  The weights need the largest squared distance
 // of the case before the first term can be summed, which is what makes the reference (and the two-pass form of this kernel) read every
 // neighbourhood twice — 1.31 GB instead of 0.85 through the fabric per 1M configs[1] cases, and a first pass whose few
@@ -473,41 +284,39 @@ struct AccLists { int* ws; long long ngroups; int no_run_store; int set; };     
 // are sorted by distance (scipy's cKDTree.query, wlsqm.hip.knn: the reference's examples and every BASELINE config), so the LAST
 // neighbour is the farthest: the pass runs with that guess while it also tracks the true maximum, and the guess is VERIFIED bit for
 // bit afterwards.  A group with a wrong guess (unsorted neighbours: a ball query) or an operand outside the safe range of the fast
-// sequences is written to the redo list and fitted again by the two-pass kernel: speculation, never approximation.
-template <int DIM, int ORDER, bool DENSE, bool SPEC, bool RED1>
-__device__ __forceinline__ void accurate_group(const KParams& p, const long long t0, const AccLists& lists, double* const lds) {
+// sequences is fitted again, from scratch, by the two-pass form: speculation, never approximation.
+// Returns true (wave-uniform, SPEC only) when the caller must run the two-pass form on this group; nothing has been stored then.
+template <int DIM, int ORDER, bool DENSE, bool SPEC>
+__device__ __forceinline__ bool accurate_group(const KParams& p, const long long t0, double* const lds) {
     using namespace strict;
     using namespace acc;
     static_assert(!SPEC || DENSE, "the speculative single pass stages dense rows");
-    constexpr int NO = ndofs(DIM, ORDER);
-    constexpr int O0 = RED1 ? 1 : 0, N = NO - O0, NE = N * (N + 1) / 2;      // the system: DOFs O0 .. NO - 1
-    constexpr unsigned FULL = (NO >= 32) ? ~0u : ((1u << NO) - 1u);
-    constexpr int CH = chunk_of(N);
+    constexpr int N = ndofs(DIM, ORDER), NE = N * (N + 1) / 2;
+    constexpr unsigned FULL = (N >= 32) ? ~0u : ((1u << N) - 1u);
     constexpr int XPC = CH * DIM * 8 / 16, FPC = CH * 8 / 16;        // 16-byte pieces of one case's chunk: coordinates, values
     constexpr int XPITCH = CH * DIM + 2, FPITCH = CH + 2;            // doubles per staged row (+ 16 bytes: conflict-free b128 reads)
     double* const xs = lds;
     double* const fs = lds + 64 * XPITCH;
 
     const long long ncases = live_cases(p);
+    // the speculative form moves whole 64-case groups in whole chunks only (no predicated loads in its loop): the last, partial group
+    // of a launch is the clean-up kernel's (the launcher sends neighbour counts that are not a multiple of CH to the two-pass form altogether)
+    if constexpr (SPEC) { if (ncases - t0 < 64) return true; }
     const int lane = threadIdx.x;
     const long long t = t0 + lane;
     const bool in_batch = t < ncases;
     const long long j = in_batch ? (p.case_index ? p.case_index[t] : t) : 0;
     // (p.do_sens / p.iterative never reach this kernel)
-    const long long kn = in_batch ? p.knowns[j * p.sknowns] : 0;
-    const bool mine = in_batch && accurate_takes_case<NO, RED1>(kn);
-    const unsigned known = mine ? ((unsigned)kn & FULL) : 0u;         // RED1: 1
-    const bool active = mine && known != FULL;                        // every DOF known: nothing to solve (impl.pyx:740-742)
-    if constexpr (SPEC) {
-        if (__any(in_batch && !mine) && lane == 0) lists.ws[ACC_LIST_BASE + lists.ngroups + atomicAdd(lists.ws + 2 * lists.set + 1, 1)] = (int)(t0 >> 6);
-        // the speculative kernel moves whole 64-case groups in whole chunks only (no predicated loads in its loop): the last,
-        // partial group of a launch goes to the two-pass kernel (the launcher sends neighbour counts that are not a multiple of CH there altogether)
-        if (ncases - t0 < 64) {
-            if (__any(active) && lane == 0) lists.ws[ACC_LIST_BASE + atomicAdd(lists.ws + 2 * lists.set, 1)] = (int)(t0 >> 6);
-            return;
-        }
+    // the mask: `known` = rows of the identity, never written (known DOFs, and the unknown DOFs the reference's nr leaves out when the mask
+    // has stray bits: effective_mask); `elim` = the DOFs whose value moves to the right-hand side (impl.pyx:792-823)
+    unsigned known = 0u, elim = 0u;
+    if (in_batch) {
+        unsigned long long k64, d64;
+        effective_mask<N>(p.knowns[j * p.sknowns], k64, d64);
+        known = (unsigned)k64; elim = (unsigned)(k64 & ~d64);
     }
-    if (!__any(active)) return;
+    const bool active = in_batch && known != FULL;                    // every DOF known: nothing to solve (impl.pyx:740-742)
+    if (!__any(active)) return false;
     const int K = (int)p.max_nk;
     const int nk = active ? min(p.nk[j * p.snk], K) : 0;
     const bool uniform = active ? (p.wm[j * p.swm] == WLSQM_WEIGHT_UNIFORM) : true;
@@ -545,8 +354,8 @@ __device__ __forceinline__ void accurate_group(const KParams& p, const long long
     const unsigned xg0 = (unsigned)xc0 * xrowb + (unsigned)xsub * 16u, fg0 = (unsigned)fc0 * frowb + (unsigned)fsub * 16u;
     const bool xlane = lane < XCPI * XPC;
     d2_ xr[DENSE ? XNI : 1], fr[DENSE ? FNI : 1];
-    // pass 1 (largest squared distance) does a few instructions per neighbour: a chunk does not cover the latency of the next
-    // one's loads.  It keeps W1 chunks in flight instead (their registers are free: the matrix is not live yet).
+    // pass 1 of the two-pass form (largest squared distance) does a few instructions per neighbour: a chunk does not cover the latency of
+    // the next one's loads.  It keeps W1 chunks in flight instead (their registers are free: the matrix is not live yet).
     constexpr int W1 = DENSE ? (XNI <= 8 ? WLSQM_ACC_W1 : 2) : 1;
     d2_ xw[W1][DENSE ? XNI : 1];
     const char* const xtile = DENSE ? reinterpret_cast<const char*>(p.xk + t0 * (long long)K * DIM) : nullptr;
@@ -602,7 +411,7 @@ __device__ __forceinline__ void accurate_group(const KParams& p, const long long
         const double* xrow = xs + lane * XPITCH;
         const double* frow = fs + lane * FPITCH;
         // (the 10-unknown systems run one wave per SIMD with registers to spare: the whole chunk at once, 0.758 against 0.809 ms)
-        constexpr int GRP = N > 10 ? 2 : N > 6 ? CH : acc::GRP;
+        constexpr int GRP = N > 6 ? CH : acc::GRP;
         if (SPEC || (q + 1) * CH <= K) {
 #pragma nounroll
             for (int g = 0; g < CH / GRP; ++g) {
@@ -697,74 +506,37 @@ __device__ __forceinline__ void accurate_group(const KParams& p, const long long
         else run_pass_windowed(std::true_type{}, next_want_f, consume);
     };
 
-    // SYM: the upper triangle U (the accurate mode of the systems up to 10 unknowns).  RED1: all N x N sums, entry (row j, column m) —
-    // rows [0, R0) in LDS behind the staging rows (entry (r, m) of lane l at [(r N + m) 64 + l]), rows [R0, N) in registers; 196
-    // doubles beside the equilibration's 84 are more than a lane's 512 registers hold.
-    constexpr int R0 = lu_lds_rows(N);
-    double U[RED1 ? (N - R0) * N : NE], b[N];
-    double* const Ltop = lds + (DENSE ? 64 * XPITCH + 64 * FPITCH : 0) + lane;
-    // (the empty asm keeps an LDS read a VALUE: left alone, the optimizer turns `sw ? lds_entry : register_entry` into a load through a
-    // selected generic pointer and the register rows become a stack array — 1.7 KB of scratch per lane)
-    auto mat = [&](int r, int m) __attribute__((always_inline)) -> double {
-        if (r < R0) { double v = Ltop[(r * N + m) * 64]; asm("" : "+v"(v)); return v; }
-        return U[(r - R0) * N + m];
-    };
-    auto mat_put = [&](int r, int m, double v) __attribute__((always_inline)) { if (r < R0) Ltop[(r * N + m) * 64] = v; else U[(r - R0) * N + m] = v; };
-    if constexpr (!RED1) {
+    // the upper triangle U of the normal matrix and the right-hand side sums
+    double U[NE], b[N];
 #pragma unroll
-        for (int e = 0; e < NE; ++e) U[e] = 0.;
-    }
+    for (int e = 0; e < NE; ++e) U[e] = 0.;
 #pragma unroll
     for (int i = 0; i < N; ++i) b[i] = 0.;
-    // make_A (impl.pyx:566-602) and the right-hand side sums of solve (impl.pyx:768-787): one neighbour's terms (SYM)
-    auto add_terms = [&](const double (&c)[NO], double w, double f) __attribute__((always_inline)) {
+    // make_A (impl.pyx:566-602) and the right-hand side sums of solve (impl.pyx:768-787): one neighbour's terms
+    auto add_terms = [&](const double (&c)[N], double w, double f) __attribute__((always_inline)) {
         const double wf = w * f;
 #pragma unroll
         for (int om = 0; om < N; ++om) {
-            const double wc = w * c[om + O0];
+            const double wc = w * c[om];
 #pragma unroll
-            for (int oj = 0; oj <= om; ++oj) U[utri<N>(oj, om)] += wc * c[oj + O0];
+            for (int oj = 0; oj <= om; ++oj) U[utri<N>(oj, om)] += wc * c[oj];
         }
 #pragma unroll
-        for (int oj = 0; oj < N; ++oj) b[oj] += wf * c[oj + O0];
+        for (int oj = 0; oj < N; ++oj) b[oj] += wf * c[oj];
     };
-    // RED1: the matrix rows [J0, J1) of one neighbour into `acc` (a pass sums 4-5 rows: 56-70 accumulators fit the lane's
-    // architectural registers beside the monomials; all 196 do not), the right-hand side with the first rows
-    auto add_rows = [&](auto j0_tag, auto j1_tag, double (&acc)[5 * (RED1 ? N : 1)], const double (&c)[NO], double w, double f) __attribute__((always_inline)) {
-        constexpr int J0 = decltype(j0_tag)::value, J1 = decltype(j1_tag)::value;
-        static_assert(J1 - J0 <= 5, "rows per pass");
-#pragma unroll
-        for (int om = 0; om < N; ++om) {
-            const double wc = w * c[om + O0];
-#pragma unroll
-            for (int oj = J0; oj < J1; ++oj) acc[(oj - J0) * N + om] += wc * c[oj + O0];
-        }
-        if constexpr (J0 == 0) {
-            const double wf = w * f;
-#pragma unroll
-            for (int oj = 0; oj < N; ++oj) b[oj] += wf * c[oj + O0];
-        }
-    };
-    constexpr int JA = (N + 2) / 3, JB = 2 * JA < N ? 2 * JA : N;     // three passes over the neighbours: rows [0, JA), [JA, JB), [JB, N)
-    using T0 = std::integral_constant<int, 0>;
-    using TA = std::integral_constant<int, JA>;
-    using TB = std::integral_constant<int, JB>;
-    using TN = std::integral_constant<int, N>;
     // Known DOFs of the masked full system (the header): rows of the identity, right-hand side 0 (a wave-uniform test: the common
-    // wave has none).  RED1 assembles the reduced system directly.
-    const bool any_known = !RED1 && __any(active && known != 0u);
+    // wave has none).
+    const bool any_known = __any(active && known != 0u);
     auto mask_knowns = [&]() __attribute__((always_inline)) {
-        if constexpr (!RED1) {
-            if (any_known) {
+        if (any_known) {
 #pragma unroll
-                for (int i = 0; i < N; ++i) {
+            for (int i = 0; i < N; ++i) {
 #pragma unroll
-                    for (int m = i; m < N; ++m) {
-                        const bool kk = ((known >> i) | (known >> m)) & 1u;
-                        U[utri<N>(i, m)] = kk ? (i == m ? 1. : 0.) : U[utri<N>(i, m)];
-                    }
-                    b[i] = ((known >> i) & 1u) ? 0. : b[i];
+                for (int m = i; m < N; ++m) {
+                    const bool kk = ((known >> i) | (known >> m)) & 1u;
+                    U[utri<N>(i, m)] = kk ? (i == m ? 1. : 0.) : U[utri<N>(i, m)];
                 }
+                b[i] = ((known >> i) & 1u) ? 0. : b[i];
             }
         }
     };
@@ -775,235 +547,205 @@ __device__ __forceinline__ void accurate_group(const KParams& p, const long long
     auto eliminate = [&](const double (&rs)[N], auto&& weight_of) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < N; ++i) b[i] = rs[i] * b[i];
-        if (!RED1 && !any_known) return;
-        unsigned rem = active ? known : 0u;
+        if (!any_known) return;
+        unsigned rem = active ? elim : 0u;
         while (__any(rem != 0u)) {                                    // wave-uniform
             const bool has = rem != 0u;
             const int om = has ? (__ffs(rem) - 1) : 0;
             rem &= rem - 1u;
             const double fv = has ? fio[om] : 0.;
-            const bool only_f = RED1 || __all(!has || om == 0);       // c[k, 0] = 1: the product with it is exact and skipped
+            const bool only_f = __all(!has || om == 0);               // c[k, 0] = 1: the product with it is exact and skipped
             pass(false, false, false, false, [&](int, bool live, const double (&d)[DIM], double) {
-                double c[NO];
+                double c[N];
                 const double d2 = make_c<DIM, ORDER>(d, c);
                 double w = weight_of(d2);
                 w = live ? w : 0.;
                 double t = fv * w;
-                if (!only_f) t = t * pick<NO>(c, om);
+                if (!only_f) t = t * pick<N>(c, om);
 #pragma unroll
-                for (int i = 0; i < N; ++i) b[i] -= t * c[i + O0] * rs[i];
+                for (int i = 0; i < N; ++i) b[i] -= t * c[i] * rs[i];
             });
         }
-        if constexpr (!RED1) {
 #pragma unroll
-            for (int i = 0; i < N; ++i) b[i] = ((known >> i) & 1u) ? 0. : b[i];
+        for (int i = 0; i < N; ++i) b[i] = ((known >> i) & 1u) ? 0. : b[i];
+    };
+    auto solve_store = [&](const double (&rs)[N]) __attribute__((always_inline)) {
+        // A full group of cases without a known DOF and contiguous fi rows: the wave's 64 rows are ONE run of 64 N doubles; they go
+        // through LDS (the staging rows are free: the last pass is over) and leave as whole 16-byte pieces, non-temporal — separate
+        // 8-byte stores at a row pitch are partial-sector writes (fit_stage.hip: -2.5 % on configs[1]).  Wave-uniform choice.
+        // (systems up to 6 unknowns: the 10-unknown kernels are at their 512 registers and paid for it with spills in their sweeps)
+        const bool run = DENSE && N <= 6 && (64 * N) % 2 == 0 && (N * 64 * 8 <= (int)sizeof(double) * (64 * XPITCH + 64 * FPITCH)) && nvalid == 64 &&
+                         !p.case_index && p.sfi_j == N && ((reinterpret_cast<uintptr_t>(p.fi) & 15u) == 0) && __all(active && known == 0u);
+        if (active) lu_solve_store<N>(U, rs, b, known, run ? nullptr : fio);
+        if (run) {
+            __syncthreads();                                          // the last chunk has been read
+#pragma unroll
+            for (int i = 0; i < N; ++i) lds[lane * N + i] = b[i];
+            __syncthreads();
+            d2_* out = reinterpret_cast<d2_*>(p.fi + t0 * N);
+            const d2_* src = reinterpret_cast<const d2_*>(lds);
+#pragma unroll
+            for (int q = lane; q < 64 * N / 2; q += 64) __builtin_nontemporal_store(src[q], &out[q]);
         }
     };
-    auto solve_store = [&](const double (&rs)[N], const double (&cs)[N]) __attribute__((always_inline)) {
-        if constexpr (RED1) { if (active) lu_aug_solve_store<N>(mat, mat_put, rs, cs, b, fio + O0); }
-        else {
-            // A full group of cases without a known DOF and contiguous fi rows: the wave's 64 rows are ONE run of 64 N doubles; they go
-            // through LDS (the staging rows are free: the last pass is over) and leave as whole 16-byte pieces, non-temporal — separate
-            // 8-byte stores at a row pitch are partial-sector writes (fit_stage.hip: -2.5 % on configs[1]).  Wave-uniform choice.
-            // (systems up to 6 unknowns: the 10-unknown kernels are at their 512 registers and paid for it with spills in their sweeps)
-            const bool run = DENSE && N <= 6 && !lists.no_run_store && (64 * N) % 2 == 0 && (N * 64 * 8 <= (int)sizeof(double) * (64 * XPITCH + 64 * FPITCH)) && nvalid == 64 &&
-                             !p.case_index && p.sfi_j == N && ((reinterpret_cast<uintptr_t>(p.fi) & 15u) == 0) && __all(active && known == 0u);
-            if (active) lu_solve_store<N>(U, rs, b, known, run ? nullptr : fio);
-            if (run) {
-                __syncthreads();                                      // the last chunk has been read
-#pragma unroll
-                for (int i = 0; i < N; ++i) lds[lane * N + i] = b[i];
-                __syncthreads();
-                d2_* out = reinterpret_cast<d2_*>(p.fi + t0 * N);
-                const d2_* src = reinterpret_cast<const d2_*>(lds);
-#pragma unroll
-                for (int q = lane; q < 64 * N / 2; q += 64) __builtin_nontemporal_store(src[q], &out[q]);
-            }
-        }
-    };
-    // the equilibration: true when the fast sequences could vouch for it
-    auto equilibrate = [&](auto ops_tag, double (&rs)[N], double (&cs)[N]) __attribute__((always_inline)) -> bool {
-        using OPS = decltype(ops_tag);
-        if constexpr (RED1) return ruiz_full<N, OPS, std::is_same<OPS, FastOps>::value && SPEC && WLSQM_ACC_RUIZ_DIAG != 0>(mat, rs, cs);
-        else return ruiz_sym<N, OPS, std::is_same<OPS, FastOps>::value && SPEC && WLSQM_ACC_RUIZ_DIAG != 0>(U, rs);
-    };
-    auto in_range = [&]() __attribute__((always_inline)) -> bool {
-        if constexpr (RED1) return entries_in_range_full<N>(mat); else return entries_in_range<N>(U);
-    };
-    // RED1: one pass over the neighbours for the matrix rows [J0, J1)
-    auto rows_pass = [&](auto j0_tag, auto j1_tag, bool want_f, bool prefetched, auto&& weight_of, auto&& give_up, auto&& track) __attribute__((always_inline)) {
-        constexpr int J0 = decltype(j0_tag)::value, J1 = decltype(j1_tag)::value;
-        double acc[5 * (RED1 ? N : 1)];
-#pragma unroll
-        for (int e = 0; e < 5 * (RED1 ? N : 1); ++e) acc[e] = 0.;
-        pass_until(want_f, prefetched, false, false, [&](int, bool live, const double (&d)[DIM], double f) {
-            double c[NO];
-            const double d2 = make_c<DIM, ORDER>(d, c);
-            track(live, d2);
-            double w = weight_of(d2);
-            w = live ? w : 0.;
-            add_rows(j0_tag, j1_tag, acc, c, w, f);
-        }, give_up);
-#pragma unroll
-        for (int r = J0; r < J1; ++r)
-#pragma unroll
-            for (int m = 0; m < N; ++m) mat_put(r, m, acc[(r - J0) * N + m]);
-        return acc[0];
-    };
-    auto never = [] { return false; };
-    auto no_track = [](bool, double) {};
     if constexpr (SPEC) {
         // ---- the speculative single pass (see above): guess = squared distance of the last neighbour, same operations as make_c
         double guess = 0.;
         if (active && nk > 0) {
             const double* q = p.xk + j * (long long)K * DIM + (long long)(nk - 1) * DIM;
-            double dg[DIM], cg[NO];
+            double dg[DIM], cg[N];
 #pragma unroll
             for (int m = 0; m < DIM; ++m) dg[m] = q[m] - xi[m];
             guess = make_c<DIM, ORDER>(dg, cg);
         }
         fetch(0, true);
-        const double rg = rcp_refined(guess);
-        double max_d2 = 0., min_d2 = RANGE_HI;
+        double rg = 0., max_d2 = 0., min_d2 = RANGE_HI;
         auto weight_of = [&](double d2) __attribute__((always_inline)) {
             const double tmp = 1. - FastOps::sqrt(div_by(d2, guess, rg));
             return uniform ? 1. : weights_alpha + weights_beta * tmp * tmp;
         };
-        auto track = [&](bool live, double d2) __attribute__((always_inline)) {
-            if (live) { max_d2 = __builtin_fmax(max_d2, d2); min_d2 = __builtin_fmin(min_d2, d2); }
-        };
-        // (unsorted neighbours — a ball query — refute the guess within the first chunk: the group leaves for the two-pass kernel
-        // there instead of finishing a pass whose sums are thrown away)
-#ifndef WLSQM_ACC_EARLY_OUT
-#define WLSQM_ACC_EARLY_OUT 1
-#endif
-        auto give_up = [&] { return WLSQM_ACC_EARLY_OUT && __any(!uniform && max_d2 > guess); };
-        double first = 0.;                                            // a finite sum of the pass (NaN test)
-        if constexpr (RED1) first = rows_pass(T0{}, TA{}, true, true, weight_of, give_up, track);
-        else {
+        // ROUND 6: a wave whose guess is refuted (unsorted neighbours — a ball query — show it within the first chunk) does not leave for
+        // another kernel any more: it finds the true maxima in a pass of its own (coordinates only, a few instructions per neighbour) and
+        // runs THE SAME sums again with them — one copy of the code, executed twice, as the fast kernels do it (fit_stage.hip).  A lane
+        // whose guess was right gets the same bits again.  1M configs[1] cases with shuffled rows: 0.63 -> 0.3x ms.
+        bool second = false;
+#pragma nounroll
+        for (;;) {
+#pragma unroll
+            for (int e = 0; e < NE; ++e) U[e] = 0.;
+#pragma unroll
+            for (int i = 0; i < N; ++i) b[i] = 0.;
+            max_d2 = 0.; min_d2 = RANGE_HI;
+            rg = rcp_refined(guess);
             pass_until(true, true, false, false, [&](int, bool live, const double (&d)[DIM], double f) {
-                double c[NO];
+                double c[N];
                 const double d2 = make_c<DIM, ORDER>(d, c);
-                track(live, d2);
+                if (live) { max_d2 = __builtin_fmax(max_d2, d2); min_d2 = __builtin_fmin(min_d2, d2); }
                 double w = weight_of(d2);
                 w = live ? w : 0.;
                 add_terms(c, w, f);
-            }, give_up);
-            first = U[0];
+            }, [&] { return !second && __any(active && !uniform && max_d2 > guess); });
+            if (second || !__any(active && !uniform && max_d2 != guess)) break;      // (a NaN distance: fmax drops it, the sum test below sees it)
+            // the largest squared distance of every case, the reference's way (make_c_nD: `if d2 > max_d2`).  Every lane walks ITS OWN row
+            // (plain loads, a handful of registers: staged through LDS like the sums, this pass made the whole kernel — the sorted input's
+            // pass too — spill: 217 registers without it, 256 + 6..91 spilled with it); the rows come from L2, the abandoned pass has just
+            // asked for their first chunk and the sums will ask for all of them again
+            double m2 = 0.;
+            {
+                const double* row = p.xk + j * (long long)K * DIM;
+#pragma nounroll
+                for (int k = 0; k < nk; ++k) {
+                    double d[DIM], c[N];
+#pragma unroll
+                    for (int m = 0; m < DIM; ++m) d[m] = row[k * DIM + m] - xi[m];
+                    const double d2 = make_c<DIM, ORDER>(d, c);
+                    if (d2 > m2) m2 = d2;
+                }
+            }
+            __syncthreads();                                          // (the abandoned pass's chunk has been read by every lane)
+            fetch(0, true);
+            guess = m2;
+            second = true;
         }
+        const double first = U[0];                                    // a finite sum of the pass (NaN test)
         // vouch for the case: the guess WAS the largest squared distance (bit for bit), every squared distance in the safe range
         // of the fast quotient and root (fmax / fmin drop a NaN distance: the sum test catches it), every matrix entry and every
         // running scale factor of the equilibration too
         bool sure = !active || ((uniform || (max_d2 == guess && min_d2 >= RANGE_LO && max_d2 <= RANGE_HI)) && nk > 0 &&
                                 (first - first == 0.));
-        if constexpr (RED1) {
-            if (__all(sure)) {                                        // the other rows, with the verified maximum
-                (void)rows_pass(TA{}, TB{}, false, false, weight_of, never, no_track);
-                (void)rows_pass(TB{}, TN{}, false, false, weight_of, never, no_track);
-            }
-        }
         mask_knowns();
-        sure = sure && (!active || in_range());
-        double rs[N], cs[N];
+        sure = sure && (!active || entries_in_range<N>(U));
+        double rs[N];
 #pragma unroll
-        for (int i = 0; i < N; ++i) { rs[i] = 1.; cs[i] = 1.; }
-        if (__all(sure)) sure = !active || equilibrate(FastOps{}, rs, cs);
-        if (!__all(sure)) {                                           // wave-uniform: the whole group goes to the two-pass kernel
-            if (lane == 0) lists.ws[ACC_LIST_BASE + atomicAdd(lists.ws + 2 * lists.set, 1)] = (int)(t0 >> 6);
-            return;
-        }
+        for (int i = 0; i < N; ++i) rs[i] = 1.;
+        if (__all(sure)) sure = !active || ruiz_sym<N, FastOps, WLSQM_ACC_RUIZ_DIAG != 0>(U, rs);
+        if (!__all(sure)) return true;                                // wave-uniform: the whole group again, with the IEEE sequences
         eliminate(rs, weight_of);
-        solve_store(rs, cs);
-        return;
-    }
-    // ---- pass 1 (make_c_nD, first half): the largest squared distance; the smallest too, for the range check of the fast weights
-    double max_d2 = 0., min_d2 = RANGE_HI;
-#ifndef WLSQM_ACC_WINDOW
-#define WLSQM_ACC_WINDOW 1
-#endif
-    auto pass1 = [&](auto&& consume) { if (WLSQM_ACC_WINDOW) pass_windowed(true, consume); else pass(false, false, true, true, consume); };
-    pass1([&](int, bool live, const double (&d)[DIM], double) {
-        double c[NO];
-        const double d2 = make_c<DIM, ORDER>(d, c);
-        if (live) { if (d2 > max_d2) max_d2 = d2; if (!(d2 >= min_d2)) min_d2 = d2; }      // (a NaN distance lands in min_d2)
-    });
-    // fast weights: every squared distance of the case in the safe range (a neighbour AT the centre, a NaN or an empty
-    // neighbourhood fail it and take the IEEE sequences); uniform weighting computes no quotient at all
-    const bool w_ok = !active || uniform || (min_d2 >= RANGE_LO && max_d2 <= RANGE_HI && nk > 0);
-    const bool fast_w = __all(w_ok);
+        solve_store(rs);
+        return false;
+    } else {
+        // ---- pass 1 (make_c_nD, first half): the largest squared distance; the smallest too, for the range check of the fast weights
+        double max_d2 = 0., min_d2 = RANGE_HI;
+        pass_windowed(true, [&](int, bool live, const double (&d)[DIM], double) {
+            double c[N];
+            const double d2 = make_c<DIM, ORDER>(d, c);
+            if (live) { if (d2 > max_d2) max_d2 = d2; if (!(d2 >= min_d2)) min_d2 = d2; }      // (a NaN distance lands in min_d2)
+        });
+        // fast weights: every squared distance of the case in the safe range (a neighbour AT the centre, a NaN or an empty
+        // neighbourhood fail it and take the IEEE sequences); uniform weighting computes no quotient at all
+        const bool w_ok = !active || uniform || (min_d2 >= RANGE_LO && max_d2 <= RANGE_HI && nk > 0);
+        const bool fast_w = __all(w_ok);
 
-    // ---- pass 2 (make_A, right-hand side sums), equilibration (fast sequences where every operand is in their safe range, the IEEE
-    // sequences for the whole wave otherwise: the same bits where both apply), knowns, scaling, LU, solve
-    auto rest = [&](auto ops_tag) __attribute__((always_inline)) {
-        using OPS = decltype(ops_tag);
-        const double rmax = OPS::rcp_of(max_d2);
-        auto weight_of = [&](double d2) __attribute__((always_inline)) {
-            const double tmp = 1. - OPS::sqrt(OPS::div_r(d2, max_d2, rmax));
-            return uniform ? 1. : weights_alpha + weights_beta * tmp * tmp;
-        };
-        if constexpr (RED1) {
-            (void)rows_pass(T0{}, TA{}, true, true, weight_of, never, no_track);
-            (void)rows_pass(TA{}, TB{}, false, false, weight_of, never, no_track);
-            (void)rows_pass(TB{}, TN{}, false, false, weight_of, never, no_track);
-        } else {
+        // ---- pass 2 (make_A, right-hand side sums), equilibration (fast sequences where every operand is in their safe range, the IEEE
+        // sequences for the whole wave otherwise: the same bits where both apply), knowns, scaling, LU, solve
+        auto rest = [&](auto ops_tag) __attribute__((always_inline)) {
+            using OPS = decltype(ops_tag);
+            const double rmax = OPS::rcp_of(max_d2);
+            auto weight_of = [&](double d2) __attribute__((always_inline)) {
+                const double tmp = 1. - OPS::sqrt(OPS::div_r(d2, max_d2, rmax));
+                return uniform ? 1. : weights_alpha + weights_beta * tmp * tmp;
+            };
             pass(true, true, false, false, [&](int, bool live, const double (&d)[DIM], double f) {
-                double c[NO];
+                double c[N];
                 const double d2 = make_c<DIM, ORDER>(d, c);
                 double w = weight_of(d2);
                 w = live ? w : 0.;
                 add_terms(c, w, f);
             });
-        }
-        mask_knowns();
-        double rs[N], cs[N];
+            mask_knowns();
+            double rs[N];
 #pragma unroll
-        for (int i = 0; i < N; ++i) { rs[i] = 1.; cs[i] = 1.; }
-        bool r_ok = !active || in_range(), fast_done = false;
-        if (__all(r_ok)) { r_ok = !active || equilibrate(FastOps{}, rs, cs); fast_done = true; }
-        if (!fast_done || !__all(r_ok)) { if (active) (void)equilibrate(IeeeOps{}, rs, cs); }
-        eliminate(rs, weight_of);
-        solve_store(rs, cs);
-    };
-    if (fast_w) rest(FastOps{}); else rest(IeeeOps{});
+            for (int i = 0; i < N; ++i) rs[i] = 1.;
+            bool r_ok = !active || entries_in_range<N>(U), fast_done = false;
+            if (__all(r_ok)) { r_ok = !active || ruiz_sym<N, FastOps, false>(U, rs); fast_done = true; }
+            if (!fast_done || !__all(r_ok)) { if (active) (void)ruiz_sym<N, IeeeOps, false>(U, rs); }
+            eliminate(rs, weight_of);
+            solve_store(rs);
+        };
+        if (fast_w) rest(FastOps{}); else rest(IeeeOps{});
+        return false;
+    }
 }
 
-// LDS of a one-wave workgroup, in doubles: the staging rows; for RED1 the top rows of the matrix behind them
-template <int DIM, int ORDER, bool DENSE, bool RED1>
+// LDS of a one-wave workgroup, in doubles: the staging rows
+template <int DIM, bool DENSE>
 __host__ __device__ constexpr int acc_lds_doubles() {
-    constexpr int N = ndofs(DIM, ORDER) - (RED1 ? 1 : 0), CHN = acc::chunk_of(N);
-    constexpr int stage = DENSE ? 64 * (CHN * DIM + 2) + 64 * (CHN + 2) : 0;
-    constexpr int top = RED1 ? 64 * acc::lu_lds_rows(N) * N : 0;
-    return stage + top > 2 ? stage + top : 2;
+    constexpr int stage = DENSE ? 64 * (acc::CH * DIM + 2) + 64 * (acc::CH + 2) : 0;
+    return stage > 2 ? stage : 2;
 }
 
-template <int DIM, int ORDER, bool DENSE, bool SPEC, bool RED1>
-__global__ __launch_bounds__(64, acc::minw(ndofs(DIM, ORDER))) void fit_accurate_kernel(const KParams p, const AccLists lists, const long long ngroups) {
-    __shared__ __attribute__((aligned(16))) double lds[acc_lds_doubles<DIM, ORDER, DENSE, RED1>()];
-    // (a workgroup per resident slot walks the groups: a finished wave's slot took ~5 us to be handed a new workgroup — 1.67 resident
-    // waves per SIMD of the 2 the registers allow with one group per workgroup)
+// SPEC: the speculative form.  status[g] = 1: the wave could not vouch for group g (an operand outside the safe range of the fast
+// sequences): the clean-up kernel behind this one fits it again with the IEEE sequences.  A workgroup takes the groups blockIdx.x,
+// blockIdx.x + gridDim.x, ...
+template <int DIM, int ORDER, bool DENSE, bool SPEC>
+__global__ __launch_bounds__(64, acc::minw(ndofs(DIM, ORDER))) void fit_accurate_kernel(const KParams p, const long long ngroups, unsigned char* const status) {
+    __shared__ __attribute__((aligned(16))) double lds[acc_lds_doubles<DIM, DENSE>()];
     for (long long g = blockIdx.x; g < ngroups; g += gridDim.x) {
-        accurate_group<DIM, ORDER, DENSE, SPEC, RED1>(p, g * 64, lists, lds);
-        if (DENSE || RED1) __syncthreads();                           // the LDS is reused by the next group
+        const bool again = accurate_group<DIM, ORDER, DENSE, SPEC>(p, g * 64, lds);
+        if constexpr (SPEC) { if (threadIdx.x == 0) status[g] = again ? 1 : 0; }
+        if (DENSE) __syncthreads();                                   // the LDS is reused by the next group
     }
 }
 
-// the redo groups of a speculative launch: a grid of the resident waves walks the list (empty in the common case: idle waves)
-template <int DIM, int ORDER, bool RED1>
-__global__ __launch_bounds__(64, acc::minw(ndofs(DIM, ORDER))) void fit_accurate_redo_kernel(const KParams p, const AccLists lists) {
-    __shared__ __attribute__((aligned(16))) double lds[acc_lds_doubles<DIM, ORDER, true, RED1>()];
-    const int n = lists.ws[2 * lists.set];
-    for (int g = blockIdx.x; g < n; g += gridDim.x) {
-        accurate_group<DIM, ORDER, true, false, RED1>(p, (long long)lists.ws[strict::ACC_LIST_BASE + g] * 64, lists, lds);
-        __syncthreads();                                              // the LDS is reused by the next group
+// the groups the speculative kernel could not vouch for (none in the common case: ~2 us of idle waves, tools/ubench/launch_gap.hip):
+// a small grid looks at the status bytes, 64 groups per wave and step
+template <int DIM, int ORDER>
+__global__ __launch_bounds__(64, acc::minw(ndofs(DIM, ORDER))) void fit_accurate_cleanup_kernel(const KParams p, const long long ngroups, const unsigned char* const status) {
+    __shared__ __attribute__((aligned(16))) double lds[acc_lds_doubles<DIM, true>()];
+    for (long long g0 = (long long)blockIdx.x * 64; g0 < ngroups; g0 += (long long)gridDim.x * 64) {
+        const long long g = g0 + threadIdx.x;
+        unsigned long long todo = __ballot(g < ngroups && status[g] != 0);
+        while (todo) {                                                // wave-uniform
+            const int q = __ffsll((long long)todo) - 1;
+            todo &= todo - 1ull;
+            (void)accurate_group<DIM, ORDER, true, false>(p, (g0 + q) * 64, lds);
+            __syncthreads();                                          // the LDS is reused by the next group
+        }
     }
 }
-
-__global__ void acc_lists_zero_kernel(int* ws) { if (threadIdx.x < strict::ACC_LIST_BASE) ws[threadIdx.x] = 0; }
 
 template <int DIM, int ORDER>
-static int launch_accurate(const KParams& p, hipStream_t stream, int** lists_out, int* set_out, bool* handled) {
-    constexpr bool RED1 = strict::accurate_red1(DIM, ORDER);
-    *lists_out = nullptr;
+static int launch_accurate(const KParams& p, hipStream_t stream) {
     const long long groups = (p.ncases + 63) / 64;
     if (groups <= 0) return WLSQM_OK;
     if (groups > 0x3fffffffLL) { set_error("too many cases for one launch"); return WLSQM_EVALUE; }
@@ -1011,74 +753,47 @@ static int launch_accurate(const KParams& p, hipStream_t stream, int** lists_out
     const bool dense = !p.hoods && !p.case_index && p.xk && p.fk && K >= 2 && K % 2 == 0 && p.sxk_k == DIM && p.sxk_j == K * DIM &&
                        p.sfk_k == 1 && p.sfk_j == K && ((reinterpret_cast<uintptr_t>(p.xk) | reinterpret_cast<uintptr_t>(p.fk)) & 15u) == 0 &&
                        !getenv("WLSQM_HIP_ACCURATE_NO_STAGE");
-    const char* nospec = getenv("WLSQM_HIP_ACCURATE_NO_SPEC");        // A/B and tests: the two-pass kernel for every group
-    const char* rs_env = getenv("WLSQM_HIP_ACCURATE_RUN_STORE");
-    AccLists lists{nullptr, groups, (rs_env && rs_env[0] == '0') ? 1 : 0, 0};
-    // grid: one workgroup per group (default), or with WLSQM_HIP_ACCURATE_PERSIST=1 the resident slots times a small factor
-    auto grid_for = [&](const void* kern, unsigned* out) {
-        static KernelSetup setup[2];
-        long long slots = groups;
-        const char* e = getenv("WLSQM_HIP_ACCURATE_PERSIST");
-        if (e && e[0] == '1') {                                     // (measured: 0.331 against 0.304 ms on configs[1]: the dispatcher balances short workgroups better)
-            const int rc = persistent_grid(kern, 64, 0, 0, false, setup[0], &slots);
-            if (rc != WLSQM_OK) return rc;
-            slots = (long long)((double)slots / grid_multiple());     // (persistent_grid applies the tile kernels' multiple)
-            const char* m = getenv("WLSQM_HIP_ACCURATE_GRID_MULT");
-            if (m) slots = (long long)(slots * atof(m));
-            if (slots < 1) slots = 1;
-        }
-        *out = (unsigned)(slots < groups ? slots : groups);
-        return (int)WLSQM_OK;
-    };
-    unsigned grid = 0;
-    if constexpr (RED1) {
-        // (the 14 x 14 form — off by default, WLSQM_HIP_LANE14 — exists for dense rows in whole 4-neighbour chunks only: its four kernels for
-        // the other layouts were a quarter of this file's compile time; those batches keep the row-per-lane strict kernel)
-        if (!(dense && K % acc::chunk_of(ndofs(DIM, ORDER) - 1) == 0 && !(nospec && nospec[0] == '1'))) { *handled = false; return WLSQM_OK; }
-    }
-    if (dense && K % acc::chunk_of(ndofs(DIM, ORDER) - (RED1 ? 1 : 0)) == 0 && !(nospec && nospec[0] == '1')) {
-        // the work lists: the stream's persistent buffer (its counters are left at zero by the consumers of the previous call); inside
-        // a graph capture that has no buffer yet, stream-ordered scratch and a kernel that clears the counters
-        int rc = stream_counters_acquire(&lists.ws, (size_t)(strict::ACC_LIST_BASE + 2 * groups), stream, &lists.set);
+    const char* nospec = getenv("WLSQM_HIP_ACCURATE_NO_SPEC");        // A/B and tests: the two-pass form for every group
+    if (dense && K % acc::CH == 0 && !(nospec && nospec[0] == '1')) {
+        // one status byte per group, written by the speculative kernel for EVERY group: no clearing, no counters, no state between calls
+        // (round 5's work lists with their alternating counter sets are gone)
+        CallScratch cs;
+        int rc = call_scratch_acquire(&cs, (size_t)groups, stream);
         if (rc != WLSQM_OK) return rc;
-        if (!lists.ws) {
-            rc = scratch_alloc_async(reinterpret_cast<void**>(&lists.ws), (size_t)(strict::ACC_LIST_BASE + 2 * groups) * sizeof(int), stream);
-            if (rc != WLSQM_OK) return rc;
-            hipLaunchKernelGGL(acc_lists_zero_kernel, dim3(1), dim3(64), 0, stream, lists.ws);
+        unsigned char* const status = static_cast<unsigned char*>(cs.p);
+        hipLaunchKernelGGL((fit_accurate_kernel<DIM, ORDER, true, true>), dim3((unsigned)groups), dim3(64), 0, stream, p, groups, status);
+        hipError_t le = hipGetLastError();
+        if (le == hipSuccess) {
+            const long long want = (groups + 63) / 64, resident = 512LL * acc::minw(ndofs(DIM, ORDER));
+            hipLaunchKernelGGL((fit_accurate_cleanup_kernel<DIM, ORDER>), dim3((unsigned)(want < resident ? want : resident)), dim3(64), 0, stream, p, groups, status);
+            le = hipGetLastError();
         }
-        *lists_out = lists.ws; *set_out = lists.set;                  // (released / freed by the caller behind the strict kernels, which read the leftover list)
-        rc = grid_for(reinterpret_cast<const void*>(&fit_accurate_kernel<DIM, ORDER, true, true, RED1>), &grid);
-        if (rc != WLSQM_OK) return rc;
-        hipLaunchKernelGGL((fit_accurate_kernel<DIM, ORDER, true, true, RED1>), dim3(grid), dim3(64), 0, stream, p, lists, groups);
-        // the redo grid fills the chip when every group comes back (unsorted neighbours: with 256 workgroups 1M configs[1] cases took
-        // 1.72 ms, profiles/r04s_ab_early_out.txt) and is a few microseconds of idle waves when none does
-        const long long resident = 1024LL * acc::minw(ndofs(DIM, ORDER));
-        const unsigned redo_grid = (unsigned)(groups < resident ? groups : resident);
-        hipLaunchKernelGGL((fit_accurate_redo_kernel<DIM, ORDER, RED1>), dim3(redo_grid), dim3(64), 0, stream, p, lists);
-    } else if constexpr (!RED1) {
-        if (dense) {
-            const int rc = grid_for(reinterpret_cast<const void*>(&fit_accurate_kernel<DIM, ORDER, true, false, false>), &grid);
-            if (rc != WLSQM_OK) return rc;
-            hipLaunchKernelGGL((fit_accurate_kernel<DIM, ORDER, true, false, false>), dim3(grid), dim3(64), 0, stream, p, lists, groups);
-        } else {
-            hipLaunchKernelGGL((fit_accurate_kernel<DIM, ORDER, false, false, false>), dim3((unsigned)groups), dim3(64), 0, stream, p, lists, groups);
-        }
+        rc = call_scratch_release(&cs, stream);
+        if (le != hipSuccess) return hip_fail(le, "fit_accurate_kernel");
+        return rc;
     }
+    if (dense)
+        hipLaunchKernelGGL((fit_accurate_kernel<DIM, ORDER, true, false>), dim3((unsigned)groups), dim3(64), 0, stream, p, groups, (unsigned char*)nullptr);
+    else
+        hipLaunchKernelGGL((fit_accurate_kernel<DIM, ORDER, false, false>), dim3((unsigned)groups), dim3(64), 0, stream, p, groups, (unsigned char*)nullptr);
     WLSQM_HIP_CHECK(hipGetLastError());
     return WLSQM_OK;
 }
 
-// Accurate mode, basic fits of the 2D / 3D systems up to 10 unknowns and of 2D order 4 with exactly the function value known: every
-// case strict::accurate_takes_case names is fitted here (the strict kernels, launched behind this one by launch_fit_strict, leave
-// exactly those cases alone).  *handled = false: the shape has no accurate kernel (1D, 3D orders 3-4) and the strict kernels take
-// every case.
-int launch_fit_accurate(int dimension, int order, const KParams& p, hipStream_t stream, bool* handled, int** lists_out, int* set_out) {
+// Accurate mode, basic fits of the 2D / 3D systems up to 10 unknowns: EVERY case of the call is fitted here — one kernel, and behind
+// it a clean-up kernel that is idle unless a group's operands left the safe range of the fast sequences.
+// *handled = false: the shape or the call has no accurate kernel (1D, 2D order 4, 3D orders 3-4, sensitivities, refinement) and the
+// strict kernels take every case.
+int launch_fit_accurate(int dimension, int order, const KParams& p, hipStream_t stream, bool* handled) {
     *handled = false;
-    *lists_out = nullptr; *set_out = 0;
     if (p.do_sens || p.iterative) return WLSQM_OK;
-#define CASE(D, O) if (dimension == D && order == O) { *handled = true; return launch_accurate<D, O>(p, stream, lists_out, set_out, handled); }
-    CASE(2, 0) CASE(2, 1) CASE(2, 2) CASE(2, 3) CASE(2, 4)
+#define CASE(D, O) if (dimension == D && order == O) { *handled = true; return launch_accurate<D, O>(p, stream); }
+#ifdef WLSQM_ACC_DEV_ONLY22      // (development: one shape, for quick looks at the ISA)
+    CASE(2, 2)
+#else
+    CASE(2, 0) CASE(2, 1) CASE(2, 2) CASE(2, 3)
     CASE(3, 0) CASE(3, 1) CASE(3, 2)
+#endif
 #undef CASE
     return WLSQM_OK;
 }

@@ -138,7 +138,7 @@ __device__ __forceinline__ double taylor(const double (&d)[DIM], const FI& f) {
 
 __device__ __forceinline__ bool fit_strict_group_is_plain(const KParams& p, long long t, long long ncases, long long want = 0);
 
-// (vblock: the workgroup's number in the batch — blockIdx.x, or a 64-case group of the leftover list in accurate mode)
+// (vblock: the workgroup's number in the batch)
 template <int DIM, int ORDER>
 __device__ __forceinline__ void fit_strict_block(const KParams& p, const StrictDebug& dbg, const int skip_plain_groups, const long long vblock,
                                                  double* smem) {
@@ -157,9 +157,6 @@ __device__ __forceinline__ void fit_strict_block(const KParams& p, const StrictD
     const long long t = vblock * LPW + lane;
     if (t >= live_cases(p)) return;
     const long long j = p.case_index ? p.case_index[t] : t;
-    // 2 = accurate mode: fit_accurate_kernel has every CASE it takes (strict::accurate_takes_case), whatever its group
-    // (the lanes of this kernel never meet again: no barrier below)
-    if (skip_plain_groups == 2 && accurate_takes_case<NO, accurate_red1(DIM, ORDER)>(p.knowns[j * p.sknowns])) return;
 
     // LDS image of this case: slot s at smem[s * LPW + lane]
     double* const base = smem + lane;
@@ -427,20 +424,10 @@ __device__ __forceinline__ void fit_strict_block(const KParams& p, const StrictD
     if (p.iters_out) atomicMax(p.iters_out, iters);
 }
 
-// Accurate mode behind the speculative kernel (fit_accurate.hip): `lists` holds the 64-case groups with a known DOF somewhere
-// ([1] their number, [2 + ngroups ..) the groups); a small grid walks them — none in the common case: a few idle waves.
 template <int DIM, int ORDER>
-__global__ __launch_bounds__(64) void fit_strict_kernel(const KParams p, const StrictDebug dbg, const int skip_plain_groups,
-                                                        int* __restrict__ lists, const long long ngroups, const int lset) {
+__global__ __launch_bounds__(64) void fit_strict_kernel(const KParams p, const StrictDebug dbg, const int skip_plain_groups) {
     extern __shared__ double smem[];
-    if (!lists) { fit_strict_block<DIM, ORDER>(p, dbg, skip_plain_groups, blockIdx.x, smem); return; }
-    constexpr int PER = 64 / strict::lanes_for(ndofs(DIM, ORDER));   // workgroups of this kernel per 64-case group
-    strict::acc_list_clear_other_set(lists, lset);                    // (the last kernel of the call: the other counter set for the next call)
-    const long long n = (long long)lists[2 * lset + 1] * PER;
-    for (long long v = blockIdx.x; v < n; v += gridDim.x) {
-        fit_strict_block<DIM, ORDER>(p, dbg, skip_plain_groups, (long long)lists[strict::ACC_LIST_BASE + ngroups + v / PER] * PER + v % PER, smem);
-        __syncthreads();
-    }
+    fit_strict_block<DIM, ORDER>(p, dbg, skip_plain_groups, blockIdx.x, smem);
 }
 
 // The same operations with EVERYTHING in registers, for the common case of a workgroup whose 64 cases have no knowns at all (the
@@ -664,10 +651,8 @@ __device__ __forceinline__ void fit_strict_reg_block(const KParams& p, const lon
 }
 
 template <int DIM, int ORDER, bool KN1>
-__global__ __launch_bounds__(64, reg_minw(ndofs(DIM, ORDER))) void fit_strict_reg_kernel(const KParams p, const int* __restrict__ lists, const long long ngroups) {
-    if (!lists) { fit_strict_reg_block<DIM, ORDER, KN1>(p, blockIdx.x); return; }
-    const long long n = lists[1];                                     // (see fit_strict_kernel)
-    for (long long v = blockIdx.x; v < n; v += gridDim.x) fit_strict_reg_block<DIM, ORDER, KN1>(p, lists[strict::ACC_LIST_BASE + ngroups + v]);
+__global__ __launch_bounds__(64, reg_minw(ndofs(DIM, ORDER))) void fit_strict_reg_kernel(const KParams p) {
+    fit_strict_reg_block<DIM, ORDER, KN1>(p, blockIdx.x);
 }
 
 constexpr int STRICT_REG_MAX_NO = 10;      // register kernel: systems up to this size (3D order 2 / 2D order 3: one wave per SIMD)
@@ -716,10 +701,9 @@ __host__ __device__ constexpr int rows_minw(int NO) {
     return WLSQM_STRICT_ROWS_MINW ? WLSQM_STRICT_ROWS_MINW : (NO > 16 ? 1 : NO > 10 ? 3 : 4);
 }
 
-// (vblock: the workgroup's number in the batch; skip_red1: accurate mode — fit_accurate_kernel<.., RED1> has the cases with exactly
-// the function value known, they are idle lanes here)
+// (vblock: the workgroup's number in the batch)
 template <int DIM, int ORDER, int LPC>
-__device__ __forceinline__ void fit_strict_rows_block(const KParams& p, const int KP, const long long vblock, const bool skip_red1, double* smem) {
+__device__ __forceinline__ void fit_strict_rows_block(const KParams& p, const int KP, const long long vblock, double* smem) {
     using namespace strict;
     constexpr int NO = ndofs(DIM, ORDER);
     constexpr int G = 64 / LPC;                       // cases per wave
@@ -727,9 +711,8 @@ __device__ __forceinline__ void fit_strict_rows_block(const KParams& p, const in
     const int lane = threadIdx.x, g = lane / LPC, i = lane % LPC;
     const long long ncases = live_cases(p);
     const long long t = vblock * G + g;
-    bool valid = t < ncases;
+    const bool valid = t < ncases;
     const long long j = valid ? (p.case_index ? p.case_index[t] : t) : 0;
-    if (skip_red1 && valid && accurate_takes_case<NO, true>(p.knowns[j * p.sknowns])) valid = false;
     // LDS of the group: w[KP], f[KP], res[KP], d[DIM][KP]; the pitch is odd in 8-byte words so that the G broadcast reads of one
     // instruction fall into different banks
     const int pitch = ((3 + DIM) * KP) | 1;
@@ -1036,24 +1019,14 @@ __device__ __forceinline__ void fit_strict_rows_block(const KParams& p, const in
     if (valid && i == 0 && p.iters_out) atomicMax(p.iters_out, iters);
 }
 
-// Accurate mode behind fit_accurate_kernel<2, 4, .., RED1>: `lists` as for fit_strict_kernel (the 64-case groups that hold a case the
-// accurate kernel did not take); without it (no speculative launch) every workgroup runs and skips the taken cases.
 template <int DIM, int ORDER, int LPC>
-__global__ __launch_bounds__(64, rows_minw(ndofs(DIM, ORDER))) void fit_strict_rows_kernel(const KParams p, const int KP, const int skip_red1,
-                                                                                          int* __restrict__ lists, const long long ngroups, const int lset) {
+__global__ __launch_bounds__(64, rows_minw(ndofs(DIM, ORDER))) void fit_strict_rows_kernel(const KParams p, const int KP) {
     extern __shared__ double smem[];
-    if (!lists) { fit_strict_rows_block<DIM, ORDER, LPC>(p, KP, blockIdx.x, skip_red1 != 0, smem); return; }
-    constexpr int PER = LPC;                                          // workgroups (64 / LPC cases each) per 64-case group
-    strict::acc_list_clear_other_set(lists, lset);
-    const long long n = (long long)lists[2 * lset + 1] * PER;
-    for (long long v = blockIdx.x; v < n; v += gridDim.x) {
-        fit_strict_rows_block<DIM, ORDER, LPC>(p, KP, (long long)lists[strict::ACC_LIST_BASE + ngroups + v / PER] * PER + v % PER, skip_red1 != 0, smem);
-        __syncthreads();
-    }
+    fit_strict_rows_block<DIM, ORDER, LPC>(p, KP, blockIdx.x, smem);
 }
 
 template <int DIM, int ORDER>
-static int launch_strict(const KParams& p, const StrictDebug& dbg, hipStream_t stream, const bool accurate_taken, int* lists, const int lset) {
+static int launch_strict(const KParams& p, const StrictDebug& dbg, hipStream_t stream) {
     constexpr int NO = ndofs(DIM, ORDER);
     constexpr int LPW = strict::lanes_for(NO);
     constexpr size_t lds = (size_t)strict::slots(NO) * LPW * sizeof(double);
@@ -1086,65 +1059,46 @@ static int launch_strict(const KParams& p, const StrictDebug& dbg, hipStream_t s
             }
             const long long wgs = (p.ncases + (64 / LPC) - 1) / (64 / LPC);
             if (wgs > 0x7fffffffLL) { set_error("too many cases for one launch"); return WLSQM_EVALUE; }
-            // (accurate mode, 2D order 4: the cases with exactly F known are fit_accurate_kernel's; a small grid walks the leftover list)
-            const bool skip = accurate_taken && strict::accurate_red1(DIM, ORDER);
-            hipLaunchKernelGGL((fit_strict_rows_kernel<DIM, ORDER, LPC>), dim3((unsigned)(skip && lists && wgs > 512 ? 512 : wgs)), dim3(64), rl, stream, p,
-                               KP, skip ? 1 : 0, skip ? lists : (int*)nullptr, (p.ncases + 63) / 64, lset);
+            hipLaunchKernelGGL((fit_strict_rows_kernel<DIM, ORDER, LPC>), dim3((unsigned)wgs), dim3(64), rl, stream, p, KP);
             WLSQM_HIP_CHECK(hipGetLastError());
-            note_kernel(skip ? (accurate_mode() ? "accurate" : "strict-lane") : "strict-rows");
+            note_kernel("strict-rows");
             return WLSQM_OK;
         }
     }
     // basic fits of the small systems: the all-unknown 64-case groups run the register kernel, the others the LDS kernel
-    // ACCURATE mode (fit_accurate.hip): every case without a known DOF has been fitted by fit_accurate_kernel (launched by
-    // launch_fit_strict in front of this function); the kernels below leave exactly those cases alone — per CASE, so that the
-    // arithmetic a case gets does not depend on the other cases of its group
-    // (accurate mode: fit_accurate_kernel has taken every case without stray mask bits — the LDS kernel walks what is left)
     bool split = false;
     if constexpr (NO <= STRICT_REG_MAX_NO) {
         const char* e = getenv("WLSQM_HIP_STRICT_NO_REG");
-        split = !accurate_taken && !p.do_sens && !p.iterative && !dbg.A && !dbg.w && !(e && e[0] == '1');
+        split = !p.do_sens && !p.iterative && !dbg.A && !dbg.w && !(e && e[0] == '1');
         if (split) {
             const long long groups = (p.ncases + 63) / 64;
-            hipLaunchKernelGGL((fit_strict_reg_kernel<DIM, ORDER, false>), dim3((unsigned)groups), dim3(64), 0, stream, p, (const int*)nullptr, 0ll);
+            hipLaunchKernelGGL((fit_strict_reg_kernel<DIM, ORDER, false>), dim3((unsigned)groups), dim3(64), 0, stream, p);
             WLSQM_HIP_CHECK(hipGetLastError());
             if constexpr (NO >= 2) {
-                hipLaunchKernelGGL((fit_strict_reg_kernel<DIM, ORDER, true>), dim3((unsigned)groups), dim3(64), 0, stream, p, (const int*)nullptr, 0ll);
+                hipLaunchKernelGGL((fit_strict_reg_kernel<DIM, ORDER, true>), dim3((unsigned)groups), dim3(64), 0, stream, p);
                 WLSQM_HIP_CHECK(hipGetLastError());
             }
         }
     }
-    hipLaunchKernelGGL((fit_strict_kernel<DIM, ORDER>), dim3((unsigned)(lists && blocks > 128 ? 128 : blocks)), dim3(64), lds, stream, p, dbg,
-                       accurate_taken ? 2 : (split ? 1 : 0), lists, (p.ncases + 63) / 64, lset);
+    hipLaunchKernelGGL((fit_strict_kernel<DIM, ORDER>), dim3((unsigned)blocks), dim3(64), lds, stream, p, dbg, split ? 1 : 0);
     WLSQM_HIP_CHECK(hipGetLastError());
-    note_kernel(accurate_taken ? "accurate" : "strict");
+    note_kernel("strict");
     return WLSQM_OK;
 }
 
-int launch_fit_accurate(int dimension, int order, const KParams& p, hipStream_t stream, bool* handled, int** lists_out, int* set_out);      // fit_accurate.hip
+int launch_fit_accurate(int dimension, int order, const KParams& p, hipStream_t stream, bool* handled);      // fit_accurate.hip
 
 int launch_fit_strict(int dimension, int order, const KParams& p, const StrictDebug* dbg_in, hipStream_t stream) {
     const StrictDebug dbg = dbg_in ? *dbg_in : StrictDebug{};
-    bool accurate_taken = false;
-    int* lists = nullptr; int lset = 0;               // work lists of the speculative accurate kernel and the counter set of this call, or null
-    // accurate mode: fit_accurate.hip takes the cases strict::accurate_takes_case names.  Its 2D order-4 form (exactly the function value
-    // known: the 14 x 14 system of the reference's default mask; the strict arithmetic itself with one lane per case, bit-identical to
-    // the row-per-lane kernel) is OFF by default in both modes: it needs 196 matrix entries beside the equilibration's 84 scale factors
-    // in one lane, spills 1.7 KB per lane and runs 3.5-3.9 ms per 400k cases against the row-per-lane kernel's 3.3
-    // (profiles/r05a_lane14.txt: 81k vector instructions per 64 cases, 70 % of the wave cycles waiting on scratch).
-    // WLSQM_HIP_LANE14=1 turns it on (tests: bit-identity with the strict kernels' CPU checker).
-    const char* l14 = getenv("WLSQM_HIP_LANE14");
-    const bool lane14 = strict::accurate_red1(dimension, order) && l14 && l14[0] == '1';
-    if (((accurate_mode() && !strict::accurate_red1(dimension, order)) || lane14) && !dbg_in) {
-        const int rc = launch_fit_accurate(dimension, order, p, stream, &accurate_taken, &lists, &lset);
-        if (rc != WLSQM_OK) { (void)scratch_free_async(lists, stream); return rc; }
+    // accurate mode: fit_accurate.hip fits EVERY case of a basic call on the 2D / 3D systems up to 10 unknowns, in one launch; every other
+    // call of the mode (2D order 4, 3D orders 3-4, 1D, sensitivities, refinement, the debug capture) is the strict mode's
+    if (accurate_mode() && !dbg_in) {
+        bool taken = false;
+        const int rc = launch_fit_accurate(dimension, order, p, stream, &taken);
+        if (rc != WLSQM_OK) return rc;
+        if (taken) { note_kernel("accurate"); return WLSQM_OK; }
     }
-    // (the stream's persistent buffer goes back clean once every consumer has been launched; a failed launch leaves it to be cleared)
-    auto done = [&](int rc) {
-        if (is_stream_counters(lists)) { if (rc == WLSQM_OK) stream_counters_release_clean(lists); return rc; }
-        const int rf = scratch_free_async(lists, stream); return rc != WLSQM_OK ? rc : rf;
-    };
-#define CASE(D, O) if (dimension == D && order == O) return done(launch_strict<D, O>(p, dbg, stream, accurate_taken, lists, lset));
+#define CASE(D, O) if (dimension == D && order == O) return launch_strict<D, O>(p, dbg, stream);
     CASE(1, 0) CASE(1, 1) CASE(1, 2) CASE(1, 3) CASE(1, 4)
     CASE(2, 0) CASE(2, 1) CASE(2, 2) CASE(2, 3) CASE(2, 4)
     CASE(3, 0) CASE(3, 1) CASE(3, 2) CASE(3, 3) CASE(3, 4)

@@ -1,6 +1,7 @@
 // wlsqm_internal.hpp — host-side declarations shared by the translation units of libwlsqm_hip.so.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <stdint.h>
 #include <cstdlib>
 #include <string>
@@ -197,19 +198,20 @@ struct DeviceScope {
 int scratch_alloc_async(void** out, size_t bytes, hipStream_t stream);
 int scratch_free_async(void* p, hipStream_t stream);
 
-// A small device buffer of ints that PERSISTS per (device, stream) — counters and short work lists a call's kernels hand to each
-// other.  Zeroed when it is first handed out and whenever its previous user did not release it clean; a user whose kernels put
-// the counters back to zero themselves (wlsqm_strict.hpp: acc_list_clear_other_set) releases it clean and the next call on the stream pays
-// nothing.  *out = nullptr (WLSQM_OK) when the stream is being captured into a graph (a replay would reuse one counter set every time):
-// the caller falls back to scratch_alloc_async and a clearing kernel.  scratch_free_async ignores these buffers.
-int stream_counters_acquire(int** out, size_t ints, hipStream_t stream, int* set_out = nullptr);      // *set_out: 0 / 1, alternating per call on the stream
-void stream_counters_release_clean(const void* p);
+// Hand-over space between the kernels of ONE call (status bytes, small lists): a device buffer that PERSISTS per (device, stream) — a
+// stream-ordered allocation per call costs the stream a marker on either side (~10 us of a 0.27 ms accurate-mode call, measured in rounds
+// 5 and 6).  The contents are UNDEFINED when it is handed out (the call's first kernel writes what its later kernels read: no clearing,
+// no state between calls).  The caller keeps the CallScratch — it holds a lock — until it has enqueued every kernel that touches the
+// buffer: two host threads that share a stream cannot interleave their launches around it.  Inside a graph capture (and when the
+// table is full of other streams' buffers) the space is stream-ordered scratch instead: call_scratch_release frees it behind the kernels.
+struct CallScratch { void* p = nullptr; bool pooled = false; std::unique_lock<std::mutex> lock; };
+int call_scratch_acquire(CallScratch* cs, size_t bytes, hipStream_t stream);
+int call_scratch_release(CallScratch* cs, hipStream_t stream);
 // What the staged launches of this (dimension, order) on the stream have reported about their input so far: *unsorted = most sampled groups
 // of the latest reports that have ARRIVED had neighbours in no order (false until a report arrives; sticky between reports — launches are
 // asynchronous), *dev = where this launch's sampled groups report (nullptr inside a graph capture or if host-mapped memory is not to be
 // had: the caller takes its default form).
 int stage_hint_acquire(int dimension, int order, hipStream_t stream, unsigned char** dev, bool* unsorted);
-bool is_stream_counters(const void* p);
 
 // Host mirror of effective_mask() in wlsqm_kernels.hpp (infra.pyx:119-121 quirk): returns the
 // mask of DOFs the reference never writes (true knowns | dropped) and the dropped subset.

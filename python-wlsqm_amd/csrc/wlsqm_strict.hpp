@@ -118,29 +118,6 @@ __device__ __forceinline__ double pick(const double (&c)[N], int a) {
 }
 
 
-// ACCURATE mode (fit_accurate.hip): which cases its kernels take — a property of the case alone; the strict kernels launched behind
-// them skip exactly these.  RED1 (2D order 4: the 14 x 14 system of the reference's default mask): exactly the function value known.
-// Otherwise (2D orders 0-3, 3D orders 0-2): any mask without stray bits beyond the polynomial's DOFs (infra.pyx:119-121).
-__host__ __device__ constexpr bool accurate_red1(int dim, int order) { return dim == 2 && order == 4; }
-__host__ __device__ constexpr bool accurate_shape(int dim, int order) { return (dim == 2 && order <= 4) || (dim == 3 && order <= 2); }
-template <int NO, bool RED1>
-__host__ __device__ __forceinline__ bool accurate_takes_case(long long raw) {
-    if (RED1) return raw == 1;
-    return ((unsigned long long)raw >> NO) == 0ull;
-}
-
-// Work lists of an accurate-mode launch (fit_accurate.hip writes, its redo kernel and the strict kernels behind it read): ints
-// [2 s] number of REDO groups, [2 s + 1] number of LEFTOVER groups of counter set s = 0 / 1, then from ACC_LIST_BASE on the redo groups
-// and, G entries later, the leftover groups (G = 64-case groups of the launch).  The buffer persists per stream (wlsqm_internal.hpp:
-// stream_counters_acquire) and consecutive calls on a stream ALTERNATE between the two counter sets: the last kernel of a call (the
-// strict kernel that walks the leftover list) clears the OTHER set — dead since the previous call finished — for the next call, so a
-// call needs neither an allocation nor a kernel (nor atomics: a last-workgroup ticket on one address cost the 2 048-workgroup redo
-// grid 50 us) to start from zeroed counters (round 5: ~30 us of a 290 us call on BASELINE configs[1]).
-constexpr int ACC_LIST_BASE = 4;
-__device__ __forceinline__ void acc_list_clear_other_set(int* ws, int set) {      // one thread of the call's last kernel
-    if (blockIdx.x == 0 && threadIdx.x == 0) { ws[2 * (1 - set)] = 0; ws[2 * (1 - set) + 1] = 0; }
-}
-
 }  // namespace strict
 
 // ---- correctly rounded quotients and roots without the range machinery (round 4; fit_accurate.hip's header has the story) ----

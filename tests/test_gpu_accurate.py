@@ -38,13 +38,11 @@ def _bits(a):
 
 
 def _taken(dim, order, kn):
-    """Cases the accurate kernels take (strict::accurate_takes_case): 2D order 4 — exactly the function value known (there the kernel
-    replays the strict arithmetic: the oracle's bits); the systems up to 10 unknowns — every mask without stray bits beyond the
-    polynomial's DOFs (variants.c V_SYM).  Everything else runs the strict kernels (the oracle's bits)."""
-    no = K.NDOF[dim][order]
+    """Cases the accurate kernel takes: every case of the systems up to 10 unknowns, whatever its mask (round 6: stray bits beyond the
+    polynomial's DOFs too — variants.c V_SYM applies the reference's nr quirk to them).  2D order 4 runs the strict kernels (the oracle's bits)."""
     if dim == 2 and order == 4:
-        return np.zeros(len(kn), bool)                      # (taken or not: the oracle's bits)
-    return (kn >> no) == 0
+        return np.zeros(len(kn), bool)
+    return np.ones(len(kn), bool)
 
 
 def _expected(oracle, dim, order, xk, fk, nk, xi, fi0, kn, wm):
@@ -60,22 +58,16 @@ def _expected(oracle, dim, order, xk, fk, nk, xi, fi0, kn, wm):
 
 
 @pytest.mark.parametrize("name", K.DENSE)
-@pytest.mark.parametrize("lane14", [False, True])
-def test_accurate_mode_at_the_headline_density(wlsqm, oracle, name, lane14, monkeypatch):
+def test_accurate_mode_at_the_headline_density(wlsqm, oracle, name):
     """BASELINE configs[1] / configs[4] at the density the metric is quoted on (every 977th case of the 1M / 16M-point clouds):
     bit-identical to variants.c V_SYM, and E_m <= 0.5e-10 on EVERY column against the reference's own output.  configs[2]
     (14 unknowns, F known: the reference's default mask) has no free change — the mirrored triangle alone is 1.4e-4 from the
-    reference there (profiles/r03_attribution.txt) — so the accurate mode runs the strict arithmetic on it: the row-per-lane kernel
-    by default, and with WLSQM_HIP_LANE14=1 the one-lane-per-case form of csrc/fit_accurate.hip (196 sums in three passes, LU with
-    the substitution riding along): both bit-identical to the oracle."""
+    reference there (profiles/r03_attribution.txt) — so the accurate mode runs the strict arithmetic on it (the row-per-lane kernel):
+    bit-identical to the oracle."""
     import torch
     import wlsqm.hip as whip
     c = K.config_dense(name)
     dim, order, no = c["dim"], c["order"], c["no"]
-    if lane14:
-        if no <= 10:
-            pytest.skip("the switch only concerns 2D order 4")
-        monkeypatch.setenv("WLSQM_HIP_LANE14", "1")
     fi = _t(c["fi0"])
     with whip.accurate():
         whip.fit_many_device(dim, order, _t(c["xk"]), _t(c["fk"]), _t(c["nk_a"]), _t(c["xi"]), fi, _t(c["knowns_a"]), _t(c["wm_a"]))
@@ -89,7 +81,7 @@ def test_accurate_mode_at_the_headline_density(wlsqm, oracle, name, lane14, monk
         E = P.column_metric(got, c["g"]["fi"])
         assert np.all(E <= TOL_REF), "%s: E = %s" % (name, E)
     else:
-        assert kern == ("accurate" if lane14 else "strict-rows"), kern
+        assert kern == "strict-rows", kern
 
 
 def test_accurate_and_strict_modes_with_the_default_mask(wlsqm, oracle):
@@ -137,21 +129,18 @@ def _hetero(dim, order, Kn, n, seed, wlsqm):
 @pytest.mark.parametrize("dim,order,Kn", [(2, 0, 8), (2, 1, 12), (2, 2, 32), (2, 2, 30), (2, 2, 18), (2, 3, 40), (3, 0, 6), (3, 1, 14),
                                           (3, 2, 40), (3, 2, 26), (2, 2, 7), (3, 2, 33), (2, 4, 64), (2, 4, 40), (2, 4, 37)])
 @pytest.mark.parametrize("n", [1, 63, 64, 65, 1000])
-def test_accurate_mode_heterogeneous_batches(wlsqm, oracle, dim, order, Kn, n, monkeypatch):
+def test_accurate_mode_heterogeneous_batches(wlsqm, oracle, dim, order, Kn, n):
     """Ragged nk, both weightings, knowns masks (none / F / one derivative / two / everything / stray high bits), batch sizes around the
-    64-case groups, odd K (per-lane rows instead of the LDS staging): every case the accurate kernels take carries the bits of
-    variants.c V_SYM (2D order 4: the oracle's), every other case the oracle's (strict kernels) — per CASE, whatever shares its group."""
+    64-case groups, odd K (per-lane rows instead of the LDS staging): every case carries the bits of variants.c V_SYM (2D order 4: the
+    oracle's — the strict kernels) — per CASE, whatever shares its group."""
     import torch
     import wlsqm.hip as whip
     b = _hetero(dim, order, Kn, n, 7 * Kn + n, wlsqm)
-    if (dim, order) == (2, 4):
-        monkeypatch.setenv("WLSQM_HIP_LANE14", "1")          # the one-lane-per-case form of the 14 x 14 system (off by default)
     fi = _t(b["fi0"])
     with whip.accurate():
         whip.fit_many_device(dim, order, _t(b["xk"]), _t(b["fk"]), _t(b["nk"]), _t(b["xi"]), fi, _t(b["kn"]), _t(b["wm"]))
         torch.cuda.synchronize()
-        # (the 14 x 14 one-lane form takes dense rows in whole 4-neighbour chunks; other layouts of 2D order 4 keep the row-per-lane kernel)
-        assert whip.last_kernel() == ("strict-rows" if (dim, order) == (2, 4) and Kn % 4 else "accurate"), whip.last_kernel()
+        assert whip.last_kernel() == ("strict-rows" if (dim, order) == (2, 4) else "accurate"), whip.last_kernel()
     got = fi.cpu().numpy()
     want = _expected(oracle, dim, order, b["xk"], b["fk"], b["nk"], b["xi"], b["fi0"], b["kn"], b["wm"])
     bad = np.nonzero((_bits(got) != _bits(want)).any(axis=1))[0]
@@ -259,11 +248,11 @@ def test_accurate_mode_through_the_reference_signatures_and_expertsolver(wlsqm, 
         assert np.array_equal(_bits(fi), _bits(want))
 
 
-def test_accurate_mode_work_lists_across_streams_graphs_and_repeated_calls(wlsqm, oracle):
-    """Round 5: the accurate mode's work lists live in a buffer that persists per stream, with two counter sets used alternately (the last
-    kernel of a call clears the set of the next one).  Many calls in a row on one stream, calls alternating between two streams, batches
-    that DO fill both lists (unsorted neighbours: every group is redone; stray mask bits: leftover groups) and a call captured into a
-    HIP graph and replayed must all return the bits of a fresh call."""
+def test_accurate_mode_across_streams_graphs_and_repeated_calls(wlsqm, oracle):
+    """Round 6: an accurate-mode call is ONE launch without any state between calls (round 5 kept work lists in a per-stream buffer).  Many
+    calls in a row on one stream, calls alternating between two streams, batches whose groups DO take the two-pass form on the spot
+    (unsorted neighbours) and cases with stray mask bits, and a call captured into a HIP graph and replayed must all return the bits of
+    a fresh call."""
     import torch
     import wlsqm.hip as whip
     rng = np.random.default_rng(21)
