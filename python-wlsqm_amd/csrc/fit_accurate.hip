@@ -58,7 +58,7 @@
 // the same kernel: the same code as before, the same bits), and no case is left over: no lists, no counters, no second kernel.
 // 2D order 4, sensitivities, refinement and 1D fits are NOT taken here: in accurate mode they run the strict kernels (the reference's
 // operations one for one, i.e. at least as close to the reference).  (Round 5's one-lane-per-case strict form of 2D order 4 with F known —
-// `LANE14`: bit-identical to the oracle, 1 693 spilled registers, slower than the row-per-lane kernel — is gone from the library; it is
+// `LANE14`: bit-identical to the strict kernels, 1 693 spilled registers, slower than the row-per-lane kernel — is gone from the library; it is
 // in the history at commit c9ef97d.)
 #include <atomic>
 #include <type_traits>
