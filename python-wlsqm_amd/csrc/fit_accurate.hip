@@ -304,46 +304,14 @@ __device__ __forceinline__ bool accurate_group(const KParams& p, const long long
     if constexpr (SPEC) { if (ncases - t0 < 64) return true; }
     const int lane = threadIdx.x;
     const long long t = t0 + lane;
-    const bool in_batch = t < ncases;
+    const bool in_batch = SPEC ? true : t < ncases;                   // (the speculative form takes whole groups only: straight-line loads, no exec-masked blocks at the head)
     const long long j = in_batch ? (p.case_index ? p.case_index[t] : t) : 0;
-    // (p.do_sens / p.iterative never reach this kernel)
-    // the mask: `known` = rows of the identity, never written (known DOFs, and the unknown DOFs the reference's nr leaves out when the mask
-    // has stray bits: effective_mask); `elim` = the DOFs whose value moves to the right-hand side (impl.pyx:792-823)
-    unsigned known = 0u, elim = 0u;
-    if (in_batch) {
-        unsigned long long k64, d64;
-        effective_mask<N>(p.knowns[j * p.sknowns], k64, d64);
-        known = (unsigned)k64; elim = (unsigned)(k64 & ~d64);
-    }
-    const bool active = in_batch && known != FULL;                    // every DOF known: nothing to solve (impl.pyx:740-742)
-    if (!__any(active)) return false;
-    const int K = (int)p.max_nk;
-    const int nk = active ? min(p.nk[j * p.snk], K) : 0;
-    const bool uniform = active ? (p.wm[j * p.swm] == WLSQM_WEIGHT_UNIFORM) : true;
-    double* const fio = p.fi + j * p.sfi_j;
-    double xi[DIM];
-    Rows<DIM> rows{};
-    if constexpr (DENSE) {
-#pragma unroll
-        for (int m = 0; m < DIM; ++m) xi[m] = in_batch ? p.xi[j * p.sxi_j + m] : 0.;
-    } else {
-        if (p.hoods) {
-            const long long pj = own_point(p, j);
-#pragma unroll
-            for (int m = 0; m < DIM; ++m) xi[m] = in_batch ? p.S[pj * DIM + m] : 0.;
-            rows = Rows<DIM>{nullptr, 0, nullptr, 0, p.hoods + j * p.shoods_j, p.S, p.F};
-        } else {
-#pragma unroll
-            for (int m = 0; m < DIM; ++m) xi[m] = in_batch ? p.xi[j * p.sxi_j + m] : 0.;
-            rows = Rows<DIM>{p.xk + j * p.sxk_j, p.sxk_k, p.fk + j * p.sfk_j, p.sfk_k, nullptr, nullptr, nullptr};
-        }
-    }
-
     // ---- one pass over the neighbours of the wave's cases: consume(k, live, d, f) per lane, k ascending.  DENSE: chunks of CH
     // neighbours through LDS, the next chunk in flight in registers.  MASKED = false: every active lane has nk == K (wave-uniform).
     // A load instruction moves the chunks of XCPI (FCPI) whole cases, XPC (FPC) consecutive lanes per case: the lane's global
     // offset is ONE 32-bit register for every instruction and chunk (the rest of the address is wave-uniform) and its LDS position a
     // compile-time distance from the first one.
+    const int K = (int)p.max_nk;
     const int Q = (K + CH - 1) / CH;
     const int nvalid = (ncases - t0 < 64) ? (int)(ncases - t0) : 64;
     constexpr int XCPI = 64 / XPC, XNI = (64 + XCPI - 1) / XCPI;      // 2D: 8 cases x 8 instructions; 3D: 5 x 13 (lanes 60..63 idle)
@@ -352,7 +320,7 @@ __device__ __forceinline__ bool accurate_group(const KParams& p, const long long
     const int xsub = lane % XPC, xc0 = lane / XPC, fsub = lane % FPC, fc0 = lane / FPC;
     const unsigned xrowb = (unsigned)K * DIM * 8, frowb = (unsigned)K * 8;
     const unsigned xg0 = (unsigned)xc0 * xrowb + (unsigned)xsub * 16u, fg0 = (unsigned)fc0 * frowb + (unsigned)fsub * 16u;
-    const bool xlane = lane < XCPI * XPC;
+    const bool xlane = (XCPI * XPC >= 64) || lane < XCPI * XPC;       // (2D: every lane, and the compiler must see it — a predicated block of loads ends in a wait for all of them)
     d2_ xr[DENSE ? XNI : 1], fr[DENSE ? FNI : 1];
     // pass 1 of the two-pass form (largest squared distance) does a few instructions per neighbour: a chunk does not cover the latency of
     // the next one's loads.  It keeps W1 chunks in flight instead (their registers are free: the matrix is not live yet).
@@ -404,6 +372,50 @@ __device__ __forceinline__ bool accurate_group(const KParams& p, const long long
         }
     };
     auto park = [&](bool want_f) { park_from(xr, want_f); };
+    // ---- the head of a group.  ROUND 6: everything the wave needs first is REQUESTED before any of it is looked at — the first staged chunk
+    // (its addresses depend on the launch parameters alone), the cases' scalars, the centres and (speculative form) the LAST slot of every
+    // row, which holds the farthest neighbour of a case with nk == K: in source order the mask, then nk, then the last neighbour's address
+    // were three memory round trips in a row before the first chunk was even asked for (SQ_WAIT_INST_ANY: a quarter of the wave cycles).
+    // (p.do_sens / p.iterative never reach this kernel)
+    if constexpr (SPEC) fetch(0, true);
+    const long long kn_raw = in_batch ? p.knowns[j * p.sknowns] : 0;
+    const int nk_raw = in_batch ? p.nk[j * p.snk] : 0;
+    const int wm_raw = in_batch ? p.wm[j * p.swm] : WLSQM_WEIGHT_UNIFORM;
+    double xi[DIM], xlast[DIM];
+    Rows<DIM> rows{};
+    if constexpr (DENSE) {
+#pragma unroll
+        for (int m = 0; m < DIM; ++m) xi[m] = in_batch ? p.xi[j * p.sxi_j + m] : 0.;
+        if constexpr (SPEC) {
+#pragma unroll
+            for (int m = 0; m < DIM; ++m) xlast[m] = in_batch ? p.xk[j * (long long)K * DIM + (long long)(K - 1) * DIM + m] : 0.;
+        }
+    } else {
+        if (p.hoods) {
+            const long long pj = own_point(p, j);
+#pragma unroll
+            for (int m = 0; m < DIM; ++m) xi[m] = in_batch ? p.S[pj * DIM + m] : 0.;
+            rows = Rows<DIM>{nullptr, 0, nullptr, 0, p.hoods + j * p.shoods_j, p.S, p.F};
+        } else {
+#pragma unroll
+            for (int m = 0; m < DIM; ++m) xi[m] = in_batch ? p.xi[j * p.sxi_j + m] : 0.;
+            rows = Rows<DIM>{p.xk + j * p.sxk_j, p.sxk_k, p.fk + j * p.sfk_j, p.sfk_k, nullptr, nullptr, nullptr};
+        }
+    }
+    // the mask: `known` = rows of the identity, never written (known DOFs, and the unknown DOFs the reference's nr leaves out when the mask
+    // has stray bits: effective_mask); `elim` = the DOFs whose value moves to the right-hand side (impl.pyx:792-823)
+    unsigned known = 0u, elim = 0u;
+    if (in_batch) {
+        unsigned long long k64, d64;
+        effective_mask<N>(kn_raw, k64, d64);
+        known = (unsigned)k64; elim = (unsigned)(k64 & ~d64);
+    }
+    const bool active = in_batch && known != FULL;                    // every DOF known: nothing to solve (impl.pyx:740-742)
+    if (!__any(active)) return false;
+    const int nk = active ? min(nk_raw, K) : 0;
+    const bool uniform = active ? (wm_raw == WLSQM_WEIGHT_UNIFORM) : true;
+    double* const fio = p.fi + j * p.sfi_j;
+
     // the neighbours of chunk q, staged in LDS: straight-line code for GRP neighbours at a time (all CH at once: the scheduler hoists
     // every LDS read and the kernel spills; the group size itself measured flat, profiles/r04b_ab_accurate.txt)
     auto chunk = [&](auto masked_tag, int q, bool want_f, auto&& consume) {
@@ -447,7 +459,11 @@ __device__ __forceinline__ bool accurate_group(const KParams& p, const long long
     };
     // (the staged passes run back to back: pass P's first chunk is requested under pass P - 1's last)
     // give_up(): wave-uniform, asked after every chunk — the speculative pass leaves as soon as its guess is refuted
-    auto run_pass = [&](auto masked_tag, bool want_f, bool prefetched, bool more_passes, bool next_want_f, auto&& consume, auto&& give_up) {
+    // (ONE copy of the fetch / park code for both forms of the chunk: with a loop per form the chunk in flight lived in different registers
+    // in the two loops, and the compiler — which must assume a path from one loop into the other — made the ragged form's registers wait
+    // for the full form's loads: `s_waitcnt vmcnt(0)` at the head of every chunk's arithmetic)
+    const bool wave_full = __all(!active || nk == K);
+    auto run_pass = [&](bool want_f, bool prefetched, bool more_passes, bool next_want_f, auto&& consume, auto&& give_up) {
         if constexpr (DENSE) {
             if (!prefetched) fetch(0, want_f);
             for (int q = 0; q < Q; ++q) {
@@ -456,7 +472,7 @@ __device__ __forceinline__ bool accurate_group(const KParams& p, const long long
                 __syncthreads();
                 if (q + 1 < Q) fetch(q + 1, want_f);
                 else if (more_passes) fetch(0, next_want_f);
-                chunk(masked_tag, q, want_f, consume);
+                if (wave_full) chunk(std::false_type{}, q, want_f, consume); else chunk(std::true_type{}, q, want_f, consume);
                 if (give_up()) break;
             }
         } else {
@@ -493,10 +509,8 @@ __device__ __forceinline__ bool accurate_group(const KParams& p, const long long
             }
         }
     };
-    const bool wave_full = __all(!active || nk == K);
     auto pass_until = [&](bool want_f, bool prefetched, bool more_passes, bool next_want_f, auto&& consume, auto&& give_up) {
-        if (wave_full) run_pass(std::false_type{}, want_f, prefetched, more_passes, next_want_f, consume, give_up);
-        else run_pass(std::true_type{}, want_f, prefetched, more_passes, next_want_f, consume, give_up);
+        run_pass(want_f, prefetched, more_passes, next_want_f, consume, give_up);
     };
     auto pass = [&](bool want_f, bool prefetched, bool more_passes, bool next_want_f, auto&& consume) {
         pass_until(want_f, prefetched, more_passes, next_want_f, consume, [] { return false; });
@@ -592,13 +606,16 @@ __device__ __forceinline__ bool accurate_group(const KParams& p, const long long
         // ---- the speculative single pass (see above): guess = squared distance of the last neighbour, same operations as make_c
         double guess = 0.;
         if (active && nk > 0) {
-            const double* q = p.xk + j * (long long)K * DIM + (long long)(nk - 1) * DIM;
+            if (nk != K) {                                            // a ragged case: its last neighbour sits elsewhere in the row
+                const double* q = p.xk + j * (long long)K * DIM + (long long)(nk - 1) * DIM;
+#pragma unroll
+                for (int m = 0; m < DIM; ++m) xlast[m] = q[m];
+            }
             double dg[DIM], cg[N];
 #pragma unroll
-            for (int m = 0; m < DIM; ++m) dg[m] = q[m] - xi[m];
+            for (int m = 0; m < DIM; ++m) dg[m] = xlast[m] - xi[m];
             guess = make_c<DIM, ORDER>(dg, cg);
         }
-        fetch(0, true);
         double rg = 0., max_d2 = 0., min_d2 = RANGE_HI;
         auto weight_of = [&](double d2) __attribute__((always_inline)) {
             const double tmp = 1. - FastOps::sqrt(div_by(d2, guess, rg));
