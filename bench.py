@@ -83,7 +83,7 @@ def load_traffic(config, units_per_launch):
     name = "traffic_%s.json" % config
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", name)))
-        if int(t.get("cases_per_launch", -1)) == int(units_per_launch):
+        if int(units_per_launch) in (int(t.get("cases_per_launch", -1)), int(t.get("units_per_launch", -1))):      # (C4: units = cases x stacked right-hand sides)
             return t.get("hbm_bytes_per_launch"), "profiles/" + name
     except Exception:
         pass
@@ -289,8 +289,10 @@ def measure_fit(name, cfg, n, dev, timer, steps, warmup, rank, parity=True, keep
     del h_d
     args = (dim, order, xk_d, fk_d, nk_d, xi_d, fi_d, kn_d, wm_d)
     if extras:
-        # the fit with sensitivities / refinement is one or several kernels per call: the whole call is timed with events on its stream
-        kw = dict(sens=torch.zeros((n, nk, no), dtype=torch.float64, device=dev)) if extras == "sens" else dict(iterative=True, max_iter=10)
+        # the fit with sensitivities / refinement / in the accurate numerics mode is one or several kernels per call: the whole call is timed
+        # with events on its stream
+        kw = (dict(sens=torch.zeros((n, nk, no), dtype=torch.float64, device=dev)) if extras == "sens" else
+              dict(strict="accurate") if extras == "accurate" else dict(iterative=True, max_iter=10))
         dt = timer.run(lambda: whip.fit_many_device(*args, **kw), steps, warmup)
         kernel = whip.last_kernel()
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
@@ -302,12 +304,29 @@ def measure_fit(name, cfg, n, dev, timer, steps, warmup, rank, parity=True, keep
         ms_kernel = e0.elapsed_time(e1) / reps
         B_fit = bytes_per_fit(dim, order, nk, cfg["knowns"]) + (8 * nk * no if extras == "sens" else 0)
         achieved = B_fit * n / (ms_kernel * 1e-3) / 1e9
-        return {"workload": "%s with %s: %s; %d local fits per GPU per step, device-resident dense xk/fk"
-                            % (name, "sensitivities (do_sens)" if extras == "sens" else "iterative refinement (max_iter 10)", cfg["desc"], n),
-                "fits_per_gpu": n, "bytes_per_fit": B_fit, "ms_per_step": dt / steps * 1e3, "fits_per_s": n * steps / dt,
-                "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                             "traffic": None, "kernel_ms": ms_kernel, "kernel": kernel, "algorithmic_bytes_per_launch": B_fit * n,
-                             "note": "whole call (every kernel of the path), HIP events on the launch stream"}}, dt
+        res = {"workload": "%s with %s: %s%s; %d local fits per GPU per step, device-resident dense xk/fk"
+                           % (name, {"sens": "sensitivities (do_sens)", "accurate": "the ACCURATE numerics mode (reference arithmetic, mirrored triangle)"}.get(
+                               extras, "iterative refinement (max_iter 10)"), cfg["desc"], ", neighbours in RANDOM order" if unsorted else "", n),
+               "fits_per_gpu": n, "bytes_per_fit": B_fit, "ms_per_step": dt / steps * 1e3, "fits_per_s": n * steps / dt,
+               "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                            "traffic": None, "kernel_ms": ms_kernel, "kernel": kernel, "algorithmic_bytes_per_launch": B_fit * n,
+                            "note": "whole call (every kernel of the path), HIP events on the launch stream"}}
+        if extras == "accurate" and parity and rank == 0:
+            # the first 1 024 cases against the mode's CPU statement (variants.c V_SYM: bit for bit) and against the CPU port of the reference
+            from oracle import oracle
+            m = 1024
+            xk, fk, xi = (a[:m].cpu().numpy() for a in (xk_d, fk_d, xi_d))
+            got = fi_d[:m].cpu().numpy()
+            kn = np.full(m, cfg["knowns"], np.int64); wm = np.full(m, cfg["wm"], np.int32); nka = np.full(m, nk, np.int32)
+            sym = np.zeros((m, no)); sym[:, 0] = F[:m]
+            oracle.variant_fit_many(dim, order, xk, fk, nka, xi, sym, kn, wm, flags=oracle.V_SYM)
+            ref = np.zeros((m, no)); ref[:, 0] = F[:m]
+            oracle.fit_many(dim, xk, fk, nka, xi, ref, None, 0, np.full(m, order, np.int32), kn, wm, ntasks=8)
+            scale = np.abs(ref).max(axis=0)
+            E = np.abs(got - ref).max(axis=0) / np.where(scale > 0, scale, 1.0)
+            res["parity"] = {"vs_cpu_statement": {"cases": m, "bit_identical_cases": int((got.view(np.int64) == sym.view(np.int64)).all(axis=1).sum())},
+                             "vs_oracle": {"cases": m, "E_max": float(E.max()), "columns": int(no), "columns_le_1e-10": int((E <= 1e-10).sum())}}
+        return res, dt
     dt = timer.run(lambda: whip.fit_many_device(*args), steps, warmup)
     kernel = whip.last_kernel()
     # dominant kernel: HIP events over the timed region itself (Timer.run), on the stream it is launched on; a dedicated run of the same
@@ -828,6 +847,12 @@ def side_configs(a, dev, timer, rank, parity):
         add("%s-unsorted@1M" % cname, lambda cname=cname: measure_extra_shape(cname + "-unsorted", CONFIGS[cname], 1_000_000, dev, timer,
                                                                              short["steps"], short["warmup"], rank, parity, unsorted=True))
     add("C3-ball@400k", lambda: measure_ball("C3-ball", 400_000, dev, timer, short["steps"], short["warmup"], rank, parity))
+    # the ACCURATE mode beyond the headline's parity block: configs[4]'s shape, the reference's default mask, shuffled rows
+    add("C5-accurate@1M", lambda: measure_fit("C5-accurate", CONFIGS["C5"], 1_000_000, dev, timer, short["steps"], short["warmup"], rank, parity, extras="accurate"))
+    add("C2-accurate-Fknown@1M", lambda: measure_fit("C2-accurate-Fknown", dict(CONFIGS["C2"], knowns=1, desc=CONFIGS["C2"]["desc"] + " [F known: simple.pyx:60-61]"),
+                                                       1_000_000, dev, timer, short["steps"], short["warmup"], rank, parity, extras="accurate"))
+    add("C2-accurate-unsorted@1M", lambda: measure_fit("C2-accurate-unsorted", CONFIGS["C2"], 1_000_000, dev, timer, short["steps"], short["warmup"], rank,
+                                                         parity, extras="accurate", unsorted=True))
     # (3Do4-64nb: 40 neighbours for 35 unknowns is a nearly determined fit — its parity block is mostly conditioning noise; 64 is the workload
     # a user of that order would run)
     for key, order, cn, knb in (("3Do3@1M", 3, 1_000_000, 40), ("3Do4@400k", 4, 400_000, 40), ("3Do4-64nb@200k", 4, 200_000, 64)):

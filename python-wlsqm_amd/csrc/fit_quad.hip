@@ -251,172 +251,9 @@ __global__ __launch_bounds__(64, 1) void quad_solve_kernel(const KParams p) {
     });
 }
 
-// ---- SIXTEEN LANES PER CASE (round 5): the same solve with the pivot row broadcast INSIDE the multiply-add.
-//
-// gfx950 has one DPP form for 64-bit operands, row_newbcast:N (every lane of a row of 16 lanes reads lane N of its own row), and the
-// 64-bit fused multiply-add accepts it on its first source: v_fmac_f64_dpp d, a, b row_newbcast:N  =  d += a[lane N of my row] * b
-// (tools/ubench/dpp_newbcast.hip: checked on the part; v_mul_f64 / v_fma_f64 are VOP3 and have no DPP form).  With a case on the 16
-// lanes of a row — matrix row i in lane i mod 16, slot i / 16; three slots of 36 columns (column 35 = the right-hand side), FULL rows,
-// kept symmetric — an elimination step needs no broadcast instruction and no select at all: the multiplier of row i is its OWN
-// entry (i, j) times the pivot's reciprocal, the pivot row arrives as the DPP operand of the update itself.  1 694 multiply-adds per
-// wave of four cases instead of the quad form's 2 815 + 1 500 broadcasts + 1 600 selects for sixteen: more arithmetic per case
-// (full rows: both triangles are updated), but 108 doubles per lane — TWO waves per SIMD, no LDS rows, no accumulation-register
-// parking, no scratch — where the quad form owns its SIMD with 442 registers and runs at a third of the issue rate.
-// Hazard: a register written by a VALU instruction may be read through DPP two wait states later at the earliest, and inline
-// assembly is invisible to the compiler's hazard recogniser: the statements below are ordered so that no DPP source is written by
-// one of the two instructions in front of its reader (columns ascending, slots descending: the pivot row's own slot is updated last),
-// an s_nop follows the two places that compute a value and broadcast it at once, and tools/check_dpp_hazard.py verifies the
-// compiled kernel instruction by instruction (the compiler is free to put a copy in front of a statement).
-namespace row16 {
-using namespace quad;
-constexpr int SL = 3;                                                 // slots: rows l, 16 + l, 32 + l of the lane
-template <int LJ> __device__ __forceinline__ void fmac_bcast(double& d, const double& a, const double& b) {      // d += a[lane LJ of the row] * b
-    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(a), "v"(b), "n"(LJ));
-}
-template <int LJ> __device__ __forceinline__ void fmac_bcast_fresh(double& d, const double& a, const double& b) { // the same, `a` written by the instruction in front
-    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(a), "v"(b), "n"(LJ));
-}
-}  // namespace row16
-
-__global__ __launch_bounds__(64, 2) void row16_solve_kernel(const KParams p) {
-    using namespace row16;
-    __shared__ __attribute__((aligned(16))) double mom[4 * PITCH];
-    __shared__ unsigned int s_idx32[NP * NP / 4];
-    const int lane = threadIdx.x, l = lane & 15, c = lane >> 4;
-    const long long case0 = (long long)blockIdx.x * 4;
-    for (int w = lane; w < NP * NP / 4; w += 64) s_idx32[w] = reinterpret_cast<const unsigned int*>(g_tab.idx)[w];
-    {
-        // the 4 cases of this wave are 4 consecutive lanes of one 64-case group of the moment kernels: 32 contiguous bytes per entry
-        const double* src = p.ws + (case0 >> 6) * (long long)(NW * 64) + (case0 & 63);
-        const int cc = lane & 3, e0 = lane >> 2;
-#pragma unroll
-        for (int it = 0; it < (NW + 15) / 16; ++it) {
-            const int e = it * 16 + e0;
-            if (e < NW) mom[cc * PITCH + e] = src[e * 64 + cc];
-        }
-        if (lane < 4) mom[lane * PITCH + NW] = 0.0;
-    }
-    __syncthreads();
-    const unsigned char* const s_idx = reinterpret_cast<const unsigned char*>(s_idx32);
-    const long long t = case0 + c;
-    const bool valid = t < p.ncases;
-    const long long j = valid ? t : p.ncases - 1;                      // lanes past the end replay the last case (never stored)
-    unsigned long long known, dropped;
-    effective_mask<NO>(p.knowns[j * p.sknowns], known, dropped);
-    const unsigned long long vals = known & ~dropped;                  // DOFs whose value is in fi
-    const bool any_known = __any(known != 0ull);                       // wave-uniform: the common wave has no known DOF at all
-    double* const fio = p.fi + j * p.sfi_j;
-    const double* const mc = mom + c * PITCH;
-
-    // ---- the lane's three rows from the moments (rows 35 .. 47 do not exist: their table entries point at the zero slot), masked to
-    // identity in the known DOFs, the known values taken out of the right-hand side first (quad_solve_kernel's operations)
-    double R[SL][NP];
-    double fa[SL];
-#pragma unroll
-    for (int s = 0; s < SL; ++s) {
-        const int i = 16 * s + l;
-        fa[s] = i < NP ? g_tab.fact[i < NP ? i : 0] : 0.0;
-        R[s][NP - 1] = i < NP ? mc[g_tab.nuidx[i < NP ? i : NP - 1]] * fa[s] : 0.0;
-    }
-    if (any_known) {
-        for (int om = 0; om < NO; ++om) {                              // (rolled: the rare path must not cost the common one its registers)
-            const double v = ((vals >> om) & 1ull) ? fio[om] : 0.0;
-            const double fom = g_tab.fact[om];
-#pragma unroll
-            for (int s = 0; s < SL; ++s) {
-                const int i = 16 * s + l;
-                const double vi = (i == om || i >= NO) ? 0.0 : v;
-                const double m = i < NO ? mc[s_idx[i * NP + om]] : 0.0;
-                R[s][NP - 1] = fma(-(m * (fa[s] * fom)), vi, R[s][NP - 1]);
-            }
-        }
-#pragma unroll
-        for (int s = 0; s < SL; ++s) { const int i = 16 * s + l; R[s][NP - 1] = (i < NO && ((known >> i) & 1ull)) ? 0.0 : R[s][NP - 1]; }
-    }
-    static_for<0, SL>([&](auto s_) __attribute__((always_inline)) {
-        constexpr int s = decltype(s_)::value;
-        const int i = 16 * s + l;
-        const bool real = i < NO;
-        const bool bi = real && ((known >> i) & 1ull);
-        unsigned int w[NP / 4];
-        static_for<0, NP / 4>([&](auto g_) __attribute__((always_inline)) { w[decltype(g_)::value] = s_idx32[(real ? i : NP - 1) * (NP / 4) + decltype(g_)::value]; });
-        __builtin_amdgcn_sched_barrier(0);
-        static_for<0, (NO + 7) / 8>([&](auto h_) __attribute__((always_inline)) {
-            constexpr int m0 = 8 * decltype(h_)::value;
-            double v[8];
-            static_for<0, 8>([&](auto e_) __attribute__((always_inline)) {
-                constexpr int m = m0 + decltype(e_)::value;
-                if constexpr (m < NO) v[decltype(e_)::value] = mc[(w[m / 4] >> (8 * (m % 4))) & 0xffu];
-            });
-            __builtin_amdgcn_sched_barrier(0);
-            static_for<0, 8>([&](auto e_) __attribute__((always_inline)) {
-                constexpr int m = m0 + decltype(e_)::value;
-                if constexpr (m < NO) {
-                    double x = v[decltype(e_)::value] * (fa[s] * fact_of(m));      // (a row that does not exist reads the zero slot)
-                    if (any_known) {
-                        const bool bm = (known >> m) & 1ull;
-                        x = (bi || bm) ? ((i == m) ? 1.0 : 0.0) : x;
-                    }
-                    R[s][m] = x;
-                }
-            });
-            __builtin_amdgcn_sched_barrier(0);
-        });
-    });
-
-    // ---- LDL^T by rows, right-looking, both triangles; the right-hand side rides along as column 35 (= the forward substitution)
-    static_for<0, NO>([&](auto jj_) __attribute__((always_inline)) {
-        constexpr int jj = decltype(jj_)::value, sj = jj / 16, lj = jj % 16;
-        double inv = recip(R[sj][jj]);                                 // (lane lj's is the pivot's)
-        double nt[SL];
-        static_for<sj, SL>([&](auto s_) __attribute__((always_inline)) {
-            constexpr int s = decltype(s_)::value;
-            double tt = 0.0;
-            if constexpr (s == sj) fmac_bcast_fresh<lj>(tt, inv, R[s][jj]); else fmac_bcast<lj>(tt, inv, R[s][jj]);      // tt = inv[lane lj] * R[s][jj]
-            if constexpr (s == sj) tt = (l > lj) ? tt : 0.0;           // rows up to the pivot row are finished
-            nt[s] = -tt;
-        });
-        // columns ascending, slots descending: the pivot row's own slot — a DPP source of this column — is written last
-        static_for<jj + 1, NP>([&](auto m_) __attribute__((always_inline)) {
-            constexpr int m = decltype(m_)::value;
-            static_for<0, SL - sj>([&](auto r_) __attribute__((always_inline)) {
-                constexpr int s = SL - 1 - decltype(r_)::value;
-                fmac_bcast<lj>(R[s][m], R[sj][m], nt[s]);
-            });
-        });
-        R[sj][jj] = (l == lj) ? inv : R[sj][jj];                       // the owner keeps 1 / d_j where d_j was
-    });
-
-    // ---- back substitution by columns; the unknown DOFs leave from their row's owner
-    static_for<0, NO>([&](auto r_) __attribute__((always_inline)) {
-        constexpr int m = NO - 1 - decltype(r_)::value, sm = m / 16, lm = m % 16;
-        const double x = R[sm][NP - 1] * R[sm][m];                     // (lane lm's is x_m)
-        if (l == lm && valid && !((known >> m) & 1ull)) fio[m] = x;
-        double nx = -x;
-        static_for<0, sm + 1>([&](auto s_) __attribute__((always_inline)) {
-            constexpr int s = decltype(s_)::value;
-            double u = R[s][m];
-            if constexpr (s == sm) u = (l < lm) ? u : 0.0;
-            if constexpr (s == 0) fmac_bcast_fresh<lm>(R[s][NP - 1], nx, u); else fmac_bcast<lm>(R[s][NP - 1], nx, u);
-        });
-    });
-}
-
-// The solve of p.ncases cases whose moments are in p.ws (see the kernels).  WLSQM_HIP_QUAD=row16: the sixteen-lanes-per-case form —
-// MEASURED AND OFF (profiles/r05d_row16.txt): 400k cases x 40 neighbours 1.417 ms against 1.207 with the quad form, 200k x 64 0.841
-// against 0.750.  No scratch, two waves per SIMD, but 4.0k instructions per wave of FOUR cases (the quad form: 9.6k per sixteen), and
-// v_fmac_f64_dpp issues at half the rate of a plain 64-bit multiply-add (the timing fits 8 cycles per DPP instruction): the
-// broadcast inside the instruction costs what the separate move did.
+// The solve of p.ncases cases whose moments are in p.ws (see the kernel).  (Round 5's sixteen-lanes-per-case form with v_fmac_f64_dpp
+// row_newbcast — 1.417 against 1.207 ms per 400k cases: profiles/r05d_row16.txt — is out of the library: tools/experiments/fit_quad_row16.hip.txt.)
 int launch_quad_solve(const KParams& p, hipStream_t stream) {
-    const char* e = getenv("WLSQM_HIP_QUAD");
-    if (e && e[0] == 'r') {
-        const long long waves = (p.ncases + 3) / 4;
-        if (waves <= 0) return WLSQM_OK;
-        if (waves > 0x7fffffffLL) { set_error("fit_quad: batch too large for one launch"); return WLSQM_EVALUE; }
-        hipLaunchKernelGGL(row16_solve_kernel, dim3((unsigned)waves), dim3(64), 0, stream, p);
-        WLSQM_HIP_CHECK(hipGetLastError());
-        return WLSQM_OK;
-    }
     const long long waves = (p.ncases + 15) / 16;
     if (waves <= 0) return WLSQM_OK;
     if (waves > 0x7fffffffLL) { set_error("fit_quad: batch too large for one launch"); return WLSQM_EVALUE; }

@@ -428,6 +428,13 @@ int launch_fit_sens(int dimension, int order, const KParams& p, long long K, hip
     if (per > p.ncases) per = p.ncases;
     double* inv = nullptr;
     int rc = scratch_alloc_async(reinterpret_cast<void**>(&inv), (size_t)((per + 63) / 64 * 64) * no * no * sizeof(double), stream);
+    // (a card short of memory gets smaller slices, not an error — down to 16 MB of inverses)
+    while (rc != WLSQM_OK && per > 1024 && (size_t)per * no * no * sizeof(double) > (16u << 20)) {
+        (void)hipGetLastError();
+        per = ((per / 2) / 64) * 64;
+        if (per < 1024) per = 1024;
+        rc = scratch_alloc_async(reinterpret_cast<void**>(&inv), (size_t)((per + 63) / 64 * 64) * no * no * sizeof(double), stream);
+    }
     if (rc != WLSQM_OK) return rc;
     for (long long j0 = 0; j0 < p.ncases && rc == WLSQM_OK; j0 += per) {
         const long long n = (p.ncases - j0 < per) ? (p.ncases - j0) : per;

@@ -166,13 +166,7 @@ __global__ __launch_bounds__(64, (PART == 5 ? 1 : ndofs(DIM, ORDER) <= 6 ? (GATH
     // GATHER: the chunk in flight (nx, nf) and the chunk being consumed (cx, cf)
     double nx[GATHER ? CH : 1][DIM], nf[GATHER ? CH : 1], cx[GATHER ? CH : 1][DIM], cf[GATHER ? CH : 1];
     const bool rows16 = GATHER && ((reinterpret_cast<uintptr_t>(p.hoods) & 15u) == 0) && (p.shoods_j % 4 == 0);      // wave-uniform
-    // DEEP: TWO chunks in flight (two register sets, chunk c in set (Q - 1 - c) & 1): the systems that own their SIMD have the
-    // registers, and a lone wave has nobody to cover the gap between the landing of a chunk and the request for the next
-#ifndef WLSQM_STAGE_DEEP
-#define WLSQM_STAGE_DEEP 0      // (measured: the second register set spills — 512 registers + 108 B — and configs[2] runs 0.475 instead of 0.432 ms)
-#endif
-    constexpr bool DEEP = (WLSQM_STAGE_DEEP != 0) && (WLSQM_STAGE_DEEP == 2 ? (NO > 6 && NO <= 10) : NO > 10);
-    d2_ xr[XNI], fr[FNI], xr2[DEEP ? XNI : 1], fr2[DEEP ? FNI : 1];
+    d2_ xr[XNI], fr[FNI];
     bool want_f = true;                                               // wave-uniform: the pass that only looks for the largest squared distance moves no values
     auto fetch_into = [&](d2_ (&xr)[XNI], d2_ (&fr)[FNI], int q) __attribute__((always_inline)) {
         unsigned xo = (unsigned)q * (CH * DIM * 8) + (unsigned)xsub * 16u, fo = (unsigned)q * (CH * 8) + (unsigned)fsub * 16u;
@@ -231,7 +225,7 @@ __global__ __launch_bounds__(64, (PART == 5 ? 1 : ndofs(DIM, ORDER) <= 6 ? (GATH
                     unsigned long long keepx;
                     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_mov_b64 %1, exec\n\ts_and_b64 exec, %1, %5\n\tglobal_load_lds_dwordx4 %2, %3 nt\n\t"
                                  "s_andn2_b64 exec, %1, %5\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
-                                 : "=&s"(keep), "=&s"(keepx) : "v"(xo + (unsigned)cc * xrowb), "s"(xt), "s"(slot + (unsigned)i * 1024u), "s"(inner) : "memory");
+                                 : "=&s"(keep), "=&s"(keepx) : "v"(xo + (unsigned)cc * xrowb), "s"(xt), "s"(slot + (unsigned)i * 1024u), "s"(inner) : "memory", "scc");      // (s_and_b64 / s_andn2_b64 write SCC: ADVICE r5)
                 } else
                 asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" WLSQM_STAGE_DMA_POLICY "\n\ts_mov_b32 m0, %0"
                              : "=&s"(keep) : "v"(xo + (unsigned)cc * xrowb), "s"(xt), "s"(slot + (unsigned)i * 1024u) : "memory");
@@ -330,72 +324,6 @@ __global__ __launch_bounds__(64, (PART == 5 ? 1 : ndofs(DIM, ORDER) <= 6 ? (GATH
         guess = sqdist(dg);
     }
 
-    // AGPR (round 5; the lone-wave shapes, dense input): TWO chunks in flight with no register set of their own in the vector file.  The
-    // loads of a chunk land in the accumulation file (global_load_dwordx4 a[..]: gfx950 loads and LDS stores take AGPR data operands)
-    // and are parked from there (ds_write_b128 v, a[..]), so the second set costs no architectural register and no v_accvgpr move —
-    // the second set in the vector file spilled (WLSQM_STAGE_DEEP: configs[2] 0.475 against 0.432 ms).  The compiler does not see
-    // inline-assembly loads: the wait before a park is written by hand, `s_waitcnt vmcnt(loads of the ONE younger chunk)` (in-order
-    // counter: any other memory operation in flight only makes the wait longer, never too short).  Chunk c uses set (Q - 1 - c) & 1.
-    // MEASURED AND OFF (profiles/r05c_ab_stage_agpr.txt, same box, tools/ab_unit.sh): configs[2] 0.4047 ms with it against 0.3898 without,
-    // configs[4] 0.2936 against 0.2857 — a second chunk in flight is not what a lone wave is short of (VERDICT r4 item 7's premise), and the
-    // sets take the accumulation registers the solve parks its matrix in (84 / 276 B of scratch outside the loops).
-#ifndef WLSQM_STAGE_AGPR
-#define WLSQM_STAGE_AGPR 0
-#endif
-    constexpr bool AGPR = (WLSQM_STAGE_AGPR != 0) && !GATHER && NO > 6 && NO <= 15 && !DEEP;      // (the 20- and 35-unknown systems need the accumulation file for their sums: 1.0-1.3 KB of scratch with the sets there)
-    d2_ ax[AGPR ? 2 : 1][AGPR ? XNI : 1], af[AGPR ? 2 : 1][AGPR ? FNI : 1];
-    auto fetch_agpr = [&](auto set_tag, int q) __attribute__((always_inline)) {
-        auto& ax_ = ax; auto& af_ = af; const char* const xt = xtile; const char* const ft = ftile;      // (named outside the discarded statement: implicit capture in nested generic lambdas)
-        (void)ax_; (void)af_; (void)xt; (void)ft;
-        if constexpr (AGPR) {
-            constexpr int S = decltype(set_tag)::value;
-            unsigned xo = (unsigned)q * (CH * DIM * 8) + (unsigned)xsub * 16u, fo = (unsigned)q * (CH * 8) + (unsigned)fsub * 16u;
-            xo = xo < xrowb ? xo : xrowb - 16u; fo = fo < frowb ? fo : frowb - 16u;
-#pragma unroll
-            for (int i = 0; i < XNI; ++i) {
-                int cc = xc0 + i * XCPI;
-                cc = cc < nvalid ? cc : nvalid - 1;                   // (idle lanes of the last instruction and tail groups replay a valid row; idle lanes never park)
-                asm volatile("global_load_dwordx4 %0, %1, %2" : "=a"(ax_[S][i]) : "v"(xo + (unsigned)cc * xrowb), "s"(xt) : "memory");
-            }
-            if (want_f) {
-#pragma unroll
-                for (int i = 0; i < FNI; ++i) {
-                    int cc = fc0 + i * FCPI;
-                    cc = cc < nvalid ? cc : nvalid - 1;
-                    asm volatile("global_load_dwordx4 %0, %1, %2" : "=a"(af_[S][i]) : "v"(fo + (unsigned)cc * frowb), "s"(ft) : "memory");
-                }
-            }
-        }
-    };
-    // wait until every load but the `younger` most recent chunks' has landed (younger = 0 / 1 chunks of XNI (+ FNI) loads)
-    auto wait_agpr = [&](bool one_younger) __attribute__((always_inline)) {
-        if constexpr (AGPR) {
-            if (!one_younger) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (want_f) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(XNI + FNI) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(XNI) : "memory");
-        }
-    };
-    auto park_agpr = [&](auto set_tag) __attribute__((always_inline)) {
-        auto& ax_ = ax; auto& af_ = af;
-        (void)ax_; (void)af_;
-        if constexpr (AGPR) {
-            constexpr int S = decltype(set_tag)::value;
-            const unsigned xa = (unsigned)(uintptr_t)(xs + xc0 * XPITCH + xsub * 2), fa = (unsigned)(uintptr_t)(fs + fc0 * FPITCH + fsub * 2);
-            if (xlane) {
-#pragma unroll
-                for (int i = 0; i < XNI; ++i)
-                    if (i * XCPI + XCPI <= 64 || xc0 + i * XCPI < 64)
-                        asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(xa), "a"(ax_[S][i]), "n"(i * XCPI * XPITCH * 8) : "memory");
-            }
-            if (want_f) {
-#pragma unroll
-                for (int i = 0; i < FNI; ++i)
-                    asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(fa), "a"(af_[S][i]), "n"(i * FCPI * FPITCH * 8) : "memory");
-            }
-        }
-    };
-    using S0 = std::integral_constant<int, 0>;
-    using S1 = std::integral_constant<int, 1>;
     auto gather = [&](int q) __attribute__((always_inline)) {
         if constexpr (GATHER) {
             int idx[CH];
@@ -442,17 +370,8 @@ __global__ __launch_bounds__(64, (PART == 5 ? 1 : ndofs(DIM, ORDER) <= 6 ? (GATH
         } else park_from(xr, fr);
     };
 
-    // TRIPLE: unsorted neighbours in ONE pass where three sets of accumulators fit the lane (wlsqm_moments.hpp: accumulate_moments_triple;
-    // VERDICT r4 item 4's proposal).  Built, tested, measured and OFF: 1M configs[1] cases with shuffled neighbours 0.270 ms against 0.249 for
-    // the two passes (113 instead of 72 vector instructions per neighbour: the kernel turns VALU-bound) and the combination of the three
-    // sums cancels a digit — E_max against the CPU port 3.6e-9 instead of ~4e-10 (profiles/r05b_unsorted.txt).
-#ifndef WLSQM_STAGE_TRIPLE
-#define WLSQM_STAGE_TRIPLE 0
-#endif
-    constexpr bool TRIPLE = WLSQM_STAGE_TRIPLE && DIM == 2 && ORDER <= 2 && PART == 0;
     constexpr bool INVERSE = PART == 4;                               // (the moment pass of PART 4 is PART 0's)
     double mu[NM], nu[NO];
-    double mu3[TRIPLE ? 3 : 1][TRIPLE ? NM : 1], nu3[TRIPLE ? 3 : 1][TRIPLE ? NO : 1];
     double max_d2 = 0.0;
     // One pass over the neighbours.  MAXONLY: only the largest squared distance is computed; otherwise the moments, with `maxv` as the
     // largest squared distance of the lane's case.  MASKED (some case of the group is ragged, or K is not a multiple of CH) is decided
@@ -461,22 +380,13 @@ __global__ __launch_bounds__(64, (PART == 5 ? 1 : ndofs(DIM, ORDER) <= 6 ? (GATH
     // Q - 1 is already parked and chunk Q - 2 in flight (the prologue below).
     auto pass_impl = [&](auto masked_tag, auto mode_tag, const double maxv, const bool warm) __attribute__((always_inline)) {
         constexpr bool MASKED = decltype(masked_tag)::value;
-        constexpr int MODE = decltype(mode_tag)::value;               // 0: moments with the maximum `maxv`; 1: the maximum only; 2: the three sets + the maximum
+        constexpr int MODE = decltype(mode_tag)::value;               // 0: moments with the maximum `maxv`; 1: the maximum only
         constexpr bool MAXONLY = MODE != 0;                           // (no weight in this pass)
         if constexpr (MODE == 0) {
 #pragma unroll
             for (int e = 0; e < NM; ++e) mu[e] = 0.0;
 #pragma unroll
             for (int a = 0; a < NO; ++a) nu[a] = 0.0;
-        }
-        if constexpr (MODE == 2) {
-#pragma unroll
-            for (int s3 = 0; s3 < 3; ++s3) {
-#pragma unroll
-                for (int e = 0; e < NM; ++e) mu3[s3][e] = 0.0;
-#pragma unroll
-                for (int a = 0; a < NO; ++a) nu3[s3][a] = 0.0;
-            }
         }
         max_d2 = 0.0;
         const double inv_max = MAXONLY ? 0.0 : inverse_max(maxv);
@@ -494,13 +404,6 @@ __global__ __launch_bounds__(64, (PART == 5 ? 1 : ndofs(DIM, ORDER) <= 6 ? (GATH
                     for (int m = 0; m < DIM; ++m) { d[m] = (GATHER ? cx[ks][m] : xrow[ks * DIM + m]) - xi[m]; if (MASKED) d[m] = live ? d[m] : 0.0; }
                     const double d2 = sqdist(d);
                     max_d2 = d2 > max_d2 ? d2 : max_d2;               // (a masked slot contributes 0)
-                    if constexpr (MODE == 2) {
-                        if constexpr (TRIPLE) {
-                            double f = GATHER ? cf[ks] : frow[ks];
-                            if (MASKED) f = live ? f : 0.0;
-                            accumulate_moments_triple<DIM, ORDER>(mu3, nu3, d, (MASKED && !live) ? 0.0 : 1.0, sqrt_unit(d2), d2, f);
-                        }
-                    }
                     if constexpr (MODE == 0) {
                         double w = weight(d2, inv_max, uniform);
                         double f = GATHER ? cf[ks] : frow[ks];
@@ -518,28 +421,8 @@ __global__ __launch_bounds__(64, (PART == 5 ? 1 : ndofs(DIM, ORDER) <= 6 ? (GATH
                 if constexpr (SCHED_BARRIER) __builtin_amdgcn_sched_barrier(0);      // GRP neighbours in flight at a time
             }
         };
-        if constexpr (AGPR) {
-            // (warm: chunk Q - 1 parked, chunks Q - 2 (set 1) and Q - 3 (set 0) in flight: the prologue)
-            if (!warm) { fetch_agpr(S0{}, Q - 1); if (Q > 1) fetch_agpr(S1{}, Q - 2); }
-            for (int c = Q - 1; c >= 0; c -= 2) {
-                if (!(warm && c == Q - 1)) {
-                    wait_agpr(c >= 1);                                // (the loads of chunk c - 1 are younger)
-                    __syncthreads();                                  // the previous chunk has been read by every lane
-                    park_agpr(S0{});
-                    __syncthreads();
-                    if (c >= 2) fetch_agpr(S0{}, c - 2);
-                }
-                chunk(c);
-                if (c >= 1) {
-                    wait_agpr(c >= 2);
-                    __syncthreads();
-                    park_agpr(S1{});
-                    __syncthreads();
-                    if (c >= 3) fetch_agpr(S1{}, c - 3);
-                    chunk(c - 1);
-                }
-            }
-        } else if constexpr (DMA) {
+        if constexpr (DMA) {
+            // (warm: chunk Q - 1 landed        } else if constexpr (DMA) {
             // (warm: chunk Q - 1 landed, chunks Q - 2 .. Q - 1 - PF in flight: the prologue)
             if (!warm) dma_prime();
             for (int q = Q - 1; q >= 0; --q) {
@@ -548,25 +431,6 @@ __global__ __launch_bounds__(64, (PART == 5 ? 1 : ndofs(DIM, ORDER) <= 6 ? (GATH
                     dma_wait(q < PF ? q : PF);
                 }
                 chunk(q);
-            }
-        } else if constexpr (DEEP) {
-            // (warm: chunk Q - 1 parked, chunks Q - 2 (second set) and Q - 3 (first set) in flight)
-            if (!warm) { fetch_into(xr, fr, Q - 1); if (Q > 1) fetch_into(xr2, fr2, Q - 2); }
-            for (int c = Q - 1; c >= 0; c -= 2) {
-                if (!(warm && c == Q - 1)) {
-                    __syncthreads();
-                    park_from(xr, fr);
-                    __syncthreads();
-                    if (c >= 2) fetch_into(xr, fr, c - 2);
-                }
-                chunk(c);
-                if (c >= 1) {
-                    __syncthreads();
-                    park_from(xr2, fr2);
-                    __syncthreads();
-                    if (c >= 3) fetch_into(xr2, fr2, c - 3);
-                    chunk(c - 1);
-                }
             }
         } else {
             if (!warm) fetch(Q - 1);
@@ -584,7 +448,6 @@ __global__ __launch_bounds__(64, (PART == 5 ? 1 : ndofs(DIM, ORDER) <= 6 ? (GATH
     const bool full = (K % CH == 0) && __all(nkc >= K);               // wave-uniform: no ragged case in this group, whole chunks
     using M0 = std::integral_constant<int, 0>;
     using M1 = std::integral_constant<int, 1>;
-    using M2 = std::integral_constant<int, 2>;
     auto moments = [&](const double maxv, const bool warm) __attribute__((always_inline)) {
         if (full) pass_impl(std::false_type{}, M0{}, maxv, warm); else pass_impl(std::true_type{}, M0{}, maxv, warm);
     };
@@ -592,15 +455,7 @@ __global__ __launch_bounds__(64, (PART == 5 ? 1 : ndofs(DIM, ORDER) <= 6 ? (GATH
     // then (a wrong guess costs a whole second pass: 1.9x): the squared distances of that chunk must be non-decreasing in every
     // lane — by chance for unsorted neighbours with probability 1 / 8! per case.  Unsorted input (a ball query) takes the plain two
     // passes instead: the largest squared distance first (a few instructions per neighbour), then the moments.
-    if constexpr (AGPR) {
-        fetch_agpr(S0{}, Q - 1);
-        if (Q > 1) fetch_agpr(S1{}, Q - 2);
-        wait_agpr(Q > 1);
-        __syncthreads();
-        park_agpr(S0{});
-        __syncthreads();
-        if (Q > 2) fetch_agpr(S0{}, Q - 3);
-    } else if constexpr (DMA) {
+    if constexpr (DMA) {
         if constexpr (!EARLY) dma_prime();
         if constexpr (!(EARLY && PF == 0)) { if (Q - 1 - PF >= 0) dma_fetch(Q - 1 - PF); }
         dma_wait(Q - 1 < PF ? Q - 1 : PF);
@@ -609,8 +464,7 @@ __global__ __launch_bounds__(64, (PART == 5 ? 1 : ndofs(DIM, ORDER) <= 6 ? (GATH
         __syncthreads();
         park();
         __syncthreads();
-        if constexpr (DEEP) { if (Q > 1) fetch_into(xr2, fr2, Q - 2); if (Q > 2) fetch_into(xr, fr, Q - 3); }
-        else { if (Q > 1) fetch(Q - 2); }
+        if (Q > 1) fetch(Q - 2);
     }
     bool mono = true;
     {
@@ -628,9 +482,10 @@ __global__ __launch_bounds__(64, (PART == 5 ? 1 : ndofs(DIM, ORDER) <= 6 ? (GATH
     }
     // Which arithmetic a case gets is a property of the case alone (its bits do not depend on its wave-mates): a case whose first staged
     // chunk is sorted — and every uniformly weighted case — gets the moments weighted with its largest squared distance (speculative
-    // pass, repeated if the guess was wrong); where three sets of sums fit the lane (TRIPLE) a case with an unsorted chunk gets the
-    // one-pass form, and a uniformly weighted case has the same bits in both.  A wave that holds both kinds runs both passes.
-    const bool elig_r = uniform || mono, elig_t = TRIPLE && (uniform || !mono);
+    // pass, repeated if the guess was wrong); a wave with an unsorted chunk runs the two plain passes (same bits either way).
+    // (Round 5's one-pass form with three sets of sums — 0.270 against 0.249 ms and a digit lost to cancellation, profiles/r05b_unsorted.txt —,
+    // its DEEP / AGPR forms of two chunks in flight — r05c_ab_stage_agpr.txt — are out of the source since round 6: git history, commit c9ef97d.)
+    const bool elig_r = uniform || mono;
     if constexpr (!GATHER && (PART == 0 || PART == 5)) {
         // (sampled groups tell the NEXT call on the stream whether this input was sorted by distance: launch_stage)
         if (p.hint != nullptr && (int)(blockIdx.x % (unsigned)p.hint_stride) == 0 && blockIdx.x / (unsigned)p.hint_stride < 64u) {
@@ -643,17 +498,6 @@ __global__ __launch_bounds__(64, (PART == 5 ? 1 : ndofs(DIM, ORDER) <= 6 ? (GATH
         // the guess must have been the largest squared distance, bit for bit (uniform weighting does not use it); otherwise the wave
         // repeats the pass with the true maxima — lanes whose guess was right get the same bits again
         if (!__all(uniform || max_d2 == guess)) moments(max_d2, false);
-    } else if constexpr (TRIPLE) {
-        // unsorted neighbours, small system: one pass with three sets of sums (the rows cross the fabric once)
-        if (full) pass_impl(std::false_type{}, M2{}, 0.0, true); else pass_impl(std::true_type{}, M2{}, 0.0, true);
-        const double inv_max = inverse_max(max_d2), root_inv = sqrt_unit(inv_max);
-        combine_triple<NM>(mu3[0], mu3, inv_max, root_inv, uniform);
-        combine_triple<NO>(nu3[0], nu3, inv_max, root_inv, uniform);
-        if (!__all(elig_t)) moments(max_d2, false);                   // a mixed wave: the sorted-looking cases keep the arithmetic they get among their own kind
-#pragma unroll
-        for (int e = 0; e < NM; ++e) mu[e] = elig_t ? mu3[0][e] : mu[e];
-#pragma unroll
-        for (int a = 0; a < NO; ++a) nu[a] = elig_t ? nu3[0][a] : nu[a];
     } else {
         // unsorted neighbours: the largest squared distance first (coordinates only: the values travel with the second pass), then the moments
         if constexpr (!GATHER) want_f = false;

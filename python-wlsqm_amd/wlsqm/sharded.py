@@ -185,7 +185,10 @@ class HaloCloudSolver:
                 # its points lies in a marked cell) and publishes the marks (all_gather of one byte per cell, <= 64^dim cells); a point
                 # is sent to the ranks whose marks cover its cell.  The band shrinks to the block's own outline; the search result —
                 # verified against r below as before — cannot change (tests/test_sharded_gloo.py: bit-identical to one rank).
-                ncell = torch.clamp((ext / r).floor(), 1, {1: 4096, 2: 256, 3: 64}[dim]).to(torch.int64)      # cells per axis, side ext / ncell >= r
+                # (cells per axis, side ext / ncell >= r (1 + 1e-9): the margin keeps a neighbour EXACTLY r away along an axis — ext / r an exact
+                # integer — within one cell of its point after the floating-point floor below: ADVICE r5.  A zero extent along an axis gives
+                # one cell there.)
+                ncell = torch.clamp((ext / (r * (1.0 + 1e-9))).floor(), 1, {1: 4096, 2: 256, 3: 64}[dim]).to(torch.int64)
                 hcell = ext / ncell.to(torch.float64)
                 stride = torch.ones(dim, dtype=torch.int64, device=dev)
                 for m in range(dim - 2, -1, -1):

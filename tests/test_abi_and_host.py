@@ -340,3 +340,22 @@ def test_numerics_mode_codes():
             h.set_strict("fastest")
     finally:
         h.set_strict(prev)
+
+
+def test_isa_record_is_of_these_sources():
+    """profiles/isa_r06.txt (tools/isa_stats.sh: registers, spills, scratch, LDS of every kernel the BASELINE configs run) must have been made
+    from the sources in the tree: its first line carries the hash of what libwlsqm_hip.manifest lists (round 5's record
+    predated the round's last kernels)."""
+    import glob
+    import hashlib
+    rec = os.path.join(ROOT, "profiles", "isa_r06.txt")
+    assert os.path.exists(rec), "profiles/isa_r06.txt is missing: bash tools/isa_stats.sh <units> > profiles/isa_r06.txt"
+    first = open(rec).readline().strip()
+    assert first.startswith("# sources sha256: "), first
+    pkg = os.path.join(ROOT, "python-wlsqm_amd")
+    names = sorted(glob.glob(os.path.join(pkg, "csrc", "*.hip"))) + sorted(glob.glob(os.path.join(pkg, "csrc", "*.hpp")))
+    lines = ["%s  %s\n" % (hashlib.sha256(open(f, "rb").read()).hexdigest(), os.path.relpath(f, pkg)) for f in names]
+    lines += ["%s  %s\n" % (hashlib.sha256(open(f, "rb").read()).hexdigest(), os.path.relpath(f, ROOT))
+              for f in sorted(glob.glob(os.path.join(ROOT, "include", "*.h")))]
+    want = hashlib.sha256("".join(lines).encode()).hexdigest()
+    assert first.split(": ")[1] == want, "profiles/isa_r06.txt was made from other sources: regenerate it (tools/isa_stats.sh)"

@@ -8,12 +8,12 @@ PKG=python-wlsqm_amd
 ORIG="$(mktemp /tmp/lib_orig_XXXXXX.so)"; VAR="$(mktemp /tmp/unit_var_XXXXXX.o)"
 cp $PKG/wlsqm/_lib/libwlsqm_hip.so "$ORIG"
 trap 'cp "$ORIG" $PKG/wlsqm/_lib/libwlsqm_hip.so; rm -f "$ORIG" "$VAR"' EXIT
-echo "== as built"; $CMD
+echo "== as built"; bash -c "$CMD"
 for flags in "$@"; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fopenmp -I include -I $PKG/csrc $flags -c $PKG/csrc/$UNIT.hip -o $VAR 2>/dev/null
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fopenmp -I include -I $PKG/csrc $flags -c $PKG/csrc/$UNIT.hip -o $VAR 
   objs=(); for o in $PKG/build/*.o; do [[ "$(basename $o)" == "$UNIT.o" ]] && objs+=("$VAR") || objs+=("$o"); done
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fopenmp -o $PKG/wlsqm/_lib/libwlsqm_hip.so "${objs[@]}"
-  echo "== [$flags]"; $CMD
+  echo "== [$flags]"; bash -c "$CMD"
 done
 cp "$ORIG" $PKG/wlsqm/_lib/libwlsqm_hip.so
-echo "== as built again"; $CMD
+echo "== as built again"; bash -c "$CMD"

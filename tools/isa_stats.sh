@@ -8,6 +8,9 @@ HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
 FILES=("$@")
 if (( ${#FILES[@]} == 0 )); then FILES=(fit_tile.hip fit_ring.hip fit_ring_gather.hip solve_op.hip fit_chunk.hip fit_strict.hip fit_rows.hip fit_tilek.hip); fi
 FILTER="${ISA_FILTER:-.}"
+# the record is stamped with the sources it was made from (the lines of libwlsqm_hip.manifest, hashed): tests/test_abi_and_host.py fails
+# when profiles/isa_rNN.txt of the current round and the tree disagree
+echo "# sources sha256: $(cd "$HERE/python-wlsqm_amd" && export LC_ALL=C && sha256sum csrc/*.hip csrc/*.hpp ../include/*.h | sed 's#\.\./include#include#' | sha256sum | cut -d' ' -f1)"
 for f in "${FILES[@]}"; do
   src="$HERE/python-wlsqm_amd/csrc/$f"
   out="$(mktemp /tmp/isa_XXXX.s)"
