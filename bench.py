@@ -847,6 +847,7 @@ def side_configs(a, dev, timer, rank, parity):
         add("%s-unsorted@1M" % cname, lambda cname=cname: measure_extra_shape(cname + "-unsorted", CONFIGS[cname], 1_000_000, dev, timer,
                                                                              short["steps"], short["warmup"], rank, parity, unsorted=True))
     add("C3-ball@400k", lambda: measure_ball("C3-ball", 400_000, dev, timer, short["steps"], short["warmup"], rank, parity))
+    add("C3-ball-nkorder@400k", lambda: measure_ball("C3-ball-nkorder", 400_000, dev, timer, short["steps"], short["warmup"], rank, parity, nk_order=True))
     # the ACCURATE mode beyond the headline's parity block: configs[4]'s shape, the reference's default mask, shuffled rows
     add("C5-accurate@1M", lambda: measure_fit("C5-accurate", CONFIGS["C5"], 1_000_000, dev, timer, short["steps"], short["warmup"], rank, parity, extras="accurate"))
     add("C2-accurate-Fknown@1M", lambda: measure_fit("C2-accurate-Fknown", dict(CONFIGS["C2"], knowns=1, desc=CONFIGS["C2"]["desc"] + " [F known: simple.pyx:60-61]"),
@@ -861,7 +862,7 @@ def side_configs(a, dev, timer, rank, parity):
     return side
 
 
-def measure_ball(name, n, dev, timer, steps, warmup, rank, parity, order=4, max_nk=100, mean_nk=64):
+def measure_ball(name, n, dev, timer, steps, warmup, rank, parity, order=4, max_nk=100, mean_nk=64, nk_order=False):
     """The shape of the reference's own harness (examples/wlsqm_example.py:103-133: `cKDTree.query_ball_point`, order 4, knowns = F,
     max_nk = 100): every point's neighbours are ALL points within a radius — a ragged count per case, in NO particular order (the
     tree's), padded to max_nk slots.  Radius chosen for ~mean_nk neighbours on n Halton points; the GPU ball search returns them
@@ -879,17 +880,25 @@ def measure_ball(name, n, dev, timer, steps, warmup, rank, parity, order=4, max_
     keys[torch.arange(max_nk, device=dev)[None, :] >= nk_d[:, None]] = 2.0          # padding stays behind the valid entries
     h_d = torch.gather(h_d, 1, torch.argsort(keys, dim=1)).contiguous()
     del keys
+    cases = torch.arange(n, device=dev)
+    if nk_order:
+        # the CASES in neighbour-count order (what the host entry points do themselves while they stage a ragged batch, csrc/api.hip; a caller
+        # of the device-resident API lays its rows out as it likes): a wave's 64 cases then need the same chunks
+        cases = torch.argsort(nk_d, stable=True)
+        h_d = h_d[cases].contiguous(); nk_d = nk_d[cases].contiguous()
     hh = h_d.long()
     xk_d = S_d[hh].contiguous(); fk_d = F_d[hh].contiguous()
     del hh
-    xi_d = S_d.clone()
-    fi_d = torch.zeros((n, no), dtype=torch.float64, device=dev); fi_d[:, 0] = F_d
+    xi_d = S_d[cases].contiguous()
+    fi_d = torch.zeros((n, no), dtype=torch.float64, device=dev); fi_d[:, 0] = F_d[cases]
     kn_d = torch.ones((n,), dtype=torch.int64, device=dev)
     wm_d = torch.full((n,), 2, dtype=torch.int32, device=dev)
     args = (dim, order, xk_d, fk_d, nk_d, xi_d, fi_d, kn_d, wm_d)
-    dt = timer.run(lambda: whip.fit_many_device(*args), steps, warmup)
-    kernel = whip.last_kernel()
-    ms_kernel = whip.time_fit_device(*args, reps=min(max(steps, 10), 100))
+    # (device-resident counts: the caller says that its rows are ragged — wlsqm.hip.row_hint; the host entry points see it themselves)
+    with whip.row_hint("ragged"):
+        dt = timer.run(lambda: whip.fit_many_device(*args), steps, warmup)
+        kernel = whip.last_kernel()
+        ms_kernel = whip.time_fit_device(*args, reps=min(max(steps, 10), 100))
     nk_mean = float(nk_d.double().mean()); nk_min = int(nk_d.min()); nk_max = int(nk_d.max())
     B_fit = 8.0 * nk_mean * (dim + 1) + 8 * dim + 8 * no + 8 + 20          # SURVEY section 8d with the cases' own neighbour counts
     achieved = B_fit * n / (ms_kernel * 1e-3) / 1e9
@@ -901,11 +910,14 @@ def measure_ball(name, n, dev, timer, steps, warmup, rank, parity, order=4, max_
                         "note": "algorithmic bytes count the valid neighbours only; the rows are padded to %d slots" % max_nk}}
     if parity and rank == 0:
         from oracle import oracle
-        sel = torch.nonzero(nk_d >= no + 8)[:1024, 0]                      # (nearly determined neighbourhoods are noise, not signal)
+        sel = torch.nonzero(nk_d >= no + 8)[:, 0]                          # (nearly determined neighbourhoods are noise, not signal)
+        if nk_order and sel.numel() > 1024:
+            sel = sel[torch.linspace(0, sel.numel() - 1, 1024, device=dev).long()]      # (every neighbour count, not the smallest only)
+        sel = sel[:1024]
         m = int(sel.numel())
         xk, fk, xi = (t[sel].cpu().numpy() for t in (xk_d, fk_d, xi_d))
         got = fi_d[sel].cpu().numpy()
-        ref = np.zeros((m, no)); ref[:, 0] = F_d[sel].cpu().numpy()
+        ref = np.zeros((m, no)); ref[:, 0] = F_d[cases[sel]].cpu().numpy()
         oracle.fit_many(dim, xk, fk, nk_d[sel].cpu().numpy(), xi, ref, None, 0, np.full(m, order, np.int32), np.ones(m, np.int64),
                         np.full(m, 2, np.int32), ntasks=8)
         scale = np.abs(ref).max(axis=0)

@@ -131,6 +131,17 @@ int wlsqm_hip_fit_many_device_orders(const wlsqm_batch* b, int device, void* str
 int wlsqm_hip_set_strict(int mode);
 int wlsqm_hip_get_strict(void);
 
+/* Round 6: what the calling thread knows about the neighbour counts nk[j] of the DENSE DEVICE-RESIDENT batches it hands over (only
+ * entries below nk[j] of a row are touched: simple.pyx:147; the reference's own harness passes ball-query rows of 100 slots with 30..100
+ * valid entries, examples/wlsqm_example.py:103-133):
+ *   1 (default) every case fills its row, or nearly: the plain kernels;
+ *   2 ragged: the staged kernels run the copy whose waves move only the chunks their own 64 cases need (csrc/fit_stage.hip);
+ *   0 unknown: the plain kernels mark the waves none of whose cases reaches the row's last chunk and the ragged copy runs those
+ *     behind them (an idle launch, ~2 us, for a batch of full rows).
+ * A hint, never a condition of correctness: every setting returns the same bits.  The host entry points (wlsqm_hip_fit_many_host)
+ * look at the counts themselves and ignore it.  Returns the previous value. */
+int wlsqm_hip_set_row_hint(int hint);
+
 /* Test hook of the strict mode: runs the reference-order fit of `b` (uniform order) and also stores the reference's intermediates,
  * for bit-for-bit comparison with values captured from the reference (tests/golden/sweep_*.npz): w[j * w_stride + k]
  * (Case_make_weights), the unscaled A and the scaled LU factor as nr x nr Fortran-order blocks at [j * mat_stride]

@@ -48,6 +48,10 @@ int launch_fit_stage_refine(int dimension, int order, const KParams& p, long lon
 // (fit_accurate.hip: reference-order arithmetic with the normal matrix assembled from its upper triangle).  The first use on a
 // thread takes WLSQM_HIP_STRICT from the environment (unset / 0, 1, 2 or "accurate"); wlsqm_hip_set_strict() overrides it.
 static thread_local int g_strict = -1;
+// what the calling thread says about the neighbour counts of the dense DEVICE-resident batches it hands over (wlsqm_hip_set_row_hint; the host
+// entry points look at the counts themselves): 1 every case fills its row (default), 2 ragged, 0 unknown (the kernels find out)
+static thread_local int g_row_hint = 1;
+int row_hint_value() { return g_row_hint; }
 static int strict_mode_value();
 bool accurate_mode() { return strict_mode_value() == 2; }
 bool strict_mode() { return strict_mode_value() >= 1; }
@@ -402,6 +406,7 @@ static KParams params_from(const wlsqm_batch* b) {
     p.iterative = b->iterative ? 1 : 0;
     p.max_iter = b->max_iter;
     p.iters_out = nullptr;
+    p.ragged = row_hint_value();                                    // (device-resident counts: the caller's word; the host entry points overwrite it with what they see)
     return p;
 }
 
@@ -426,6 +431,12 @@ int wlsqm_hip_set_strict(int mode) {
     return prev;
 }
 int wlsqm_hip_get_strict(void) { return strict_mode_value(); }
+
+int wlsqm_hip_set_row_hint(int hint) {
+    const int prev = g_row_hint;
+    g_row_hint = (hint == 0 || hint == 2) ? hint : 1;
+    return prev;
+}
 
 int wlsqm_hip_number_of_dofs(int dimension, int order) {
     if (dimension < 1 || dimension > 3) return -1;
@@ -692,6 +703,28 @@ int wlsqm_hip_fit_many_host(const wlsqm_batch* b, int device, int32_t* iteration
     if (bad_order) { set_error("order must be 0, 1, 2, 3 or 4"); return WLSQM_EVALUE; }
     if (bad_nk) { set_error("nk must be >= 0"); return WLSQM_EVALUE; }
     if (b->max_nk > 0 && max_nk > b->max_nk) { set_error("max(nk) exceeds the neighbour axis (max_nk)"); return WLSQM_EVALUE; }
+    // RAGGED batches (the reference's own harness: a ball query, nk 30..100 per case — examples/wlsqm_example.py:103-133) are packed in
+    // NEIGHBOUR-COUNT order: the staged kernels move the chunks a wave's 64 cases need (fit_stage.hip), so waves of equal counts move no
+    // padding.  A stable counting sort on the host, applied while the rows are staged for the upload anyway; results go back to the
+    // caller's rows.  (Uniform-order batches only: the order buckets have an index of their own.)  WLSQM_HIP_HOST_NK_ORDER=0: off.
+    std::vector<int64_t> perm;
+    {
+        const char* e = getenv("WLSQM_HIP_HOST_NK_ORDER");
+        int32_t min_nk = n > 0 ? h_nk[0] : 0;
+        bool same_order = true;
+        for (int64_t j = 0; j < n; ++j) { if (h_nk[j] < min_nk) min_nk = h_nk[j]; same_order = same_order && h_order[j] == h_order[0]; }
+        if (!(e && e[0] == '0') && same_order && n >= 1024 && max_nk - min_nk >= 8) {
+            std::vector<int64_t> start((size_t)max_nk + 2, 0);
+            for (int64_t j = 0; j < n; ++j) ++start[(size_t)h_nk[j] + 1];
+            for (size_t v = 1; v < start.size(); ++v) start[v] += start[v - 1];
+            perm.resize((size_t)n);
+            for (int64_t j = 0; j < n; ++j) perm[(size_t)start[(size_t)h_nk[j]]++] = j;
+            auto apply = [&](auto& v) { auto w = v; for (int64_t r = 0; r < n; ++r) v[(size_t)r] = w[(size_t)perm[(size_t)r]]; };
+            apply(h_nk); apply(h_order); apply(h_wm); apply(h_no); apply(h_kn);
+        }
+    }
+    const int64_t* const pm = perm.empty() ? nullptr : perm.data();
+    auto user_row = [&](int64_t r) { return pm ? pm[r] : r; };
     mark("metadata");
     DeviceScope scope;
     rc = scope.enter(device);
@@ -713,11 +746,11 @@ int wlsqm_hip_fit_many_host(const wlsqm_batch* b, int device, int32_t* iteration
     hipStream_t s = nullptr;
     mark("buffers");
     if (max_nk > 0) {
-        if ((rc = cx->st.upload_rows(cx->xk.b.p, b->xk, n, max_nk * dim, b->xk_stride_case, b->xk_stride_k, dim, 8, s, K * dim))) return rc;
-        if ((rc = cx->st.upload_rows(cx->fk.b.p, b->fk, n, max_nk, b->fk_stride_case, b->fk_stride_k, 1, 8, s, K))) return rc;
+        if ((rc = cx->st.upload_rows(cx->xk.b.p, b->xk, n, max_nk * dim, b->xk_stride_case, b->xk_stride_k, dim, 8, s, K * dim, pm))) return rc;
+        if ((rc = cx->st.upload_rows(cx->fk.b.p, b->fk, n, max_nk, b->fk_stride_case, b->fk_stride_k, 1, 8, s, K, pm))) return rc;
     }
-    if ((rc = cx->st.upload_rows(cx->xi.b.p, b->xi, n, dim, b->xi_stride_case, dim, dim, 8, s))) return rc;
-    if ((rc = cx->st.upload_rows(cx->fi.b.p, b->fi, n, max_no, b->fi_stride_case, max_no, max_no, 8, s))) return rc;
+    if ((rc = cx->st.upload_rows(cx->xi.b.p, b->xi, n, dim, b->xi_stride_case, dim, dim, 8, s, 0, pm))) return rc;
+    if ((rc = cx->st.upload_rows(cx->fi.b.p, b->fi, n, max_no, b->fi_stride_case, max_no, max_no, 8, s, 0, pm))) return rc;
     WLSQM_HIP_CHECK(hipMemcpyAsync(cx->nk.b.p, h_nk.data(), n * 4, hipMemcpyHostToDevice, s));
     WLSQM_HIP_CHECK(hipMemcpyAsync(cx->wm.b.p, h_wm.data(), n * 4, hipMemcpyHostToDevice, s));
     WLSQM_HIP_CHECK(hipMemcpyAsync(cx->kn.b.p, h_kn.data(), n * 8, hipMemcpyHostToDevice, s));
@@ -736,6 +769,11 @@ int wlsqm_hip_fit_many_host(const wlsqm_batch* b, int device, int32_t* iteration
     p.wm = cx->wm.as<int>(); p.swm = 1;
     p.do_sens = want_sens ? 1 : 0; p.iterative = b->iterative ? 1 : 0; p.max_iter = b->max_iter;
     p.iters_out = cx->it.as<int>();
+    {
+        int32_t lo = n > 0 ? h_nk[0] : 0;
+        for (int64_t j = 0; j < n; ++j) lo = h_nk[j] < lo ? h_nk[j] : lo;
+        p.ragged = (max_nk - lo >= 8) ? 2 : 1;                         // (the staged kernels: their RAGGED copy, or the plain one without the marking)
+    }
 
     // bucket by order (the kernels are specialised per (dimension, order))
     if (uniform_order) {
@@ -764,7 +802,7 @@ int wlsqm_hip_fit_many_host(const wlsqm_batch* b, int device, int32_t* iteration
     // commit: everything was read before anything is written back (simple.pyx:1010-1019)
     rc = cx->st.download_rows(cx->fi.b.p, n, max_no, 8, s, [&](int64_t j, const char* row) {
         if (wlsqm_hip_number_of_reduced_dofs(h_no[j], h_kn[j]) < 1) return;     // nr < 1: the reference leaves the case untouched
-        std::memcpy(b->fi + j * b->fi_stride_case, row, (size_t)h_no[j] * 8);
+        std::memcpy(b->fi + user_row(j) * b->fi_stride_case, row, (size_t)h_no[j] * 8);
     });
     if (rc != WLSQM_OK) return rc;
     if (want_sens) {
@@ -773,7 +811,7 @@ int wlsqm_hip_fit_many_host(const wlsqm_batch* b, int device, int32_t* iteration
             unsigned long long known, dropped;
             effective_mask_host(h_no[j], h_kn[j], known, dropped);
             const double* r = reinterpret_cast<const double*>(row);
-            double* sr = b->sens + j * b->sens_stride_case;
+            double* sr = b->sens + user_row(j) * b->sens_stride_case;
             for (int64_t k = 0; k < h_nk[j]; ++k)
                 for (int a = 0; a < h_no[j]; ++a) {
                     if ((dropped >> a) & 1ull) continue;       // never written by the reference

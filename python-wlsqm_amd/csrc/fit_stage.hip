@@ -94,8 +94,16 @@ constexpr int CH = 8;               // neighbours per staged chunk
 // case's neighbours, so the data arrives in the lane that consumes it: no LDS staging — the next chunk's eight points are in flight in
 // registers while the current ones are consumed.  Everything behind the fetch is the dense kernel's code (same bits as the dense
 // kernel on the gathered rows).
-template <int DIM, int ORDER, int PART = 0, bool GATHER = false>
-__global__ __launch_bounds__(64, (PART == 5 ? 1 : ndofs(DIM, ORDER) <= 6 ? (GATHER ? WLSQM_STAGE_MINW6G : WLSQM_STAGE_MINW6) : ndofs(DIM, ORDER) <= 10 ? (GATHER ? WLSQM_STAGE_MINW10G : WLSQM_STAGE_MINW10) : ndofs(DIM, ORDER) <= 15 ? WLSQM_STAGE_MINW15 : (ndofs(DIM, ORDER) == 35 && !GATHER) ? WLSQM_STAGE_MINW35 : 1)) void fit_stage_kernel(const KParams p) {
+// RAGGED (round 6): a copy of the same code whose passes run over the chunks ITS wave's cases need — Q = ceil(max over the lanes of nk / CH)
+// instead of the row's QK — for the reference's own harness shape: a ball query, nk 30..100 in rows of 100 slots (examples/wlsqm_example.py:
+// 103-133; only entries below nk[j] are touched: simple.pyx:147).  A COPY, not a run-time choice inside one kernel: BASELINE configs[2]'s kernel
+// is a lone wave per SIMD walking ~85 KB of code past a 64 KB instruction cache, and every version that carried the ragged path inside it lost
+// 10-13 % on full rows (chunk count and warm start as run-time values: 0.457 against 0.405 ms; profiles/r06c_ragged.txt).  status != nullptr
+// (RAGGED = false, a batch whose neighbour counts the host has not seen): a wave none of whose cases reaches the row's last chunk marks its
+// group and leaves; fit_stage_ragged_kernel behind it runs the marked groups through the RAGGED copy.
+template <int DIM, int ORDER, int PART, bool GATHER, int RAG>      // RAG: 0 the plain kernel, 1 it marks its short waves in `status` and leaves them, 2 the RAGGED copy
+__device__ __forceinline__ void stage_group(const KParams& p, const unsigned grp, unsigned char* const status) {
+    constexpr bool RAGGED = RAG == 2;
     using namespace stage;
     constexpr int NO = ndofs(DIM, ORDER), NE = NO * (NO + 1) / 2, NM = mom_count<DIM>(2 * ORDER);
 #ifndef WLSQM_STAGE_CH10
@@ -151,12 +159,12 @@ __global__ __launch_bounds__(64, (PART == 5 ? 1 : ndofs(DIM, ORDER) <= 6 ? (GATH
     double* const fs = lds + 64 * XPITCH;
 
     const int lane = threadIdx.x;
-    const long long t0 = (long long)blockIdx.x * 64, t = t0 + lane;
+    const long long t0 = (long long)grp * 64, t = t0 + lane;
     const int nvalid = (p.ncases - t0 < 64) ? (int)(p.ncases - t0) : 64;      // wave-uniform
     const bool valid = lane < nvalid;
     const long long j = valid ? t : t0 + nvalid - 1;                          // tail lanes replay the last case (never stored)
     const int K = (int)p.max_nk;
-    const int Q = (K + CH - 1) / CH;                                  // (a last partial chunk: its pieces beyond the row replay the row's last one; masked)
+    const int QK = (K + CH - 1) / CH;                                 // chunks of a whole row (a last partial chunk: its pieces beyond the row replay the row's last one; masked)
     // ---- staging: a load instruction moves the chunks of XCPI (FCPI) whole cases, XPC (FPC) consecutive lanes per case
     const int xsub = lane % XPC, xc0 = lane / XPC, fsub = lane % FPC, fc0 = lane / FPC;
     const unsigned xrowb = (unsigned)K * DIM * 8, frowb = (unsigned)K * 8;
@@ -251,9 +259,9 @@ __global__ __launch_bounds__(64, (PART == 5 ? 1 : ndofs(DIM, ORDER) <= 6 ? (GATH
             else { if (want_f) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PF >= 3 ? 3 * (XNI + FNI) : 0) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PF >= 3 ? 3 * XNI : 0) : "memory"); }
         }
     };
-    auto dma_prime = [&]() __attribute__((always_inline)) {            // the first PF chunks of a pass (processed last chunk first)
+    auto dma_prime = [&](const int Qn) __attribute__((always_inline)) {      // the first PF chunks of a pass over Qn chunks (processed last chunk first)
 #pragma unroll
-        for (int i = 1; i <= PF; ++i) if (Q - i >= 0) dma_fetch(Q - i);
+        for (int i = 1; i <= PF; ++i) if (Qn - i >= 0) dma_fetch(Qn - i);
     };
     // the rows of lane's case in chunk q
     auto xrow_of = [&](int q, bool image) __attribute__((always_inline)) -> const double* {
@@ -271,13 +279,9 @@ __global__ __launch_bounds__(64, (PART == 5 ? 1 : ndofs(DIM, ORDER) <= 6 ? (GATH
 #ifndef WLSQM_STAGE_EARLY_FETCH
 #define WLSQM_STAGE_EARLY_FETCH 2
 #endif
-    constexpr bool EARLY = (WLSQM_STAGE_EARLY_FETCH != 0) && !GATHER && (WLSQM_STAGE_EARLY_FETCH == 1 || NO > 10);      // (2: the 15-unknown systems and up only)
-    if constexpr (EARLY && DMA) { dma_prime(); if constexpr (PF == 0) dma_fetch(Q - 1); }      // (a ring of one slot: its only chunk)
-    else if constexpr (EARLY) fetch_into(xr, fr, Q - 1);
-#ifndef WLSQM_STAGE_SCALARS_FIRST
-#define WLSQM_STAGE_SCALARS_FIRST 1
-#endif
-#if WLSQM_STAGE_SCALARS_FIRST
+    constexpr bool EARLY = (WLSQM_STAGE_EARLY_FETCH != 0) && !GATHER && !RAGGED && (WLSQM_STAGE_EARLY_FETCH == 1 || NO > 10);      // (2: the 15-unknown systems and up only)
+    if constexpr (EARLY && DMA) { dma_prime(QK); if constexpr (PF == 0) dma_fetch(QK - 1); }      // (a ring of one slot: its only chunk)
+    else if constexpr (EARLY) fetch_into(xr, fr, QK - 1);
     // (every scalar of the case is requested before the first of them is looked at: the mask arithmetic below waits for its own)
     double xi[DIM];
     const long long pj = GATHER ? (own_point(p, j)) : 0;      // the case's own point (also the stand-in for padding slots)
@@ -289,19 +293,21 @@ __global__ __launch_bounds__(64, (PART == 5 ? 1 : ndofs(DIM, ORDER) <= 6 ? (GATH
     const long long kn_raw = p.knowns[j * p.sknowns];
     const int nkc = min(nk_raw, K);
     const bool uniform = (wm_raw == WLSQM_WEIGHT_UNIFORM);
+    // Q: the chunks this wave's passes run over
+    int Qw = QK;
+    if constexpr (RAGGED) {
+        int nkmax = nkc;                                              // (tail lanes replay the group's last case)
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) nkmax = max(nkmax, __shfl_xor(nkmax, sft, 64));
+        Qw = max(1, (__builtin_amdgcn_readfirstlane(nkmax) + CH - 1) / CH);
+    } else if constexpr (RAG == 1) {
+        const bool short_wave = (QK > 1) && !__any(nkc > (QK - 1) * CH);      // wave-uniform
+        if (lane == 0) status[grp] = short_wave ? 1 : 0;
+        if (short_wave) return;
+    }
+    const int Q = Qw;
     unsigned long long known, dropped;
     effective_mask<NO>(kn_raw, known, dropped);
-#else
-    const int nkc = min(p.nk[j * p.snk], K);
-    const bool uniform = (p.wm[j * p.swm] == WLSQM_WEIGHT_UNIFORM);
-    unsigned long long known, dropped;
-    effective_mask<NO>(p.knowns[j * p.sknowns], known, dropped);
-    double xi[DIM];
-    const long long pj = GATHER ? (own_point(p, j)) : 0;      // the case's own point (also the stand-in for padding slots)
-    const int* const hrow = GATHER ? p.hoods + j * p.shoods_j : nullptr;
-#pragma unroll
-    for (int m = 0; m < DIM; ++m) xi[m] = GATHER ? p.S[pj * DIM + m] : p.xi[j * p.sxi_j + m];
-#endif
 
     auto sqdist = [&](const double (&d)[DIM]) {       // one rounding sequence for the guess and for the pass: they are compared for equality
         double d2 = d[0] * d[0];
@@ -378,7 +384,7 @@ __global__ __launch_bounds__(64, (PART == 5 ? 1 : ndofs(DIM, ORDER) <= 6 ? (GATH
     // ONCE per pass: with the choice inside the chunk loop the two variants' 60 accumulators met in different registers and every
     // iteration paid ~50 copies per 4 neighbours at the join (first version: 179 instructions per neighbour).  warm: chunk 0 is
     // Q - 1 is already parked and chunk Q - 2 in flight (the prologue below).
-    auto pass_impl = [&](auto masked_tag, auto mode_tag, const double maxv, const bool warm) __attribute__((always_inline)) {
+    auto pass_impl = [&](auto masked_tag, auto mode_tag, const double maxv, const bool warm, const int Q) __attribute__((always_inline)) {      // Q: chunks of the pass (the row's, or a wave of short cases' own)
         constexpr bool MASKED = decltype(masked_tag)::value;
         constexpr int MODE = decltype(mode_tag)::value;               // 0: moments with the maximum `maxv`; 1: the maximum only
         constexpr bool MAXONLY = MODE != 0;                           // (no weight in this pass)
@@ -422,9 +428,8 @@ __global__ __launch_bounds__(64, (PART == 5 ? 1 : ndofs(DIM, ORDER) <= 6 ? (GATH
             }
         };
         if constexpr (DMA) {
-            // (warm: chunk Q - 1 landed        } else if constexpr (DMA) {
             // (warm: chunk Q - 1 landed, chunks Q - 2 .. Q - 1 - PF in flight: the prologue)
-            if (!warm) dma_prime();
+            if (!warm) dma_prime(Q);
             for (int q = Q - 1; q >= 0; --q) {
                 if (!(warm && q == Q - 1)) {
                     if (q - PF >= 0) dma_fetch(q - PF);               // into the slot of chunk q + 1: consumed
@@ -449,14 +454,14 @@ __global__ __launch_bounds__(64, (PART == 5 ? 1 : ndofs(DIM, ORDER) <= 6 ? (GATH
     using M0 = std::integral_constant<int, 0>;
     using M1 = std::integral_constant<int, 1>;
     auto moments = [&](const double maxv, const bool warm) __attribute__((always_inline)) {
-        if (full) pass_impl(std::false_type{}, M0{}, maxv, warm); else pass_impl(std::true_type{}, M0{}, maxv, warm);
+        if (full) pass_impl(std::false_type{}, M0{}, maxv, warm, Q); else pass_impl(std::true_type{}, M0{}, maxv, warm, Q);
     };
     // ---- prologue: the LAST chunk parked, the one before it requested; is this group's input SORTED by distance?  The speculation below pays only
     // then (a wrong guess costs a whole second pass: 1.9x): the squared distances of that chunk must be non-decreasing in every
     // lane — by chance for unsorted neighbours with probability 1 / 8! per case.  Unsorted input (a ball query) takes the plain two
     // passes instead: the largest squared distance first (a few instructions per neighbour), then the moments.
     if constexpr (DMA) {
-        if constexpr (!EARLY) dma_prime();
+        if constexpr (!EARLY) dma_prime(Q);
         if constexpr (!(EARLY && PF == 0)) { if (Q - 1 - PF >= 0) dma_fetch(Q - 1 - PF); }
         dma_wait(Q - 1 < PF ? Q - 1 : PF);
     } else {
@@ -488,9 +493,9 @@ __global__ __launch_bounds__(64, (PART == 5 ? 1 : ndofs(DIM, ORDER) <= 6 ? (GATH
     const bool elig_r = uniform || mono;
     if constexpr (!GATHER && (PART == 0 || PART == 5)) {
         // (sampled groups tell the NEXT call on the stream whether this input was sorted by distance: launch_stage)
-        if (p.hint != nullptr && (int)(blockIdx.x % (unsigned)p.hint_stride) == 0 && blockIdx.x / (unsigned)p.hint_stride < 64u) {
+        if (p.hint != nullptr && (int)(grp % (unsigned)p.hint_stride) == 0 && grp / (unsigned)p.hint_stride < 64u) {
             const bool sorted_group = __all(elig_r);
-            if (lane == 0) p.hint[blockIdx.x / (unsigned)p.hint_stride] = sorted_group ? 2 : 1;
+            if (lane == 0) p.hint[grp / (unsigned)p.hint_stride] = sorted_group ? 2 : 1;
         }
     }
     if (__all(elig_r)) {
@@ -501,7 +506,7 @@ __global__ __launch_bounds__(64, (PART == 5 ? 1 : ndofs(DIM, ORDER) <= 6 ? (GATH
     } else {
         // unsorted neighbours: the largest squared distance first (coordinates only: the values travel with the second pass), then the moments
         if constexpr (!GATHER) want_f = false;
-        if (full) pass_impl(std::false_type{}, M1{}, 0.0, true); else pass_impl(std::true_type{}, M1{}, 0.0, true);
+        if (full) pass_impl(std::false_type{}, M1{}, 0.0, true, Q); else pass_impl(std::true_type{}, M1{}, 0.0, true, Q);
         want_f = true;
         moments(max_d2, false);
     }
@@ -509,7 +514,7 @@ __global__ __launch_bounds__(64, (PART == 5 ? 1 : ndofs(DIM, ORDER) <= 6 ? (GATH
     if constexpr (PART == 1 || PART == 2) {
         // ---- this half of the moments to the workspace: 512 contiguous bytes per entry (tail lanes store their replayed case too: the
         // solve reads whole 16-case runs)
-        double* const out = p.ws + (long long)blockIdx.x * (200 * 64) + lane;
+        double* const out = p.ws + (long long)grp * (200 * 64) + lane;
 #pragma unroll
         for (int r = 0; r <= 2 * ORDER; ++r) {
             if (stage_part(r) != PART) continue;
@@ -741,7 +746,7 @@ __global__ __launch_bounds__(64, (PART == 5 ? 1 : ndofs(DIM, ORDER) <= 6 ? (GATH
         // one per neighbour); a column of the wave's 64 cases is one contiguous run of 64 NO doubles, through LDS.  Rows and columns of
         // known DOFs are zero.  Tail lanes replay the last case into their own slot of the scratch block (sized in whole groups).
         static_assert(R0 == 0, "the inverse is emitted from a factor in registers");
-        double* const blk = p.ws + (long long)blockIdx.x * (64 * NO * NO);
+        double* const blk = p.ws + (long long)grp * (64 * NO * NO);
 #pragma unroll 1
         for (int col = 0; col < NO; ++col) {
             double o[NO];
@@ -774,6 +779,32 @@ __global__ __launch_bounds__(64, (PART == 5 ? 1 : ndofs(DIM, ORDER) <= 6 ? (GATH
     }   // PART == 0
 }
 
+__host__ __device__ constexpr int stage_minw(int NO, int PART, bool GATHER) {
+    return PART == 5 ? 1 : NO <= 6 ? (GATHER ? WLSQM_STAGE_MINW6G : WLSQM_STAGE_MINW6) : NO <= 10 ? (GATHER ? WLSQM_STAGE_MINW10G : WLSQM_STAGE_MINW10) :
+           NO <= 15 ? WLSQM_STAGE_MINW15 : (NO == 35 && !GATHER) ? WLSQM_STAGE_MINW35 : 1;
+}
+
+template <int DIM, int ORDER, int PART = 0, bool GATHER = false, int RAG = 0>
+__global__ __launch_bounds__(64, stage_minw(ndofs(DIM, ORDER), PART, GATHER)) void fit_stage_kernel(const KParams p, unsigned char* const status) {
+    stage_group<DIM, ORDER, PART, GATHER, RAG>(p, blockIdx.x, status);
+}
+
+// the groups a RAG = 1 launch marked (none for a batch of full rows: ~2 us of idle waves): workgroup b looks at the groups b, b + gridDim.x, ...,
+// 64 of them per step — one status byte per lane
+template <int DIM, int ORDER>
+__global__ __launch_bounds__(64, stage_minw(ndofs(DIM, ORDER), 0, false)) void fit_stage_ragged_kernel(const KParams p, const long long ngroups, const unsigned char* const status) {
+    for (long long g0 = blockIdx.x; g0 < ngroups; g0 += (long long)gridDim.x * 64) {
+        const long long g = g0 + (long long)threadIdx.x * gridDim.x;
+        unsigned long long todo = __ballot(g < ngroups && status[g] != 0);
+        while (todo) {                                                // wave-uniform
+            const int q = __ffsll((long long)todo) - 1;
+            todo &= todo - 1ull;
+            stage_group<DIM, ORDER, 0, false, 2>(p, (unsigned)(g0 + (long long)q * gridDim.x), nullptr);
+            __syncthreads();                                          // the LDS is reused by the next group
+        }
+    }
+}
+
 template <int DIM, int ORDER, bool GATHER = false>
 static int launch_stage(const KParams& p, hipStream_t stream) {
     const long long groups = (p.ncases + 63) / 64;
@@ -788,6 +819,42 @@ static int launch_stage(const KParams& p, hipStream_t stream) {
     // usually not run yet when the next is enqueued; a stale or missing report only costs speed).
     // WLSQM_HIP_STAGE_FORM=two / one forces a form (A/B, tests).
     constexpr int NO = ndofs(DIM, ORDER);
+    // RAGGED batches (round 6): p.ragged = 2 (the host entry points have seen the neighbour counts): the RAGGED copy for every group;
+    // p.ragged = 0 (device-resident counts nobody has looked at): the plain kernel marks the waves none of whose cases reaches the row's last
+    // chunk and the RAGGED copy runs those behind it — an idle launch for a batch of full rows; p.ragged = 1 (full rows, known): as before.
+    constexpr bool RAG_SHAPE = !GATHER && NO <= 20 && !(DIM == 3 && ORDER == 4);
+    const char* rg = getenv("WLSQM_HIP_STAGE_RAGGED");                // 0: off (A/B)
+    const bool rag_on = RAG_SHAPE && !(rg && rg[0] == '0') && p.max_nk > stage::CH;
+    if constexpr (RAG_SHAPE) {
+        if (rag_on && p.ragged == 2) {
+            hipLaunchKernelGGL((fit_stage_kernel<DIM, ORDER, 0, false, 2>), dim3((unsigned)groups), dim3(64), 0, stream, p, (unsigned char*)nullptr);
+            WLSQM_HIP_CHECK(hipGetLastError());
+            note_kernel("stage-ragged");
+            return WLSQM_OK;
+        }
+    }
+    const bool mark = rag_on && p.ragged == 0;
+    CallScratch cs;
+    unsigned char* status = nullptr;
+    if (mark) {
+        const int rc = call_scratch_acquire(&cs, (size_t)groups, stream);
+        if (rc != WLSQM_OK) return rc;
+        status = static_cast<unsigned char*>(cs.p);
+    }
+    auto finish = [&](const char* name) {
+        hipError_t le = hipGetLastError();
+        if constexpr (RAG_SHAPE) {
+            if (mark && le == hipSuccess) {
+                const long long want = groups < 2048 ? groups : 2048;
+                hipLaunchKernelGGL((fit_stage_ragged_kernel<DIM, ORDER>), dim3((unsigned)want), dim3(64), 0, stream, p, groups, status);
+                le = hipGetLastError();
+            }
+        }
+        const int rc = mark ? call_scratch_release(&cs, stream) : (int)WLSQM_OK;
+        if (le != hipSuccess) return hip_fail(le, "fit_stage_kernel");
+        note_kernel(name);
+        return rc;
+    };
     if constexpr (!GATHER && NO <= 10) {
         const char* e = getenv("WLSQM_HIP_STAGE_FORM");
         bool own_simd = false;
@@ -795,19 +862,26 @@ static int launch_stage(const KParams& p, hipStream_t stream) {
         if (e && (e[0] == 't' || e[0] == 'o')) own_simd = e[0] == 'o';
         else {
             const int rc = stage_hint_acquire(DIM, ORDER, stream, &q.hint, &own_simd);
-            if (rc != WLSQM_OK) return rc;
+            if (rc != WLSQM_OK) { if (mark) (void)call_scratch_release(&cs, stream); return rc; }
             q.hint_stride = (int)(groups / 64 > 0 ? groups / 64 : 1);
         }
-        if (own_simd) hipLaunchKernelGGL((fit_stage_kernel<DIM, ORDER, 5, false>), dim3((unsigned)groups), dim3(64), 0, stream, q);
-        else hipLaunchKernelGGL((fit_stage_kernel<DIM, ORDER, 0, false>), dim3((unsigned)groups), dim3(64), 0, stream, q);
-        WLSQM_HIP_CHECK(hipGetLastError());
-        note_kernel("stage");
-        return WLSQM_OK;
+        if (mark) {
+            if (own_simd) hipLaunchKernelGGL((fit_stage_kernel<DIM, ORDER, 5, false, 1>), dim3((unsigned)groups), dim3(64), 0, stream, q, status);
+            else hipLaunchKernelGGL((fit_stage_kernel<DIM, ORDER, 0, false, 1>), dim3((unsigned)groups), dim3(64), 0, stream, q, status);
+        } else {
+            if (own_simd) hipLaunchKernelGGL((fit_stage_kernel<DIM, ORDER, 5, false, 0>), dim3((unsigned)groups), dim3(64), 0, stream, q, status);
+            else hipLaunchKernelGGL((fit_stage_kernel<DIM, ORDER, 0, false, 0>), dim3((unsigned)groups), dim3(64), 0, stream, q, status);
+        }
+        return finish("stage");
     }
-    hipLaunchKernelGGL((fit_stage_kernel<DIM, ORDER, 0, GATHER>), dim3((unsigned)groups), dim3(64), 0, stream, p);
-    WLSQM_HIP_CHECK(hipGetLastError());
-    note_kernel(GATHER ? "stage-gather" : "stage");
-    return WLSQM_OK;
+    if constexpr (RAG_SHAPE) {
+        if (mark) {
+            hipLaunchKernelGGL((fit_stage_kernel<DIM, ORDER, 0, GATHER, 1>), dim3((unsigned)groups), dim3(64), 0, stream, p, status);
+            return finish("stage");
+        }
+    }
+    hipLaunchKernelGGL((fit_stage_kernel<DIM, ORDER, 0, GATHER, 0>), dim3((unsigned)groups), dim3(64), 0, stream, p, status);
+    return finish(GATHER ? "stage-gather" : "stage");
 }
 
 int launch_quad_solve(const KParams& p, hipStream_t stream);          // fit_quad.hip
@@ -826,7 +900,7 @@ int launch_fit_stage_inverse(int dimension, int order, const KParams& p, long lo
     if (groups <= 0 || groups > 0x7fffffffLL) return WLSQM_OK;
     KParams q = p;
     q.ws = inv; q.do_sens = 0; q.sens = nullptr; q.iterative = 0;
-    hipLaunchKernelGGL((fit_stage_kernel<2, 4, 4, false>), dim3((unsigned)groups), dim3(64), 0, stream, q);
+    hipLaunchKernelGGL((fit_stage_kernel<2, 4, 4, false>), dim3((unsigned)groups), dim3(64), 0, stream, q, (unsigned char*)nullptr);
     WLSQM_HIP_CHECK(hipGetLastError());
     *handled = true;
     return WLSQM_OK;
@@ -851,10 +925,10 @@ static int launch_stage34(const KParams& p, hipStream_t stream) {
         // (round 5: both halves in ONE launch — the second pass re-staging the rows from L2 — was built and dropped: the compiler's register
         // allocation of the fused kernel puts 380-780 accumulation-register moves into every 8-neighbour chunk where the two kernels have
         // ~60, and 848 B of scratch)
-        hipLaunchKernelGGL((fit_stage_kernel<3, 4, 1, GATHER>), dim3((unsigned)groups), dim3(64), 0, stream, q);
+        hipLaunchKernelGGL((fit_stage_kernel<3, 4, 1, GATHER>), dim3((unsigned)groups), dim3(64), 0, stream, q, (unsigned char*)nullptr);
         hipError_t le = hipGetLastError();                            // (a failed moment launch must not run the solve on an uninitialised workspace)
         if (le == hipSuccess) {
-            hipLaunchKernelGGL((fit_stage_kernel<3, 4, 2, GATHER>), dim3((unsigned)groups), dim3(64), 0, stream, q);
+            hipLaunchKernelGGL((fit_stage_kernel<3, 4, 2, GATHER>), dim3((unsigned)groups), dim3(64), 0, stream, q, (unsigned char*)nullptr);
             le = hipGetLastError();
         }
         rc = le == hipSuccess ? launch_quad_solve(q, stream) : hip_fail(le, "fit_stage_kernel<3, 4>");

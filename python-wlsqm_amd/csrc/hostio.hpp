@@ -72,15 +72,16 @@ struct Stager {
     // contiguous elements (group = dim for xk rows, 1 for fk).  Unit inner stride -> memcpy per row (or per chunk).
     // `dst_row_elems` (>= row_elems, default = row_elems) is the row length of the device array: the tail of each
     // device row is padding that is transferred but never read.
+    // `perm` (optional): device row r is source row perm[r] (the host path packs ragged batches in neighbour-count order).
     int upload_rows(void* dst_dev, const void* src, int64_t nrows, int64_t row_elems, int64_t src_row_stride,
-                    int64_t inner_stride, int64_t group, size_t esz, hipStream_t s, int64_t dst_row_elems = 0) {
+                    int64_t inner_stride, int64_t group, size_t esz, hipStream_t s, int64_t dst_row_elems = 0, const int64_t* perm = nullptr) {
         if (nrows <= 0 || row_elems <= 0) return WLSQM_OK;
         if (dst_row_elems < row_elems) dst_row_elems = row_elems;
         const size_t copy_bytes = (size_t)row_elems * esz;
         const size_t row_bytes = (size_t)dst_row_elems * esz;
         const int64_t rows_per_chunk = std::max<int64_t>(1, (int64_t)(CHUNK / row_bytes));
         const bool inner_contig = (inner_stride == group) || (row_elems == group);
-        const bool fully_contig = inner_contig && src_row_stride == row_elems && dst_row_elems == row_elems;
+        const bool fully_contig = inner_contig && src_row_stride == row_elems && dst_row_elems == row_elems && !perm;
         for (int64_t r0 = 0; r0 < nrows; r0 += rows_per_chunk) {
             const int64_t nr = std::min<int64_t>(rows_per_chunk, nrows - r0);
             int slot; int rc = acquire(slot); if (rc != WLSQM_OK) return rc;
@@ -97,12 +98,12 @@ struct Stager {
             } else if (inner_contig) {
 #pragma omp parallel for schedule(static) num_threads(copy_threads())
                 for (int64_t r = 0; r < nr; ++r)
-                    std::memcpy(stage + (size_t)r * row_bytes, base + (size_t)(r0 + r) * src_row_stride * esz, copy_bytes);
+                    std::memcpy(stage + (size_t)r * row_bytes, base + (size_t)(perm ? perm[r0 + r] : r0 + r) * src_row_stride * esz, copy_bytes);
             } else {
                 const int64_t ngroups = row_elems / group;
 #pragma omp parallel for schedule(static) num_threads(copy_threads())
                 for (int64_t r = 0; r < nr; ++r) {
-                    const char* sr = base + (size_t)(r0 + r) * src_row_stride * esz;
+                    const char* sr = base + (size_t)(perm ? perm[r0 + r] : r0 + r) * src_row_stride * esz;
                     char* dr = stage + (size_t)r * row_bytes;
                     for (int64_t g = 0; g < ngroups; ++g)
                         std::memcpy(dr + (size_t)g * group * esz, sr + (size_t)g * inner_stride * esz, (size_t)group * esz);

@@ -59,6 +59,9 @@ struct KParams {
     // kernel form by it (stage_hint_acquire).  nullptr: nothing is reported.
     unsigned char* hint = nullptr;
     int hint_stride = 1;
+    // what the caller knows about the neighbour counts of a dense batch: 0 nothing (device-resident counts), 1 every case fills its row,
+    // 2 ragged (the host entry points look: fit_stage.hip runs its RAGGED copy)
+    int ragged = 0;
 };
 
 // Cases a launch really has (see KParams::ncases_dev).

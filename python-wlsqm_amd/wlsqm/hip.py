@@ -166,6 +166,26 @@ def _stream_and_device(t, stream):
     return C.c_void_p(int(stream) if stream else 0), dev
 
 
+class row_hint:
+    """with wlsqm.hip.row_hint("ragged"): ... — what the calling thread knows about the neighbour counts of the dense device-resident batches
+    it hands over (wlsqm_hip_set_row_hint): "full" (default: every case fills its row), "ragged" (e.g. ball-query rows: the staged kernels'
+    waves move only the chunks their own cases need) or None / "unknown" (the kernels find out: one idle launch for full rows).  A hint: the
+    results are the same bits either way."""
+    _CODE = {"full": 1, True: 2, "ragged": 2, None: 0, "unknown": 0, False: 1}
+
+    def __init__(self, what):
+        self.code = self._CODE[what]
+
+    def __enter__(self):
+        self.prev = B.lib().wlsqm_hip_set_row_hint(self.code) if hasattr(B.lib(), "wlsqm_hip_set_row_hint") else 1
+        return self
+
+    def __exit__(self, *exc):
+        if hasattr(B.lib(), "wlsqm_hip_set_row_hint"):
+            B.lib().wlsqm_hip_set_row_hint(self.prev)
+        return False
+
+
 def fit_many_device(dimension, order, xk, fk, nk, xi, fi, knowns, weighting_method, sens=None, iterative=False,
                     max_iter=10, case_index=None, stream=None, want_iterations=False, strict=None, max_order=4):
     """fit_{1,2,3}D[_iterative]_many on device-resident tensors.  `order`: an int (all cases of that polynomial order: the fast

@@ -341,7 +341,7 @@ def test_staged_kernel_bits_do_not_depend_on_wave_mates(wlsqm, dim, order, Kn):
         fi = _t(fi0[sel])
         whip.fit_many_device(dim, order, _t(xk), _t(fk), _t(nk[sel]), _t(xi[sel]), fi, _t(kn[sel]), _t(wm[sel]))
         torch.cuda.synchronize()
-        assert whip.last_kernel() == "stage"
+        assert whip.last_kernel() in ("stage", "stage-ragged")
         return fi.cpu().numpy().view(np.int64)
     all_sorted, all_unsorted = run(srt), run(off)
     mixed = srt.copy(); odd = np.arange(n) % 2 == 1
@@ -384,7 +384,7 @@ def test_staged_kernel_forms_agree_and_follow_the_input(wlsqm, monkeypatch, dim,
         args = (dim, order, _t(xk), _t(fk), _t(nk), _t(xi), fi, _t(kn), _t(wm))
         whip.fit_many_device(*args)
         torch.cuda.synchronize()
-        assert whip.last_kernel() == "stage"
+        assert whip.last_kernel() in ("stage", "stage-ragged")
         return fi.cpu().numpy().view(np.int64), args
     want = {}
     for form in ("two", "one"):
