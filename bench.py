@@ -327,12 +327,15 @@ def measure_fit(name, cfg, n, dev, timer, steps, warmup, rank, parity=True, keep
             res["parity"] = {"vs_cpu_statement": {"cases": m, "bit_identical_cases": int((got.view(np.int64) == sym.view(np.int64)).all(axis=1).sum())},
                              "vs_oracle": {"cases": m, "E_max": float(E.max()), "columns": int(no), "columns_le_1e-10": int((E <= 1e-10).sum())}}
         return res, dt
+    hint = whip.row_hint(sorted=not unsorted)                         # (the caller's word about its rows: wlsqm_hip_set_order_hint)
+    hint.__enter__()
     dt = timer.run(lambda: whip.fit_many_device(*args), steps, warmup)
     kernel = whip.last_kernel()
     # dominant kernel: HIP events over the timed region itself (Timer.run), on the stream it is launched on; a dedicated run of the same
     # launch (events inside the library, no Python between the launches) is kept beside it in the full record
     ms_region = getattr(timer, "last_event_ms_per_step", None)
     ms_dedicated = whip.time_fit_device(*args, reps=min(max(steps, 20), 500))
+    hint.__exit__()
     launch_bound = (not ms_region) or ms_region > 1.5 * ms_dedicated          # tiny launches: the span measures Python's launch rate, not the kernel
     ms_kernel = ms_dedicated if launch_bound else ms_region
     B_fit = bytes_per_fit(dim, order, nk, cfg["knowns"])
@@ -895,7 +898,7 @@ def measure_ball(name, n, dev, timer, steps, warmup, rank, parity, order=4, max_
     wm_d = torch.full((n,), 2, dtype=torch.int32, device=dev)
     args = (dim, order, xk_d, fk_d, nk_d, xi_d, fi_d, kn_d, wm_d)
     # (device-resident counts: the caller says that its rows are ragged — wlsqm.hip.row_hint; the host entry points see it themselves)
-    with whip.row_hint("ragged"):
+    with whip.row_hint("ragged", sorted=False):
         dt = timer.run(lambda: whip.fit_many_device(*args), steps, warmup)
         kernel = whip.last_kernel()
         ms_kernel = whip.time_fit_device(*args, reps=min(max(steps, 10), 100))

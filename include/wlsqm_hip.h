@@ -142,6 +142,14 @@ int wlsqm_hip_get_strict(void);
  * look at the counts themselves and ignore it.  Returns the previous value. */
 int wlsqm_hip_set_row_hint(int hint);
 
+/* Round 6: are the neighbours of every row sorted by distance (1, the default: what a k-nearest-neighbour search returns — scipy's cKDTree.query,
+ * wlsqm_hip_knn — and every BASELINE config) or in no order (0: a ball query)?  The weights need the largest squared distance of a case before
+ * the first term can be summed (infra.pyx:668-702); sorted rows give it away (the last neighbour), unsorted rows cost a pass of their own.
+ * The staged kernels of the small dense systems have a form for either (csrc/fit_stage.hip) and the CALLER's word picks it — the time of a
+ * call is a function of its arguments, not of what ran before it on the stream.  A hint, never a condition of correctness: the kernels verify
+ * the order bit for bit and the results are the same bits either way.  Belongs to the calling thread; returns the previous value. */
+int wlsqm_hip_set_order_hint(int sorted);
+
 /* Test hook of the strict mode: runs the reference-order fit of `b` (uniform order) and also stores the reference's intermediates,
  * for bit-for-bit comparison with values captured from the reference (tests/golden/sweep_*.npz): w[j * w_stride + k]
  * (Case_make_weights), the unscaled A and the scaled LU factor as nr x nr Fortran-order blocks at [j * mat_stride]

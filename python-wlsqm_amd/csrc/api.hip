@@ -51,7 +51,9 @@ static thread_local int g_strict = -1;
 // what the calling thread says about the neighbour counts of the dense DEVICE-resident batches it hands over (wlsqm_hip_set_row_hint; the host
 // entry points look at the counts themselves): 1 every case fills its row (default), 2 ragged, 0 unknown (the kernels find out)
 static thread_local int g_row_hint = 1;
+static thread_local int g_order_hint = 1;                            // the neighbours of a row: 1 sorted by distance (default: a k-nearest-neighbour search's rows), 0 in no order
 int row_hint_value() { return g_row_hint; }
+int order_hint_value() { return g_order_hint; }
 static int strict_mode_value();
 bool accurate_mode() { return strict_mode_value() == 2; }
 bool strict_mode() { return strict_mode_value() >= 1; }
@@ -321,59 +323,6 @@ int call_scratch_release(CallScratch* cs, hipStream_t stream) {
     if (cs->lock.owns_lock()) cs->lock.unlock();
     return rc;
 }
-namespace {
-struct StageHint { int dev; hipStream_t stream; int shape; unsigned char* host; unsigned char* device; bool unsorted; };
-std::vector<StageHint>& stage_hint_table() { static std::vector<StageHint> t; return t; }
-}  // namespace
-int stage_hint_acquire(int dimension, int order, hipStream_t stream, unsigned char** dev_out, bool* unsorted) {
-    *dev_out = nullptr; *unsorted = false;
-    int dev = 0;
-    WLSQM_HIP_CHECK(hipGetDevice(&dev));
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(stream, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
-    if (cap != hipStreamCaptureStatusNone) return WLSQM_OK;         // (no allocation inside a capture; a replay would report into the same slots for ever)
-    const int shape = dimension * 8 + order;
-    static std::mutex hint_mutex;
-    std::lock_guard<std::mutex> lock(hint_mutex);
-    StageHint* hit = nullptr;
-    for (auto& e : stage_hint_table()) if (e.dev == dev && e.stream == stream && e.shape == shape) hit = &e;
-    if (!hit) {
-        if (stage_hint_table().size() >= 256) {
-            // a process that keeps creating streams: the oldest entry of this device changes hands WITH its memory (never freed: a launch
-            // that is still running may report into it — into somebody else's heuristic, at worst)
-            for (size_t i = 0; i < stage_hint_table().size() && !hit; ++i)
-                if (stage_hint_table()[i].dev == dev) {
-                    StageHint e = stage_hint_table()[i];
-                    stage_hint_table().erase(stage_hint_table().begin() + (long)i);
-                    e.stream = stream; e.shape = shape; e.unsorted = false;
-                    std::memset(e.host, 0, 64);
-                    stage_hint_table().push_back(e);
-                    hit = &stage_hint_table().back();
-                }
-            if (!hit) return WLSQM_OK;
-        } else {
-            unsigned char* h = nullptr; unsigned char* d = nullptr;
-            if (hipHostMalloc(reinterpret_cast<void**>(&h), 64, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return WLSQM_OK; }
-            if (hipHostGetDevicePointer(reinterpret_cast<void**>(&d), h, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(h); return WLSQM_OK; }
-            std::memset(h, 0, 64);
-            stage_hint_table().push_back(StageHint{dev, stream, shape, h, d, false});
-            hit = &stage_hint_table().back();
-        }
-    }
-    // (plain reads of memory earlier launches' groups wrote — or are still writing: a heuristic, never a result).  Launches are
-    // asynchronous: the previous one has usually not RUN yet when the next is enqueued, so the verdict is sticky — it changes when reports
-    // have arrived and say otherwise, and the slots are cleared only then (a later launch's reports overwrite them)
-    volatile unsigned char* v = hit->host;
-    int n_sorted = 0, n_unsorted = 0;
-    for (int i = 0; i < 64; ++i) { const unsigned char b = v[i]; if (b == 2) ++n_sorted; else if (b == 1) ++n_unsorted; }
-    if (n_sorted + n_unsorted > 0) {
-        hit->unsorted = n_unsorted > n_sorted;
-        for (int i = 0; i < 64; ++i) v[i] = 0;
-    }
-    *unsorted = hit->unsorted;
-    *dev_out = hit->device;
-    return WLSQM_OK;
-}
 int scratch_free_async(void* p, hipStream_t stream) {
     if (!p) return WLSQM_OK;
     WLSQM_HIP_CHECK(hipFreeAsync(p, stream));
@@ -407,6 +356,7 @@ static KParams params_from(const wlsqm_batch* b) {
     p.max_iter = b->max_iter;
     p.iters_out = nullptr;
     p.ragged = row_hint_value();                                    // (device-resident counts: the caller's word; the host entry points overwrite it with what they see)
+    p.rows_sorted = order_hint_value();
     return p;
 }
 
@@ -435,6 +385,11 @@ int wlsqm_hip_get_strict(void) { return strict_mode_value(); }
 int wlsqm_hip_set_row_hint(int hint) {
     const int prev = g_row_hint;
     g_row_hint = (hint == 0 || hint == 2) ? hint : 1;
+    return prev;
+}
+int wlsqm_hip_set_order_hint(int sorted) {
+    const int prev = g_order_hint;
+    g_order_hint = sorted ? 1 : 0;
     return prev;
 }
 
@@ -773,6 +728,27 @@ int wlsqm_hip_fit_many_host(const wlsqm_batch* b, int device, int32_t* iteration
         int32_t lo = n > 0 ? h_nk[0] : 0;
         for (int64_t j = 0; j < n; ++j) lo = h_nk[j] < lo ? h_nk[j] : lo;
         p.ragged = (max_nk - lo >= 8) ? 2 : 1;                         // (the staged kernels: their RAGGED copy, or the plain one without the marking)
+        // ... and at the rows themselves: are the neighbours sorted by distance?  64 cases spread over the batch (in the caller's memory: the
+        // arrays are right here); more than half of them out of order: the form of the staged kernels for unsorted rows (fit_stage.hip)
+        int looked = 0, unsorted = 0;
+        const int64_t step = n / 64 > 0 ? n / 64 : 1;
+        for (int64_t r = 0; r < n && looked < 64; r += step) {
+            const int64_t j = user_row(r);
+            const int32_t nkj = h_nk[r];
+            if (nkj < 3) continue;
+            ++looked;
+            double prev = -1.0; bool mono = true;
+            for (int32_t k = 0; k < nkj && mono; ++k) {
+                double d2 = 0.0;
+                for (int m = 0; m < dim; ++m) {
+                    const double d = b->xk[j * b->xk_stride_case + (int64_t)k * b->xk_stride_k + m] - b->xi[j * b->xi_stride_case + m];
+                    d2 += d * d;
+                }
+                mono = d2 >= prev; prev = d2;
+            }
+            if (!mono) ++unsorted;
+        }
+        p.rows_sorted = (looked > 0 && 2 * unsorted > looked) ? 0 : 1;
     }
 
     // bucket by order (the kernels are specialised per (dimension, order))

@@ -491,13 +491,6 @@ __device__ __forceinline__ void stage_group(const KParams& p, const unsigned grp
     // (Round 5's one-pass form with three sets of sums — 0.270 against 0.249 ms and a digit lost to cancellation, profiles/r05b_unsorted.txt —,
     // its DEEP / AGPR forms of two chunks in flight — r05c_ab_stage_agpr.txt — are out of the source since round 6: git history, commit c9ef97d.)
     const bool elig_r = uniform || mono;
-    if constexpr (!GATHER && (PART == 0 || PART == 5)) {
-        // (sampled groups tell the NEXT call on the stream whether this input was sorted by distance: launch_stage)
-        if (p.hint != nullptr && (int)(grp % (unsigned)p.hint_stride) == 0 && grp / (unsigned)p.hint_stride < 64u) {
-            const bool sorted_group = __all(elig_r);
-            if (lane == 0) p.hint[grp / (unsigned)p.hint_stride] = sorted_group ? 2 : 1;
-        }
-    }
     if (__all(elig_r)) {
         moments(guess, true);
         // the guess must have been the largest squared distance, bit for bit (uniform weighting does not use it); otherwise the wave
@@ -856,23 +849,23 @@ static int launch_stage(const KParams& p, hipStream_t stream) {
         return rc;
     };
     if constexpr (!GATHER && NO <= 10) {
+        // TWO FORMS of the dense systems up to 10 unknowns: two waves per SIMD (PART 0), or one wave that owns its SIMD (PART 5: register-staged
+        // chunks; same bits per case).  Rows whose neighbours are NOT sorted by distance take two passes per group, and the second pass finds
+        // the rows in L2 only with one wave per SIMD resident: 1M cases with shuffled rows, configs[1] 0.218 -> 0.200 ms, configs[4] 0.406 ->
+        // 0.373 — while sorted rows lose 5-9 % there.  ROUND 6: the form is a function of the ARGUMENTS — the caller's word about its rows
+        // (wlsqm_hip_set_order_hint; default: sorted, what every k-nearest-neighbour search returns) — not of what earlier launches on the
+        // stream reported (round 5: host-mapped bytes written by sampled groups; the same call could be timed at 0.20 or 0.22 ms depending on
+        // its predecessor).  WLSQM_HIP_STAGE_FORM=two / one forces a form (A/B, tests).
         const char* e = getenv("WLSQM_HIP_STAGE_FORM");
-        bool own_simd = false;
-        KParams q = p;
-        if (e && (e[0] == 't' || e[0] == 'o')) own_simd = e[0] == 'o';
-        else {
-            const int rc = stage_hint_acquire(DIM, ORDER, stream, &q.hint, &own_simd);
-            if (rc != WLSQM_OK) { if (mark) (void)call_scratch_release(&cs, stream); return rc; }
-            q.hint_stride = (int)(groups / 64 > 0 ? groups / 64 : 1);
-        }
+        const bool own_simd = (e && (e[0] == 't' || e[0] == 'o')) ? e[0] == 'o' : p.rows_sorted == 0;
         if (mark) {
-            if (own_simd) hipLaunchKernelGGL((fit_stage_kernel<DIM, ORDER, 5, false, 1>), dim3((unsigned)groups), dim3(64), 0, stream, q, status);
-            else hipLaunchKernelGGL((fit_stage_kernel<DIM, ORDER, 0, false, 1>), dim3((unsigned)groups), dim3(64), 0, stream, q, status);
+            if (own_simd) hipLaunchKernelGGL((fit_stage_kernel<DIM, ORDER, 5, false, 1>), dim3((unsigned)groups), dim3(64), 0, stream, p, status);
+            else hipLaunchKernelGGL((fit_stage_kernel<DIM, ORDER, 0, false, 1>), dim3((unsigned)groups), dim3(64), 0, stream, p, status);
         } else {
-            if (own_simd) hipLaunchKernelGGL((fit_stage_kernel<DIM, ORDER, 5, false, 0>), dim3((unsigned)groups), dim3(64), 0, stream, q, status);
-            else hipLaunchKernelGGL((fit_stage_kernel<DIM, ORDER, 0, false, 0>), dim3((unsigned)groups), dim3(64), 0, stream, q, status);
+            if (own_simd) hipLaunchKernelGGL((fit_stage_kernel<DIM, ORDER, 5, false, 0>), dim3((unsigned)groups), dim3(64), 0, stream, p, status);
+            else hipLaunchKernelGGL((fit_stage_kernel<DIM, ORDER, 0, false, 0>), dim3((unsigned)groups), dim3(64), 0, stream, p, status);
         }
-        return finish("stage");
+        return finish(own_simd ? "stage-own" : "stage");
     }
     if constexpr (RAG_SHAPE) {
         if (mark) {

@@ -54,11 +54,10 @@ struct KParams {
     int it_first = 0, it_stop = 0;
     long long* cont_list = nullptr; long long* cont_count = nullptr;
     double* it_state = nullptr;
-    // fit_stage.hip, dense systems up to 10 unknowns: 64 bytes of host-mapped memory per (stream, shape) in which sampled 64-case groups
-    // (every hint_stride-th) report whether their neighbours were sorted by distance (2) or not (1): the NEXT call on the stream picks the
-    // kernel form by it (stage_hint_acquire).  nullptr: nothing is reported.
-    unsigned char* hint = nullptr;
-    int hint_stride = 1;
+    // the neighbours of every row come sorted by distance (1: a k-nearest-neighbour search's rows — the default) or in no order (0: a ball
+    // query): the caller's word (wlsqm_hip_set_order_hint).  Picks the FORM of the staged kernel of the small dense systems (fit_stage.hip:
+    // two waves per SIMD, or one that owns its SIMD and finds the second pass's rows in L2) — the same bits either way.
+    int rows_sorted = 1;
     // what the caller knows about the neighbour counts of a dense batch: 0 nothing (device-resident counts), 1 every case fills its row,
     // 2 ragged (the host entry points look: fit_stage.hip runs its RAGGED copy)
     int ragged = 0;
@@ -210,11 +209,6 @@ int scratch_free_async(void* p, hipStream_t stream);
 struct CallScratch { void* p = nullptr; bool pooled = false; std::unique_lock<std::mutex> lock; };
 int call_scratch_acquire(CallScratch* cs, size_t bytes, hipStream_t stream);
 int call_scratch_release(CallScratch* cs, hipStream_t stream);
-// What the staged launches of this (dimension, order) on the stream have reported about their input so far: *unsorted = most sampled groups
-// of the latest reports that have ARRIVED had neighbours in no order (false until a report arrives; sticky between reports — launches are
-// asynchronous), *dev = where this launch's sampled groups report (nullptr inside a graph capture or if host-mapped memory is not to be
-// had: the caller takes its default form).
-int stage_hint_acquire(int dimension, int order, hipStream_t stream, unsigned char** dev, bool* unsorted);
 
 // Host mirror of effective_mask() in wlsqm_kernels.hpp (infra.pyx:119-121 quirk): returns the
 // mask of DOFs the reference never writes (true knowns | dropped) and the dropped subset.

@@ -82,6 +82,8 @@ def lib():
     if hasattr(L, "wlsqm_hip_set_row_hint"):                         # (tools/ab_lib.sh times older builds of the library through this binding)
         L.wlsqm_hip_set_row_hint.argtypes = [C.c_int]
         L.wlsqm_hip_set_row_hint.restype = C.c_int
+        L.wlsqm_hip_set_order_hint.argtypes = [C.c_int]
+        L.wlsqm_hip_set_order_hint.restype = C.c_int
     L.wlsqm_hip_strict_intermediates_device.argtypes = [C.POINTER(Batch), C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64,
                                                         C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                                         C.c_int64]

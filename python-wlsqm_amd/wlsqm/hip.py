@@ -173,16 +173,24 @@ class row_hint:
     results are the same bits either way."""
     _CODE = {"full": 1, True: 2, "ragged": 2, None: 0, "unknown": 0, False: 1}
 
-    def __init__(self, what):
+    def __init__(self, what="full", sorted=True):
+        # sorted: the neighbours of every row come sorted by distance (a k-nearest-neighbour search's rows: the default) or not (a ball
+        # query's: sorted=False) — wlsqm_hip_set_order_hint: picks the form of the staged kernels of the small dense systems
         self.code = self._CODE[what]
+        self.sorted = 1 if sorted else 0
 
     def __enter__(self):
-        self.prev = B.lib().wlsqm_hip_set_row_hint(self.code) if hasattr(B.lib(), "wlsqm_hip_set_row_hint") else 1
+        L = B.lib()
+        self.prev = L.wlsqm_hip_set_row_hint(self.code) if hasattr(L, "wlsqm_hip_set_row_hint") else 1
+        self.prev_sorted = L.wlsqm_hip_set_order_hint(self.sorted) if hasattr(L, "wlsqm_hip_set_order_hint") else 1
         return self
 
     def __exit__(self, *exc):
-        if hasattr(B.lib(), "wlsqm_hip_set_row_hint"):
-            B.lib().wlsqm_hip_set_row_hint(self.prev)
+        L = B.lib()
+        if hasattr(L, "wlsqm_hip_set_row_hint"):
+            L.wlsqm_hip_set_row_hint(self.prev)
+        if hasattr(L, "wlsqm_hip_set_order_hint"):
+            L.wlsqm_hip_set_order_hint(self.prev_sorted)
         return False
 
 

@@ -357,11 +357,12 @@ def test_staged_kernel_bits_do_not_depend_on_wave_mates(wlsqm, dim, order, Kn):
 
 @pytest.mark.parametrize("dim,order,Kn", [(2, 2, 32), (2, 2, 46), (2, 3, 30), (3, 2, 40), (3, 2, 26)])
 def test_staged_kernel_forms_agree_and_follow_the_input(wlsqm, monkeypatch, dim, order, Kn):
-    """Round 5: the dense systems up to 10 unknowns have two forms of the staged kernel — two waves per SIMD (default; chunks by LDS-DMA for
-    the 10-unknown systems) and one that owns its SIMD (faster when the neighbours are NOT sorted by distance: the second pass finds the
-    rows in L2).  The launch picks by what sampled groups of the PREVIOUS launch on the stream reported (host-mapped bytes, no
-    synchronisation).  Whatever is picked, a case's bits are the same: forced forms (WLSQM_HIP_STAGE_FORM=two / one) and the automatic choice
-    over a sequence of sorted, shuffled and mixed batches, eager and inside a replayed graph."""
+    """The dense systems up to 10 unknowns have two forms of the staged kernel — two waves per SIMD (default; chunks by LDS-DMA for the
+    10-unknown systems) and one that owns its SIMD (faster when the neighbours are NOT sorted by distance: the second pass finds the rows
+    in L2).  ROUND 6: the form is picked by the CALLER's word about its rows (wlsqm.hip.row_hint(sorted=...), wlsqm_hip_set_order_hint;
+    round 5 picked it from what earlier launches on the stream had reported) — the FIRST call with sorted=False runs the own-SIMD form,
+    alternating calls each get theirs.  Whatever is picked, a case's bits are the same: forced forms (WLSQM_HIP_STAGE_FORM=two / one), hinted
+    forms on sorted, shuffled and mixed batches (a wrong hint included), eager and inside a replayed graph."""
     import torch
     import wlsqm.hip as whip
     rng = np.random.default_rng(99 + Kn)
@@ -376,31 +377,37 @@ def test_staged_kernel_forms_agree_and_follow_the_input(wlsqm, monkeypatch, dim,
     kn = rng.choice(np.array([0, 0, 1], np.int64), n)
     wm = np.full(n, wlsqm.WEIGHT_CENTER, np.int32)
     fi0 = rng.uniform(-1, 1, (n, no))
+    staged = order >= 3 or dim == 3 or Kn >= 32                       # (2D order 2 below 32 neighbours keeps the tile kernels)
 
-    def run(o, fi=None):
+    def run(o, fi=None, expect=None):
         xk = xi[:, None, :] + o
         fk = np.sin(3 * xk[..., 0]) * np.cos(2 * xk[..., -1])
         fi = _t(fi0) if fi is None else fi
         args = (dim, order, _t(xk), _t(fk), _t(nk), _t(xi), fi, _t(kn), _t(wm))
         whip.fit_many_device(*args)
         torch.cuda.synchronize()
-        assert whip.last_kernel() in ("stage", "stage-ragged")
+        assert whip.last_kernel() in ("stage", "stage-own", "stage-ragged")
+        if expect is not None and staged:
+            assert whip.last_kernel() == expect, (whip.last_kernel(), expect)
         return fi.cpu().numpy().view(np.int64), args
     want = {}
     for form in ("two", "one"):
         monkeypatch.setenv("WLSQM_HIP_STAGE_FORM", form)
         for name, o in (("sorted", srt), ("shuffled", off), ("mixed", mixed)):
-            got, _ = run(o)
+            got, _ = run(o, expect="stage" if form == "two" else "stage-own")
             if form == "two":
                 want[name] = got
             else:
                 assert np.array_equal(got, want[name]), "the two forms differ on %s input" % name
     monkeypatch.delenv("WLSQM_HIP_STAGE_FORM")
-    # automatic: every call sees the reports of the one before it
-    for name, o in (("sorted", srt), ("shuffled", off), ("shuffled", off), ("shuffled", off), ("mixed", mixed), ("sorted", srt), ("sorted", srt)):
-        got, args = run(o)
-        assert np.array_equal(got, want[name]), name
-    # captured (no reports inside a capture) and replayed after shuffled calls
+    # the caller's word: the first call on shuffled rows runs the own-SIMD form; alternating batches each get theirs; a wrong word costs time only
+    for name, o, word in (("shuffled", off, False), ("sorted", srt, True), ("shuffled", off, False), ("mixed", mixed, True), ("sorted", srt, False),
+                          ("shuffled", off, True)):
+        with whip.row_hint(sorted=word):
+            got, args = run(o, expect="stage" if word else "stage-own")
+        assert np.array_equal(got, want[name]), (name, word)
+    # captured and replayed
+    _, args = run(srt)
     s = torch.cuda.Stream()
     fi_g = _t(fi0)
     gargs = args[:6] + (fi_g,) + args[7:]
