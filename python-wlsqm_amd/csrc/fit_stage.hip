@@ -150,7 +150,17 @@ __device__ __forceinline__ void stage_group(const KParams& p, const unsigned grp
 #define WLSQM_STAGE_DMA_SLOTS35 2
 #endif
     constexpr int NSLOT = DMA ? ((NO > 6 && NO <= 10) ? WLSQM_STAGE_DMA_SLOTS10 : NO == 35 ? WLSQM_STAGE_DMA_SLOTS35 : WLSQM_STAGE_DMA_SLOTS) : 1, PF = NSLOT - 1;
-    constexpr int SLOT_D = (XNI + FNI) * 128;                         // doubles of one slot: a KiB per load instruction
+    // SKEW (round 6): instruction i lands at i (1 KiB + 16 B), not at i KiB.  A lane reads ITS case's neighbours with
+    // ds_read_b128, and the 16 lanes of a read group (MI355X_MICROARCH.md: {0-3, 12-15, 20-27}, ...) must hit 16 different 16-byte slots of the
+    // 256-byte bank row; in the dense KiB image the slot of case c was (12 (c mod 5)) mod 16 (3D: 192-byte chunks, 5 cases per KiB) — four
+    // slots for sixteen lanes, 6-way conflicts (`SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE` 0.80 on configs[4], profiles/r05_C5_pmc_summary.json)
+    // — or (8 (c mod 8)) mod 16 (2D order 3: 8-way).  With the instruction's KiB shifted by one slot the worst group is 2-3-way (brute force
+    // over the four lane groups: 25 -> 9 of an ideal 4 cycles per read in 3D, 32 -> 8 in 2D, 16 -> 8 for the values).
+#ifndef WLSQM_STAGE_DMA_SKEW
+#define WLSQM_STAGE_DMA_SKEW 16
+#endif
+    constexpr int KIB_B = 1024 + WLSQM_STAGE_DMA_SKEW, KIB_D = KIB_B / 8;      // bytes / doubles from one instruction's image to the next
+    constexpr int SLOT_D = (XNI + FNI) * KIB_D;                        // doubles of one slot
     static_assert(!DMA || (NSLOT >= 1 && PF * (XNI + FNI) <= 63), "the chunks in flight must fit the vmcnt counter");
     constexpr int STAGE_D = DMA ? NSLOT * SLOT_D : 64 * XPITCH + 64 * FPITCH, OUT_D = 64 * NO;
     constexpr int LDS_D = (STAGE_D > OUT_D ? STAGE_D : OUT_D) > TOP_D ? (STAGE_D > OUT_D ? STAGE_D : OUT_D) : TOP_D;
@@ -233,10 +243,10 @@ __device__ __forceinline__ void stage_group(const KParams& p, const unsigned grp
                     unsigned long long keepx;
                     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_mov_b64 %1, exec\n\ts_and_b64 exec, %1, %5\n\tglobal_load_lds_dwordx4 %2, %3 nt\n\t"
                                  "s_andn2_b64 exec, %1, %5\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
-                                 : "=&s"(keep), "=&s"(keepx) : "v"(xo + (unsigned)cc * xrowb), "s"(xt), "s"(slot + (unsigned)i * 1024u), "s"(inner) : "memory", "scc");      // (s_and_b64 / s_andn2_b64 write SCC: ADVICE r5)
+                                 : "=&s"(keep), "=&s"(keepx) : "v"(xo + (unsigned)cc * xrowb), "s"(xt), "s"(slot + (unsigned)i * (unsigned)KIB_B), "s"(inner) : "memory", "scc");      // (s_and_b64 / s_andn2_b64 write SCC: ADVICE r5)
                 } else
                 asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" WLSQM_STAGE_DMA_POLICY "\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep) : "v"(xo + (unsigned)cc * xrowb), "s"(xt), "s"(slot + (unsigned)i * 1024u) : "memory");
+                             : "=&s"(keep) : "v"(xo + (unsigned)cc * xrowb), "s"(xt), "s"(slot + (unsigned)i * (unsigned)KIB_B) : "memory");
             }
             if (want_f) {
 #pragma unroll
@@ -245,7 +255,7 @@ __device__ __forceinline__ void stage_group(const KParams& p, const unsigned grp
                     cc = cc < nvalid ? cc : nvalid - 1;
                     unsigned keep;
                     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" WLSQM_STAGE_DMA_POLICY "\n\ts_mov_b32 m0, %0"
-                                 : "=&s"(keep) : "v"(fo + (unsigned)cc * frowb), "s"(ft), "s"(slot + (unsigned)(XNI + i) * 1024u) : "memory");
+                                 : "=&s"(keep) : "v"(fo + (unsigned)cc * frowb), "s"(ft), "s"(slot + (unsigned)(XNI + i) * (unsigned)KIB_B) : "memory");
                 }
             }
         }
@@ -265,10 +275,10 @@ __device__ __forceinline__ void stage_group(const KParams& p, const unsigned grp
     };
     // the rows of lane's case in chunk q
     auto xrow_of = [&](int q, bool image) __attribute__((always_inline)) -> const double* {
-        return image ? lds + (q % NSLOT) * SLOT_D + (lane / XCPI) * 128 + (lane % XCPI) * (XPC * 2) : xs + lane * XPITCH;
+        return image ? lds + (q % NSLOT) * SLOT_D + (lane / XCPI) * KIB_D + (lane % XCPI) * (XPC * 2) : xs + lane * XPITCH;
     };
     auto frow_of = [&](int q, bool image) __attribute__((always_inline)) -> const double* {
-        return image ? lds + (q % NSLOT) * SLOT_D + XNI * 128 + (lane / FCPI) * 128 + (lane % FCPI) * (FPC * 2) : fs + lane * FPITCH;
+        return image ? lds + (q % NSLOT) * SLOT_D + XNI * KIB_D + (lane / FCPI) * KIB_D + (lane % FCPI) * (FPC * 2) : fs + lane * FPITCH;
     };
     // EARLY FETCH (round 5): the first staged chunk is requested BEFORE the case's scalars are — its addresses depend on the launch
     // parameters alone.  In source order the scalars (nk, weighting, knowns: one round trip), then the centre and a ragged case's last
