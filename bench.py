@@ -75,6 +75,14 @@ def flops_per_fit(dim, order, nk, knowns):
     return nk * per_nb + no * (no + 1) // 2 + no ** 3 // 3 + 2 * no * no
 
 
+def sweep_flops(dim, order, nk):
+    """fp64 operations of ONE refinement sweep of solve_iterative (impl.pyx:986-1083; FMA = 2): per neighbour the offsets (dim), the Taylor
+    model by Horner's rule (2 no), the residual (1), its weighted right-hand-side moments (1 + 2 no) and the norm (1); per case the two
+    substitutions with the stored factor (2 no^2) and the update (no)."""
+    no = NDOF[dim][order]
+    return nk * (dim + 4 * no + 3) + 2 * no * no + no
+
+
 def load_traffic(config, units_per_launch):
     """HBM bytes per launch from the committed PMC summary (profiles/traffic_<config>.json, tools/make_traffic.py) and the
     file it came from, or (None, None) when there is none for this config / launch size.  This is a RECORDED measurement
@@ -311,6 +319,27 @@ def measure_fit(name, cfg, n, dev, timer, steps, warmup, rank, parity=True, keep
                "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                             "traffic": None, "kernel_ms": ms_kernel, "kernel": kernel, "algorithmic_bytes_per_launch": B_fit * n,
                             "note": "whole call (every kernel of the path), HIP events on the launch stream"}}
+        if extras == "iter":
+            # where the roof is: sweeps per case from the CPU port on a sample (the stop rule is an exact equality of two
+            # residual norms, impl.pyx:1057: counts differ by a sweep between implementations, their distribution does not), the arithmetic of
+            # the call against the fp64 vector peak, and the bytes of the rows the sweeps read again (from L2 / the Infinity Cache, not HBM)
+            sw = None
+            if parity and rank == 0:
+                from oracle import oracle
+                m = 256
+                xk, fk, xi = (a[:m].cpu().numpy() for a in (xk_d, fk_d, xi_d))
+                its = []
+                for j in range(m):
+                    fij = np.zeros((1, no)); fij[0, 0] = F[j]
+                    its.append(oracle.fit_many(dim, xk[j:j + 1], fk[j:j + 1], np.full(1, nk, np.int32), xi[j:j + 1], fij, None, 0, np.full(1, order, np.int32),
+                                               np.full(1, cfg["knowns"], np.int64), np.full(1, cfg["wm"], np.int32), iterative=True, max_iter=10))
+                sw = {"cases": m, "mean": float(np.mean(its)), "max": int(np.max(its)), "min": int(np.min(its)), "source": "CPU port, one case per call"}
+            mean_sw = sw["mean"] if sw else 10.0
+            fl = flops_per_fit(dim, order, nk, cfg["knowns"]) + mean_sw * sweep_flops(dim, order, nk)
+            tf = fl * n / (ms_kernel * 1e-3) / 1e12
+            res["roofline"].update({"valu_flop_per_fit": fl, "valu_achieved_tflops": tf, "valu_peak_tflops": FP64_PEAK_TFLOPS, "valu_frac": tf / FP64_PEAK_TFLOPS,
+                                    "sweeps_per_case": sw, "rows_reread_bytes_per_fit": mean_sw * 8.0 * nk * (dim + 1),
+                                    "note": res["roofline"]["note"] + "; valu_frac counts the fit and the MEAN number of sweeps (a wave runs the maximum over its 64 cases)"})
         if extras == "accurate" and parity and rank == 0:
             # the first 1 024 cases against the mode's CPU statement (variants.c V_SYM: bit for bit) and against the CPU port of the reference
             from oracle import oracle
@@ -828,7 +857,7 @@ def side_configs(a, dev, timer, rank, parity):
     for cname, cn in (("C2", 1_000_000), ("C3", 400_000), ("C5", 1_000_000)):
         for ex in ("sens", "iter"):
             add("%s+%s@%s" % (cname, ex, "1M" if cn == 1_000_000 else "400k"),
-                lambda cname=cname, cn=cn, ex=ex: measure_fit(cname, CONFIGS[cname], cn, dev, timer, short["steps"], short["warmup"], rank, False, extras=ex))
+                lambda cname=cname, cn=cn, ex=ex: measure_fit(cname, CONFIGS[cname], cn, dev, timer, short["steps"], short["warmup"], rank, parity and ex == "iter", extras=ex))
 
     def sharded():
         b = copy.copy(a)

@@ -23,6 +23,7 @@ struct wlsqm_expert_geometry {
     int device = 0, dimension = 0;
     int64_t ncases = 0, max_nk = 1;
     int64_t slots = 2;                 // neighbour slots per device row (>= max_nk; preferred_slots in fit_tile.hip)
+    int ragged = 1;                    // 2: the neighbour counts differ by a chunk or more (KParams::ragged)
     int max_no = 0;
     bool ready = false, uniform_order = true;
     std::vector<int32_t> nk, order, wm, no;
@@ -83,6 +84,7 @@ static KParams expert_params(const wlsqm_expert* h, const double* d_fk, int64_t 
     p.xk = h->g->d_xk.as<double>(); p.sxk_j = h->g->slots * dim; p.sxk_k = dim;
     p.fk = d_fk; p.sfk_j = sfk_j; p.sfk_k = 1;
     p.nk = h->g->d_nk.as<int>(); p.snk = 1; p.max_nk = h->g->slots;
+    p.ragged = h->g->ragged;                                        // (the constructor has seen nk: fit_stage.hip's RAGGED copy for ragged geometries)
     p.xi = h->g->d_xi.as<double>(); p.sxi_j = dim;
     p.fi = d_fi; p.sfi_j = sfi_j;
     p.sens = nullptr; p.ss_j = 0; p.ss_k = 0;
@@ -133,6 +135,7 @@ int wlsqm_hip_expert_create(wlsqm_expert** out, int device, int dimension, int64
         g.no[j] = no; g.max_no = std::max(g.max_no, no); mk = std::max<int64_t>(mk, nk[j]);
     }
     g.max_nk = std::max<int64_t>(mk, 1);
+    { int64_t lo = mk; for (int64_t j = 0; j < ncases; ++j) lo = std::min<int64_t>(lo, nk[j]); g.ragged = (mk - lo >= 8) ? 2 : 1; }
     g.uniform_order = std::all_of(g.order.begin(), g.order.end(), [&](int o) { return o == g.order[0]; });
     g.slots = preferred_slots(dimension, g.uniform_order ? g.order[0] : -1, g.max_nk);
     DeviceScope scope; int rc = scope.enter(device);

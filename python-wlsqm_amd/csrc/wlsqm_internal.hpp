@@ -60,7 +60,7 @@ struct KParams {
     int rows_sorted = 1;
     // what the caller knows about the neighbour counts of a dense batch: 0 nothing (device-resident counts), 1 every case fills its row,
     // 2 ragged (the host entry points look: fit_stage.hip runs its RAGGED copy)
-    int ragged = 0;
+    int ragged = 1;
 };
 
 // Cases a launch really has (see KParams::ncases_dev).

@@ -107,6 +107,7 @@ wr = sum(d["derived"].get("hbm_write_bytes", 0.0) for d in sel)
 if rd and wr and len(sys.argv) > 5:
     cases, alg = int(sys.argv[4]), float(sys.argv[5])
     json.dump(dict(config=cfg, tag=tag, kernels=sorted(out["kernels"]), cases_per_launch=cases,
+                   units_per_launch=cases * (int(os.environ.get("PMC_C4_NRHS", "256")) if cfg == "C4" else 1),      # (C4: a unit = a case x a stacked right-hand side: what bench.py's side line asks for)
                    correction="FETCH_SIZE x2 (gfx950, 16-B/lane coalesced streams; MI355X_MICROARCH.md HBM section); WRITE_SIZE as read",
                    hbm_read_bytes_per_launch=rd, hbm_write_bytes_per_launch=wr, hbm_bytes_per_launch=rd + wr,
                    algorithmic_bytes_per_launch=alg, source="%s_%s_pmc_summary.json" % (tag, cfg)),
