@@ -101,7 +101,14 @@ __global__ __launch_bounds__(64, (!RESIDENT && !SENS && CACHE == 0 && ndofs(DIM,
     constexpr int FCPI = 64 / FPC, FNI = 64 / FCPI;
     constexpr int GRP = WLSQM_SITER_GRP < CH ? WLSQM_SITER_GRP : CH;
     constexpr int XP2s = pitch2(CH * DIM), FP2s = pitch2(CH);         // chunk staging pitches (not RESIDENT)
-    constexpr int SLOT2 = (XNI + FNI) * 64;                           // (DMA) 16-byte units of a slot: a KiB per load instruction
+    // (DMA) 16-byte units from one load instruction's image to the next: a KiB + ONE slot (round 6, as in fit_stage.hip: dense KiB blocks put the
+    // 16 lanes of a ds_read_b128 group on two to four slots of the bank row — `SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE` 0.84 on configs[2]
+    // with refinement, profiles/r05_pmc_refine.txt; 2D: slot (8 (c mod 8)) mod 16 unskewed)
+#ifndef WLSQM_SITER_DMA_SKEW
+#define WLSQM_SITER_DMA_SKEW 1
+#endif
+    constexpr int KIB2 = 64 + WLSQM_SITER_DMA_SKEW;
+    constexpr int SLOT2 = (XNI + FNI) * KIB2;                         // 16-byte units of a slot
     constexpr int STAGE2 = DMA ? 2 * SLOT2 : 64 * XP2s + 64 * FP2s, OUT2 = 64 * NO / 2;
     constexpr int ROWS2s = STAGE2 > OUT2 ? STAGE2 : OUT2;
     __shared__ __attribute__((aligned(16))) d2_ lds_s[RESIDENT ? 1 : ROWS2s + TILE2];
@@ -184,8 +191,8 @@ __global__ __launch_bounds__(64, (!RESIDENT && !SENS && CACHE == 0 && ndofs(DIM,
     constexpr bool WARM = (WLSQM_SITER_WARM != 0) && !RESIDENT && !DEEP;
     bool inflight = false;                                            // (wave-uniform) chunk Q - 1 of the next pass is on its way in (xr, fr)
     double* const wrow = reinterpret_cast<double*>(lds_d) + lane * FP2r;      // (WCACHE / FCACHE) this lane's weights / values; FP2r: the pitch in doubles (odd)
-    const d2_* const xrow = DMA ? lds + (lane / XCPI) * 64 + (lane % XCPI) * XPC : xs + lane * XP2;      // (DMA: in slot 0; slot q & 1 at + SLOT2)
-    const d2_* const frow = DMA ? lds + XNI * 64 + (lane / FCPI) * 64 + (lane % FCPI) * FPC : fs + lane * FP2;
+    const d2_* const xrow = DMA ? lds + (lane / XCPI) * KIB2 + (lane % XCPI) * XPC : xs + lane * XP2;      // (DMA: in slot 0; slot q & 1 at + SLOT2)
+    const d2_* const frow = DMA ? lds + XNI * KIB2 + (lane / FCPI) * KIB2 + (lane % FCPI) * FPC : fs + lane * FP2;
     auto dma_fetch = [&](int q, auto nof_tag) __attribute__((always_inline)) {
         constexpr bool NOF = decltype(nof_tag)::value;
         const char* const xt = xtile; const char* const ft = ftile;
@@ -200,7 +207,7 @@ __global__ __launch_bounds__(64, (!RESIDENT && !SENS && CACHE == 0 && ndofs(DIM,
                 cc = cc < nvalid ? cc : nvalid - 1;
                 unsigned keep;
                 asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep) : "v"(xo + (unsigned)cc * xrowb), "s"(xt), "s"(slot + (unsigned)i * 1024u) : "memory");
+                             : "=&s"(keep) : "v"(xo + (unsigned)cc * xrowb), "s"(xt), "s"(slot + (unsigned)i * (unsigned)(KIB2 * 16)) : "memory");
             }
             if constexpr (!NOF) {
 #pragma unroll
@@ -209,7 +216,7 @@ __global__ __launch_bounds__(64, (!RESIDENT && !SENS && CACHE == 0 && ndofs(DIM,
                     cc = cc < nvalid ? cc : nvalid - 1;
                     unsigned keep;
                     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                                 : "=&s"(keep) : "v"(fo + (unsigned)cc * frowb), "s"(ft), "s"(slot + (unsigned)(XNI + i) * 1024u) : "memory");
+                                 : "=&s"(keep) : "v"(fo + (unsigned)cc * frowb), "s"(ft), "s"(slot + (unsigned)(XNI + i) * (unsigned)(KIB2 * 16)) : "memory");
                 }
             }
         }
@@ -608,7 +615,7 @@ static int launch_stage_refine(const KParams& p, long long K, hipStream_t stream
         // 15-unknown systems, whose weight cache therefore ends at 30 neighbours instead of 48)
         constexpr bool dma15 = (WLSQM_SITER_DMA != 0) && ndofs(DIM, ORDER) == 15;
         constexpr int xni = 64 / (64 / (CH * DIM * 8 / 16)) + ((64 % (64 / (CH * DIM * 8 / 16))) ? 1 : 0), fni = 64 / (64 / (CH * 8 / 16));
-        const size_t wbytes = (size_t)64 * WP * 8, stat = dma15 ? (size_t)2 * (xni + fni) * 1024 : (size_t)64 * (pitch2(CH * DIM) + pitch2(CH)) * 16;
+        const size_t wbytes = (size_t)64 * WP * 8, stat = dma15 ? (size_t)2 * (xni + fni) * (1024 + 16 * WLSQM_SITER_DMA_SKEW) : (size_t)64 * (pitch2(CH * DIM) + pitch2(CH)) * 16;
         size_t budget = 40 * 1024;                                   // four waves per CU (WLSQM_HIP_REFINE_CACHE_KB: A/B)
         if (const char* b = getenv("WLSQM_HIP_REFINE_CACHE_KB")) budget = (size_t)atol(b) * 1024;
         if (!(e && e[0] == '0') && p.max_iter >= 1 && ndofs(DIM, ORDER) > 6 && wbytes + stat <= budget && wbytes + stat <= 64 * 1024) {        // (no opt-in to more than 64 KB of LDS for this kernel)
