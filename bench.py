@@ -403,7 +403,7 @@ def measure_fit(name, cfg, n, dev, timer, steps, warmup, rank, parity=True, keep
         am = res["parity"]["vs_reference_golden"].get("accurate_mode")
         if am:
             with whip.accurate():
-                ms_acc = whip.time_fit_device(*args, reps=5)
+                ms_acc = whip.time_fit_device(*args, reps=20)             # (as many launches as the headline's timed region: 5 left the first launch's latency in every repetition)
             am["ms_per_step"] = ms_acc                                # the WHOLE call: speculative kernel + its (idle) clean-up kernels
             am["slowdown_vs_fast"] = ms_acc / ms_kernel
             am["frac"] = B_fit * n / (ms_acc * 1e-3) / (HBM_PEAK_GBPS * 1e9)

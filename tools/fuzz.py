@@ -133,16 +133,16 @@ while time.time() - t0 < budget:
             assert it_s == it_o, desc + ": STRICT iteration count %d vs oracle %d" % (it_s, it_o)
         strict_trials += 1
     if mode == "basic" and dim >= 2 and K <= 128 and rng.random() < 0.35:
-        # the same call in the ACCURATE numerics mode (csrc/fit_accurate.hip): per order bucket, the cases of the systems up to 10 unknowns
-        # whose knowns mask has no stray bit beyond the polynomial's DOFs (round 5: known DOFs are taken too) must carry the bits of
-        # oracle/variants.c with V_SYM, every other case the oracle's (strict kernels)
+        # the same call in the ACCURATE numerics mode (csrc/fit_accurate.hip): per order bucket, the cases of the systems up to 10 unknowns —
+        # every knowns mask, stray bits beyond the polynomial's DOFs included (round 6) — must carry the bits of oracle/variants.c with
+        # V_SYM, every other case the oracle's (strict kernels)
         fi_a = fi0.copy()
         with whip.accurate():
             f(xk_a, fk, nk, xi_a, fi_a, None, 0, orders, knowns, wm, **kw)
         want = fi_o.copy()
         for o in np.unique(orders):
             no_o = NDOF[dim][int(o)]
-            sel = np.nonzero((orders == o) & ((knowns >> no_o) == 0))[0]
+            sel = np.nonzero(orders == o)[0]
             if no_o > 10 or sel.size == 0:
                 continue
             sub = np.ascontiguousarray(fi0[sel][:, :no_o])
