@@ -813,14 +813,6 @@ static int launch_stage(const KParams& p, hipStream_t stream) {
     const long long groups = (p.ncases + 63) / 64;
     if (groups <= 0) return WLSQM_OK;
     if (groups > 0x7fffffffLL) { set_error("fit_stage: batch too large for one launch"); return WLSQM_EVALUE; }
-    // TWO FORMS for the dense systems up to 10 unknowns (round 5).  The default (PART 0) runs two waves per SIMD; PART 5 is the same code
-    // compiled to own its SIMD (register-staged chunks; same bits per case).  Neighbours that are NOT sorted by distance take two passes over
-    // a group's rows, and the second pass finds them in L2 only with one wave per SIMD resident: 1M cases with shuffled rows, configs[1]
-    // 0.218 -> 0.200 ms, configs[4] 0.406 -> 0.373 — while sorted input loses 5-9 % there.  Sortedness is a property of the data, known only
-    // on the device: sampled groups report it into host-mapped memory and the NEXT launch of the shape on the stream picks its form from what
-    // the reports that have arrived say (no synchronisation, nothing enqueued; the verdict is sticky between reports — the previous launch has
-    // usually not run yet when the next is enqueued; a stale or missing report only costs speed).
-    // WLSQM_HIP_STAGE_FORM=two / one forces a form (A/B, tests).
     constexpr int NO = ndofs(DIM, ORDER);
     // RAGGED batches (round 6): p.ragged = 2 (the host entry points have seen the neighbour counts): the RAGGED copy for every group;
     // p.ragged = 0 (device-resident counts nobody has looked at): the plain kernel marks the waves none of whose cases reaches the row's last

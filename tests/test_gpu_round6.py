@@ -126,3 +126,43 @@ def test_host_path_packs_ragged_batches_in_neighbour_count_order(wlsqm, oracle, 
     oracle.fit_many(dim, b["xk"], b["fk"], b["nk"], b["xi"], ref, None, 0, oa, kna, wm, ntasks=8)
     truth = P.truth_fit(dim, b["xk"], b["fk"], b["nk"], b["xi"], np.ascontiguousarray(wide[:, :no]), oa, kna, wm)
     P.assert_parity(fi_a[:, :no], ref, truth, "host path, ragged batch in neighbour-count order")
+
+
+def test_unknown_row_hint_across_streams_and_in_a_graph(wlsqm, oracle):
+    """wlsqm_hip_set_row_hint(0): the plain kernel marks its short waves in per-group status bytes and the RAGGED copy runs them behind it.
+    The bytes live in a buffer that persists per stream (handed out under a lock held across the two enqueues) — or in stream-ordered
+    scratch inside a graph capture: calls alternating between two streams and a captured, replayed call return the bits of a plain call."""
+    import torch
+    import wlsqm.hip as whip
+    dim, order, Kn, n = 2, 4, 64, 64 * 40 + 5
+    no = K.NDOF[dim][order]
+    b = _ragged(dim, order, Kn, n, 77, [(no + 6, 30), (Kn, Kn), (no + 6, Kn)])
+    kna = np.ones(n, np.int64); wm = np.full(n, wlsqm.WEIGHT_CENTER, np.int32)
+    args = [_t(b[k]) for k in ("xk", "fk", "nk", "xi")]
+    kn_d, wm_d = _t(kna), _t(wm)
+    fi = _t(b["fi0"])
+    whip.fit_many_device(dim, order, *args, fi, kn_d, wm_d)             # the default hint: the plain kernel for every wave
+    torch.cuda.synchronize()
+    want = fi.cpu().numpy().view(np.int64)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    with whip.row_hint(None):
+        for rep in range(4):
+            for st in (s1, s2):
+                f2 = _t(b["fi0"])
+                st.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(st):
+                    whip.fit_many_device(dim, order, *args, f2, kn_d, wm_d)
+                outs.append(f2)
+        torch.cuda.synchronize()
+        for f2 in outs:
+            assert np.array_equal(f2.cpu().numpy().view(np.int64), want)
+        fg = _t(b["fi0"])
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s1):
+            whip.fit_many_device(dim, order, *args, fg, kn_d, wm_d)
+        for rep in range(3):
+            fg.copy_(_t(b["fi0"]))
+            g.replay()
+            torch.cuda.synchronize()
+            assert np.array_equal(fg.cpu().numpy().view(np.int64), want), "replay %d" % rep
