@@ -403,8 +403,12 @@ def measure_fit(name, cfg, n, dev, timer, steps, warmup, rank, parity=True, keep
         am = res["parity"]["vs_reference_golden"].get("accurate_mode")
         if am:
             with whip.accurate():
-                ms_acc = whip.time_fit_device(*args, reps=20)             # (as many launches as the headline's timed region: 5 left the first launch's latency in every repetition)
-            am["ms_per_step"] = ms_acc                                # the WHOLE call: speculative kernel + its (idle) clean-up kernels
+                # (three measurements of as many launches as the headline's timed region; the mode's kernel runs at the edge of the clocks the box
+                # sustains: one box gave 0.245-0.268 ms within one minute, tools/time_accurate_reps.py — the median is reported, the best beside it)
+                acc_ms = sorted(whip.time_fit_device(*args, reps=20) for _ in range(3))
+            ms_acc = acc_ms[1]
+            am["ms_per_step"] = ms_acc                                # the WHOLE call: the speculative kernel + its (idle) clean-up kernel
+            am["ms_best_of_3"] = acc_ms[0]
             am["slowdown_vs_fast"] = ms_acc / ms_kernel
             am["frac"] = B_fit * n / (ms_acc * 1e-3) / (HBM_PEAK_GBPS * 1e9)
             res["parity"]["accurate_mode"] = am
