@@ -192,7 +192,8 @@ int wlsqm_hip_expert_create_guest(wlsqm_expert** out, wlsqm_expert* host, int al
 int wlsqm_hip_expert_prepare(wlsqm_expert* h, const double* xi, int64_t xi_stride_case,
                              const double* xk, int64_t xk_stride_case, int64_t xk_stride_k, int64_t max_nk);
 /* Extension: prepare() from device-resident arrays (xi[ncases, xi_stride_case], xk[ncases, xk_stride_case / dimension,
- * dimension] with xk_stride_k == dimension); the geometry is copied device-to-device on `stream` into the solver's own block. */
+ * dimension] with xk_stride_k == dimension); the geometry is copied device-to-device on `stream` into the solver's own block.
+ * The calling thread's wlsqm_hip_set_order_hint is recorded with the geometry (the host form looks at the rows itself). */
 int wlsqm_hip_expert_prepare_device(wlsqm_expert* h, void* stream, const double* xi, int64_t xi_stride_case,
                                     const double* xk, int64_t xk_stride_case, int64_t xk_stride_k);
 /* expert.pyx:467-655 solve(fk, fi, sens): host arrays; returns max iterations via *iterations_out. */

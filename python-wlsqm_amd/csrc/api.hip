@@ -730,25 +730,8 @@ int wlsqm_hip_fit_many_host(const wlsqm_batch* b, int device, int32_t* iteration
         p.ragged = (max_nk - lo >= 8) ? 2 : 1;                         // (the staged kernels: their RAGGED copy, or the plain one without the marking)
         // ... and at the rows themselves: are the neighbours sorted by distance?  64 cases spread over the batch (in the caller's memory: the
         // arrays are right here); more than half of them out of order: the form of the staged kernels for unsorted rows (fit_stage.hip)
-        int looked = 0, unsorted = 0;
-        const int64_t step = n / 64 > 0 ? n / 64 : 1;
-        for (int64_t r = 0; r < n && looked < 64; r += step) {
-            const int64_t j = user_row(r);
-            const int32_t nkj = h_nk[r];
-            if (nkj < 3) continue;
-            ++looked;
-            double prev = -1.0; bool mono = true;
-            for (int32_t k = 0; k < nkj && mono; ++k) {
-                double d2 = 0.0;
-                for (int m = 0; m < dim; ++m) {
-                    const double d = b->xk[j * b->xk_stride_case + (int64_t)k * b->xk_stride_k + m] - b->xi[j * b->xi_stride_case + m];
-                    d2 += d * d;
-                }
-                mono = d2 >= prev; prev = d2;
-            }
-            if (!mono) ++unsorted;
-        }
-        p.rows_sorted = (looked > 0 && 2 * unsorted > looked) ? 0 : 1;
+        p.rows_sorted = sampled_rows_sorted(n, dim, b->xk, b->xk_stride_case, b->xk_stride_k, b->xi, b->xi_stride_case,
+                                            [&](int64_t r) { return h_nk[r]; }, user_row);
     }
 
     // bucket by order (the kernels are specialised per (dimension, order))

@@ -24,6 +24,7 @@ struct wlsqm_expert_geometry {
     int64_t ncases = 0, max_nk = 1;
     int64_t slots = 2;                 // neighbour slots per device row (>= max_nk; preferred_slots in fit_tile.hip)
     int ragged = 1;                    // 2: the neighbour counts differ by a chunk or more (KParams::ragged)
+    int rows_sorted = 1;               // 0: prepare() found the neighbours out of distance order (KParams::rows_sorted)
     int max_no = 0;
     bool ready = false, uniform_order = true;
     std::vector<int32_t> nk, order, wm, no;
@@ -85,6 +86,7 @@ static KParams expert_params(const wlsqm_expert* h, const double* d_fk, int64_t 
     p.fk = d_fk; p.sfk_j = sfk_j; p.sfk_k = 1;
     p.nk = h->g->d_nk.as<int>(); p.snk = 1; p.max_nk = h->g->slots;
     p.ragged = h->g->ragged;                                        // (the constructor has seen nk: fit_stage.hip's RAGGED copy for ragged geometries)
+    p.rows_sorted = h->g->rows_sorted;                              // (prepare() has seen the rows, or was told: the form for unsorted ones)
     p.xi = h->g->d_xi.as<double>(); p.sxi_j = dim;
     p.fi = d_fi; p.sfi_j = sfi_j;
     p.sens = nullptr; p.ss_j = 0; p.ss_k = 0;
@@ -199,6 +201,8 @@ int wlsqm_hip_expert_prepare(wlsqm_expert* h, const double* xi, int64_t xi_strid
     DeviceScope scope; int rc = scope.enter(h->g->device);
     if (rc != WLSQM_OK) return rc;
     const int dim = h->g->dimension; const int64_t n = h->g->ncases, K = h->g->slots, mk = h->g->max_nk;
+    h->g->rows_sorted = sampled_rows_sorted(n, dim, xk, xk_stride_case, xk_stride_k, xi, xi_stride_case,
+                                            [&](int64_t r) { return h->g->nk[r]; }, [](int64_t r) { return r; });
     if ((rc = h->st.ensure(h->g->device))) return rc;
     hipStream_t s = nullptr;
     if ((rc = h->st.upload_rows(h->g->d_xk.p, xk, n, mk * dim, xk_stride_case, xk_stride_k, dim, 8, s, K * dim))) return rc;
@@ -227,6 +231,7 @@ int wlsqm_hip_expert_prepare_device(wlsqm_expert* h, void* stream, const double*
     }
     g.ready = false;
     g.op_state = 0;                    // a new geometry: the stored solution operator is stale
+    g.rows_sorted = order_hint_value();                                // (device-resident rows: the caller's word, wlsqm_hip_set_order_hint)
     DeviceScope scope; int rc = scope.enter(g.device);
     if (rc != WLSQM_OK) return rc;
     hipStream_t s = (hipStream_t)stream;

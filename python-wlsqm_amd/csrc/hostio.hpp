@@ -161,4 +161,28 @@ struct GrowBuf {
     template <class T> T* as() const { return b.as<T>(); }
 };
 
+// Are the neighbours of these rows sorted by distance from the case's point?  64 cases spread over the batch, in the CALLER's memory (host
+// arrays); more than half of them out of order says "unsorted": the form of the staged kernels for such rows (KParams::rows_sorted,
+// fit_stage.hip).  nk_of(r) / row_of(r): the neighbour count and the caller's row of the r-th case.
+template <class NkOf, class RowOf>
+inline int sampled_rows_sorted(int64_t n, int dim, const double* xk, int64_t sxk_j, int64_t sxk_k, const double* xi, int64_t sxi_j,
+                               NkOf nk_of, RowOf row_of) {
+    int looked = 0, unsorted = 0;
+    const int64_t step = n / 64 > 0 ? n / 64 : 1;
+    for (int64_t r = 0; r < n && looked < 64; r += step) {
+        const int64_t j = row_of(r);
+        const int64_t nkj = nk_of(r);
+        if (nkj < 3) continue;
+        ++looked;
+        double prev = -1.0; bool mono = true;
+        for (int64_t k = 0; k < nkj && mono; ++k) {
+            double d2 = 0.0;
+            for (int m = 0; m < dim; ++m) { const double d = xk[j * sxk_j + k * sxk_k + m] - xi[j * sxi_j + m]; d2 += d * d; }
+            mono = d2 >= prev; prev = d2;
+        }
+        if (!mono) ++unsorted;
+    }
+    return (looked > 0 && 2 * unsorted > looked) ? 0 : 1;
+}
+
 }  // namespace wlsqm

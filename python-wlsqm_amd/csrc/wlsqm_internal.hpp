@@ -210,6 +210,10 @@ struct CallScratch { void* p = nullptr; bool pooled = false; std::unique_lock<st
 int call_scratch_acquire(CallScratch* cs, size_t bytes, hipStream_t stream);
 int call_scratch_release(CallScratch* cs, hipStream_t stream);
 
+// the calling thread's word about the rows of the device-resident batches it hands over (wlsqm_hip_set_row_hint / _order_hint, api.hip)
+int row_hint_value();
+int order_hint_value();
+
 // Host mirror of effective_mask() in wlsqm_kernels.hpp (infra.pyx:119-121 quirk): returns the
 // mask of DOFs the reference never writes (true knowns | dropped) and the dropped subset.
 inline void effective_mask_host(int no, long long raw, unsigned long long& known, unsigned long long& dropped) {

@@ -166,3 +166,41 @@ def test_unknown_row_hint_across_streams_and_in_a_graph(wlsqm, oracle):
             g.replay()
             torch.cuda.synchronize()
             assert np.array_equal(fg.cpu().numpy().view(np.int64), want), "replay %d" % rep
+
+
+def test_expert_solver_picks_the_form_for_its_rows_at_prepare(wlsqm):
+    """ExpertSolver.prepare() has the rows in the caller's memory: it looks at 64 of them, and solve() runs the staged kernel's form for
+    unsorted rows when most are out of distance order (prepare_device: the caller's word, wlsqm.hip.row_hint(sorted=...)).  The same bits
+    as the one-shot call on the same cases either way."""
+    import torch
+    import wlsqm.hip as whip
+    dim, order, Kn, n = 2, 3, 48, 64 * 30 + 9                             # (the two forms exist for the dense systems of up to 10 unknowns)
+    no = K.NDOF[dim][order]
+    rng = np.random.default_rng(5)
+    xi = rng.uniform(0, 1, (n, dim))
+    off = 0.05 * rng.uniform(-1, 1, (n, Kn, dim))
+    srt = np.take_along_axis(off, np.argsort((off ** 2).sum(-1), axis=1)[..., None], axis=1)
+    nk = np.full(n, Kn, np.int32); kna = np.ones(n, np.int64); wm = np.full(n, wlsqm.WEIGHT_CENTER, np.int32); oa = np.full(n, order, np.int32)
+    for name, o, kern in (("shuffled", off, "stage-own"), ("sorted", srt, "stage")):
+        xk = xi[:, None, :] + o
+        fk = np.sin(3 * xk[..., 0]) * np.cos(2 * xk[..., -1])
+        fi0 = np.zeros((n, no)); fi0[:, 0] = np.sin(3 * xi[:, 0]) * np.cos(2 * xi[:, 1])
+        fi_d = _t(fi0)
+        with whip.row_hint(sorted=(name == "sorted")):
+            whip.fit_many_device(dim, order, _t(xk), _t(fk), _t(nk), _t(xi), fi_d, _t(kna), _t(wm))
+            torch.cuda.synchronize()
+        want = fi_d.cpu().numpy().view(np.int64)
+        s = wlsqm.ExpertSolver(dimension=dim, nk=nk, order=oa, knowns=kna, weighting_method=wm, algorithm=wlsqm.ALGO_BASIC, do_sens=False, ntasks=1)
+        s.prepare(xi=xi, xk=xk)
+        fi = fi0.copy()
+        s.solve(fk=fk, fi=fi)
+        assert whip.last_kernel() == kern, (name, whip.last_kernel())
+        assert np.array_equal(fi.view(np.int64), want), name
+        s2 = wlsqm.ExpertSolver(dimension=dim, nk=nk, order=oa, knowns=kna, weighting_method=wm, algorithm=wlsqm.ALGO_BASIC, do_sens=False, ntasks=1)
+        with whip.row_hint(sorted=(name == "sorted")):
+            s2.prepare_device(_t(xi), _t(xk))
+        fi2 = _t(fi0)
+        s2.solve_device(_t(fk), fi2)
+        torch.cuda.synchronize()
+        assert whip.last_kernel() == kern, (name, whip.last_kernel())
+        assert np.array_equal(fi2.cpu().numpy().view(np.int64), want), name
