@@ -286,6 +286,46 @@ def test_strict_mode_flag_is_per_thread_and_restored(binding, monkeypatch):
         whip.set_strict(prev)
 
 
+def test_row_hints_are_per_thread_and_restored(binding):
+    """wlsqm_hip_set_row_hint / wlsqm_hip_set_order_hint (no GPU needed): the setters return the previous value, wlsqm.hip.row_hint
+    restores it (nested too, and when the body raises), another thread starts from the defaults (full rows, sorted by distance), and
+    values outside the documented codes mean the default."""
+    import threading
+    sys.path.insert(0, os.path.join(ROOT, "python-wlsqm_amd"))
+    import wlsqm.hip as whip
+    L = binding.lib()
+
+    def now():
+        r = L.wlsqm_hip_set_row_hint(1); L.wlsqm_hip_set_row_hint(r)
+        o = L.wlsqm_hip_set_order_hint(1); L.wlsqm_hip_set_order_hint(o)
+        return r, o
+    r0, o0 = now()
+    try:
+        L.wlsqm_hip_set_row_hint(1); L.wlsqm_hip_set_order_hint(1)
+        with whip.row_hint("ragged", sorted=False):
+            assert now() == (2, 0)
+            with whip.row_hint(None):
+                assert now() == (0, 1)
+            assert now() == (2, 0)
+            seen = {}
+
+            def other():
+                seen["other"] = now()
+            t = threading.Thread(target=other); t.start(); t.join()
+            assert seen["other"] == (1, 1)
+        assert now() == (1, 1)
+        with pytest.raises(RuntimeError):
+            with whip.row_hint(sorted=False):
+                assert now() == (1, 0)
+                raise RuntimeError("body")
+        assert now() == (1, 1)
+        for bad in (-1, 3, 77):
+            L.wlsqm_hip_set_row_hint(bad)
+            assert now()[0] == 1
+    finally:
+        L.wlsqm_hip_set_row_hint(r0); L.wlsqm_hip_set_order_hint(o0)
+
+
 def test_default_device_precedence(monkeypatch):
     """Host-array entry points: WLSQM_HIP_DEVICE, then a non-default torch device, then LOCAL_RANK, then torch's device."""
     import types
